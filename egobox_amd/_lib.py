@@ -1,0 +1,141 @@
+"""ctypes binding of libegx_gp_hip.so (include/egx_gp.h).
+
+This is the same C ABI a Rust `extern "C"` shim would bind.  The library is
+built in-tree by `__graft_entry__.build()` / `make -C egobox_amd/csrc`; if it is missing the
+import fails loudly -- there is no Python or CPU fallback for the compute path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libegx_gp_hip.so")
+
+# return codes / status values (egx_rc, egx_status)
+SUCCESS, ERR_INVALID_VALUE, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_FITTED, ERR_LINALG, ERR_LIKELIHOOD, ERR_UNSUPPORTED = range(8)
+STATUS_OK, STATUS_NOT_POSITIVE_DEFINITE, STATUS_ILL_CONDITIONED_FT, STATUS_ILL_CONDITIONED_F, STATUS_NAN_THETA = range(5)
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_int64_p = C.POINTER(C.c_int64)
+
+
+class GpConfig(C.Structure):
+    _fields_ = [("corr", C.c_int32), ("mean", C.c_int32), ("nugget", C.c_double), ("device", C.c_int32),
+                ("n_workspaces", C.c_int32), ("w_star", c_double_p), ("kpls_dim", C.c_int64)]
+
+
+class InnerView(C.Structure):
+    _fields_ = [(k, c_double_p) for k in (
+        "theta", "likelihood", "sigma2", "beta", "gamma", "r_chol", "ft", "ft_qr_r", "x_mean", "x_std",
+        "y_mean", "y_std", "xt_norm", "yt_norm")]
+
+
+class Timings(C.Structure):
+    _fields_ = [("corr_build_ms", C.c_double), ("potrf_ms", C.c_double), ("potrf_syrk_ms", C.c_double),
+                ("solve_ms", C.c_double), ("host_ms", C.c_double), ("total_ms", C.c_double),
+                ("potrf_flops", C.c_int64), ("corr_bytes", C.c_int64)]
+
+
+#: every symbol include/egx_gp.h declares: (name, restype, argtypes)
+SIGNATURES = [
+    ("egx_abi_version", C.c_int32, []),
+    ("egx_last_error", C.c_char_p, []),
+    ("egx_device_count", C.c_int32, []),
+    ("egx_gp_config_default", None, [C.POINTER(GpConfig)]),
+    ("egx_normalize", C.c_int32, [c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
+    ("egx_regression_ncols", C.c_int64, [C.c_int32, C.c_int64]),
+    ("egx_regression_basis", C.c_int32, [C.c_int32, c_double_p, C.c_int64, C.c_int64, c_double_p]),
+    ("egx_gp_create", C.c_int32, [C.POINTER(GpConfig), c_double_p, c_double_p, C.c_int64, C.c_int64,
+                                  C.POINTER(C.c_void_p)]),
+    ("egx_gp_destroy", None, [C.c_void_p]),
+    ("egx_gp_dims", C.c_int32, [C.c_void_p, c_int64_p, c_int64_p, c_int64_p, c_int64_p]),
+    ("egx_gp_likelihood", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_int32_p]),
+    ("egx_gp_likelihood_batch", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_int32_p]),
+    ("egx_gp_likelihood_grad", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p, c_int32_p]),
+    ("egx_gp_finalize", C.c_int32, [C.c_void_p, c_double_p, C.c_int64]),
+    ("egx_gp_fit", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_int64, C.c_int64,
+                               c_int64_p]),
+    ("egx_gp_predict", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
+    ("egx_gp_predict_var", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
+    ("egx_gp_predict_valvar", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
+    ("egx_gp_get_inner", C.c_int32, [C.c_void_p, C.POINTER(InnerView)]),
+    ("egx_corr_matrix", C.c_int32, [C.c_int32, c_double_p, C.c_int64, C.c_int64, c_double_p, C.c_double, c_double_p]),
+    ("egx_cross_corr", C.c_int32, [C.c_int32, c_double_p, C.c_int64, c_double_p, C.c_int64, C.c_int64, c_double_p,
+                                   c_double_p]),
+    ("egx_potrf", C.c_int32, [c_double_p, C.c_int64, c_int32_p]),
+    ("egx_gp_last_timings", C.c_int32, [C.c_void_p, C.POINTER(Timings)]),
+    ("egx_mfma_probe", C.c_int32, [c_double_p]),
+]
+
+
+class EgxError(RuntimeError):
+    """Base error; `.rc` is the egx_rc.  Subclasses mirror GpError (crates/gp/src/errors.rs:8-40)."""
+
+    def __init__(self, rc, msg):
+        super().__init__(msg)
+        self.rc = rc
+
+
+class InvalidValueError(EgxError, ValueError):
+    pass
+
+
+class NoDeviceError(EgxError):
+    pass
+
+
+class NotFittedError(EgxError):
+    pass
+
+
+class LinalgError(EgxError):
+    pass
+
+
+class LikelihoodComputationError(EgxError):
+    pass
+
+
+_ERR = {ERR_INVALID_VALUE: InvalidValueError, ERR_NO_DEVICE: NoDeviceError, ERR_NOT_FITTED: NotFittedError,
+        ERR_LINALG: LinalgError, ERR_LIKELIHOOD: LikelihoodComputationError}
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the shared library.  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C egobox_amd/csrc`).  egobox_amd has no fallback compute path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SIGNATURES:
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != SUCCESS:
+        msg = load().egx_last_error().decode("utf-8", "replace")
+        raise _ERR.get(rc, EgxError)(rc, msg)
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def as_f64(a, ndim=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if ndim is not None and a.ndim != ndim:
+        raise InvalidValueError(ERR_INVALID_VALUE, f"expected a {ndim}-d array, got shape {a.shape}")
+    return a

@@ -1,0 +1,79 @@
+// Internal declarations shared by the HIP translation units of libegx_gp_hip.so.
+// gfx950 (MI355X / CDNA4) only: wave64, FP64 MFMA 16x16x4, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/egx_gp.h"
+
+namespace egx {
+
+// ---- error plumbing --------------------------------------------------------
+void set_error(const std::string &msg);
+#define EGX_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ::egx::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));         \
+            return EGX_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+
+// ---- geometry ---------------------------------------------------------------
+constexpr int kTile = 128;      // row/col granularity of the padded correlation matrix
+constexpr int kNB = 256;        // outer Cholesky block (K of the trailing update)
+constexpr int kDiagTile = 64;   // diagonal tile factored in registers by one wave
+constexpr int kRhsPad = 128;    // rows appended below R for the fused forward solves
+constexpr int kMaxDim = 64;     // d <= 64 (north_star: "d up to 64")
+
+inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// ---- kernels_corr.hip -------------------------------------------------------
+// coef is (d x hcols) row-major: per-dimension scale (w = I: hcols = 1, coef[j] = theta_j;
+// KPLS: sq-exp/abs-exp collapse to hcols = 1, Matern keeps theta_l*|w_jl|).
+// xT is k-major (d x ldx): xT[k*ldx + i] = xnorm[i][k]; rows >= n are padding.
+int launch_corr_sym(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d,
+                    const double *coef, int hcols, double nugget, double *M, int64_t ld, int n_pad);
+// full (m_pad x n_pad) cross correlation block, row-major into R (ld), no diagonal handling
+int launch_cross_corr(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad,
+                      const double *xT, int64_t ldx, int n_pad, int d, const double *coef,
+                      int hcols, double *R, int64_t ld);
+// racc[q] = sum_i k(xq, x_i) * gamma[i]   (gamma zero padded to n_pad)
+int launch_predict_mean(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad,
+                        const double *xT, int64_t ldx, int n_pad, int d, const double *coef,
+                        int hcols, const double *gamma, double *racc);
+// dst[(r0 + l) * ld + i] = src[l * lds + i] for l < nrows, i < ncols; rest of [r0, r0+rows_pad) x [0, ld) zeroed
+int launch_fill_rows(hipStream_t s, double *M, int64_t ld, int r0, int rows_pad, const double *src,
+                     int64_t lds, int nrows, int ncols);
+int launch_gather_diag(hipStream_t s, const double *M, int64_t ld, int n, double *out);
+// per-row reductions over the first n columns of rows [0, m): s0[q] = sum rt^2, sl[q*p + l] = sum rt*ft_l
+int launch_row_reduce(hipStream_t s, const double *RT, int64_t ld, int m, int n, const double *ftT,
+                      int64_t ldf, int p, double *s0, double *sl);
+// zero the strict upper triangle of the leading n x n block
+int launch_zero_upper(hipStream_t s, double *M, int64_t ld, int n);
+// likelihood-gradient accumulation (new capability): for all i>j
+//   tr[k]  += 2*Rinv[i][j]*dR_k[i][j],  q[k] += 2*gamma_i*gamma_j*dR_k[i][j]
+int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d,
+                      const double *theta, const double *Rinv, int64_t ld, const double *gamma,
+                      double *out /*2*d, zeroed by the launcher*/);
+
+// ---- kernels_chol.hip -------------------------------------------------------
+// In-place blocked right-looking Cholesky of the leading n_pad x n_pad block (lower), applied to
+// all m_tot >= n_pad rows (rows >= n_pad are right-hand sides: on return they hold (C^-1 B)^T).
+// dinv receives the inverses of the 64x64 diagonal tiles ((n_pad/64) * 4096 doubles).
+// info (device int): 0 or 1-based index of the first non-positive pivot.
+// ev_syrk: optional accumulation of per-launch timings is done by the caller via events.
+int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info);
+// rows [0, m) of RT (ld) are right-hand sides: RT <- RT * C^-T  (C = lower factor in M, n_pad cols)
+int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, const double *dinv,
+                     double *RT, int64_t ldr, int m);
+// v (n_pad) <- C^-T v
+int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *dinv, double *v);
+// C (M x N, ldc) -= A (M x K, lda) * B (N x K, ldb)^T ; lower != 0 skips tiles strictly above the diagonal
+int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
+                       const double *B, int64_t ldb, int M, int N, int K, int lower);
+int mfma_probe(double *max_abs_err);
+int chol_init();  // one-time function attribute setup (dynamic LDS sizes)
+
+}  // namespace egx

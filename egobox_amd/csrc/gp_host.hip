@@ -1,0 +1,1200 @@
+// C ABI implementation (include/egx_gp.h): handle lifetime, the likelihood / fit / predict
+// drivers and the small host-side GLS algebra.  Mirrors, operation for operation,
+// GpValidParams::fit and reduced_likelihood (crates/gp/src/algorithm.rs:785-1056) and
+// GaussianProcess::predict* (:253-380) of the reference; the O(n^2 d) / O(n^3) / O(n^2 m) parts run
+// in the HIP kernels of kernels_corr.hip / kernels_chol.hip.  There is no CPU fallback.
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <vector>
+
+#include "egx_internal.h"
+#include "host_math.h"
+
+namespace egx {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+#define EGX_RC(call)              \
+    do {                          \
+        int _rc = (call);         \
+        if (_rc) return _rc;      \
+    } while (0)
+
+struct Workspace {
+    hipStream_t stream = nullptr;
+    double *M = nullptr;       // (m_tot x ld): correlation matrix / factor + appended RHS rows
+    double *dinv = nullptr;    // (n_pad/64) x 64 x 64 inverses of the diagonal tiles
+    double *d_coef = nullptr;  // d x hcols
+    double *d_diag = nullptr;  // n
+    double *d_vec = nullptr;   // n_pad (rho -> gamma)
+    int *d_info = nullptr;
+    double *h_coef = nullptr;  // pinned
+    double *h_rows = nullptr;  // pinned: q x n_pad solved RHS rows (ft^T, yt^T)
+    double *h_diag = nullptr;  // pinned: n
+    double *h_vec = nullptr;   // pinned: n_pad
+    int *h_info = nullptr;     // pinned
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+struct EvalResult {
+    double lkh = -std::numeric_limits<double>::infinity();
+    int status = EGX_STATUS_OK;
+    double sigma2n = 0.0;         // rho^2 / n in normalised units
+    std::vector<double> beta;     // p
+    std::vector<double> rho;      // n
+    std::vector<double> ft;       // n x p row-major
+    std::vector<double> ft_qr_r;  // p x p row-major
+};
+
+}  // namespace egx
+
+using namespace egx;
+
+struct egx_gp {
+    int device = 0;
+    int n = 0, d = 0, p = 0, h = 0, corr = 0, mean = 0;
+    double nugget = 0.0;
+    int n_pad = 0, rhs_pad = 0, m_tot = 0, q = 0;
+    int64_t ld = 0;
+    bool has_w = false;
+    std::vector<double> w_star;  // d x h
+    std::vector<double> x_raw, y_raw, xnorm, x_mean, x_std, ynorm, F;
+    double y_mean = 0.0, y_std = 1.0;
+    double *d_xT = nullptr;    // d x n_pad (k-major normalised inputs, zero padded)
+    double *d_rhsT = nullptr;  // q x n_pad: columns of F then y (normalised), as rows
+    std::vector<Workspace> ws;
+    std::mutex mu;
+    // fitted state (lives in ws[0])
+    bool fitted = false;
+    std::vector<double> theta;  // h
+    double likelihood = 0.0, sigma2 = 0.0;
+    std::vector<double> beta, gamma, ft, ft_qr_r;
+    std::vector<double> fit_coef;
+    int fit_hcols = 1;
+    double *d_gamma = nullptr;  // n_pad
+    double *d_fit_coef = nullptr;
+    // gradient scratch (allocated on first use)
+    double *d_W = nullptr, *d_Rinv = nullptr, *d_gout = nullptr, *d_theta = nullptr;
+    egx_timings timings{};
+};
+
+namespace egx {
+
+static int set_device(const egx_gp *gp) {
+    EGX_HIP_CHECK(hipSetDevice(gp->device));
+    return EGX_SUCCESS;
+}
+
+static void free_workspace(Workspace &w) {
+    if (w.M) hipFree(w.M);
+    if (w.dinv) hipFree(w.dinv);
+    if (w.d_coef) hipFree(w.d_coef);
+    if (w.d_diag) hipFree(w.d_diag);
+    if (w.d_vec) hipFree(w.d_vec);
+    if (w.d_info) hipFree(w.d_info);
+    if (w.h_coef) hipHostFree(w.h_coef);
+    if (w.h_rows) hipHostFree(w.h_rows);
+    if (w.h_diag) hipHostFree(w.h_diag);
+    if (w.h_vec) hipHostFree(w.h_vec);
+    if (w.h_info) hipHostFree(w.h_info);
+    for (auto &e : w.ev)
+        if (e) hipEventDestroy(e);
+    if (w.stream) hipStreamDestroy(w.stream);
+    w = Workspace();
+}
+
+static int alloc_workspace(egx_gp *gp, Workspace &w) {
+    EGX_HIP_CHECK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    EGX_HIP_CHECK(hipMalloc(&w.M, sizeof(double) * (size_t)gp->m_tot * gp->ld));
+    EGX_HIP_CHECK(hipMalloc(&w.dinv, sizeof(double) * (size_t)(gp->n_pad / 64) * 4096));
+    const int hmax = gp->has_w ? gp->h : 1;
+    EGX_HIP_CHECK(hipMalloc(&w.d_coef, sizeof(double) * (size_t)gp->d * hmax));
+    EGX_HIP_CHECK(hipMalloc(&w.d_diag, sizeof(double) * (size_t)gp->n_pad));
+    EGX_HIP_CHECK(hipMalloc(&w.d_vec, sizeof(double) * (size_t)gp->n_pad));
+    EGX_HIP_CHECK(hipMalloc(&w.d_info, sizeof(int)));
+    EGX_HIP_CHECK(hipHostMalloc(&w.h_coef, sizeof(double) * (size_t)gp->d * hmax, hipHostMallocDefault));
+    EGX_HIP_CHECK(hipHostMalloc(&w.h_rows, sizeof(double) * (size_t)gp->q * gp->n_pad, hipHostMallocDefault));
+    EGX_HIP_CHECK(hipHostMalloc(&w.h_diag, sizeof(double) * (size_t)gp->n_pad, hipHostMallocDefault));
+    EGX_HIP_CHECK(hipHostMalloc(&w.h_vec, sizeof(double) * (size_t)gp->n_pad, hipHostMallocDefault));
+    EGX_HIP_CHECK(hipHostMalloc(&w.h_info, sizeof(int), hipHostMallocDefault));
+    for (auto &e : w.ev) EGX_HIP_CHECK(hipEventCreate(&e));
+    return EGX_SUCCESS;
+}
+
+// theta (len 1 or h) -> per-dimension coefficient table (d x hcols), see kernels_corr.hip.
+// correlation_models.rs:97-98 (sq-exp theta_w), :191 (abs-exp), :333 / :505 (Matern theta_w).
+static int make_coef(const egx_gp *gp, const double *theta, int64_t theta_len, std::vector<double> &coef,
+                     int &hcols, std::vector<double> *theta_full) {
+    if (theta_len != 1 && theta_len != gp->h) {
+        set_error("theta should be either 1-dim or dim of xtrain (w_star.ncols()), got " + std::to_string(theta_len));
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::vector<double> th(gp->h);
+    for (int l = 0; l < gp->h; l++) th[l] = theta[theta_len == 1 ? 0 : l];
+    if (theta_full) *theta_full = th;
+    const int d = gp->d, h = gp->h;
+    if (!gp->has_w) {
+        hcols = 1;
+        coef.assign(th.begin(), th.end());  // h == d
+        return EGX_SUCCESS;
+    }
+    const double *w = gp->w_star.data();
+    if (gp->corr == EGX_CORR_SQUARED_EXPONENTIAL) {
+        hcols = 1;
+        coef.assign(d, 0.0);
+        for (int j = 0; j < d; j++) {
+            double s = 0.0;
+            for (int l = 0; l < h; l++) s += (th[l] * w[j * h + l]) * (th[l] * w[j * h + l]);
+            coef[j] = std::sqrt(s);
+        }
+    } else if (gp->corr == EGX_CORR_ABSOLUTE_EXPONENTIAL) {
+        hcols = 1;
+        coef.assign(d, 0.0);
+        for (int j = 0; j < d; j++) {
+            double s = 0.0;
+            for (int l = 0; l < h; l++) s += std::fabs(w[j * h + l]) * th[l];
+            coef[j] = s;
+        }
+    } else {
+        hcols = h;
+        coef.assign((size_t)d * h, 0.0);
+        for (int j = 0; j < d; j++)
+            for (int l = 0; l < h; l++) coef[j * h + l] = th[l] * std::fabs(w[j * h + l]);
+    }
+    return EGX_SUCCESS;
+}
+
+// GPU half of one likelihood evaluation: R assembly + RHS rows, factorisation with fused forward
+// solves, diagonal gather, async download of (diag C, ft^T, yt^T, info).  All asynchronous on w.stream.
+static int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coef, int hcols) {
+    std::memcpy(w.h_coef, coef.data(), sizeof(double) * coef.size());
+    EGX_HIP_CHECK(hipMemcpyAsync(w.d_coef, w.h_coef, sizeof(double) * coef.size(), hipMemcpyHostToDevice, w.stream));
+    EGX_HIP_CHECK(hipMemsetAsync(w.d_info, 0, sizeof(int), w.stream));
+    EGX_HIP_CHECK(hipEventRecord(w.ev[0], w.stream));
+    EGX_RC(launch_corr_sym(w.stream, gp->corr, gp->d_xT, gp->n_pad, gp->n, gp->d, w.d_coef, hcols, gp->nugget, w.M,
+                           gp->ld, gp->n_pad));
+    EGX_RC(launch_fill_rows(w.stream, w.M, gp->ld, gp->n_pad, gp->rhs_pad, gp->d_rhsT, gp->n_pad, gp->q, gp->n_pad));
+    EGX_HIP_CHECK(hipEventRecord(w.ev[1], w.stream));
+    EGX_RC(launch_potrf(w.stream, w.M, gp->ld, gp->n_pad, gp->m_tot, w.dinv, w.d_info));
+    EGX_HIP_CHECK(hipEventRecord(w.ev[2], w.stream));
+    EGX_RC(launch_gather_diag(w.stream, w.M, gp->ld, gp->n, w.d_diag));
+    EGX_HIP_CHECK(hipMemcpyAsync(w.h_diag, w.d_diag, sizeof(double) * gp->n, hipMemcpyDeviceToHost, w.stream));
+    EGX_HIP_CHECK(hipMemcpyAsync(w.h_rows, w.M + (size_t)gp->n_pad * gp->ld, sizeof(double) * (size_t)gp->q * gp->n_pad,
+                                 hipMemcpyDeviceToHost, w.stream));
+    EGX_HIP_CHECK(hipMemcpyAsync(w.h_info, w.d_info, sizeof(int), hipMemcpyDeviceToHost, w.stream));
+    EGX_HIP_CHECK(hipEventRecord(w.ev[3], w.stream));
+    return EGX_SUCCESS;
+}
+
+// Host half: algorithm.rs:1007-1043 on the downloaded ft, yt, diag(C).
+static int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, bool keep) {
+    EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+    const int n = gp->n, p = gp->p, n_pad = gp->n_pad;
+    out = EvalResult();
+    if (*w.h_info != 0) {
+        out.status = EGX_STATUS_NOT_POSITIVE_DEFINITE;
+        return EGX_SUCCESS;
+    }
+    for (int i = 0; i < n; i++)
+        if (!(w.h_diag[i] > 0.0) || !std::isfinite(w.h_diag[i])) {
+            out.status = EGX_STATUS_NOT_POSITIVE_DEFINITE;
+            return EGX_SUCCESS;
+        }
+    // ft (column-major copy for the QR), yt
+    std::vector<double> a((size_t)n * p), qty(n);
+    for (int l = 0; l < p; l++) std::memcpy(&a[(size_t)l * n], w.h_rows + (size_t)l * n_pad, sizeof(double) * n);
+    std::memcpy(qty.data(), w.h_rows + (size_t)p * n_pad, sizeof(double) * n);
+    std::vector<double> yt(qty);
+    std::vector<double> ftcm;
+    ftcm = a;                     // keep ft (column-major) for rho
+    hm::qr_apply(a, n, p, &qty);  // :1007  a -> R (upper), qty -> Q^T yt
+    std::vector<double> R((size_t)p * p, 0.0);
+    for (int i = 0; i < p; i++)
+        for (int l = i; l < p; l++) R[(size_t)i * p + l] = (i < n) ? a[(size_t)l * n + i] : 0.0;
+    // :1010-1027 conditioning of the p x p factor
+    std::vector<double> sv = hm::singular_values(R, p);
+    const double cond_ft = sv[p - 1] / sv[0];
+    if (!(cond_ft >= 1e-10)) {
+        std::vector<double> fcm((size_t)n * p);
+        for (int l = 0; l < p; l++)
+            for (int i = 0; i < n; i++) fcm[(size_t)l * n + i] = gp->F[(size_t)i * p + l];
+        hm::qr_apply(fcm, n, p, nullptr);
+        std::vector<double> RF((size_t)p * p, 0.0);
+        for (int i = 0; i < p; i++)
+            for (int l = i; l < p; l++) RF[(size_t)i * p + l] = (i < n) ? fcm[(size_t)l * n + i] : 0.0;
+        std::vector<double> svf = hm::singular_values(RF, p);
+        out.status = (svf[0] / svf[p - 1] > 1e15) ? EGX_STATUS_ILL_CONDITIONED_F : EGX_STATUS_ILL_CONDITIONED_FT;
+        return EGX_SUCCESS;
+    }
+    // :1030 beta = R^-1 (Q^T yt)[:p]
+    std::vector<double> beta(p);
+    for (int i = p - 1; i >= 0; i--) {
+        double s = qty[i];
+        for (int l = i + 1; l < p; l++) s -= R[(size_t)i * p + l] * beta[l];
+        beta[i] = s / R[(size_t)i * p + i];
+    }
+    // :1031-1032 rho = yt - ft beta
+    std::vector<double> rho(yt);
+    for (int l = 0; l < p; l++) {
+        const double b = beta[l];
+        const double *col = &ftcm[(size_t)l * n];
+        for (int i = 0; i < n; i++) rho[i] -= col[i] * b;
+    }
+    double rho_sqr = 0.0;
+    for (int i = 0; i < n; i++) rho_sqr += rho[i] * rho[i];
+    // :1039-1043
+    double slog = 0.0;
+    for (int i = 0; i < n; i++) slog += std::log10(w.h_diag[i]);
+    const double logdet = slog * 2.0 / (double)n;
+    const double sigma2n = rho_sqr / (double)n;
+    out.lkh = -(double)n * (std::log10(sigma2n) + logdet);
+    out.sigma2n = sigma2n;
+    out.status = EGX_STATUS_OK;
+    if (keep) {
+        out.beta = beta;
+        out.rho = rho;
+        out.ft_qr_r = R;
+        out.ft.assign((size_t)n * p, 0.0);
+        for (int l = 0; l < p; l++)
+            for (int i = 0; i < n; i++) out.ft[(size_t)i * p + l] = ftcm[(size_t)l * n + i];
+    }
+    return EGX_SUCCESS;
+}
+
+static void record_timings(egx_gp *gp, Workspace &w, double host_ms, double solve_ms) {
+    float t01 = 0, t12 = 0, t03 = 0;
+    hipEventElapsedTime(&t01, w.ev[0], w.ev[1]);
+    hipEventElapsedTime(&t12, w.ev[1], w.ev[2]);
+    hipEventElapsedTime(&t03, w.ev[0], w.ev[3]);
+    egx_timings &t = gp->timings;
+    t.corr_build_ms = t01;
+    t.potrf_ms = t12;
+    t.potrf_syrk_ms = 0.0;
+    t.solve_ms = solve_ms;
+    t.host_ms = host_ms;
+    t.total_ms = t03 + host_ms + solve_ms;
+    const double nn = (double)gp->n;
+    t.potrf_flops = (int64_t)(nn * nn * nn / 3.0);
+    t.corr_bytes = (int64_t)(8.0 * nn * gp->d + 8.0 * nn * (nn + 1.0) / 2.0);
+}
+
+static bool has_nan(const double *theta, int64_t len) {
+    for (int64_t i = 0; i < len; i++)
+        if (std::isnan(theta[i])) return true;
+    return false;
+}
+
+static int eval_one(egx_gp *gp, int widx, const double *theta, int64_t theta_len, EvalResult &res, bool keep) {
+    std::vector<double> coef;
+    int hcols = 1;
+    EGX_RC(make_coef(gp, theta, theta_len, coef, hcols, nullptr));
+    if (has_nan(theta, theta_len)) {  // algorithm.rs:885-891
+        res = EvalResult();
+        res.status = EGX_STATUS_NAN_THETA;
+        return EGX_SUCCESS;
+    }
+    if (widx == 0) gp->fitted = false;
+    Workspace &w = gp->ws[widx];
+    EGX_RC(enqueue_eval(gp, w, coef, hcols));
+    auto t0 = std::chrono::steady_clock::now();
+    EGX_RC(finish_eval(gp, w, res, keep));
+    // host_ms includes the wait for the stream; subtract GPU time below
+    auto t1 = std::chrono::steady_clock::now();
+    float gpu = 0;
+    hipEventElapsedTime(&gpu, w.ev[0], w.ev[3]);
+    double host_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() - gpu;
+    if (host_ms < 0) host_ms = 0;
+    if (widx == 0) record_timings(gp, w, host_ms, 0.0);
+    return EGX_SUCCESS;
+}
+
+static int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
+    std::vector<double> coef, thfull;
+    int hcols = 1;
+    EGX_RC(make_coef(gp, theta, theta_len, coef, hcols, &thfull));
+    if (has_nan(theta, theta_len)) {
+        set_error("theta contains NaN");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    gp->fitted = false;
+    Workspace &w = gp->ws[0];
+    EvalResult res;
+    EGX_RC(enqueue_eval(gp, w, coef, hcols));
+    auto t0 = std::chrono::steady_clock::now();
+    EGX_RC(finish_eval(gp, w, res, true));
+    auto t1 = std::chrono::steady_clock::now();
+    if (res.status == EGX_STATUS_NOT_POSITIVE_DEFINITE) {
+        set_error("LinalgError: matrix is not positive definite (pivot " + std::to_string(*w.h_info) + ")");
+        return EGX_ERR_LINALG;
+    }
+    if (res.status == EGX_STATUS_ILL_CONDITIONED_F) {
+        set_error("LikelihoodComputation computation error: F is too ill conditioned. Poor combination of "
+                  "regression model and observations.");
+        return EGX_ERR_LIKELIHOOD;
+    }
+    if (res.status == EGX_STATUS_ILL_CONDITIONED_FT) {
+        set_error("LikelihoodComputation computation error: ft is too ill conditioned, try another theta again");
+        return EGX_ERR_LIKELIHOOD;
+    }
+    // gamma = C^-T rho   (algorithm.rs:1034)
+    const int n = gp->n, n_pad = gp->n_pad;
+    std::memset(w.h_vec, 0, sizeof(double) * n_pad);
+    std::memcpy(w.h_vec, res.rho.data(), sizeof(double) * n);
+    EGX_HIP_CHECK(hipMemcpyAsync(w.d_vec, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
+    EGX_HIP_CHECK(hipEventRecord(w.ev[4], w.stream));
+    EGX_RC(launch_trsv_t(w.stream, w.M, gp->ld, n_pad, w.dinv, w.d_vec));
+    EGX_HIP_CHECK(hipMemcpyAsync(gp->d_gamma, w.d_vec, sizeof(double) * n_pad, hipMemcpyDeviceToDevice, w.stream));
+    EGX_HIP_CHECK(hipMemcpyAsync(w.h_vec, w.d_vec, sizeof(double) * n_pad, hipMemcpyDeviceToHost, w.stream));
+    EGX_HIP_CHECK(hipMemcpyAsync(gp->d_fit_coef, w.d_coef, sizeof(double) * coef.size(), hipMemcpyDeviceToDevice,
+                                 w.stream));
+    EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+    auto t2 = std::chrono::steady_clock::now();
+    gp->gamma.assign(w.h_vec, w.h_vec + n);
+    gp->theta = thfull;
+    gp->likelihood = res.lkh;
+    gp->sigma2 = res.sigma2n * gp->y_std * gp->y_std;  // algorithm.rs:1048
+    gp->beta = res.beta;
+    gp->ft = res.ft;
+    gp->ft_qr_r = res.ft_qr_r;
+    gp->fit_coef = coef;
+    gp->fit_hcols = hcols;
+    gp->fitted = true;
+    float gpu = 0;
+    hipEventElapsedTime(&gpu, w.ev[0], w.ev[3]);
+    double host_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() - gpu;
+    if (host_ms < 0) host_ms = 0;
+    record_timings(gp, w, host_ms, std::chrono::duration<double, std::milli>(t2 - t1).count());
+    return EGX_SUCCESS;
+}
+
+// ---- prediction -------------------------------------------------------------------------------
+struct QueryChunk {
+    int m = 0, m_pad = 0;
+    std::vector<double> xn;  // m x d normalised
+    double *d_xqT = nullptr; // d x m_pad
+};
+
+static int upload_queries(egx_gp *gp, const double *xq, int64_t m0, int m, QueryChunk &qc, hipStream_t s) {
+    const int d = gp->d;
+    qc.m = m;
+    qc.m_pad = (int)round_up(m, kTile);
+    qc.xn.resize((size_t)m * d);
+    std::vector<double> xt((size_t)d * qc.m_pad, 0.0);
+    for (int a = 0; a < m; a++)
+        for (int j = 0; j < d; j++) {
+            const double v = (xq[(size_t)(m0 + a) * d + j] - gp->x_mean[j]) / gp->x_std[j];  // algorithm.rs:254
+            qc.xn[(size_t)a * d + j] = v;
+            xt[(size_t)j * qc.m_pad + a] = v;
+        }
+    EGX_HIP_CHECK(hipMalloc(&qc.d_xqT, sizeof(double) * xt.size()));
+    EGX_HIP_CHECK(hipMemcpyAsync(qc.d_xqT, xt.data(), sizeof(double) * xt.size(), hipMemcpyHostToDevice, s));
+    EGX_HIP_CHECK(hipStreamSynchronize(s));  // xt is a stack-owned pageable buffer
+    return EGX_SUCCESS;
+}
+
+static int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *vout) {
+    if (!gp->fitted) {
+        set_error("model is not fitted (call egx_gp_finalize or egx_gp_fit first)");
+        return EGX_ERR_NOT_FITTED;
+    }
+    if (m < 0 || (m > 0 && !xq)) {
+        set_error("bad query array");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    EGX_RC(set_device(gp));
+    Workspace &w = gp->ws[0];
+    const int n = gp->n, n_pad = gp->n_pad, d = gp->d, p = gp->p;
+    // chunk so that the (m_tile x n_pad) block of predict_var stays <= 1 GiB
+    int64_t cap = ((int64_t)1 << 27) / n_pad / kTile * kTile;
+    if (cap < kTile) cap = kTile;
+    if (cap > 16384) cap = 16384;
+    if (!vout) cap = 65536;
+    std::vector<double> f(p), rhs(p), u(p);
+    for (int64_t m0 = 0; m0 < m; m0 += cap) {
+        const int mc = (int)((m - m0 < cap) ? (m - m0) : cap);
+        QueryChunk qc;
+        int rc = upload_queries(gp, xq, m0, mc, qc, w.stream);
+        if (rc) return rc;
+        double *d_racc = nullptr, *d_RT = nullptr, *d_s0 = nullptr, *d_sl = nullptr;
+        std::vector<double> racc, s0, sl;
+        auto cleanup = [&]() {
+            if (qc.d_xqT) hipFree(qc.d_xqT);
+            if (d_racc) hipFree(d_racc);
+            if (d_RT) hipFree(d_RT);
+            if (d_s0) hipFree(d_s0);
+            if (d_sl) hipFree(d_sl);
+        };
+#define EGX_RCC(call)           \
+    do {                        \
+        int _rc = (call);       \
+        if (_rc) {              \
+            cleanup();          \
+            return _rc;         \
+        }                       \
+    } while (0)
+#define EGX_HIPC(expr)                                                            \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));         \
+            cleanup();                                                            \
+            return EGX_ERR_HIP;                                                   \
+        }                                                                         \
+    } while (0)
+        if (yout) {
+            racc.resize(qc.m_pad);
+            EGX_HIPC(hipMalloc(&d_racc, sizeof(double) * qc.m_pad));
+            EGX_RCC(launch_predict_mean(w.stream, gp->corr, qc.d_xqT, qc.m_pad, qc.m_pad, gp->d_xT, n_pad, n_pad, d,
+                                        gp->d_fit_coef, gp->fit_hcols, gp->d_gamma, d_racc));
+            EGX_HIPC(hipMemcpyAsync(racc.data(), d_racc, sizeof(double) * qc.m_pad, hipMemcpyDeviceToHost, w.stream));
+        }
+        if (vout) {
+            s0.resize(qc.m_pad);
+            sl.resize((size_t)qc.m_pad * p);
+            EGX_HIPC(hipMalloc(&d_RT, sizeof(double) * (size_t)qc.m_pad * n_pad));
+            EGX_HIPC(hipMalloc(&d_s0, sizeof(double) * qc.m_pad));
+            EGX_HIPC(hipMalloc(&d_sl, sizeof(double) * (size_t)qc.m_pad * p));
+            // corr (m x n): algorithm.rs:372-380 ; rt = C^-1 corr^T: :337-350 (held transposed, row per query)
+            EGX_RCC(launch_cross_corr(w.stream, gp->corr, qc.d_xqT, qc.m_pad, qc.m_pad, gp->d_xT, n_pad, n_pad, d,
+                                      gp->d_fit_coef, gp->fit_hcols, d_RT, n_pad));
+            EGX_RCC(launch_trsm_rows(w.stream, w.M, gp->ld, n_pad, w.dinv, d_RT, n_pad, qc.m_pad));
+            // sum rt^2 and ft^T rt (:352): ft^T rows live below the factor in the workspace
+            EGX_RCC(launch_row_reduce(w.stream, d_RT, n_pad, qc.m_pad, n, w.M + (size_t)n_pad * gp->ld, gp->ld, p, d_s0,
+                                      d_sl));
+            EGX_HIPC(hipMemcpyAsync(s0.data(), d_s0, sizeof(double) * qc.m_pad, hipMemcpyDeviceToHost, w.stream));
+            EGX_HIPC(hipMemcpyAsync(sl.data(), d_sl, sizeof(double) * (size_t)qc.m_pad * p, hipMemcpyDeviceToHost,
+                                    w.stream));
+        }
+        EGX_HIPC(hipStreamSynchronize(w.stream));
+        for (int a = 0; a < mc; a++) {
+            hm::regression_row(gp->mean, &qc.xn[(size_t)a * d], d, f.data());
+            if (yout) {
+                double fb = 0.0;
+                for (int l = 0; l < p; l++) fb += f[l] * gp->beta[l];
+                yout[m0 + a] = (fb + racc[a]) * gp->y_std + gp->y_mean;  // algorithm.rs:260-262
+            }
+            if (vout) {
+                // u = (Rq^T)^-1 (ft^T rt - f^T)   algorithm.rs:352-367 ; Rq^T lower triangular
+                for (int l = 0; l < p; l++) rhs[l] = sl[(size_t)a * p + l] - f[l];
+                double usq = 0.0;
+                for (int i = 0; i < p; i++) {
+                    double sacc = rhs[i];
+                    for (int l = 0; l < i; l++) sacc -= gp->ft_qr_r[(size_t)l * p + i] * u[l];
+                    u[i] = sacc / gp->ft_qr_r[(size_t)i * p + i];
+                    usq += u[i] * u[i];
+                }
+                double mse = gp->sigma2 * (1.0 - s0[a] + usq);  // algorithm.rs:272-274
+                vout[m0 + a] = (mse < 0.0) ? 0.0 : mse;         // :278
+            }
+        }
+        cleanup();
+    }
+    return EGX_SUCCESS;
+}
+
+// ---- derivative-free maximiser (stand-in for cobyla 0.8.0, optimization.rs:122-169) -------------
+// Nelder-Mead on x = log10(theta) inside the box, initial simplex edge rhobeg = 0.5, relative
+// tolerance 1e-4 on f, maxeval evaluations.  The reference's optimised theta* is "parity unpinned"
+// (it depends on the un-vendored COBYLA trajectory), so only the contract is mirrored: minimise
+// -likelihood over log10 theta within bounds, errors count as +inf, return the best point.
+struct NmResult {
+    double f;
+    std::vector<double> x;
+    int64_t evals;
+};
+
+template <typename F>
+static NmResult nelder_mead(F &&fn, const std::vector<double> &x0, const std::vector<double> &lo,
+                            const std::vector<double> &hi, int64_t maxeval) {
+    const int h = (int)x0.size();
+    auto clip = [&](std::vector<double> &x) {
+        for (int i = 0; i < h; i++) x[i] = std::fmin(hi[i], std::fmax(lo[i], x[i]));
+    };
+    std::vector<std::vector<double>> sx(h + 1, x0);
+    std::vector<double> sf(h + 1);
+    int64_t evals = 0;
+    clip(sx[0]);
+    for (int i = 0; i < h; i++) {
+        sx[i + 1] = sx[0];
+        double step = 0.5;
+        if (sx[i + 1][i] + step > hi[i]) step = -step;
+        sx[i + 1][i] += step;
+        clip(sx[i + 1]);
+    }
+    for (int i = 0; i <= h && evals < maxeval; i++) {
+        sf[i] = fn(sx[i]);
+        evals++;
+    }
+    for (int i = (int)evals; i <= h; i++) sf[i] = std::numeric_limits<double>::infinity();
+    std::vector<int> ord(h + 1);
+    while (evals < maxeval) {
+        for (int i = 0; i <= h; i++) ord[i] = i;
+        for (int i = 0; i <= h; i++)
+            for (int j = i + 1; j <= h; j++)
+                if (sf[ord[j]] < sf[ord[i]]) std::swap(ord[i], ord[j]);
+        const int b = ord[0], wv = ord[h], sw = ord[h > 0 ? h - 1 : 0];
+        if (std::isfinite(sf[b]) && std::isfinite(sf[wv]) &&
+            std::fabs(sf[wv] - sf[b]) <= 1e-4 * std::fabs(sf[b]) + 1e-300)
+            break;
+        std::vector<double> c(h, 0.0);
+        for (int i = 0; i <= h; i++)
+            if (i != wv)
+                for (int k = 0; k < h; k++) c[k] += sx[i][k] / h;
+        auto along = [&](double t) {
+            std::vector<double> x(h);
+            for (int k = 0; k < h; k++) x[k] = c[k] + t * (sx[wv][k] - c[k]);
+            clip(x);
+            return x;
+        };
+        std::vector<double> xr = along(-1.0);
+        const double fr = fn(xr);
+        evals++;
+        if (fr < sf[b]) {
+            if (evals < maxeval) {
+                std::vector<double> xe = along(-2.0);
+                const double fe = fn(xe);
+                evals++;
+                if (fe < fr) { sx[wv] = xe; sf[wv] = fe; } else { sx[wv] = xr; sf[wv] = fr; }
+            } else { sx[wv] = xr; sf[wv] = fr; }
+        } else if (fr < sf[sw]) {
+            sx[wv] = xr; sf[wv] = fr;
+        } else {
+            if (evals >= maxeval) break;
+            std::vector<double> xc = along(fr < sf[wv] ? -0.5 : 0.5);
+            const double fc = fn(xc);
+            evals++;
+            if (fc < std::fmin(fr, sf[wv])) { sx[wv] = xc; sf[wv] = fc; }
+            else {
+                for (int i = 0; i <= h && evals < maxeval; i++) {
+                    if (i == b) continue;
+                    for (int k = 0; k < h; k++) sx[i][k] = sx[b][k] + 0.5 * (sx[i][k] - sx[b][k]);
+                    sf[i] = fn(sx[i]);
+                    evals++;
+                }
+            }
+        }
+    }
+    int best = 0;
+    for (int i = 1; i <= h; i++)
+        if (sf[i] < sf[best]) best = i;
+    return NmResult{sf[best], sx[best], evals};
+}
+
+}  // namespace egx
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+int32_t egx_abi_version(void) { return EGX_GP_ABI_VERSION; }
+const char *egx_last_error(void) { return g_last_error.c_str(); }
+
+int32_t egx_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+void egx_gp_config_default(egx_gp_config *cfg) {
+    if (!cfg) return;
+    cfg->corr = EGX_CORR_SQUARED_EXPONENTIAL;  // Kriging = ConstantMean + SquaredExponentialCorr, algorithm.rs:200-207
+    cfg->mean = EGX_MEAN_CONSTANT;
+    cfg->nugget = 100.0 * std::numeric_limits<double>::epsilon();  // parameters.rs:118
+    cfg->device = -1;
+    cfg->n_workspaces = 1;
+    cfg->w_star = nullptr;
+    cfg->kpls_dim = 0;
+}
+
+int32_t egx_normalize(const double *x, int64_t n, int64_t d, double *xnorm, double *mean, double *std_) {
+    if (!x || !xnorm || !mean || !std_ || n < 2 || d < 1) {
+        set_error("egx_normalize: need n >= 2, d >= 1 and non-null arrays");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    hm::normalize(x, n, d, xnorm, mean, std_);
+    return EGX_SUCCESS;
+}
+
+int64_t egx_regression_ncols(int32_t mean, int64_t d) { return hm::regression_ncols(mean, d); }
+
+int32_t egx_regression_basis(int32_t mean, const double *x, int64_t n, int64_t d, double *f) {
+    const int64_t p = hm::regression_ncols(mean, d);
+    if (p < 0 || !x || !f || n < 0 || d < 1) {
+        set_error("egx_regression_basis: bad arguments");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    for (int64_t i = 0; i < n; i++) hm::regression_row(mean, x + i * d, d, f + i * p);
+    return EGX_SUCCESS;
+}
+
+int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double *y, int64_t n, int64_t d,
+                      egx_gp **out) {
+    if (!out) {
+        set_error("out handle pointer is NULL");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    *out = nullptr;
+    egx_gp_config cfg;
+    if (cfg_in) cfg = *cfg_in; else egx_gp_config_default(&cfg);
+    if (!x || !y) {
+        set_error("x / y is NULL");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (n < 2) {
+        set_error("need at least 2 training points (sample standard deviation, utils.rs:48), got " + std::to_string(n));
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (d < 1 || d > kMaxDim) {
+        set_error("input dimension must be in [1, 64], got " + std::to_string(d));
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (cfg.corr < 0 || cfg.corr > 3 || cfg.mean < 0 || cfg.mean > 2) {
+        set_error("unknown correlation / regression model");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (!std::isfinite(cfg.nugget)) {  // the reference does not constrain the nugget's sign
+        set_error("nugget must be finite");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (cfg.w_star) {
+        if (cfg.kpls_dim == 0) {  // parameters.rs:290-294
+            set_error("`kpls_dim` canot be 0!");
+            return EGX_ERR_INVALID_VALUE;
+        }
+        if (cfg.kpls_dim < 0 || cfg.kpls_dim > d) {  // algorithm.rs:798-807
+            set_error("Dimension reduction " + std::to_string(cfg.kpls_dim) +
+                      " should be smaller than actual training input dimensions " + std::to_string(d));
+            return EGX_ERR_INVALID_VALUE;
+        }
+    }
+    for (int64_t i = 0; i < n * d; i++)
+        if (!std::isfinite(x[i])) {
+            set_error("x contains non-finite values");
+            return EGX_ERR_INVALID_VALUE;
+        }
+    for (int64_t i = 0; i < n; i++)
+        if (!std::isfinite(y[i])) {
+            set_error("y contains non-finite values");
+            return EGX_ERR_INVALID_VALUE;
+        }
+    const int64_t p = hm::regression_ncols(cfg.mean, d);
+    if (p >= n) {
+        // the reference would produce a rank-deficient GLS; refuse explicitly
+        set_error("need more training points than regression basis columns");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device: libegx_gp_hip has no CPU fallback (needs an MI355X / gfx950 GPU)");
+        return EGX_ERR_NO_DEVICE;
+    }
+    int dev = cfg.device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    }
+    if (dev >= ndev) {
+        set_error("device ordinal out of range");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    egx_gp *gp = new egx_gp();
+    gp->device = dev;
+    gp->n = (int)n;
+    gp->d = (int)d;
+    gp->p = (int)p;
+    gp->corr = cfg.corr;
+    gp->mean = cfg.mean;
+    gp->nugget = cfg.nugget;
+    gp->has_w = cfg.w_star != nullptr;
+    gp->h = gp->has_w ? (int)cfg.kpls_dim : (int)d;
+    if (gp->has_w) gp->w_star.assign(cfg.w_star, cfg.w_star + d * cfg.kpls_dim);
+    gp->q = gp->p + 1;
+    gp->n_pad = (int)round_up(n, kTile);
+    gp->rhs_pad = (int)round_up(gp->q, kRhsPad);
+    gp->m_tot = gp->n_pad + gp->rhs_pad;
+    gp->ld = gp->n_pad;
+    gp->x_raw.assign(x, x + n * d);
+    gp->y_raw.assign(y, y + n);
+    gp->xnorm.resize(n * d);
+    gp->x_mean.resize(d);
+    gp->x_std.resize(d);
+    gp->ynorm.resize(n);
+    hm::normalize(x, n, d, gp->xnorm.data(), gp->x_mean.data(), gp->x_std.data());  // algorithm.rs:840
+    hm::normalize(y, n, 1, gp->ynorm.data(), &gp->y_mean, &gp->y_std);               // algorithm.rs:841
+    gp->F.resize(n * p);
+    for (int64_t i = 0; i < n; i++) hm::regression_row(gp->mean, &gp->xnorm[i * d], d, &gp->F[i * p]);  // :866
+
+    auto fail = [&](int rc) {
+        egx_gp_destroy(gp);
+        return rc;
+    };
+    if (hipSetDevice(dev) != hipSuccess) {
+        set_error("hipSetDevice failed");
+        return fail(EGX_ERR_HIP);
+    }
+    int rc = chol_init();
+    if (rc) return fail(rc);
+    // k-major, zero padded copies
+    std::vector<double> xT((size_t)d * gp->n_pad, 0.0), rhsT((size_t)gp->q * gp->n_pad, 0.0);
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < d; j++) xT[(size_t)j * gp->n_pad + i] = gp->xnorm[i * d + j];
+    for (int64_t l = 0; l < p; l++)
+        for (int64_t i = 0; i < n; i++) rhsT[(size_t)l * gp->n_pad + i] = gp->F[i * p + l];
+    for (int64_t i = 0; i < n; i++) rhsT[(size_t)p * gp->n_pad + i] = gp->ynorm[i];
+#define EGX_HIPF(expr)                                                            \
+    do {                                                                          \
+        hipError_t _e = (expr);                                                   \
+        if (_e != hipSuccess) {                                                   \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));         \
+            return fail(EGX_ERR_HIP);                                             \
+        }                                                                         \
+    } while (0)
+    EGX_HIPF(hipMalloc(&gp->d_xT, sizeof(double) * xT.size()));
+    EGX_HIPF(hipMalloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
+    EGX_HIPF(hipMalloc(&gp->d_gamma, sizeof(double) * gp->n_pad));
+    EGX_HIPF(hipMalloc(&gp->d_fit_coef, sizeof(double) * (size_t)d * (gp->has_w ? gp->h : 1)));
+    EGX_HIPF(hipMemcpy(gp->d_xT, xT.data(), sizeof(double) * xT.size(), hipMemcpyHostToDevice));
+    EGX_HIPF(hipMemcpy(gp->d_rhsT, rhsT.data(), sizeof(double) * rhsT.size(), hipMemcpyHostToDevice));
+    int nws = cfg.n_workspaces < 1 ? 1 : cfg.n_workspaces;
+    gp->ws.resize(nws);
+    for (int i = 0; i < nws; i++) {
+        rc = alloc_workspace(gp, gp->ws[i]);
+        if (rc) return fail(rc);
+    }
+    *out = gp;
+    return EGX_SUCCESS;
+}
+
+void egx_gp_destroy(egx_gp *gp) {
+    if (!gp) return;
+    hipSetDevice(gp->device);
+    for (auto &w : gp->ws) free_workspace(w);
+    if (gp->d_xT) hipFree(gp->d_xT);
+    if (gp->d_rhsT) hipFree(gp->d_rhsT);
+    if (gp->d_gamma) hipFree(gp->d_gamma);
+    if (gp->d_fit_coef) hipFree(gp->d_fit_coef);
+    if (gp->d_W) hipFree(gp->d_W);
+    if (gp->d_Rinv) hipFree(gp->d_Rinv);
+    if (gp->d_gout) hipFree(gp->d_gout);
+    if (gp->d_theta) hipFree(gp->d_theta);
+    delete gp;
+}
+
+int32_t egx_gp_dims(const egx_gp *gp, int64_t *n, int64_t *d, int64_t *p, int64_t *h) {
+    if (!gp) {
+        set_error("NULL handle");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (n) *n = gp->n;
+    if (d) *d = gp->d;
+    if (p) *p = gp->p;
+    if (h) *h = gp->h;
+    return EGX_SUCCESS;
+}
+
+int32_t egx_gp_likelihood(egx_gp *gp, const double *theta, int64_t theta_len, double *lkh, int32_t *status) {
+    if (!gp || !theta || !lkh || !status) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::lock_guard<std::mutex> lock(gp->mu);
+    EGX_RC(set_device(gp));
+    EvalResult res;
+    EGX_RC(eval_one(gp, 0, theta, theta_len, res, false));
+    *lkh = res.lkh;
+    *status = res.status;
+    return EGX_SUCCESS;
+}
+
+int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len, double *lkh,
+                                int32_t *status) {
+    if (!gp || (k > 0 && (!thetas || !lkh || !status)) || k < 0) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::lock_guard<std::mutex> lock(gp->mu);
+    EGX_RC(set_device(gp));
+    const int nws = (int)gp->ws.size();
+    // waves of nws candidates: every workspace has its own stream, so the serial panel
+    // factorisations of one candidate overlap the trailing updates of the others.
+    for (int64_t c0 = 0; c0 < k; c0 += nws) {
+        const int cnt = (int)((k - c0 < nws) ? (k - c0) : nws);
+        std::vector<int> launched(cnt, 0);
+        for (int i = 0; i < cnt; i++) {
+            const double *th = thetas + (c0 + i) * theta_len;
+            std::vector<double> coef;
+            int hcols = 1;
+            EGX_RC(make_coef(gp, th, theta_len, coef, hcols, nullptr));
+            if (has_nan(th, theta_len)) {
+                lkh[c0 + i] = -std::numeric_limits<double>::infinity();
+                status[c0 + i] = EGX_STATUS_NAN_THETA;
+                continue;
+            }
+            if (i == 0) gp->fitted = false;
+            EGX_RC(enqueue_eval(gp, gp->ws[i], coef, hcols));
+            launched[i] = 1;
+        }
+        for (int i = 0; i < cnt; i++) {
+            if (!launched[i]) continue;
+            EvalResult res;
+            EGX_RC(finish_eval(gp, gp->ws[i], res, false));
+            lkh[c0 + i] = res.lkh;
+            status[c0 + i] = res.status;
+            if (i == 0) record_timings(gp, gp->ws[0], 0.0, 0.0);
+        }
+    }
+    return EGX_SUCCESS;
+}
+
+int32_t egx_gp_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
+    if (!gp || !theta) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::lock_guard<std::mutex> lock(gp->mu);
+    EGX_RC(set_device(gp));
+    return do_finalize(gp, theta, theta_len);
+}
+
+int32_t egx_gp_fit(egx_gp *gp, const double *theta0s, int64_t n_starts, const double *lo, const double *hi,
+                   int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out) {
+    if (!gp || !theta0s || !lo || !hi || n_starts < 1) {
+        set_error("NULL argument / no start point");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    const int h = gp->h;
+    if (bounds_len != 1 && bounds_len != h) {  // algorithm.rs:901-912
+        set_error("Bounds for theta should be either 1-dim or dim of xtrain (" + std::to_string(h) + "), got " +
+                  std::to_string(bounds_len));
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::vector<double> blo(h), bhi(h);
+    for (int i = 0; i < h; i++) {
+        const double l = lo[bounds_len == 1 ? 0 : i], u = hi[bounds_len == 1 ? 0 : i];
+        if (!(l > 0.0) || !(u >= l)) {
+            set_error("theta bounds must satisfy 0 < lo <= hi");
+            return EGX_ERR_INVALID_VALUE;
+        }
+        blo[i] = std::log10(l);  // optimization.rs:32-35
+        bhi[i] = std::log10(u);
+    }
+    std::lock_guard<std::mutex> lock(gp->mu);
+    EGX_RC(set_device(gp));
+    // maxeval = clamp(10 h, GP_COBYLA_MIN_EVAL = 25, max_eval)  algorithm.rs:933-936
+    int64_t per_start = 10 * (int64_t)h;
+    if (per_start < 25) per_start = 25;
+    if (max_eval >= 25 && per_start > max_eval) per_start = max_eval;
+    double best_f = std::numeric_limits<double>::infinity();
+    std::vector<double> best_x(h, 0.0);
+    int64_t evals = 0;
+    int rc_inner = EGX_SUCCESS;
+    auto objective = [&](const std::vector<double> &x) -> double {
+        std::vector<double> th(h);
+        for (int i = 0; i < h; i++) th[i] = std::pow(10.0, x[i]);
+        EvalResult res;
+        int rc = eval_one(gp, 0, th.data(), h, res, false);
+        if (rc) {
+            rc_inner = rc;
+            return std::numeric_limits<double>::infinity();
+        }
+        if (res.status != EGX_STATUS_OK || std::isnan(res.lkh)) return std::numeric_limits<double>::infinity();
+        return -res.lkh;
+    };
+    for (int64_t s = 0; s < n_starts; s++) {
+        std::vector<double> x0(h);
+        for (int i = 0; i < h; i++) {
+            const double t = theta0s[s * h + i];
+            if (!(t > 0.0)) {
+                set_error("theta start points must be > 0");
+                return EGX_ERR_INVALID_VALUE;
+            }
+            x0[i] = std::log10(t);
+        }
+        NmResult r = nelder_mead(objective, x0, blo, bhi, per_start);
+        evals += r.evals;
+        if (rc_inner) return rc_inner;
+        if (r.f < best_f) {  // algorithm.rs:942-945 reduce to min
+            best_f = r.f;
+            best_x = r.x;
+        }
+    }
+    if (n_evals_out) *n_evals_out = evals;
+    std::vector<double> th(h);
+    if (std::isfinite(best_f))
+        for (int i = 0; i < h; i++) th[i] = std::pow(10.0, best_x[i]);
+    else  // every start failed: the reference falls through with ones (algorithm.rs:943) -> 10^1... keep start 0
+        for (int i = 0; i < h; i++) th[i] = theta0s[i];
+    return do_finalize(gp, th.data(), h);
+}
+
+int32_t egx_gp_predict(egx_gp *gp, const double *xq, int64_t m, double *y) {
+    if (!gp || (m > 0 && !y)) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::lock_guard<std::mutex> lock(gp->mu);
+    return predict_impl(gp, xq, m, y, nullptr);
+}
+int32_t egx_gp_predict_var(egx_gp *gp, const double *xq, int64_t m, double *var) {
+    if (!gp || (m > 0 && !var)) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::lock_guard<std::mutex> lock(gp->mu);
+    return predict_impl(gp, xq, m, nullptr, var);
+}
+int32_t egx_gp_predict_valvar(egx_gp *gp, const double *xq, int64_t m, double *y, double *var) {
+    if (!gp || (m > 0 && (!y || !var))) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::lock_guard<std::mutex> lock(gp->mu);
+    return predict_impl(gp, xq, m, y, var);
+}
+
+int32_t egx_gp_get_inner(egx_gp *gp, const egx_gp_inner_view *v) {
+    if (!gp || !v) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::lock_guard<std::mutex> lock(gp->mu);
+    if (!gp->fitted) {
+        set_error("model is not fitted");
+        return EGX_ERR_NOT_FITTED;
+    }
+    EGX_RC(set_device(gp));
+    const int n = gp->n, p = gp->p, d = gp->d;
+    if (v->theta) std::memcpy(v->theta, gp->theta.data(), sizeof(double) * gp->h);
+    if (v->likelihood) *v->likelihood = gp->likelihood;
+    if (v->sigma2) *v->sigma2 = gp->sigma2;
+    if (v->beta) std::memcpy(v->beta, gp->beta.data(), sizeof(double) * p);
+    if (v->gamma) std::memcpy(v->gamma, gp->gamma.data(), sizeof(double) * n);
+    if (v->ft) std::memcpy(v->ft, gp->ft.data(), sizeof(double) * (size_t)n * p);
+    if (v->ft_qr_r) std::memcpy(v->ft_qr_r, gp->ft_qr_r.data(), sizeof(double) * (size_t)p * p);
+    if (v->x_mean) std::memcpy(v->x_mean, gp->x_mean.data(), sizeof(double) * d);
+    if (v->x_std) std::memcpy(v->x_std, gp->x_std.data(), sizeof(double) * d);
+    if (v->y_mean) *v->y_mean = gp->y_mean;
+    if (v->y_std) *v->y_std = gp->y_std;
+    if (v->xt_norm) std::memcpy(v->xt_norm, gp->xnorm.data(), sizeof(double) * (size_t)n * d);
+    if (v->yt_norm) std::memcpy(v->yt_norm, gp->ynorm.data(), sizeof(double) * n);
+    if (v->r_chol) {
+        Workspace &w = gp->ws[0];
+        EGX_HIP_CHECK(hipMemcpy2DAsync(v->r_chol, sizeof(double) * n, w.M, sizeof(double) * gp->ld, sizeof(double) * n,
+                                       n, hipMemcpyDeviceToHost, w.stream));
+        EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+        for (int i = 0; i < n; i++)
+            for (int j = i + 1; j < n; j++) v->r_chol[(size_t)i * n + j] = 0.0;
+    }
+    return EGX_SUCCESS;
+}
+
+int32_t egx_gp_likelihood_grad(egx_gp *gp, const double *theta, int64_t theta_len, double *lkh, double *grad,
+                               int32_t *status) {
+    if (!gp || !theta || !lkh || !grad || !status) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (gp->has_w) {
+        set_error("likelihood gradient with KPLS weights is not implemented");
+        return EGX_ERR_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> lock(gp->mu);
+    EGX_RC(set_device(gp));
+    const int n = gp->n, n_pad = gp->n_pad, d = gp->d;
+    std::vector<double> coef, thfull;
+    int hcols = 1;
+    EGX_RC(make_coef(gp, theta, theta_len, coef, hcols, &thfull));
+    if (has_nan(theta, theta_len)) {
+        *lkh = -std::numeric_limits<double>::infinity();
+        *status = EGX_STATUS_NAN_THETA;
+        for (int k = 0; k < d; k++) grad[k] = 0.0;
+        return EGX_SUCCESS;
+    }
+    gp->fitted = false;
+    Workspace &w = gp->ws[0];
+    EvalResult res;
+    EGX_RC(enqueue_eval(gp, w, coef, hcols));
+    EGX_RC(finish_eval(gp, w, res, true));
+    *lkh = res.lkh;
+    *status = res.status;
+    if (res.status != EGX_STATUS_OK) {
+        for (int k = 0; k < d; k++) grad[k] = 0.0;
+        return EGX_SUCCESS;
+    }
+    const size_t sq = (size_t)n_pad * n_pad;
+    if (!gp->d_W) EGX_HIP_CHECK(hipMalloc(&gp->d_W, sizeof(double) * sq));
+    if (!gp->d_Rinv) EGX_HIP_CHECK(hipMalloc(&gp->d_Rinv, sizeof(double) * sq));
+    if (!gp->d_gout) EGX_HIP_CHECK(hipMalloc(&gp->d_gout, sizeof(double) * 2 * kMaxDim));
+    if (!gp->d_theta) EGX_HIP_CHECK(hipMalloc(&gp->d_theta, sizeof(double) * kMaxDim));
+    // gamma = C^-T rho
+    std::memset(w.h_vec, 0, sizeof(double) * n_pad);
+    std::memcpy(w.h_vec, res.rho.data(), sizeof(double) * n);
+    EGX_HIP_CHECK(hipMemcpyAsync(w.d_vec, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
+    EGX_RC(launch_trsv_t(w.stream, w.M, gp->ld, n_pad, w.dinv, w.d_vec));
+    // W = I * C^-T  (rows of the identity as right-hand sides), then -R^-1 = 0 - W W^T (lower tiles)
+    EGX_HIP_CHECK(hipMemsetAsync(gp->d_W, 0, sizeof(double) * sq, w.stream));
+    {
+        std::vector<double> ones(n_pad, 1.0);
+        EGX_HIP_CHECK(hipMemcpy2DAsync(gp->d_W, sizeof(double) * (n_pad + 1), ones.data(), sizeof(double),
+                                       sizeof(double), n_pad, hipMemcpyHostToDevice, w.stream));
+        EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+    }
+    EGX_RC(launch_trsm_rows(w.stream, w.M, gp->ld, n_pad, w.dinv, gp->d_W, n_pad, n_pad));
+    EGX_HIP_CHECK(hipMemsetAsync(gp->d_Rinv, 0, sizeof(double) * sq, w.stream));
+    EGX_RC(launch_gemm_nt_sub(w.stream, gp->d_Rinv, n_pad, gp->d_W, n_pad, gp->d_W, n_pad, n_pad, n_pad, n_pad, 1));
+    EGX_HIP_CHECK(hipMemcpyAsync(gp->d_theta, thfull.data(), sizeof(double) * d, hipMemcpyHostToDevice, w.stream));
+    EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+    EGX_RC(launch_grad_accum(w.stream, gp->corr, gp->d_xT, n_pad, n, d, gp->d_theta, gp->d_Rinv, n_pad, w.d_vec,
+                             gp->d_gout));
+    std::vector<double> gout(2 * d);
+    EGX_HIP_CHECK(hipMemcpyAsync(gout.data(), gp->d_gout, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, w.stream));
+    EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+    // dL/dtheta_k = (1/ln10) [ gamma^T dR_k gamma / sigma2 - tr(R^-1 dR_k) ] ; d_Rinv holds -R^-1
+    const double ln10 = std::log(10.0);
+    for (int k = 0; k < d; k++) grad[k] = (gout[d + k] / res.sigma2n + gout[k]) / ln10;
+    return EGX_SUCCESS;
+}
+
+// ---- kernel-level entry points ------------------------------------------------------------------
+static int upload_kmajor(const double *x, int64_t n, int64_t d, int n_pad, double **dptr) {
+    std::vector<double> xT((size_t)d * n_pad, 0.0);
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < d; j++) xT[(size_t)j * n_pad + i] = x[i * d + j];
+    EGX_HIP_CHECK(hipMalloc(dptr, sizeof(double) * xT.size()));
+    EGX_HIP_CHECK(hipMemcpy(*dptr, xT.data(), sizeof(double) * xT.size(), hipMemcpyHostToDevice));
+    return EGX_SUCCESS;
+}
+
+int32_t egx_corr_matrix(int32_t corr, const double *xnorm, int64_t n, int64_t d, const double *theta, double nugget,
+                        double *r) {
+    if (!xnorm || !theta || !r || n < 1 || d < 1 || d > kMaxDim || corr < 0 || corr > 3) {
+        set_error("egx_corr_matrix: bad arguments");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (egx_device_count() <= 0) {
+        set_error("no HIP device");
+        return EGX_ERR_NO_DEVICE;
+    }
+    const int n_pad = (int)round_up(n, kTile);
+    double *d_xT = nullptr, *d_coef = nullptr, *d_M = nullptr;
+    int rc = upload_kmajor(xnorm, n, d, n_pad, &d_xT);
+    if (rc) return rc;
+    hipMalloc(&d_coef, sizeof(double) * d);
+    hipMemcpy(d_coef, theta, sizeof(double) * d, hipMemcpyHostToDevice);
+    if (hipMalloc(&d_M, sizeof(double) * (size_t)n_pad * n_pad) != hipSuccess) {
+        hipFree(d_xT);
+        hipFree(d_coef);
+        set_error("hipMalloc failed");
+        return EGX_ERR_HIP;
+    }
+    rc = launch_corr_sym(0, corr, d_xT, n_pad, (int)n, (int)d, d_coef, 1, nugget, d_M, n_pad, n_pad);
+    if (!rc && hipMemcpy2D(r, sizeof(double) * n, d_M, sizeof(double) * n_pad, sizeof(double) * n, n,
+                           hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("hipMemcpy2D failed");
+        rc = EGX_ERR_HIP;
+    }
+    hipFree(d_xT);
+    hipFree(d_coef);
+    hipFree(d_M);
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; i++)  // mirror the lower triangle (the scatter loop writes both, algorithm.rs:999-1000)
+        for (int64_t j = i + 1; j < n; j++) r[i * n + j] = r[j * n + i];
+    return EGX_SUCCESS;
+}
+
+int32_t egx_cross_corr(int32_t corr, const double *xq_norm, int64_t m, const double *xt_norm, int64_t n, int64_t d,
+                       const double *theta, double *r) {
+    if (!xq_norm || !xt_norm || !theta || !r || n < 1 || m < 1 || d < 1 || d > kMaxDim || corr < 0 || corr > 3) {
+        set_error("egx_cross_corr: bad arguments");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (egx_device_count() <= 0) {
+        set_error("no HIP device");
+        return EGX_ERR_NO_DEVICE;
+    }
+    const int n_pad = (int)round_up(n, kTile), m_pad = (int)round_up(m, kTile);
+    double *d_xT = nullptr, *d_qT = nullptr, *d_coef = nullptr, *d_R = nullptr;
+    int rc = upload_kmajor(xt_norm, n, d, n_pad, &d_xT);
+    if (!rc) rc = upload_kmajor(xq_norm, m, d, m_pad, &d_qT);
+    if (!rc) {
+        hipMalloc(&d_coef, sizeof(double) * d);
+        hipMemcpy(d_coef, theta, sizeof(double) * d, hipMemcpyHostToDevice);
+        if (hipMalloc(&d_R, sizeof(double) * (size_t)m_pad * n_pad) != hipSuccess) {
+            set_error("hipMalloc failed");
+            rc = EGX_ERR_HIP;
+        }
+    }
+    if (!rc) rc = launch_cross_corr(0, corr, d_qT, m_pad, m_pad, d_xT, n_pad, n_pad, (int)d, d_coef, 1, d_R, n_pad);
+    if (!rc && hipMemcpy2D(r, sizeof(double) * n, d_R, sizeof(double) * n_pad, sizeof(double) * n, m,
+                           hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("hipMemcpy2D failed");
+        rc = EGX_ERR_HIP;
+    }
+    if (d_xT) hipFree(d_xT);
+    if (d_qT) hipFree(d_qT);
+    if (d_coef) hipFree(d_coef);
+    if (d_R) hipFree(d_R);
+    return rc;
+}
+
+int32_t egx_potrf(double *a, int64_t n, int32_t *info) {
+    if (!a || !info || n < 1) {
+        set_error("egx_potrf: bad arguments");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (egx_device_count() <= 0) {
+        set_error("no HIP device");
+        return EGX_ERR_NO_DEVICE;
+    }
+    const int n_pad = (int)round_up(n, kTile);
+    std::vector<double> hp((size_t)n_pad * n_pad, 0.0);
+    for (int64_t i = 0; i < n; i++) std::memcpy(&hp[(size_t)i * n_pad], a + i * n, sizeof(double) * n);
+    for (int64_t i = n; i < n_pad; i++) hp[(size_t)i * n_pad + i] = 1.0;
+    double *d_M = nullptr, *d_dinv = nullptr;
+    int *d_info = nullptr;
+    EGX_HIP_CHECK(hipMalloc(&d_M, sizeof(double) * hp.size()));
+    hipMalloc(&d_dinv, sizeof(double) * (size_t)(n_pad / 64) * 4096);
+    hipMalloc(&d_info, sizeof(int));
+    hipMemset(d_info, 0, sizeof(int));
+    hipMemcpy(d_M, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice);
+    int rc = launch_potrf(0, d_M, n_pad, n_pad, n_pad, d_dinv, d_info);
+    if (!rc) {
+        if (hipMemcpy(hp.data(), d_M, sizeof(double) * hp.size(), hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(info, d_info, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
+            set_error("hipMemcpy failed");
+            rc = EGX_ERR_HIP;
+        }
+    }
+    hipFree(d_M);
+    hipFree(d_dinv);
+    hipFree(d_info);
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < n; j++) a[i * n + j] = (j <= i) ? hp[(size_t)i * n_pad + j] : 0.0;
+    return EGX_SUCCESS;
+}
+
+int32_t egx_gp_last_timings(const egx_gp *gp, egx_timings *t) {
+    if (!gp || !t) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    *t = gp->timings;
+    return EGX_SUCCESS;
+}
+
+int32_t egx_mfma_probe(double *max_abs_err) {
+    if (!max_abs_err) return EGX_ERR_INVALID_VALUE;
+    if (egx_device_count() <= 0) {
+        set_error("no HIP device");
+        return EGX_ERR_NO_DEVICE;
+    }
+    return mfma_probe(max_abs_err);
+}
+
+}  // extern "C"

@@ -1,0 +1,530 @@
+// Blocked right-looking FP64 Cholesky + triangular solves for gfx950 (MI355X).
+//
+// Replaces, on the device, what the reference gets from linfa-linalg 0.2.1
+// `cholesky()` / `solve_triangular()` (crates/gp/src/algorithm.rs:1004-1034, :337-367) or LAPACK
+// dpotrf/dtrtrs with the `blas` feature (:1077-1115).
+//
+// Structure per 256-column block k (flat right-looking, lower, row-major, in place):
+//   A  k_potf2_block : ONE workgroup factors the 256x256 diagonal block.  64x64 tiles are factored
+//                      by a single wave with one matrix row per lane held in registers (no
+//                      barriers: pivots and multipliers travel by v_readlane); tiles below are solved
+//                      by true forward substitution (row per lane, L broadcast from LDS).  Also emits
+//                      the inverse of every 64x64 diagonal tile (used by B and by the solves).
+//   B  k_panel_trsm  : rows below the block:  X = P * L_kk^-T, block substitution over 64-column
+//                      tiles: off-diagonal part as FP64-MFMA GEMM, diagonal tile via its inverse.
+//   C  k_gemm_nt_sub : trailing update  C -= P P^T  (lower tiles only) -- the n^3/3 flops --
+//                      128x128 workgroup tiles, 4 waves of 64x64, v_mfma_f64_16x16x4_f64,
+//                      A/B staged through LDS in 16-deep K chunks (double buffered, register
+//                      prefetch), padded LDS rows (18 doubles) so ds_read_b64 is conflict free.
+// Right-hand-side rows appended below the square matrix ride along in B and C, so after the
+// factorisation they hold (C^-1 [F | y])^T: the forward solves of algorithm.rs:1006,1028 are fused
+// into the factorisation (classic augmented-matrix trick) and cost no extra pass over C.
+//
+// FP64 MFMA on gfx950 runs at the FP64 vector rate (78.6 TFLOP/s chip peak, 64 cycles per
+// 16x16x4 instruction per SIMD): the matrix core is used because one instruction carries 2048
+// flops with two 8-byte operands per lane, which keeps LDS and issue pressure negligible.
+#include "egx_internal.h"
+
+#include <vector>
+
+namespace egx {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    union {
+        double d;
+        int i[2];
+    } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+
+// =============================================================================================
+// MFMA GEMM core:  acc += A_tile (BM x K) * B_tile (BN x K)^T, both operands K-contiguous.
+// 256 threads = 4 waves laid out (BM/WM) x (BN/WN); each wave owns a WM x WN sub-tile made of
+// 16x16 MFMA tiles.  v_mfma_f64_16x16x4_f64 operand layout (lane l):
+//   A: A[i = l & 15][k = l >> 4]      B: B[k = l >> 4][j = l & 15]
+//   C/D reg r: row = (l >> 4) + 4 r, col = l & 15
+// =============================================================================================
+constexpr int KC = 16;      // K chunk staged per iteration
+constexpr int LDS_LD = 18;  // doubles per staged tile row (16 + 2 pad): conflict-free ds_read_b64
+
+template <int ROWS>
+__device__ __forceinline__ void tile_load_regs(const double *__restrict__ g, int64_t ld, int k0,
+                                               d2_t (&r)[ROWS / 32], int tid) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; i++) {
+        int p = tid + 256 * i;
+        int row = p >> 3, part = p & 7;
+        r[i] = *reinterpret_cast<const d2_t *>(g + (int64_t)row * ld + k0 + part * 2);
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void tile_store_lds(double *s, const d2_t (&r)[ROWS / 32], int tid) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 32; i++) {
+        int p = tid + 256 * i;
+        int row = p >> 3, part = p & 7;
+        *reinterpret_cast<d2_t *>(s + row * LDS_LD + part * 2) = r[i];
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+struct GemmShape {
+    static constexpr int MT = WM / 16, NT = WN / 16;
+    static constexpr int WAVES_N = BN / WN;
+    static constexpr int A_TILE = BM * LDS_LD, B_TILE = BN * LDS_LD;
+    static constexpr int STAGE = A_TILE + B_TILE;
+    static constexpr int LDS_BYTES = 2 * STAGE * 8;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+    static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows per load pass");
+};
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t lda,
+                                          const double *__restrict__ B, int64_t ldb, int K,
+                                          double4_t (&acc)[WM / 16][WN / 16], double *smem, int tid) {
+    using S = GemmShape<BM, BN, WM, WN>;
+    const int nchunks = K / KC;
+    if (nchunks <= 0) return;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm0 = (wave / S::WAVES_N) * WM, wn0 = (wave % S::WAVES_N) * WN;
+    const int frow = lane & 15, fk = lane >> 4;
+
+    d2_t ra[BM / 32], rb[BN / 32];
+    tile_load_regs<BM>(A, lda, 0, ra, tid);
+    tile_load_regs<BN>(B, ldb, 0, rb, tid);
+    tile_store_lds<BM>(smem, ra, tid);
+    tile_store_lds<BN>(smem + S::A_TILE, rb, tid);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        double *As = smem + (c & 1) * S::STAGE;
+        double *Bs = As + S::A_TILE;
+        const bool more = (c + 1 < nchunks);
+        if (more) {
+            tile_load_regs<BM>(A, lda, (c + 1) * KC, ra, tid);
+            tile_load_regs<BN>(B, ldb, (c + 1) * KC, rb, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KC / 4; kk++) {
+            double a[S::MT], b[S::NT];
+#pragma unroll
+            for (int mi = 0; mi < S::MT; mi++)
+                a[mi] = As[(wm0 + mi * 16 + frow) * LDS_LD + kk * 4 + fk];
+#pragma unroll
+            for (int ni = 0; ni < S::NT; ni++)
+                b[ni] = Bs[(wn0 + ni * 16 + frow) * LDS_LD + kk * 4 + fk];
+#pragma unroll
+            for (int mi = 0; mi < S::MT; mi++)
+#pragma unroll
+                for (int ni = 0; ni < S::NT; ni++)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (more) {
+            double *An = smem + ((c + 1) & 1) * S::STAGE;
+            tile_store_lds<BM>(An, ra, tid);
+            tile_store_lds<BN>(An + S::A_TILE, rb, tid);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C: trailing update / general  C -= A B^T.  grid = (M/128, N/128).
+// ---------------------------------------------------------------------------------------------
+using TrailShape = GemmShape<128, 128, 64, 64>;
+
+template <bool LOWER>
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_sub(double *__restrict__ C, int64_t ldc,
+                                                        const double *__restrict__ A, int64_t lda,
+                                                        const double *__restrict__ B, int64_t ldb, int K) {
+    const int bx = blockIdx.x, by = blockIdx.y;
+    if (LOWER && bx < by) return;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x;
+    double4_t acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm_core<128, 128, 64, 64>(A + (int64_t)bx * 128 * lda, lda, B + (int64_t)by * 128 * ldb, ldb, K,
+                                acc, smem, tid);
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r0 = bx * 128 + (wave >> 1) * 64 + (lane >> 4);
+    const int c0 = by * 128 + (wave & 1) * 64 + (lane & 15);
+#pragma unroll
+    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double *p = C + (int64_t)(r0 + mi * 16 + 4 * r) * ldc + (c0 + ni * 16);
+                *p -= acc[mi][ni][r];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------
+// B: panel triangular solve  X = P * L^-T  for the 64-row slab of one workgroup.
+//    P: rows of the panel (ldp), columns [0, nbk) ; L: diagonal block (ldl) ; dinv: inverses of the
+//    64x64 diagonal tiles of L (row-major 64x64 each).  Block forward substitution over 64-col tiles.
+// ---------------------------------------------------------------------------------------------
+using PanelShape = GemmShape<64, 64, 16, 64>;
+
+__global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, int64_t ldp,
+                                                       const double *__restrict__ L, int64_t ldl,
+                                                       const double *__restrict__ dinv, int nbk) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double *Pw = P + (int64_t)blockIdx.x * 64 * ldp;  // this workgroup's 64 rows
+    const int row = wave * 16 + (lane >> 4);          // + 4 r
+    const int colf = lane & 15;                       // + 16 ni
+    const int nt = nbk / 64;
+    for (int c = 0; c < nt; c++) {
+        double4_t acc[1][4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+        // sum_{t<c} X_t L[c,t]^T  (K = 64 c): X_t were written to global by this workgroup
+        gemm_core<64, 64, 16, 64>(Pw, ldp, L + (int64_t)c * 64 * ldl, ldl, 64 * c, acc, smem, tid);
+        // rhs = P_c - acc, in place
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double *p = Pw + (int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf;
+                *p -= acc[0][ni][r];
+            }
+        __syncthreads();  // workgroup-scope visibility of rhs before it is re-read as an operand
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+        // X_c = rhs * Linv_cc^T   (K = 64)
+        gemm_core<64, 64, 16, 64>(Pw + c * 64, ldp, dinv + (int64_t)c * 4096, 64, 64, acc, smem, tid);
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                Pw[(int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf] = acc[0][ni][r];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A: diagonal block factorisation (nbk x nbk, nbk in {64,128,192,256}) by ONE workgroup.
+// ---------------------------------------------------------------------------------------------
+constexpr int TS = 64;
+constexpr int TLD = 65;  // padded LDS row (doubles)
+constexpr int POTF2_LDS_BYTES = 4 * TS * TLD * 8;
+
+__global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, int64_t ld, int nbk,
+                                                        double *__restrict__ dinv, int *__restrict__ info,
+                                                        int col0, int n_valid) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *Ls = sm;             // factor of the current diagonal tile, [64][65]
+    double *Xs = sm + TS * TLD;  // up to three solved tiles below it, [3][64][65]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int nt = nbk / TS;
+    for (int s = 0; s < nt; s++) {
+        // ---- step 1: wave 0 factors tile (s,s) in registers: lane i holds row i
+        if (wave == 0) {
+            double a[TS];
+            const double *src = D + (int64_t)(s * TS + lane) * ld + s * TS;
+#pragma unroll
+            for (int c = 0; c < TS; c++) a[c] = src[c];
+#pragma unroll
+            for (int j = 0; j < TS; j++) {
+                double piv = readlane_d(a[j], j);
+                if (!(piv > 0.0)) {  // wave-uniform: NaN or non-positive pivot
+                    if (lane == 0 && (col0 + s * TS + j) < n_valid) atomicCAS(info, 0, col0 + s * TS + j + 1);
+                    piv = 1.0;
+                }
+                const double dj = sqrt(piv);
+                const double rinv = 1.0 / dj;
+                const double lij = (lane == j) ? dj : a[j] * rinv;
+                a[j] = lij;
+#pragma unroll
+                for (int c = j + 1; c < TS; c++) {
+                    const double lcj = readlane_d(lij, c);
+                    a[c] = __builtin_fma(-lij, lcj, a[c]);
+                }
+            }
+            double *dst = D + (int64_t)(s * TS + lane) * ld + s * TS;
+#pragma unroll
+            for (int c = 0; c < TS; c++) {
+                const double v = (c <= lane) ? a[c] : 0.0;
+                dst[c] = v;
+                Ls[lane * TLD + c] = v;
+            }
+        }
+        __syncthreads();
+        // ---- step 2: waves 0..2 solve the tiles below (true forward substitution, row per lane);
+        //              wave 3 inverts the diagonal tile (row r of L^-1 per lane).
+        if (wave == 3) {
+            double x[TS];
+#pragma unroll
+            for (int c = TS - 1; c >= 0; c--) {
+                double sacc = (lane == c) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = c + 1; k < TS; k++) sacc = __builtin_fma(-x[k], Ls[k * TLD + c], sacc);
+                x[c] = sacc / Ls[c * TLD + c];
+            }
+            double *dst = dinv + (int64_t)s * 4096 + lane * TS;
+#pragma unroll
+            for (int c = 0; c < TS; c++) dst[c] = x[c];
+        } else {
+            const int t = s + 1 + wave;
+            if (t < nt) {
+                double a[TS];
+                double *rowp = D + (int64_t)(t * TS + lane) * ld + s * TS;
+#pragma unroll
+                for (int c = 0; c < TS; c++) a[c] = rowp[c];
+#pragma unroll
+                for (int c = 0; c < TS; c++) {
+                    double v = a[c];
+#pragma unroll
+                    for (int k = 0; k < c; k++) v = __builtin_fma(-a[k], Ls[c * TLD + k], v);
+                    a[c] = v / Ls[c * TLD + c];
+                }
+                double *xs = Xs + wave * TS * TLD + lane * TLD;
+#pragma unroll
+                for (int c = 0; c < TS; c++) {
+                    rowp[c] = a[c];
+                    xs[c] = a[c];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- step 3: update the remaining tiles (t,u), s < u <= t < nt:  A(t,u) -= X_t X_u^T
+        {
+            int pair = 0;
+            for (int t = s + 1; t < nt; t++)
+                for (int u = s + 1; u <= t; u++, pair++) {
+                    if ((pair & 3) != wave) continue;
+                    const double *xt = Xs + (t - s - 1) * TS * TLD + lane * TLD;
+                    const double *xu = Xs + (u - s - 1) * TS * TLD;
+                    double xr[TS], acc[TS];
+                    double *rowp = D + (int64_t)(t * TS + lane) * ld + u * TS;
+#pragma unroll
+                    for (int k = 0; k < TS; k++) xr[k] = xt[k];
+#pragma unroll
+                    for (int c = 0; c < TS; c++) acc[c] = rowp[c];
+#pragma unroll
+                    for (int c = 0; c < TS; c++)
+#pragma unroll
+                        for (int k = 0; k < TS; k++) acc[c] = __builtin_fma(-xr[k], xu[c * TLD + k], acc[c]);
+#pragma unroll
+                    for (int c = 0; c < TS; c++) rowp[c] = acc[c];
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward substitution  v <- C^-T v  (gamma = C^-T rho, algorithm.rs:1034), right-looking over
+// 256-row blocks from the bottom: diagonal block solve (one workgroup) + transposed GEMV update.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trsv_t_diag(const double *__restrict__ Dg, int64_t ld,
+                                                     const double *__restrict__ dinv, int nbk,
+                                                     double *__restrict__ v) {
+    __shared__ double xs[256];
+    __shared__ double red[4][64];
+    __shared__ double ws[64];
+    const int tid = threadIdx.x, g = tid >> 6, j = tid & 63;
+    const int nt = nbk / 64;
+    for (int c = nt - 1; c >= 0; c--) {
+        double part = 0.0;
+        for (int t = c + 1; t < nt; t++)
+            for (int ii = 0; ii < 16; ii++) {
+                const int i = g + 4 * ii;
+                part = __builtin_fma(Dg[(int64_t)(t * 64 + i) * ld + c * 64 + j], xs[t * 64 + i], part);
+            }
+        red[g][j] = part;
+        __syncthreads();
+        if (g == 0) ws[j] = v[c * 64 + j] - (((red[0][j] + red[1][j]) + red[2][j]) + red[3][j]);
+        __syncthreads();
+        part = 0.0;
+        const double *li = dinv + (int64_t)c * 4096;
+        for (int ii = 0; ii < 16; ii++) {
+            const int i = g + 4 * ii;
+            part = __builtin_fma(li[i * 64 + j], ws[i], part);
+        }
+        __syncthreads();
+        red[g][j] = part;
+        __syncthreads();
+        if (g == 0) xs[c * 64 + j] = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
+        __syncthreads();
+    }
+    if (tid < nbk) v[tid] = xs[tid];
+}
+
+// v[j] -= sum_i Mrow[i*ld + j] * x[i]  for j < ncols ; grid = ncols/64
+__global__ __launch_bounds__(256) void k_gemv_t_update(const double *__restrict__ Mrow, int64_t ld, int nbk,
+                                                       const double *__restrict__ x, double *__restrict__ v) {
+    __shared__ double xs[256];
+    __shared__ double red[4][64];
+    const int tid = threadIdx.x, g = tid >> 6, jl = tid & 63;
+    const int j = blockIdx.x * 64 + jl;
+    if (tid < nbk) xs[tid] = x[tid];
+    __syncthreads();
+    double part = 0.0;
+    for (int i = g; i < nbk; i += 4) part = __builtin_fma(Mrow[(int64_t)i * ld + j], xs[i], part);
+    red[g][jl] = part;
+    __syncthreads();
+    if (g == 0) v[j] -= ((red[0][jl] + red[1][jl]) + red[2][jl]) + red[3][jl];
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA layout probe: C(16x16) = A(16x16) B(16x16) with asymmetric operands.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_mfma_probe(const double *A, const double *B, double *C) {
+    const int lane = threadIdx.x;
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    for (int k4 = 0; k4 < 4; k4++) {
+        const double a = A[(lane & 15) * 16 + k4 * 4 + (lane >> 4)];  // A[i][k]
+        const double b = B[(k4 * 4 + (lane >> 4)) * 16 + (lane & 15)];  // B[k][j]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    for (int r = 0; r < 4; r++) C[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
+}
+
+// =============================================================================================
+// host launchers
+// =============================================================================================
+static bool g_init_done = false;
+
+int chol_init() {
+    if (g_init_done) return EGX_SUCCESS;
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2_block),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, TrailShape::LDS_BYTES));
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, TrailShape::LDS_BYTES));
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel_trsm),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, PanelShape::LDS_BYTES));
+    g_init_done = true;
+    return EGX_SUCCESS;
+}
+
+int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
+                       const double *B, int64_t ldb, int M, int N, int K, int lower) {
+    if (M <= 0 || N <= 0 || K <= 0) return EGX_SUCCESS;
+    if (M % 128 || N % 128 || K % KC) {
+        set_error("gemm_nt_sub: M,N must be multiples of 128 and K of 16");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    dim3 grid(M / 128, N / 128);
+    if (lower)
+        hipLaunchKernelGGL(k_gemm_nt_sub<true>, grid, dim3(256), TrailShape::LDS_BYTES, s, C, ldc, A, lda, B, ldb, K);
+    else
+        hipLaunchKernelGGL(k_gemm_nt_sub<false>, grid, dim3(256), TrailShape::LDS_BYTES, s, C, ldc, A, lda, B, ldb, K);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info) {
+    int rc = chol_init();
+    if (rc) return rc;
+    if (n_pad % kTile || m_tot % kTile || m_tot < n_pad) {
+        set_error("potrf: padded sizes must be multiples of 128");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    for (int k0 = 0; k0 < n_pad; k0 += kNB) {
+        const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;
+        double *diag = M + (int64_t)k0 * ld + k0;
+        double *dtiles = dinv + (int64_t)(k0 / 64) * 4096;
+        hipLaunchKernelGGL(k_potf2_block, dim3(1), dim3(256), POTF2_LDS_BYTES, s, diag, ld, nbk, dtiles, info,
+                           k0, n_pad);
+        const int below = m_tot - (k0 + nbk);
+        if (below > 0) {
+            double *panel = M + (int64_t)(k0 + nbk) * ld + k0;
+            hipLaunchKernelGGL(k_panel_trsm, dim3(below / 64), dim3(256), PanelShape::LDS_BYTES, s, panel, ld,
+                               (const double *)diag, ld, (const double *)dtiles, nbk);
+            const int ncols = n_pad - (k0 + nbk);
+            if (ncols > 0) {
+                rc = launch_gemm_nt_sub(s, M + (int64_t)(k0 + nbk) * ld + (k0 + nbk), ld, panel, ld, panel, ld,
+                                        below, ncols, nbk, 1);
+                if (rc) return rc;
+            }
+        }
+    }
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, const double *dinv, double *RT,
+                     int64_t ldr, int m) {
+    int rc = chol_init();
+    if (rc) return rc;
+    if (m % kTile || n_pad % kTile) {
+        set_error("trsm_rows: sizes must be multiples of 128");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    for (int k0 = 0; k0 < n_pad; k0 += kNB) {
+        const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;
+        const double *diag = M + (int64_t)k0 * ldm + k0;
+        const double *dtiles = dinv + (int64_t)(k0 / 64) * 4096;
+        hipLaunchKernelGGL(k_panel_trsm, dim3(m / 64), dim3(256), PanelShape::LDS_BYTES, s, RT + k0, ldr, diag, ldm,
+                           dtiles, nbk);
+        const int ncols = n_pad - (k0 + nbk);
+        if (ncols > 0) {
+            rc = launch_gemm_nt_sub(s, RT + (k0 + nbk), ldr, RT + k0, ldr, M + (int64_t)(k0 + nbk) * ldm + k0, ldm,
+                                    m, ncols, nbk, 0);
+            if (rc) return rc;
+        }
+    }
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *dinv, double *v) {
+    const int nblocks = (n_pad + kNB - 1) / kNB;
+    for (int b = nblocks - 1; b >= 0; b--) {
+        const int k0 = b * kNB;
+        const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;
+        hipLaunchKernelGGL(k_trsv_t_diag, dim3(1), dim3(256), 0, s, M + (int64_t)k0 * ld + k0, ld,
+                           dinv + (int64_t)(k0 / 64) * 4096, nbk, v + k0);
+        if (k0 > 0)
+            hipLaunchKernelGGL(k_gemv_t_update, dim3(k0 / 64), dim3(256), 0, s, M + (int64_t)k0 * ld, ld, nbk,
+                               (const double *)(v + k0), v);
+    }
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int mfma_probe(double *max_abs_err) {
+    double hA[256], hB[256], hC[256];
+    for (int i = 0; i < 16; i++)
+        for (int j = 0; j < 16; j++) {
+            hA[i * 16 + j] = 1.0 + i * 0.37 - j * 0.11 + (i * j % 5) * 0.013;
+            hB[i * 16 + j] = -0.5 + i * 0.29 + j * j * 0.017 - (i % 3) * 0.21;
+        }
+    double *dA, *dB, *dC;
+    EGX_HIP_CHECK(hipMalloc(&dA, sizeof hA));
+    EGX_HIP_CHECK(hipMalloc(&dB, sizeof hB));
+    EGX_HIP_CHECK(hipMalloc(&dC, sizeof hC));
+    EGX_HIP_CHECK(hipMemcpy(dA, hA, sizeof hA, hipMemcpyHostToDevice));
+    EGX_HIP_CHECK(hipMemcpy(dB, hB, sizeof hB, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, 0, dA, dB, dC);
+    EGX_HIP_CHECK(hipGetLastError());
+    EGX_HIP_CHECK(hipMemcpy(hC, dC, sizeof hC, hipMemcpyDeviceToHost));
+    hipFree(dA);
+    hipFree(dB);
+    hipFree(dC);
+    double worst = 0.0;
+    for (int i = 0; i < 16; i++)
+        for (int j = 0; j < 16; j++) {
+            double ref = 0.0;
+            for (int k = 0; k < 16; k++) ref += hA[i * 16 + k] * hB[k * 16 + j];
+            double e = ref - hC[i * 16 + j];
+            if (e < 0) e = -e;
+            if (e > worst) worst = e;
+        }
+    *max_abs_err = worst;
+    return EGX_SUCCESS;
+}
+
+}  // namespace egx

@@ -1,0 +1,365 @@
+// Correlation kernels for gfx950: the device counterpart of
+//   DiffMatrix::_cross_diff        crates/gp/src/utils.rs:80-104
+//   pairwise_differences           crates/gp/src/utils.rs:110-131
+//   CorrelationModel::value        crates/gp/src/correlation_models.rs:91-104 (sq-exp), :185-196
+//                                  (abs-exp), :326-353 (Matern 3/2), :497-523 (Matern 5/2)
+//   the R scatter loop             crates/gp/src/algorithm.rs:997-1001
+//   _compute_correlation + predict crates/gp/src/algorithm.rs:253-263, 372-380
+// fused so that the (n(n-1)/2, d) difference table (34 GB at n = 16384, d = 32) and the (m*n, d)
+// prediction table never exist: every workgroup stages two 64-point slabs of the (k-major)
+// normalised inputs in LDS and produces a 64x64 tile of correlations with DIRECT differences
+// (no |a|^2+|b|^2-2ab trick: cancellation would break 1e-8 parity for near-duplicate points).
+// HBM traffic is the algorithmic minimum: X read once per tile row/column from L2, R written once.
+#include "egx_internal.h"
+
+namespace egx {
+
+constexpr double kSqrt3 = 1.7320508075688772;
+constexpr double kSqrt5 = 2.23606797749979;
+constexpr double k5over3 = 5.0 / 3.0;
+
+// Accumulator for one (i, j) pair, updated one input dimension at a time.
+template <int CORR>
+struct PairAcc {
+    double s;  // sum inside the exponential
+    double a;  // polynomial product (Matern)
+    __device__ __forceinline__ PairAcc() : s(0.0), a(1.0) {}
+    __device__ __forceinline__ void add(double diff, const double *__restrict__ coef, int hcols) {
+        const double ad = fabs(diff);
+        if (CORR == EGX_CORR_SQUARED_EXPONENTIAL) {
+            const double t = coef[0] * diff;
+            s = __builtin_fma(t, t, s);
+        } else if (CORR == EGX_CORR_ABSOLUTE_EXPONENTIAL) {
+            s = __builtin_fma(coef[0], ad, s);
+        } else if (CORR == EGX_CORR_MATERN32) {
+            for (int l = 0; l < hcols; l++) {
+                const double t = coef[l] * ad;
+                s += t;
+                a *= __builtin_fma(kSqrt3, t, 1.0);
+            }
+        } else {
+            for (int l = 0; l < hcols; l++) {
+                const double t = coef[l] * ad;
+                s += t;
+                a *= 1.0 + kSqrt5 * t + k5over3 * (t * t);
+            }
+        }
+    }
+    __device__ __forceinline__ double value() const {
+        if (CORR == EGX_CORR_SQUARED_EXPONENTIAL) return exp(-0.5 * s);
+        if (CORR == EGX_CORR_ABSOLUTE_EXPONENTIAL) return exp(-s);
+        if (CORR == EGX_CORR_MATERN32) return a * exp(-kSqrt3 * s);
+        return a * exp(-kSqrt5 * s);
+    }
+};
+
+// Stage a 64-point slab (all d dimensions, k-major) into LDS: dst[k*64 + i].
+__device__ __forceinline__ void stage_slab(double *dst, const double *__restrict__ xT, int64_t ldx, int i0,
+                                           int d, int tid) {
+    for (int e = tid; e < d * 64; e += 256) {
+        const int k = e >> 6, i = e & 63;
+        dst[e] = xT[(int64_t)k * ldx + i0 + i];
+    }
+}
+
+// 4x4 micro-tile of pair accumulators from two staged slabs.
+template <int CORR>
+__device__ __forceinline__ void tile_pairs(const double *xi, const double *xj, const double *__restrict__ coef,
+                                           int hcols, int d, int ty, int tx, double (&r)[4][4]) {
+    PairAcc<CORR> acc[4][4];
+    for (int k = 0; k < d; k++) {
+        double vi[4], vj[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) vi[a] = xi[k * 64 + ty * 4 + a];
+#pragma unroll
+        for (int b = 0; b < 4; b++) vj[b] = xj[k * 64 + tx * 4 + b];
+        const double *ck = coef + k * hcols;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) acc[a][b].add(vi[a] - vj[b], ck, hcols);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) r[a][b] = acc[a][b].value();
+}
+
+// K1: symmetric training correlation matrix, 64x64 tiles, 128x128-granular lower triangle.
+template <int CORR>
+__global__ __launch_bounds__(256) void k_corr_sym(const double *__restrict__ xT, int64_t ldx, int n, int d,
+                                                  const double *__restrict__ coef, int hcols, double diag,
+                                                  double *__restrict__ M, int64_t ld) {
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if ((bj >> 1) > (bi >> 1)) return;  // strictly-upper 128x128 tiles are never read
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *xi = sm, *xj = sm + d * 64;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    stage_slab(xi, xT, ldx, bi * 64, d, tid);
+    stage_slab(xj, xT, ldx, bj * 64, d, tid);
+    __syncthreads();
+    double r[4][4];
+    tile_pairs<CORR>(xi, xj, coef, hcols, d, ty, tx, r);
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int i = bi * 64 + ty * 4 + a;
+        double out[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int j = bj * 64 + tx * 4 + b;
+            double v = r[a][b];
+            if (i >= n || j >= n) v = (i == j) ? 1.0 : 0.0;  // identity padding
+            else if (i == j) v = diag;                       // 1 + nugget, algorithm.rs:997
+            out[b] = v;
+        }
+        double *p = M + (int64_t)i * ld + bj * 64 + tx * 4;
+        *reinterpret_cast<double2 *>(p) = make_double2(out[0], out[1]);
+        *reinterpret_cast<double2 *>(p + 2) = make_double2(out[2], out[3]);
+    }
+}
+
+// K2: rectangular cross-correlation block (queries x training points), full grid.
+template <int CORR>
+__global__ __launch_bounds__(256) void k_cross_corr(const double *__restrict__ xqT, int64_t ldq,
+                                                    const double *__restrict__ xT, int64_t ldx, int d,
+                                                    const double *__restrict__ coef, int hcols,
+                                                    double *__restrict__ R, int64_t ld) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *xi = sm, *xj = sm + d * 64;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    stage_slab(xi, xqT, ldq, blockIdx.x * 64, d, tid);
+    stage_slab(xj, xT, ldx, blockIdx.y * 64, d, tid);
+    __syncthreads();
+    double r[4][4];
+    tile_pairs<CORR>(xi, xj, coef, hcols, d, ty, tx, r);
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        double *p = R + (int64_t)(blockIdx.x * 64 + ty * 4 + a) * ld + blockIdx.y * 64 + tx * 4;
+        *reinterpret_cast<double2 *>(p) = make_double2(r[a][0], r[a][1]);
+        *reinterpret_cast<double2 *>(p + 2) = make_double2(r[a][2], r[a][3]);
+    }
+}
+
+// K2+K6 fused: racc[q] = sum_i k(xq, x_i) gamma_i ; one workgroup per 64 queries, loop over slabs.
+template <int CORR>
+__global__ __launch_bounds__(256) void k_predict_mean(const double *__restrict__ xqT, int64_t ldq,
+                                                      const double *__restrict__ xT, int64_t ldx, int n_pad,
+                                                      int d, const double *__restrict__ coef, int hcols,
+                                                      const double *__restrict__ gamma,
+                                                      double *__restrict__ racc) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *xi = sm, *xj = sm + d * 64, *gs = sm + 2 * d * 64;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    stage_slab(xi, xqT, ldq, blockIdx.x * 64, d, tid);
+    double sum[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j0 = 0; j0 < n_pad; j0 += 64) {
+        __syncthreads();
+        stage_slab(xj, xT, ldx, j0, d, tid);
+        if (tid < 64) gs[tid] = gamma[j0 + tid];
+        __syncthreads();
+        double r[4][4];
+        tile_pairs<CORR>(xi, xj, coef, hcols, d, ty, tx, r);
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) sum[a] = __builtin_fma(r[a][b], gs[tx * 4 + b], sum[a]);
+    }
+    // reduce over the 16 tx lanes that share the same queries (consecutive lanes of one wave)
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        double v = sum[a];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        if (tx == 0) racc[blockIdx.x * 64 + ty * 4 + a] = v;
+    }
+}
+
+__global__ void k_fill_rows(double *__restrict__ M, int64_t ld, int r0, int rows_pad, const double *__restrict__ src,
+                            int64_t lds, int nrows, int ncols) {
+    const int64_t total = (int64_t)rows_pad * ld;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(e / ld);
+        const int i = (int)(e % ld);
+        M[(int64_t)(r0 + l) * ld + i] = (l < nrows && i < ncols) ? src[(int64_t)l * lds + i] : 0.0;
+    }
+}
+
+__global__ void k_gather_diag(const double *__restrict__ M, int64_t ld, int n, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = M[(int64_t)i * ld + i];
+}
+
+__global__ void k_zero_upper(double *__restrict__ M, int64_t ld, int n) {
+    const int64_t total = (int64_t)n * n;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / n), j = (int)(e % n);
+        if (j > i) M[(int64_t)i * ld + j] = 0.0;
+    }
+}
+
+// one wave per query row: s0 = sum_i rt_i^2 ; sl[l] = sum_i rt_i * ft_l[i]
+__global__ __launch_bounds__(256) void k_row_reduce(const double *__restrict__ RT, int64_t ld, int m, int n,
+                                                    const double *__restrict__ ftT, int64_t ldf, int p,
+                                                    double *__restrict__ s0, double *__restrict__ sl) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= m) return;
+    const double *row = RT + (int64_t)q * ld;
+    double acc = 0.0;
+    for (int i = lane; i < n; i += 64) acc = __builtin_fma(row[i], row[i], acc);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) s0[q] = acc;
+    for (int l = 0; l < p; l++) {
+        const double *f = ftT + (int64_t)l * ldf;
+        double a2 = 0.0;
+        for (int i = lane; i < n; i += 64) a2 = __builtin_fma(row[i], f[i], a2);
+        for (int o = 32; o > 0; o >>= 1) a2 += __shfl_xor(a2, o);
+        if (lane == 0) sl[(int64_t)q * p + l] = a2;
+    }
+}
+
+// Likelihood-gradient accumulation (new capability; w = I only):
+//   out[k]     += sum_{i>j} 2 Rinv_ij dR_k,ij          (trace term)
+//   out[d + k] += sum_{i>j} 2 gamma_i gamma_j dR_k,ij  (quadratic term)
+// dR_k = R_ij * g_k(|x_ik - x_jk|): sq-exp -theta a^2 ; abs-exp -a ; Matern32 s3 a/(1+s3 t) - s3 a ;
+// Matern52 (s5 a + 10/3 theta a^2)/(1 + s5 t + 5/3 t^2) - s5 a.
+template <int CORR>
+__global__ __launch_bounds__(256) void k_grad_accum(const double *__restrict__ xT, int64_t ldx, int n, int d,
+                                                    const double *__restrict__ theta,
+                                                    const double *__restrict__ Rinv, int64_t ld,
+                                                    const double *__restrict__ gamma, double *__restrict__ out) {
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bj > bi) return;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *xi = sm, *xj = sm + d * 64, *red = sm + 2 * d * 64;  // red[2*d]
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    stage_slab(xi, xT, ldx, bi * 64, d, tid);
+    stage_slab(xj, xT, ldx, bj * 64, d, tid);
+    for (int e = tid; e < 2 * d; e += 256) red[e] = 0.0;
+    __syncthreads();
+    double r[4][4];
+    tile_pairs<CORR>(xi, xj, theta, 1, d, ty, tx, r);
+    double wt[4][4], wq[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int i = bi * 64 + ty * 4 + a, j = bj * 64 + tx * 4 + b;
+            const bool on = (i > j) && (i < n);
+            const double rv = on ? 2.0 * r[a][b] : 0.0;
+            wt[a][b] = on ? rv * Rinv[(int64_t)i * ld + j] : 0.0;
+            wq[a][b] = on ? rv * gamma[i] * gamma[j] : 0.0;
+        }
+    for (int k = 0; k < d; k++) {
+        const double th = theta[k];
+        double st = 0.0, sq = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const double ad = fabs(xi[k * 64 + ty * 4 + a] - xj[k * 64 + tx * 4 + b]);
+                double g;
+                if (CORR == EGX_CORR_SQUARED_EXPONENTIAL) g = -th * ad * ad;
+                else if (CORR == EGX_CORR_ABSOLUTE_EXPONENTIAL) g = -ad;
+                else if (CORR == EGX_CORR_MATERN32) g = kSqrt3 * ad / (1.0 + kSqrt3 * th * ad) - kSqrt3 * ad;
+                else {
+                    const double t = th * ad;
+                    g = (kSqrt5 * ad + (10.0 / 3.0) * th * ad * ad) / (1.0 + kSqrt5 * t + k5over3 * t * t) - kSqrt5 * ad;
+                }
+                st = __builtin_fma(wt[a][b], g, st);
+                sq = __builtin_fma(wq[a][b], g, sq);
+            }
+        for (int o = 32; o > 0; o >>= 1) {
+            st += __shfl_xor(st, o);
+            sq += __shfl_xor(sq, o);
+        }
+        if ((tid & 63) == 0) {
+            atomicAdd(&red[k], st);
+            atomicAdd(&red[d + k], sq);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * d; e += 256) atomicAdd(&out[e], red[e]);
+}
+
+// =============================================================================================
+#define EGX_DISPATCH_CORR(corr, CALL)                                                        \
+    switch (corr) {                                                                          \
+        case EGX_CORR_SQUARED_EXPONENTIAL: { constexpr int C_ = EGX_CORR_SQUARED_EXPONENTIAL; CALL; } break;   \
+        case EGX_CORR_ABSOLUTE_EXPONENTIAL: { constexpr int C_ = EGX_CORR_ABSOLUTE_EXPONENTIAL; CALL; } break; \
+        case EGX_CORR_MATERN32: { constexpr int C_ = EGX_CORR_MATERN32; CALL; } break;       \
+        case EGX_CORR_MATERN52: { constexpr int C_ = EGX_CORR_MATERN52; CALL; } break;       \
+        default: set_error("unknown correlation kind"); return EGX_ERR_INVALID_VALUE;        \
+    }
+
+int launch_corr_sym(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d, const double *coef,
+                    int hcols, double nugget, double *M, int64_t ld, int n_pad) {
+    dim3 grid(n_pad / 64, n_pad / 64);
+    const size_t lds = (size_t)2 * d * 64 * sizeof(double);
+    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_corr_sym<C_>, grid, dim3(256), lds, s, xT, ldx, n, d, coef, hcols,
+                                               1.0 + nugget, M, ld));
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_cross_corr(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad, const double *xT,
+                      int64_t ldx, int n_pad, int d, const double *coef, int hcols, double *R, int64_t ld) {
+    dim3 grid(m_pad / 64, n_pad / 64);
+    const size_t lds = (size_t)2 * d * 64 * sizeof(double);
+    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_cross_corr<C_>, grid, dim3(256), lds, s, xqT, ldq, xT, ldx, d, coef,
+                                               hcols, R, ld));
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_predict_mean(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad, const double *xT,
+                        int64_t ldx, int n_pad, int d, const double *coef, int hcols, const double *gamma,
+                        double *racc) {
+    const size_t lds = (size_t)(2 * d * 64 + 64) * sizeof(double);
+    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_predict_mean<C_>, dim3(m_pad / 64), dim3(256), lds, s, xqT, ldq, xT,
+                                               ldx, n_pad, d, coef, hcols, gamma, racc));
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_fill_rows(hipStream_t s, double *M, int64_t ld, int r0, int rows_pad, const double *src, int64_t lds,
+                     int nrows, int ncols) {
+    hipLaunchKernelGGL(k_fill_rows, dim3(1024), dim3(256), 0, s, M, ld, r0, rows_pad, src, lds, nrows, ncols);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_gather_diag(hipStream_t s, const double *M, int64_t ld, int n, double *out) {
+    hipLaunchKernelGGL(k_gather_diag, dim3((n + 255) / 256), dim3(256), 0, s, M, ld, n, out);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_zero_upper(hipStream_t s, double *M, int64_t ld, int n) {
+    hipLaunchKernelGGL(k_zero_upper, dim3(2048), dim3(256), 0, s, M, ld, n);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_row_reduce(hipStream_t s, const double *RT, int64_t ld, int m, int n, const double *ftT, int64_t ldf,
+                      int p, double *s0, double *sl) {
+    hipLaunchKernelGGL(k_row_reduce, dim3((m + 3) / 4), dim3(256), 0, s, RT, ld, m, n, ftT, ldf, p, s0, sl);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d, const double *theta,
+                      const double *Rinv, int64_t ld, const double *gamma, double *out) {
+    EGX_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double) * 2 * d, s));
+    const int nt = (n + 63) / 64;
+    dim3 grid(nt, nt);
+    const size_t lds = (size_t)(2 * d * 64 + 2 * d) * sizeof(double);
+    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_grad_accum<C_>, grid, dim3(256), lds, s, xT, ldx, n, d, theta, Rinv,
+                                               ld, gamma, out));
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+}  // namespace egx

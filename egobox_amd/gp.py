@@ -1,0 +1,516 @@
+"""Host-side mirror of egobox-gp's builder / fit / predict API on top of the HIP library.
+
+Same names, argument meaning and error behaviour as the reference for the hot path:
+
+    GaussianProcess.params(mean, corr) / Kriging.params()          crates/gp/src/algorithm.rs:200-207, 244-249
+      .theta_init .theta_bounds .theta_tuning .kpls_dim .n_start
+      .max_eval .nugget                                             crates/gp/src/parameters.rs:167-273
+      .fit(x, y) -> GaussianProcess                                 crates/gp/src/algorithm.rs:785-980
+    GaussianProcess.predict / predict_var / predict_valvar          crates/gp/src/algorithm.rs:253-307
+      .theta() .variance() .likelihood() .dims() .kpls_dim()        crates/gp/src/algorithm.rs:413-439
+
+All numerics run on the GPU through `GpHandle` (ctypes over include/egx_gp.h); nothing here
+computes a correlation, a factorisation or a solve.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+from .multistart import prepare_multistart
+
+#: crates/gp/src/lib.rs:  GP_OPTIM_N_START = 10, GP_COBYLA_MIN_EVAL = 25, GP_COBYLA_MAX_EVAL = 1000
+GP_OPTIM_N_START = 10
+GP_COBYLA_MIN_EVAL = 25
+GP_COBYLA_MAX_EVAL = 1000
+DEFAULT_NUGGET = 100.0 * np.finfo(np.float64).eps  # parameters.rs:118
+
+
+# ---- model markers (crates/gp/src/mean_models.rs, correlation_models.rs) ---------------------
+class _Named:
+    code = -1
+    name = ""
+
+    def __str__(self):
+        return self.name
+
+    def __repr__(self):
+        return f"{type(self).__name__}()"
+
+    def __eq__(self, other):
+        return type(self) is type(other)
+
+    def __hash__(self):
+        return hash(type(self))
+
+
+class ConstantMean(_Named):
+    code, name = 0, "ConstantMean"
+
+
+class LinearMean(_Named):
+    code, name = 1, "LinearMean"
+
+
+class QuadraticMean(_Named):
+    code, name = 2, "QuadraticMean"
+
+
+class SquaredExponentialCorr(_Named):
+    code, name = 0, "SquaredExponential"
+
+
+class AbsoluteExponentialCorr(_Named):
+    code, name = 1, "AbsoluteExponential"
+
+
+class Matern32Corr(_Named):
+    code, name = 2, "Matern32"
+
+
+class Matern52Corr(_Named):
+    code, name = 3, "Matern52"
+
+
+MEANS = {c.name: c for c in (ConstantMean, LinearMean, QuadraticMean)}
+CORRS = {c.name: c for c in (SquaredExponentialCorr, AbsoluteExponentialCorr, Matern32Corr, Matern52Corr)}
+
+
+class ThetaTuning:
+    """crates/gp/src/parameters.rs:14-78."""
+    DEFAULT_INIT = 1e-1
+    DEFAULT_BOUNDS = (1e-2, 1e1)
+
+    def __init__(self, kind, init, bounds=None, active=None):
+        self.kind = kind
+        self.init = np.atleast_1d(np.asarray(init, dtype=np.float64))
+        self.bounds = None if bounds is None else [tuple(map(float, b)) for b in bounds]
+        self.active = None if active is None else list(active)
+
+    @classmethod
+    def Fixed(cls, init):
+        return cls("Fixed", init)
+
+    @classmethod
+    def Full(cls, init=None, bounds=None):
+        return cls("Full", [cls.DEFAULT_INIT] if init is None else init,
+                   [cls.DEFAULT_BOUNDS] if bounds is None else bounds)
+
+    @classmethod
+    def Partial(cls, init, bounds, active):
+        return cls("Partial", init, bounds, active)
+
+    @classmethod
+    def default(cls):
+        return cls.Full()
+
+    def __repr__(self):
+        return f"ThetaTuning.{self.kind}(init={self.init.tolist()}, bounds={self.bounds}, active={self.active})"
+
+
+# ---- low level handle --------------------------------------------------------------------------
+class GpHandle:
+    """One training set resident on one GPU (opaque `egx_gp*`)."""
+
+    def __init__(self, x, y, mean=0, corr=0, nugget=DEFAULT_NUGGET, device=-1, n_workspaces=1, w_star=None):
+        lib = L.load()
+        x = L.as_f64(x)
+        if x.ndim == 1:
+            x = x.reshape(-1, 1)
+        if x.ndim != 2:
+            raise L.InvalidValueError(L.ERR_INVALID_VALUE, "Training input has to be an [nsamples, nx] array")
+        y = L.as_f64(y)
+        if y.ndim == 2 and y.shape[1] == 1:
+            y = y[:, 0]
+        if y.ndim != 1:
+            raise L.InvalidValueError(L.ERR_INVALID_VALUE, "Training output has to be one dimensional")
+        if y.shape[0] != x.shape[0]:
+            raise L.InvalidValueError(L.ERR_INVALID_VALUE,
+                                      f"x has {x.shape[0]} rows but y has {y.shape[0]} (ragged training set)")
+        y = np.ascontiguousarray(y)
+        cfg = L.GpConfig()
+        lib.egx_gp_config_default(C.byref(cfg))
+        cfg.corr, cfg.mean, cfg.nugget, cfg.device, cfg.n_workspaces = int(corr), int(mean), float(nugget), int(device), int(n_workspaces)
+        self._w = None
+        if w_star is not None:
+            self._w = L.as_f64(w_star, 2)
+            if self._w.shape[0] != x.shape[1]:
+                raise L.InvalidValueError(L.ERR_INVALID_VALUE, "w_star must be (nx, kpls_dim)")
+            cfg.w_star = L.dptr(self._w)
+            cfg.kpls_dim = self._w.shape[1]
+        self._h = C.c_void_p()
+        self._lib = lib
+        L.check(lib.egx_gp_create(C.byref(cfg), L.dptr(x), L.dptr(y), x.shape[0], x.shape[1], C.byref(self._h)))
+        n, d, p, h = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(lib.egx_gp_dims(self._h, C.byref(n), C.byref(d), C.byref(p), C.byref(h)))
+        self.n, self.d, self.p, self.h = n.value, d.value, p.value, h.value
+        self.training_data = (x.copy(), y.copy())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.egx_gp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- likelihood
+    def likelihood(self, theta):
+        theta = L.as_f64(np.atleast_1d(theta), 1)
+        lk, st = C.c_double(), C.c_int32()
+        L.check(self._lib.egx_gp_likelihood(self._h, L.dptr(theta), theta.size, C.byref(lk), C.byref(st)))
+        return lk.value, st.value
+
+    def likelihood_batch(self, thetas):
+        thetas = L.as_f64(thetas, 2)
+        k = thetas.shape[0]
+        lk = np.empty(k)
+        st = np.empty(k, dtype=np.int32)
+        L.check(self._lib.egx_gp_likelihood_batch(self._h, L.dptr(thetas), k, thetas.shape[1], L.dptr(lk),
+                                                  st.ctypes.data_as(L.c_int32_p)))
+        return lk, st
+
+    def likelihood_grad(self, theta):
+        theta = L.as_f64(np.atleast_1d(theta), 1)
+        lk, st = C.c_double(), C.c_int32()
+        g = np.zeros(self.d)
+        L.check(self._lib.egx_gp_likelihood_grad(self._h, L.dptr(theta), theta.size, C.byref(lk), L.dptr(g),
+                                                 C.byref(st)))
+        return lk.value, g, st.value
+
+    # -- fit
+    def finalize(self, theta):
+        theta = L.as_f64(np.atleast_1d(theta), 1)
+        L.check(self._lib.egx_gp_finalize(self._h, L.dptr(theta), theta.size))
+
+    def fit(self, theta0s, lo, hi, max_eval=GP_COBYLA_MAX_EVAL):
+        theta0s = L.as_f64(theta0s, 2)
+        lo = L.as_f64(np.atleast_1d(lo), 1)
+        hi = L.as_f64(np.atleast_1d(hi), 1)
+        ne = C.c_int64()
+        L.check(self._lib.egx_gp_fit(self._h, L.dptr(theta0s), theta0s.shape[0], L.dptr(lo), L.dptr(hi), lo.size,
+                                     int(max_eval), C.byref(ne)))
+        return ne.value
+
+    # -- predict
+    def _q(self, x):
+        x = L.as_f64(x)
+        if x.ndim == 1:
+            x = x.reshape(-1, self.d) if self.d > 1 else x.reshape(-1, 1)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise L.InvalidValueError(L.ERR_INVALID_VALUE, f"query points must be (m, {self.d}), got {x.shape}")
+        return np.ascontiguousarray(x)
+
+    def predict(self, x):
+        x = self._q(x)
+        out = np.empty(x.shape[0])
+        L.check(self._lib.egx_gp_predict(self._h, L.dptr(x), x.shape[0], L.dptr(out)))
+        return out
+
+    def predict_var(self, x):
+        x = self._q(x)
+        out = np.empty(x.shape[0])
+        L.check(self._lib.egx_gp_predict_var(self._h, L.dptr(x), x.shape[0], L.dptr(out)))
+        return out
+
+    def predict_valvar(self, x):
+        x = self._q(x)
+        y = np.empty(x.shape[0])
+        v = np.empty(x.shape[0])
+        L.check(self._lib.egx_gp_predict_valvar(self._h, L.dptr(x), x.shape[0], L.dptr(y), L.dptr(v)))
+        return y, v
+
+    # -- state
+    def inner(self, with_chol=False):
+        n, d, p, h = self.n, self.d, self.p, self.h
+        out = dict(theta=np.empty(h), likelihood=np.empty(1), sigma2=np.empty(1), beta=np.empty((p, 1)),
+                   gamma=np.empty((n, 1)), ft=np.empty((n, p)), ft_qr_r=np.empty((p, p)), x_mean=np.empty(d),
+                   x_std=np.empty(d), y_mean=np.empty(1), y_std=np.empty(1), xt_norm=np.empty((n, d)),
+                   yt_norm=np.empty((n, 1)))
+        if with_chol:
+            out["r_chol"] = np.empty((n, n))
+        view = L.InnerView()
+        for k, a in out.items():
+            setattr(view, k, L.dptr(a))
+        L.check(self._lib.egx_gp_get_inner(self._h, C.byref(view)))
+        out["likelihood"] = float(out["likelihood"][0])
+        out["sigma2"] = float(out["sigma2"][0])
+        return out
+
+    def fitted_scalars(self):
+        """(likelihood, sigma2) of the resident fit without downloading any array."""
+        lk, s2 = np.empty(1), np.empty(1)
+        view = L.InnerView()
+        view.likelihood, view.sigma2 = L.dptr(lk), L.dptr(s2)
+        L.check(self._lib.egx_gp_get_inner(self._h, C.byref(view)))
+        return float(lk[0]), float(s2[0])
+
+    def timings(self):
+        t = L.Timings()
+        L.check(self._lib.egx_gp_last_timings(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in L.Timings._fields_}
+
+
+# ---- kernel-level entry points -------------------------------------------------------------------
+def corr_matrix(corr, xnorm, theta, nugget=DEFAULT_NUGGET):
+    """CorrelationModel::value fused with DiffMatrix + the R scatter loop (egx_corr_matrix)."""
+    xnorm = L.as_f64(xnorm, 2)
+    n, d = xnorm.shape
+    theta = np.ascontiguousarray(np.broadcast_to(L.as_f64(np.atleast_1d(theta), 1), (d,)))
+    r = np.empty((n, n))
+    L.check(L.load().egx_corr_matrix(int(corr), L.dptr(xnorm), n, d, L.dptr(theta), float(nugget), L.dptr(r)))
+    return r
+
+
+def cross_corr(corr, xq_norm, xt_norm, theta):
+    xq_norm = L.as_f64(xq_norm, 2)
+    xt_norm = L.as_f64(xt_norm, 2)
+    m, d = xq_norm.shape
+    n = xt_norm.shape[0]
+    theta = np.ascontiguousarray(np.broadcast_to(L.as_f64(np.atleast_1d(theta), 1), (d,)))
+    r = np.empty((m, n))
+    L.check(L.load().egx_cross_corr(int(corr), L.dptr(xq_norm), m, L.dptr(xt_norm), n, d, L.dptr(theta), L.dptr(r)))
+    return r
+
+
+def potrf(a):
+    """Lower Cholesky factor on the GPU (egx_potrf). Returns (L, info)."""
+    a = np.array(a, dtype=np.float64, order="C", copy=True)
+    if a.ndim != 2 or a.shape[0] != a.shape[1]:
+        raise L.InvalidValueError(L.ERR_INVALID_VALUE, "square matrix expected")
+    info = C.c_int32()
+    L.check(L.load().egx_potrf(L.dptr(a), a.shape[0], C.byref(info)))
+    return a, info.value
+
+
+def normalize(x):
+    x = L.as_f64(x, 2)
+    n, d = x.shape
+    xn, mean, std = np.empty((n, d)), np.empty(d), np.empty(d)
+    L.check(L.load().egx_normalize(L.dptr(x), n, d, L.dptr(xn), L.dptr(mean), L.dptr(std)))
+    return xn, mean, std
+
+
+def regression_basis(mean, x):
+    x = L.as_f64(x, 2)
+    n, d = x.shape
+    p = L.load().egx_regression_ncols(int(mean), d)
+    if p < 0:
+        raise L.InvalidValueError(L.ERR_INVALID_VALUE, "unknown regression model")
+    f = np.empty((n, p))
+    L.check(L.load().egx_regression_basis(int(mean), L.dptr(x), n, d, L.dptr(f)))
+    return f
+
+
+def mfma_probe():
+    e = C.c_double()
+    L.check(L.load().egx_mfma_probe(C.byref(e)))
+    return e.value
+
+
+# ---- builder (crates/gp/src/parameters.rs:93-313) ---------------------------------------------------
+class GpParams:
+    def __init__(self, mean=None, corr=None):
+        self._mean = mean if mean is not None else ConstantMean()
+        self._corr = corr if corr is not None else SquaredExponentialCorr()
+        self._theta_tuning = ThetaTuning.default()
+        self._kpls_dim = None
+        self._kpls_weights = None
+        self._n_start = GP_OPTIM_N_START
+        self._max_eval = GP_COBYLA_MAX_EVAL
+        self._nugget = DEFAULT_NUGGET
+        self._device = -1
+        self._seed = 42  # optimization.rs:62: multistart LHS is seeded with 42
+
+    # setters return self, like the Rust builder
+    def mean(self, mean):
+        self._mean = mean
+        return self
+
+    def corr(self, corr):
+        self._corr = corr
+        return self
+
+    def kpls_dim(self, kpls_dim):
+        self._kpls_dim = kpls_dim
+        return self
+
+    def kpls_weights(self, w_star):
+        """Extension: supply the PLS rotations (nx, kpls_dim) directly (the reference computes them with
+        linfa-pls, algorithm.rs:843-855, which is outside the accelerated path)."""
+        self._kpls_weights = None if w_star is None else np.asarray(w_star, dtype=np.float64)
+        if w_star is not None:
+            self._kpls_dim = self._kpls_weights.shape[1]
+        return self
+
+    def theta_init(self, theta_init):  # parameters.rs:193-212
+        t = self._theta_tuning
+        if t.kind == "Fixed":
+            self._theta_tuning = ThetaTuning.Fixed(theta_init)
+        else:
+            self._theta_tuning = ThetaTuning.Full(theta_init, t.bounds)
+        return self
+
+    def theta_bounds(self, theta_bounds):  # parameters.rs:217-234 (no-op when Fixed)
+        t = self._theta_tuning
+        if t.kind != "Fixed":
+            self._theta_tuning = ThetaTuning.Full(t.init, theta_bounds)
+        return self
+
+    def theta_tuning(self, theta_tuning):
+        self._theta_tuning = theta_tuning
+        return self
+
+    def n_start(self, n_start):
+        self._n_start = int(n_start)
+        return self
+
+    def max_eval(self, max_eval):  # parameters.rs:251-254
+        self._max_eval = max(GP_COBYLA_MIN_EVAL, int(max_eval))
+        return self
+
+    def nugget(self, nugget):
+        self._nugget = float(nugget)
+        return self
+
+    def device(self, device):
+        self._device = int(device)
+        return self
+
+    def check(self):  # ParamGuard::check_ref, parameters.rs:287-308
+        d = self._kpls_dim
+        if d is not None:
+            if d == 0:
+                raise L.InvalidValueError(L.ERR_INVALID_VALUE, "`kpls_dim` canot be 0!")
+            th = self._theta_tuning.init
+            if th.size > 1 and d > th.size:
+                raise L.InvalidValueError(
+                    L.ERR_INVALID_VALUE,
+                    f"Dimension reduction ({d}) should be smaller than expected training input size "
+                    f"infered from given initial theta length ({th.size})")
+        return self
+
+    def fit(self, x, y):
+        """GpValidParams::fit, crates/gp/src/algorithm.rs:791-980."""
+        self.check()
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim == 1:
+            x = x.reshape(-1, 1)
+        nx = x.shape[1] if x.ndim == 2 else 0
+        w = None
+        if self._kpls_dim is not None:
+            if self._kpls_dim > nx:  # algorithm.rs:798-807
+                raise L.InvalidValueError(
+                    L.ERR_INVALID_VALUE,
+                    f"Dimension reduction {self._kpls_dim} should be smaller than actual training input dimensions {nx}")
+            if self._kpls_weights is None:
+                raise NotImplementedError(
+                    "KPLS rotations come from linfa-pls in the reference (out of the accelerated path); "
+                    "pass them with .kpls_weights(w_star)")
+            w = self._kpls_weights
+        h = GpHandle(x, y, mean=self._mean.code, corr=self._corr.code, nugget=self._nugget, device=self._device,
+                     w_star=w)
+        t = self._theta_tuning
+        dim = h.h
+        if t.init.size not in (1, dim):  # algorithm.rs:829-838 (a panic in the reference)
+            h.close()
+            raise L.InvalidValueError(
+                L.ERR_INVALID_VALUE,
+                f"Initial guess for theta should be either 1-dim or dim of xtrain (w_star.ncols()), got {t.init.size}")
+        if t.kind == "Fixed":
+            h.finalize(t.init)
+            n_evals = 1
+        elif t.kind == "Full":
+            theta0 = np.full(dim, t.init[0]) if t.init.size == 1 else t.init
+            b = t.bounds
+            if len(b) not in (1, dim):  # algorithm.rs:901-912
+                h.close()
+                raise L.InvalidValueError(
+                    L.ERR_INVALID_VALUE,
+                    f"Bounds for theta should be either 1-dim or dim of xtrain ({dim}), got {len(b)}")
+            b = b * dim if len(b) == 1 else b
+            starts_log10, _ = prepare_multistart(self._n_start, theta0, b, seed=self._seed)
+            n_evals = h.fit(10.0 ** starts_log10, [lo for lo, _ in b], [hi for _, hi in b], self._max_eval)
+        else:
+            h.close()
+            raise NotImplementedError("ThetaTuning.Partial is not on the accelerated path yet")
+        return GaussianProcess(h, self, n_evals)
+
+
+class GaussianProcess:
+    """Fitted model (crates/gp/src/algorithm.rs:174-192); state lives on the GPU."""
+
+    def __init__(self, handle, params, n_evals=1):
+        self._h = handle
+        self.params_ = params
+        self.n_evals = n_evals
+        self._inner = None
+
+    @staticmethod
+    def params(mean=None, corr=None):
+        return GpParams(mean, corr)
+
+    def predict(self, x):
+        return self._h.predict(x)
+
+    def predict_var(self, x):
+        return self._h.predict_var(x)
+
+    def predict_valvar(self, x):
+        return self._h.predict_valvar(x)
+
+    def inner_params(self, with_chol=False):
+        if self._inner is None or (with_chol and "r_chol" not in self._inner):
+            self._inner = self._h.inner(with_chol)
+        return self._inner
+
+    def theta(self):
+        return self.inner_params()["theta"]
+
+    def variance(self):
+        return self.inner_params()["sigma2"]
+
+    def likelihood(self):
+        return self.inner_params()["likelihood"]
+
+    def dims(self):
+        return (self._h.d, 1)
+
+    def kpls_dim(self):
+        return self._h.h if self._h.h < self._h.d else None
+
+    @property
+    def training_data(self):
+        return self._h.training_data
+
+    @property
+    def handle(self):
+        return self._h
+
+    def __str__(self):  # algorithm.rs:226-240
+        th = ", ".join(repr(float(v)) for v in self.theta())
+        return (f"GP(mean={self.params_._mean}, corr={self.params_._corr}, theta=[{th}], "
+                f"variance={self.variance()!r}, likelihood={self.likelihood()!r})")
+
+    def close(self):
+        self._h.close()
+
+
+class Kriging:
+    """Kriging = GP with constant mean and squared exponential correlation (algorithm.rs:198-207)."""
+
+    @staticmethod
+    def params():
+        return GpParams(ConstantMean(), SquaredExponentialCorr())

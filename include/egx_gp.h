@@ -1,0 +1,209 @@
+/*
+ * egx_gp.h -- C ABI of libegx_gp_hip.so: MI355X-native (gfx950) kriging hot path.
+ *
+ * This is the drop-in boundary for egobox-gp's fit / reduced-likelihood /
+ * predict / predict_var path.  The reference (relf/egobox 0.34.0) has no FFI
+ * today: its seams are Rust traits and one cargo-feature `cfg`.  Every entry
+ * point below names the reference interface it replaces (paths relative to the
+ * reference checkout).  A Rust `extern "C"` shim implementing those traits on
+ * top of this header is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - all arrays are caller-owned HOST memory, f64, C-contiguous row-major
+ *     (ndarray standard layout); the library owns device memory behind the
+ *     opaque handle; no callbacks cross the boundary.
+ *   - every function returns an egx_rc (0 = success); on failure
+ *     egx_last_error() returns a thread-local message.
+ *   - numerical failures of ONE likelihood evaluation are VALUES, not errors:
+ *     they come back in the per-candidate `status` (egx_status), exactly as the
+ *     reference swallows them into +inf during optimisation
+ *     (crates/gp/src/algorithm.rs:885-896).  Only egx_gp_finalize / egx_gp_fit
+ *     turn a bad status into an error return, as the reference's final
+ *     `reduced_likelihood(...)?` does (algorithm.rs:968).
+ *   - a handle is safe to call from several host threads (calls are
+ *     serialised per handle); distinct handles are independent.
+ *   - there is NO CPU fallback: without a gfx950 device egx_gp_create fails
+ *     with EGX_ERR_NO_DEVICE.
+ */
+#ifndef EGX_GP_H
+#define EGX_GP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGX_GP_ABI_VERSION 1
+
+typedef struct egx_gp egx_gp; /* opaque: one training set resident on one GPU */
+
+/* return codes */
+typedef enum {
+    EGX_SUCCESS = 0,
+    EGX_ERR_INVALID_VALUE = 1, /* GpError::InvalidValueError, crates/gp/src/errors.rs:38 (and the
+                                  panics of algorithm.rs:835-837, 907-911 turned into errors) */
+    EGX_ERR_NO_DEVICE = 2,     /* no gfx950 device / HIP runtime unusable */
+    EGX_ERR_HIP = 3,           /* a HIP call failed (message has the HIP error string) */
+    EGX_ERR_NOT_FITTED = 4,    /* predict* / get_inner before finalize/fit */
+    EGX_ERR_LINALG = 5,        /* GpError::LinalgError (not positive definite), errors.rs:19 */
+    EGX_ERR_LIKELIHOOD = 6,    /* GpError::LikelihoodComputationError, errors.rs:12 */
+    EGX_ERR_UNSUPPORTED = 7
+} egx_rc;
+
+/* per-evaluation status (the value channel) */
+typedef enum {
+    EGX_STATUS_OK = 0,
+    EGX_STATUS_NOT_POSITIVE_DEFINITE = 1, /* cholesky()? failed, algorithm.rs:1004 */
+    EGX_STATUS_ILL_CONDITIONED_FT = 2,    /* algorithm.rs:1022-1026 */
+    EGX_STATUS_ILL_CONDITIONED_F = 3,     /* algorithm.rs:1015-1020 */
+    EGX_STATUS_NAN_THETA = 4              /* algorithm.rs:885-891 */
+} egx_status;
+
+/* crates/gp/src/correlation_models.rs: the four CorrelationModel impls */
+typedef enum {
+    EGX_CORR_SQUARED_EXPONENTIAL = 0, /* :91-104  */
+    EGX_CORR_ABSOLUTE_EXPONENTIAL = 1, /* :185-196 */
+    EGX_CORR_MATERN32 = 2,            /* :277-286, :326-353 */
+    EGX_CORR_MATERN52 = 3             /* :446-455, :497-523 */
+} egx_corr;
+
+/* crates/gp/src/mean_models.rs: the three RegressionModel impls */
+typedef enum {
+    EGX_MEAN_CONSTANT = 0, /* :42-44   */
+    EGX_MEAN_LINEAR = 1,   /* :68-71   */
+    EGX_MEAN_QUADRATIC = 2 /* :97-104  */
+} egx_mean;
+
+/* Builder state that reaches the hot path: GpValidParams, crates/gp/src/parameters.rs:93-121 */
+typedef struct {
+    int32_t corr;         /* egx_corr */
+    int32_t mean;         /* egx_mean */
+    double nugget;        /* default 100*f64::EPSILON, parameters.rs:118 */
+    int32_t device;       /* HIP device ordinal; -1 = current device */
+    int32_t n_workspaces; /* correlation-matrix workspaces (concurrent likelihood evaluations), >= 1 */
+    const double *w_star; /* optional KPLS rotations (d x kpls_dim), algorithm.rs:843-855; NULL = identity */
+    int64_t kpls_dim;     /* columns of w_star (ignored when w_star == NULL) */
+} egx_gp_config;
+
+/* ---- library level ------------------------------------------------------ */
+int32_t egx_abi_version(void);
+const char *egx_last_error(void); /* thread-local, never NULL */
+int32_t egx_device_count(void);   /* number of visible HIP devices (0 when none) */
+void egx_gp_config_default(egx_gp_config *cfg);
+
+/* ---- host-side helpers (no device needed) -------------------------------- */
+/* utils.rs:45-54 normalize(): column mean, sample std (ddof=1), zero std -> 1. */
+int32_t egx_normalize(const double *x, int64_t n, int64_t d, double *xnorm /*n*d*/,
+                      double *mean /*d*/, double *std /*d*/);
+/* mean_models.rs value(): number of basis columns p for input dimension d. */
+int64_t egx_regression_ncols(int32_t mean, int64_t d);
+/* mean_models.rs value(): F (n x p) from (normalised) x (n x d). */
+int32_t egx_regression_basis(int32_t mean, const double *x, int64_t n, int64_t d, double *f /*n*p*/);
+
+/* ---- handle lifetime ------------------------------------------------------
+ * Replaces the theta-independent part of GpValidParams::fit
+ * (crates/gp/src/algorithm.rs:795-866): copies x (n x d) and y (n), normalises
+ * both, builds the regression basis, uploads, allocates workspaces. */
+int32_t egx_gp_create(const egx_gp_config *cfg, const double *x, const double *y, int64_t n,
+                      int64_t d, egx_gp **out);
+void egx_gp_destroy(egx_gp *gp);
+/* dims: n, d (dims().0, algorithm.rs:437-439), p = basis columns, h = theta length */
+int32_t egx_gp_dims(const egx_gp *gp, int64_t *n, int64_t *d, int64_t *p, int64_t *h);
+
+/* ---- likelihood (the unit COBYLA multiplies) ------------------------------
+ * One evaluation of `reduced_likelihood(fx, corr.value(d, theta, w), ...)`
+ * (algorithm.rs:892-896, 988-1056).  theta_len is h or 1 (broadcast,
+ * algorithm.rs:829-838).  *lkh is the reduced likelihood (NOT negated);
+ * on status != 0 it is -inf (the reference's objective is then +inf). */
+int32_t egx_gp_likelihood(egx_gp *gp, const double *theta, int64_t theta_len, double *lkh,
+                          int32_t *status);
+/* k candidates, thetas is (k x theta_len); the multistart / theta-sweep unit of
+ * algorithm.rs:928-945 (rayon par_iter over starts). */
+int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len,
+                                double *lkh /*k*/, int32_t *status /*k*/);
+/* NEW capability (the reference has no theta-gradient, algorithm.rs:880):
+ * dL/dtheta (length h); validated by finite differences of the parity-checked likelihood. */
+int32_t egx_gp_likelihood_grad(egx_gp *gp, const double *theta, int64_t theta_len, double *lkh,
+                               double *dlkh_dtheta /*h*/, int32_t *status);
+
+/* ---- fit ------------------------------------------------------------------
+ * ThetaTuning::Fixed fit (algorithm.rs:869-872, 966-978; python n_start=-1,
+ * python/src/gp_mix.rs:202-208): one likelihood evaluation whose factor and
+ * inner params stay resident.  Error return when the evaluation fails. */
+int32_t egx_gp_finalize(egx_gp *gp, const double *theta, int64_t theta_len);
+/* ThetaTuning::Full fit (algorithm.rs:874-948): multistart derivative-free
+ * maximisation of the likelihood over log10(theta) in [lo,hi], then finalize.
+ * theta0s is (n_starts x h) in LINEAR theta units: the caller supplies the
+ * starts (prepare_multistart, optimization.rs:26-71, stays on the caller's side
+ * because its LHS stream is the caller's RNG).  bounds_len is h or 1. */
+int32_t egx_gp_fit(egx_gp *gp, const double *theta0s, int64_t n_starts, const double *lo,
+                   const double *hi, int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out);
+
+/* ---- prediction (GaussianProcess::{predict, predict_var, predict_valvar},
+ * algorithm.rs:253-307).  xq is (m x d) in ORIGINAL units. */
+int32_t egx_gp_predict(egx_gp *gp, const double *xq, int64_t m, double *y /*m*/);
+int32_t egx_gp_predict_var(egx_gp *gp, const double *xq, int64_t m, double *var /*m*/);
+int32_t egx_gp_predict_valvar(egx_gp *gp, const double *xq, int64_t m, double *y, double *var);
+
+/* ---- fitted state download (GpInnerParams algorithm.rs:47-60 + accessors
+ * theta()/variance()/likelihood() :413-431), for serde parity.  Any pointer may
+ * be NULL (skipped).  r_chol is (n x n) lower with zero upper triangle;
+ * ft_qr_r has a positive diagonal. */
+typedef struct {
+    double *theta;      /* h */
+    double *likelihood; /* 1 */
+    double *sigma2;     /* 1 : variance() = sigma2 * y_std^2 */
+    double *beta;       /* p */
+    double *gamma;      /* n */
+    double *r_chol;     /* n*n */
+    double *ft;         /* n*p */
+    double *ft_qr_r;    /* p*p */
+    double *x_mean;     /* d */
+    double *x_std;      /* d */
+    double *y_mean;     /* 1 */
+    double *y_std;      /* 1 */
+    double *xt_norm;    /* n*d */
+    double *yt_norm;    /* n */
+} egx_gp_inner_view;
+int32_t egx_gp_get_inner(egx_gp *gp, const egx_gp_inner_view *view);
+
+/* ---- kernel-level entry points ---------------------------------------------
+ * The CorrelationModel::value seam (correlation_models.rs:19-58) fused with
+ * DiffMatrix (utils.rs:80-104) and the scatter loop (algorithm.rs:997-1001):
+ * r (n x n, full symmetric, diagonal 1+nugget) straight from normalised x.
+ * theta is the per-input-dimension scale vector (length d, w = I). */
+int32_t egx_corr_matrix(int32_t corr, const double *xnorm, int64_t n, int64_t d,
+                        const double *theta, double nugget, double *r /*n*n*/);
+/* _compute_correlation (algorithm.rs:372-380): r (m x n) between normalised
+ * query points and normalised training points. */
+int32_t egx_cross_corr(int32_t corr, const double *xq_norm, int64_t m, const double *xt_norm,
+                       int64_t n, int64_t d, const double *theta, double *r /*m*n*/);
+/* cholesky() (algorithm.rs:1004; LAPACK dpotrf with the blas feature :1077):
+ * a (n x n, symmetric, lower triangle read) -> lower factor in place (upper
+ * zeroed).  *info = 0, or 1-based index of the first non-positive pivot. */
+int32_t egx_potrf(double *a, int64_t n, int32_t *info);
+
+/* ---- measurement ------------------------------------------------------------
+ * HIP-event durations (ms) of the stages of the most recent likelihood /
+ * finalize call on workspace 0, measured on the stream the kernels ran on. */
+typedef struct {
+    double corr_build_ms; /* K1 */
+    double potrf_ms;      /* K3 incl. fused forward solves (K4) */
+    double potrf_syrk_ms; /* trailing-update launches only (when EGX_TIMING=2) */
+    double solve_ms;      /* gamma back-substitution */
+    double host_ms;       /* GLS / QR / reductions on the host */
+    double total_ms;
+    int64_t potrf_flops;  /* n^3/3 algorithmic */
+    int64_t corr_bytes;   /* 8*n*d + 8*n(n+1)/2 algorithmic */
+} egx_timings;
+int32_t egx_gp_last_timings(const egx_gp *gp, egx_timings *t);
+
+/* self-test of the FP64 MFMA fragment layout (16x16x4): returns max abs error of
+ * a 16x16x16 product computed with v_mfma_f64_16x16x4_f64 vs the host. */
+int32_t egx_mfma_probe(double *max_abs_err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGX_GP_H */

@@ -1,0 +1,121 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol
+include/egx_gp.h declares, its host-only helpers match the oracle, and it refuses to compute without a
+GPU (no fallback).  No device compute is called here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "egx_gp.h")
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+@pytest.fixture(scope="module")
+def egx():
+    import egobox_amd
+    return egobox_amd
+
+
+def _declared_functions():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = re.findall(r"\b(egx_[a-z0-9_]+)\s*\(", txt)
+    return sorted(set(names))
+
+
+def test_header_symbols_are_exported_and_bound(egx):
+    declared = _declared_functions()
+    assert len(declared) >= 20
+    lib = C.CDLL(egx._lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/egx_gp.h but not exported"
+    bound = {s[0] for s in egx._lib.SIGNATURES}
+    assert set(declared) == bound, (set(declared) ^ bound)
+    out = subprocess.run(["nm", "-D", "--defined-only", egx._lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (egx_[a-z0-9_]+)", out))
+    assert exported == set(declared), (exported ^ set(declared))
+
+
+def test_abi_version_and_default_config(egx):
+    lib = egx._lib.load()
+    assert lib.egx_abi_version() == 1
+    cfg = egx._lib.GpConfig()
+    lib.egx_gp_config_default(C.byref(cfg))
+    assert cfg.corr == 0 and cfg.mean == 0 and cfg.n_workspaces == 1 and cfg.device == -1
+    assert cfg.nugget == 100.0 * np.finfo(float).eps  # crates/gp/src/parameters.rs:118
+
+
+def test_host_normalize_matches_oracle(egx):
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((50, 4)) * [1, 10, 0.1, 5] + [0, 3, -2, 100]
+    x[:, 2] = 7.0  # zero std column -> std 1 (utils.rs:50)
+    xn, m, s = egx.normalize(x)
+    xo, mo, so = O.normalize(x)
+    np.testing.assert_allclose(xn, xo, rtol=1e-13, atol=1e-13)
+    np.testing.assert_allclose(m, mo, rtol=1e-14)
+    np.testing.assert_allclose(s, so, rtol=1e-13)
+    assert s[2] == 1.0
+    with pytest.raises(egx.InvalidValueError):
+        egx.normalize(np.zeros((1, 3)))
+
+
+@pytest.mark.parametrize("mean,name", [(0, "Constant"), (1, "Linear"), (2, "Quadratic")])
+def test_host_regression_basis_matches_oracle(egx, mean, name):
+    from oracle import gp_oracle as O
+    x = np.random.default_rng(1).standard_normal((7, 3))
+    np.testing.assert_array_equal(egx.regression_basis(mean, x), O.regression_value(name, x))
+    assert egx._lib.load().egx_regression_ncols(mean, 3) == O.regression_value(name, x).shape[1]
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback(egx):
+    assert egx._lib.load().egx_device_count() == 0
+    with pytest.raises(egx.NoDeviceError):
+        egx.GpHandle(np.random.rand(10, 2), np.random.rand(10))
+    with pytest.raises(egx.NoDeviceError):
+        egx.corr_matrix(0, np.random.rand(4, 2), [1.0, 1.0])
+    with pytest.raises(egx.NoDeviceError):
+        egx.potrf(np.eye(3))
+    with pytest.raises(egx.NoDeviceError):
+        egx.Kriging.params().fit(np.random.rand(10, 2), np.random.rand(10))
+
+
+def test_argument_validation_before_device(egx):
+    """Invalid inputs are rejected with InvalidValueError whether or not a GPU is present."""
+    good_x, good_y = np.random.rand(10, 2), np.random.rand(10)
+    with pytest.raises(egx.InvalidValueError):
+        egx.GpHandle(good_x[:1], good_y[:1])              # n < 2
+    with pytest.raises(egx.InvalidValueError):
+        egx.GpHandle(np.zeros((0, 2)), np.zeros(0))       # empty
+    with pytest.raises(egx.InvalidValueError):
+        egx.GpHandle(good_x, good_y[:9])                  # ragged
+    with pytest.raises(egx.InvalidValueError):
+        egx.GpHandle(np.random.rand(10, 65), good_y)      # d > 64
+    with pytest.raises(egx.InvalidValueError):
+        egx.GpHandle(good_x, good_y, corr=9)
+    bad = good_x.copy()
+    bad[3, 1] = np.nan
+    with pytest.raises(egx.InvalidValueError):
+        egx.GpHandle(bad, good_y)
+    with pytest.raises(egx.InvalidValueError):
+        egx.GpHandle(good_x, good_y, w_star=np.ones((2, 3)))  # kpls_dim > d (algorithm.rs:798-807)
+    with pytest.raises(egx.InvalidValueError):
+        egx.GpHandle(good_x[:3], good_y[:3], mean=2)      # p >= n
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under egobox_amd/ may reference it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "egobox_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "gp_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f

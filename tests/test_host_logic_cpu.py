@@ -1,0 +1,97 @@
+"""Host-side mirror logic (builder semantics, multistart candidates, spec handling) -- no GPU needed."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def egx():
+    import egobox_amd
+    return egobox_amd
+
+
+def test_builder_defaults_match_reference(egx):
+    p = egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr())
+    assert p._n_start == 10 and p._max_eval == 1000            # crates/gp/src/lib.rs constants
+    assert p._nugget == 100.0 * np.finfo(float).eps             # parameters.rs:118
+    t = p._theta_tuning
+    assert t.kind == "Full" and t.init.tolist() == [0.1] and t.bounds == [(1e-2, 1e1)]  # parameters.rs:36-51
+
+
+def test_builder_theta_init_bounds_transitions(egx):
+    # parameters.rs:193-234
+    p = egx.Kriging.params().theta_init([0.5, 0.6])
+    assert p._theta_tuning.kind == "Full" and p._theta_tuning.init.tolist() == [0.5, 0.6]
+    p.theta_bounds([(0.1, 1.0)])
+    assert p._theta_tuning.bounds == [(0.1, 1.0)] and p._theta_tuning.init.tolist() == [0.5, 0.6]
+    p.theta_tuning(egx.ThetaTuning.Fixed([0.3]))
+    p.theta_bounds([(0.2, 2.0)])          # no-op when Fixed
+    assert p._theta_tuning.kind == "Fixed" and p._theta_tuning.bounds is None
+    p.theta_init([0.9])
+    assert p._theta_tuning.kind == "Fixed" and p._theta_tuning.init.tolist() == [0.9]
+    p2 = egx.Kriging.params().theta_tuning(egx.ThetaTuning.Partial([0.1, 0.1], [(0.01, 10)], [0])).theta_init([0.2, 0.2])
+    assert p2._theta_tuning.kind == "Full"
+    assert egx.Kriging.params().max_eval(3)._max_eval == 25     # parameters.rs:251-254
+
+
+def test_builder_check(egx):
+    with pytest.raises(egx.InvalidValueError, match="canot be 0"):
+        egx.Kriging.params().kpls_dim(0).check()                # parameters.rs:290-294
+    with pytest.raises(egx.InvalidValueError, match="Dimension reduction"):
+        egx.Kriging.params().theta_init([0.1, 0.1]).kpls_dim(3).check()  # parameters.rs:296-304
+    egx.Kriging.params().theta_init([0.1]).kpls_dim(3).check()  # len-1 theta: no constraint
+
+
+def test_model_markers(egx):
+    assert str(egx.ConstantMean()) == "ConstantMean" and str(egx.Matern52Corr()) == "Matern52"
+    assert egx.LinearMean() == egx.LinearMean() and egx.LinearMean() != egx.QuadraticMean()
+    assert [c().code for c in (egx.SquaredExponentialCorr, egx.AbsoluteExponentialCorr, egx.Matern32Corr,
+                               egx.Matern52Corr)] == [0, 1, 2, 3]
+
+
+def test_prepare_multistart(egx):
+    # optimization.rs:26-71: log10 space, row 0 = user theta0, rows 1.. inside the log10 bounds
+    starts, bl = egx.prepare_multistart(10, np.array([0.1, 0.5, 2.0]), [(1e-2, 1e1)] * 3)
+    assert starts.shape == (11, 3)
+    np.testing.assert_allclose(starts[0], np.log10([0.1, 0.5, 2.0]))
+    assert bl == [(-2.0, 1.0)] * 3
+    assert np.all(starts[1:] >= -2.0) and np.all(starts[1:] <= 1.0)
+    # LHS property: one point per stratum in every column
+    for j in range(3):
+        strata = np.floor((starts[1:, j] + 2.0) / 3.0 * 10).astype(int)
+        assert sorted(strata.tolist()) == list(range(10))
+    s2, _ = egx.prepare_multistart(10, np.array([0.1, 0.5, 2.0]), [(1e-2, 1e1)] * 3)
+    np.testing.assert_array_equal(starts, s2)                   # seeded (42): reproducible
+    s0, _ = egx.prepare_multistart(0, np.array([0.3]), [(1e-2, 1e1)])
+    assert s0.shape == (1, 1)
+    s1, _ = egx.prepare_multistart(1, np.array([0.3]), [(1e-2, 1e1)])
+    assert s1.shape == (2, 1) and -2.0 <= s1[1, 0] <= 1.0
+
+
+def test_theta_sweep_candidates(egx):
+    c = egx.theta_sweep_candidates(512, 32)
+    assert c.shape == (512, 32)
+    assert np.all(c[0] == 0.1)
+    assert c.min() >= 1e-2 * (1 - 1e-12) and c.max() <= 1e1 * (1 + 1e-12)
+
+
+def test_gpx_spec_handling(egx):
+    with pytest.raises(NotImplementedError):
+        egx.Gpx.builder(regr_spec=egx.RegressionSpec.ALL).fit(np.random.rand(5, 1), np.random.rand(5))
+    with pytest.raises(NotImplementedError):
+        egx.Gpx.builder(n_clusters=3).fit(np.random.rand(5, 1), np.random.rand(5))
+    with pytest.raises(NotImplementedError):
+        egx.Gpx.builder(corr_spec=egx.CorrelationSpec.SQUARED_EXPONENTIAL | egx.CorrelationSpec.MATERN52) \
+            .fit(np.random.rand(5, 1), np.random.rand(5))
+
+
+def test_workload_generators(egx):
+    x = egx.workload.lhs(100, 3, seed=1)
+    assert x.shape == (100, 3) and x.min() >= 0 and x.max() <= 1
+    for j in range(3):
+        assert sorted(np.floor(x[:, j] * 100).astype(int).tolist()) == list(range(100))
+    np.testing.assert_array_equal(x, egx.workload.lhs(100, 3, seed=1))
+    g = egx.workload.griewank(np.full((1, 4), 0.5))  # x = 0 -> griewank = 0
+    assert abs(g[0]) < 1e-12
+    from oracle import gp_oracle as O
+    np.testing.assert_array_equal(O.lhs_classic(50, 2, 7), egx.workload.lhs(50, 2, 7))
+    np.testing.assert_allclose(O.griewank(x), egx.workload.griewank(x))
