@@ -64,7 +64,10 @@ int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, in
 // dinv receives the inverses of the 64x64 diagonal tiles ((n_pad/64) * 4096 doubles).
 // info (device int): 0 or 1-based index of the first non-positive pivot.
 // ev_syrk: optional accumulation of per-launch timings is done by the caller via events.
-int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info);
+// s2 / ev_lu / ev_panel: auxiliary (high priority) stream and two events for the one-block look-ahead;
+// s2 == nullptr runs everything in order on s.
+int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
+                 hipStream_t s2 = nullptr, hipEvent_t ev_lu = nullptr, hipEvent_t ev_panel = nullptr);
 // rows [0, m) of RT (ld) are right-hand sides: RT <- RT * C^-T  (C = lower factor in M, n_pad cols)
 int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, const double *dinv,
                      double *RT, int64_t ldr, int m);

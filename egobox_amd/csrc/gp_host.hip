@@ -27,6 +27,8 @@ void set_error(const std::string &msg) { g_last_error = msg; }
 
 struct Workspace {
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // look-ahead (panel) stream
+    hipEvent_t ev_lu = nullptr, ev_panel = nullptr;
     double *M = nullptr;       // (m_tot x ld): correlation matrix / factor + appended RHS rows
     double *dinv = nullptr;    // (n_pad/64) x 64 x 64 inverses of the diagonal tiles
     double *d_coef = nullptr;  // d x hcols
@@ -104,12 +106,25 @@ static void free_workspace(Workspace &w) {
     if (w.h_info) hipHostFree(w.h_info);
     for (auto &e : w.ev)
         if (e) hipEventDestroy(e);
+    if (w.ev_lu) hipEventDestroy(w.ev_lu);
+    if (w.ev_panel) hipEventDestroy(w.ev_panel);
+    if (w.stream2) hipStreamDestroy(w.stream2);
     if (w.stream) hipStreamDestroy(w.stream);
     w = Workspace();
 }
 
 static int alloc_workspace(egx_gp *gp, Workspace &w) {
     EGX_HIP_CHECK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    {
+        const char *la = std::getenv("EGX_LOOKAHEAD");
+        if (!la || la[0] != '0') {
+            int lo = 0, hi = 0;
+            EGX_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            EGX_HIP_CHECK(hipStreamCreateWithPriority(&w.stream2, hipStreamNonBlocking, hi));
+            EGX_HIP_CHECK(hipEventCreateWithFlags(&w.ev_lu, hipEventDisableTiming));
+            EGX_HIP_CHECK(hipEventCreateWithFlags(&w.ev_panel, hipEventDisableTiming));
+        }
+    }
     EGX_HIP_CHECK(hipMalloc(&w.M, sizeof(double) * (size_t)gp->m_tot * gp->ld));
     EGX_HIP_CHECK(hipMalloc(&w.dinv, sizeof(double) * (size_t)(gp->n_pad / 64) * 4096));
     const int hmax = gp->has_w ? gp->h : 1;
@@ -180,7 +195,8 @@ static int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coe
                            gp->ld, gp->n_pad));
     EGX_RC(launch_fill_rows(w.stream, w.M, gp->ld, gp->n_pad, gp->rhs_pad, gp->d_rhsT, gp->n_pad, gp->q, gp->n_pad));
     EGX_HIP_CHECK(hipEventRecord(w.ev[1], w.stream));
-    EGX_RC(launch_potrf(w.stream, w.M, gp->ld, gp->n_pad, gp->m_tot, w.dinv, w.d_info));
+    EGX_RC(launch_potrf(w.stream, w.M, gp->ld, gp->n_pad, gp->m_tot, w.dinv, w.d_info, w.stream2, w.ev_lu,
+                        w.ev_panel));
     EGX_HIP_CHECK(hipEventRecord(w.ev[2], w.stream));
     EGX_RC(launch_gather_diag(w.stream, w.M, gp->ld, gp->n, w.d_diag));
     EGX_HIP_CHECK(hipMemcpyAsync(w.h_diag, w.d_diag, sizeof(double) * gp->n, hipMemcpyDeviceToHost, w.stream));

@@ -156,15 +156,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_sub(double *__restrict__ C, 
     const int wave = tid >> 6, lane = tid & 63;
     const int r0 = bx * 128 + (wave >> 1) * 64 + (lane >> 4);
     const int c0 = by * 128 + (wave & 1) * 64 + (lane & 15);
+    // read-modify-write of the C tile in batches of 16 independent loads (a naive `*p -= acc` chain
+    // serialises on vmcnt(0) per element: measured 2x on the whole kernel)
 #pragma unroll
-    for (int mi = 0; mi < 4; mi++)
+    for (int mi = 0; mi < 4; mi++) {
+        double cv[4][4];
 #pragma unroll
         for (int ni = 0; ni < 4; ni++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                double *p = C + (int64_t)(r0 + mi * 16 + 4 * r) * ldc + (c0 + ni * 16);
-                *p -= acc[mi][ni][r];
-            }
+            for (int r = 0; r < 4; r++)
+                cv[ni][r] = C[(int64_t)(r0 + mi * 16 + 4 * r) * ldc + (c0 + ni * 16)];
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                C[(int64_t)(r0 + mi * 16 + 4 * r) * ldc + (c0 + ni * 16)] = cv[ni][r] - acc[mi][ni][r];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -190,13 +197,18 @@ __global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, i
         // sum_{t<c} X_t L[c,t]^T  (K = 64 c): X_t were written to global by this workgroup
         gemm_core<64, 64, 16, 64>(Pw, ldp, L + (int64_t)c * 64 * ldl, ldl, 64 * c, acc, smem, tid);
         // rhs = P_c - acc, in place
+        {
+            double cv[4][4];
 #pragma unroll
-        for (int ni = 0; ni < 4; ni++)
+            for (int ni = 0; ni < 4; ni++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                double *p = Pw + (int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf;
-                *p -= acc[0][ni][r];
-            }
+                for (int r = 0; r < 4; r++) cv[ni][r] = Pw[(int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf];
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    Pw[(int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf] = cv[ni][r] - acc[0][ni][r];
+        }
         __syncthreads();  // workgroup-scope visibility of rhs before it is re-read as an operand
 #pragma unroll
         for (int ni = 0; ni < 4; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -213,17 +225,37 @@ __global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, i
 
 // ---------------------------------------------------------------------------------------------
 // A: diagonal block factorisation (nbk x nbk, nbk in {64,128,192,256}) by ONE workgroup.
+//    Per 64-column panel s:
+//      1. wave 0 factors tile (s,s) in registers (row per lane; pivots / multipliers by v_readlane)
+//      2. wave 3 inverts it (row of L^-1 per lane) while waves 0..2 solve the tiles below by true
+//         forward substitution (row per lane, L broadcast from LDS) and write X back to global
+//      3. all four waves update the remaining tiles A(t,u) -= X_t X_u^T with the MFMA core (K = 64)
+//    LDS: 33 KB (L tile) + 36 KB (MFMA staging) so the kernel can share a CU with one trailing-update
+//    workgroup when it runs on the look-ahead stream.
 // ---------------------------------------------------------------------------------------------
 constexpr int TS = 64;
 constexpr int TLD = 65;  // padded LDS row (doubles)
-constexpr int POTF2_LDS_BYTES = 4 * TS * TLD * 8;
+constexpr int POTF2_LDS_BYTES = TS * TLD * 8 + GemmShape<64, 64, 16, 64>::LDS_BYTES;
+
+// sqrt(p) and 1/sqrt(p) for p > 0 (normal range): v_rsq_f64 seed + 2 Newton steps + 1 correction.
+// ~12 dependent ops instead of the ~50 of IEEE sqrt() followed by a division; error <= ~1 ulp.
+__device__ __forceinline__ void sqrt_rsqrt(double p, double &d, double &r) {
+    double y = __builtin_amdgcn_rsq(p);
+    const double h = 0.5 * p;
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    y = y * __builtin_fma(-h * y, y, 1.5);
+    double g = p * y;
+    g = __builtin_fma(__builtin_fma(-g, g, p), 0.5 * y, g);
+    d = g;
+    r = y;
+}
 
 __global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, int64_t ld, int nbk,
                                                         double *__restrict__ dinv, int *__restrict__ info,
                                                         int col0, int n_valid) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *Ls = sm;             // factor of the current diagonal tile, [64][65]
-    double *Xs = sm + TS * TLD;  // up to three solved tiles below it, [3][64][65]
+    double *Ls = sm;                // factor of the current diagonal tile, [64][65]
+    double *stage = sm + TS * TLD;  // MFMA staging (2 x (64+64) x 18 doubles)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nt = nbk / TS;
     for (int s = 0; s < nt; s++) {
@@ -236,12 +268,12 @@ __global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, 
 #pragma unroll
             for (int j = 0; j < TS; j++) {
                 double piv = readlane_d(a[j], j);
-                if (!(piv > 0.0)) {  // wave-uniform: NaN or non-positive pivot
+                if (!(piv > 0.0) || !(piv < 1.0e300)) {  // wave-uniform: NaN, inf or non-positive pivot
                     if (lane == 0 && (col0 + s * TS + j) < n_valid) atomicCAS(info, 0, col0 + s * TS + j + 1);
                     piv = 1.0;
                 }
-                const double dj = sqrt(piv);
-                const double rinv = 1.0 / dj;
+                double dj, rinv;
+                sqrt_rsqrt(piv, dj, rinv);
                 const double lij = (lane == j) ? dj : a[j] * rinv;
                 a[j] = lij;
 #pragma unroll
@@ -259,16 +291,20 @@ __global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, 
             }
         }
         __syncthreads();
-        // ---- step 2: waves 0..2 solve the tiles below (true forward substitution, row per lane);
-        //              wave 3 inverts the diagonal tile (row r of L^-1 per lane).
+        // ---- step 2
         if (wave == 3) {
             double x[TS];
 #pragma unroll
             for (int c = TS - 1; c >= 0; c--) {
-                double sacc = (lane == c) ? 1.0 : 0.0;
+                // two interleaved partial sums halve the dependent-FMA chain
+                double s0 = (lane == c) ? 1.0 : 0.0, s1 = 0.0;
 #pragma unroll
-                for (int k = c + 1; k < TS; k++) sacc = __builtin_fma(-x[k], Ls[k * TLD + c], sacc);
-                x[c] = sacc / Ls[c * TLD + c];
+                for (int k = c + 1; k + 1 < TS; k += 2) {
+                    s0 = __builtin_fma(-x[k], Ls[k * TLD + c], s0);
+                    s1 = __builtin_fma(-x[k + 1], Ls[(k + 1) * TLD + c], s1);
+                }
+                if (((TS - 1 - c) & 1) != 0) s0 = __builtin_fma(-x[TS - 1], Ls[(TS - 1) * TLD + c], s0);
+                x[c] = (s0 + s1) / Ls[c * TLD + c];
             }
             double *dst = dinv + (int64_t)s * 4096 + lane * TS;
 #pragma unroll
@@ -282,42 +318,39 @@ __global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, 
                 for (int c = 0; c < TS; c++) a[c] = rowp[c];
 #pragma unroll
                 for (int c = 0; c < TS; c++) {
-                    double v = a[c];
+                    double v0 = a[c], v1 = 0.0;
 #pragma unroll
-                    for (int k = 0; k < c; k++) v = __builtin_fma(-a[k], Ls[c * TLD + k], v);
-                    a[c] = v / Ls[c * TLD + c];
+                    for (int k = 0; k + 1 < c; k += 2) {
+                        v0 = __builtin_fma(-a[k], Ls[c * TLD + k], v0);
+                        v1 = __builtin_fma(-a[k + 1], Ls[c * TLD + k + 1], v1);
+                    }
+                    if ((c & 1) != 0) v0 = __builtin_fma(-a[c - 1], Ls[c * TLD + c - 1], v0);
+                    a[c] = (v0 + v1) / Ls[c * TLD + c];
                 }
-                double *xs = Xs + wave * TS * TLD + lane * TLD;
 #pragma unroll
-                for (int c = 0; c < TS; c++) {
-                    rowp[c] = a[c];
-                    xs[c] = a[c];
-                }
+                for (int c = 0; c < TS; c++) rowp[c] = a[c];
             }
         }
-        __syncthreads();
-        // ---- step 3: update the remaining tiles (t,u), s < u <= t < nt:  A(t,u) -= X_t X_u^T
-        {
-            int pair = 0;
-            for (int t = s + 1; t < nt; t++)
-                for (int u = s + 1; u <= t; u++, pair++) {
-                    if ((pair & 3) != wave) continue;
-                    const double *xt = Xs + (t - s - 1) * TS * TLD + lane * TLD;
-                    const double *xu = Xs + (u - s - 1) * TS * TLD;
-                    double xr[TS], acc[TS];
-                    double *rowp = D + (int64_t)(t * TS + lane) * ld + u * TS;
+        __syncthreads();  // X tiles visible (workgroup scope) before the MFMA core reads them from global
+        // ---- step 3: A(t,u) -= X_t X_u^T for s < u <= t < nt, all four waves per tile pair
+        for (int t = s + 1; t < nt; t++)
+            for (int u = s + 1; u <= t; u++) {
+                double4_t acc[1][4];
 #pragma unroll
-                    for (int k = 0; k < TS; k++) xr[k] = xt[k];
+                for (int ni = 0; ni < 4; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+                gemm_core<64, 64, 16, 64>(D + (int64_t)t * TS * ld + s * TS, ld, D + (int64_t)u * TS * ld + s * TS, ld,
+                                          TS, acc, stage, tid);
+                double *ct = D + (int64_t)(t * TS + wave * 16 + (lane >> 4)) * ld + u * TS + (lane & 15);
+                double cv[4][4];
 #pragma unroll
-                    for (int c = 0; c < TS; c++) acc[c] = rowp[c];
+                for (int ni = 0; ni < 4; ni++)
 #pragma unroll
-                    for (int c = 0; c < TS; c++)
+                    for (int r = 0; r < 4; r++) cv[ni][r] = ct[(int64_t)(4 * r) * ld + ni * 16];
 #pragma unroll
-                        for (int k = 0; k < TS; k++) acc[c] = __builtin_fma(-xr[k], xu[c * TLD + k], acc[c]);
+                for (int ni = 0; ni < 4; ni++)
 #pragma unroll
-                    for (int c = 0; c < TS; c++) rowp[c] = acc[c];
-                }
-        }
+                    for (int r = 0; r < 4; r++) ct[(int64_t)(4 * r) * ld + ni * 16] = cv[ni][r] - acc[0][ni][r];
+            }
         __syncthreads();
     }
 }
@@ -425,31 +458,60 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
     return EGX_SUCCESS;
 }
 
-int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info) {
+// Flat right-looking factorisation with one-block look-ahead: as soon as the next block column has been
+// updated (LU_k) the next diagonal-block factorisation + panel solve run on the auxiliary stream `s2`,
+// concurrently with the rest of the trailing update (RU_k) on `s`.  The serial panel work (one workgroup,
+// then latency-bound solves) is thereby hidden behind the MFMA-bound update for all but the last blocks.
+// s2 == nullptr disables the look-ahead (everything in order on `s`).
+int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
+                 hipStream_t s2, hipEvent_t ev_lu, hipEvent_t ev_panel) {
     int rc = chol_init();
     if (rc) return rc;
     if (n_pad % kTile || m_tot % kTile || m_tot < n_pad) {
         set_error("potrf: padded sizes must be multiples of 128");
         return EGX_ERR_INVALID_VALUE;
     }
-    for (int k0 = 0; k0 < n_pad; k0 += kNB) {
-        const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;
+    auto panel = [&](hipStream_t st, int k0, int nbk) {
         double *diag = M + (int64_t)k0 * ld + k0;
         double *dtiles = dinv + (int64_t)(k0 / 64) * 4096;
-        hipLaunchKernelGGL(k_potf2_block, dim3(1), dim3(256), POTF2_LDS_BYTES, s, diag, ld, nbk, dtiles, info,
-                           k0, n_pad);
+        hipLaunchKernelGGL(k_potf2_block, dim3(1), dim3(256), POTF2_LDS_BYTES, st, diag, ld, nbk, dtiles, info, k0,
+                           n_pad);
         const int below = m_tot - (k0 + nbk);
-        if (below > 0) {
-            double *panel = M + (int64_t)(k0 + nbk) * ld + k0;
-            hipLaunchKernelGGL(k_panel_trsm, dim3(below / 64), dim3(256), PanelShape::LDS_BYTES, s, panel, ld,
-                               (const double *)diag, ld, (const double *)dtiles, nbk);
-            const int ncols = n_pad - (k0 + nbk);
-            if (ncols > 0) {
-                rc = launch_gemm_nt_sub(s, M + (int64_t)(k0 + nbk) * ld + (k0 + nbk), ld, panel, ld, panel, ld,
-                                        below, ncols, nbk, 1);
-                if (rc) return rc;
-            }
+        if (below > 0)
+            hipLaunchKernelGGL(k_panel_trsm, dim3(below / 64), dim3(256), PanelShape::LDS_BYTES, st,
+                               M + (int64_t)(k0 + nbk) * ld + k0, ld, (const double *)diag, ld,
+                               (const double *)dtiles, nbk);
+    };
+    auto blk = [&](int k0) { return (n_pad - k0 < kNB) ? (n_pad - k0) : kNB; };
+    const bool look = (s2 != nullptr);
+    panel(s, 0, blk(0));
+    for (int k0 = 0; k0 < n_pad; k0 += kNB) {
+        const int nbk = blk(k0);
+        const int r1 = k0 + nbk;  // first row/col of the trailing matrix
+        if (r1 >= n_pad) break;   // (right-hand-side rows below the last block were solved by its panel)
+        const int nb1 = blk(r1);
+        const double *pan = M + (int64_t)r1 * ld + k0;
+        // LU_k: next block column only
+        rc = launch_gemm_nt_sub(s, M + (int64_t)r1 * ld + r1, ld, pan, ld, pan, ld, m_tot - r1, nb1, nbk, 1);
+        if (rc) return rc;
+        if (look) {
+            EGX_HIP_CHECK(hipEventRecord(ev_lu, s));
+            EGX_HIP_CHECK(hipStreamWaitEvent(s2, ev_lu, 0));
+            panel(s2, r1, nb1);
+            EGX_HIP_CHECK(hipEventRecord(ev_panel, s2));
         }
+        // RU_k: the rest of the trailing matrix
+        const int r2 = r1 + nb1;
+        if (r2 < n_pad) {
+            const double *pan2 = M + (int64_t)r2 * ld + k0;
+            rc = launch_gemm_nt_sub(s, M + (int64_t)r2 * ld + r2, ld, pan2, ld, pan2, ld, m_tot - r2, n_pad - r2, nbk,
+                                    1);
+            if (rc) return rc;
+        }
+        if (look)
+            EGX_HIP_CHECK(hipStreamWaitEvent(s, ev_panel, 0));
+        else
+            panel(s, r1, nb1);
     }
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;

@@ -1,0 +1,21 @@
+#!/bin/bash
+# GPU pass 2: FP64 peak microbench, parity tests, smoke, bench with/without look-ahead, rocprof kernel trace.
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+LOG=gpurun_out/run2.log
+{
+echo "=== fp64 peak"; timeout 120 ./tools/fp64_peak
+echo "=== pytest gpu"
+timeout 1800 python -m pytest tests -m gpu -q --timeout=900 --tb=short -rf -x 2>&1 | tail -60
+echo "=== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()"
+echo "=== bench lookahead=1"
+timeout 900 python bench.py --steps 6 --warmup 2
+echo "=== bench lookahead=0"
+EGX_LOOKAHEAD=0 timeout 900 python bench.py --steps 4 --warmup 1 --no-cpu-baseline
+} > $LOG 2>&1
+echo "=== rocprof" >> $LOG
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_r2" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | grep -v "simple_timer\|generateRocpd" >> "$GRAFT_REPO_ROOT/$LOG")
+python tools/rocpd_stats.py gpurun_out/prof_r2/bench_results.db >> $LOG 2>&1
+cat $LOG | cut -c1-1500
