@@ -225,17 +225,31 @@ __global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, i
 
 // ---------------------------------------------------------------------------------------------
 // A: diagonal block factorisation (nbk x nbk, nbk in {64,128,192,256}) by ONE workgroup.
-//    Per 64-column panel s:
-//      1. wave 0 factors tile (s,s) in registers (row per lane; pivots / multipliers by v_readlane)
-//      2. wave 3 inverts it (row of L^-1 per lane) while waves 0..2 solve the tiles below by true
-//         forward substitution (row per lane, L broadcast from LDS) and write X back to global
-//      3. all four waves update the remaining tiles A(t,u) -= X_t X_u^T with the MFMA core (K = 64)
-//    LDS: 33 KB (L tile) + 36 KB (MFMA staging) so the kernel can share a CU with one trailing-update
-//    workgroup when it runs on the look-ahead stream.
+//    Per 64-column panel s of the block:
+//      1. the 64x64 tile (s,s) is staged in LDS; wave 0 factors it with one matrix row per lane, in
+//         16-column register strips (right-looking inside a strip, strip-by-strip trailing update);
+//         finished columns reach the other rows through a uniform-address (broadcast) LDS read.
+//         Loops over strips are NOT unrolled: a fully unrolled 64x64 version makes hipcc materialise
+//         thousands of uniform operands in SGPRs and spill them through VGPR lanes (measured 5x slower).
+//      2. wave 0 inverts the tile the same way (row of L^-1 per lane) -> dinv (used by k_panel_trsm and
+//         the triangular solves).
+//      3. tiles below: X_t = A(t,s) Linv^T with the MFMA core (K = 64), in place.
+//      4. remaining tiles A(t,u) -= X_t X_u^T with the MFMA core (K = 64).
+//    LDS: 70 KB, so the kernel can share a CU with one trailing-update workgroup on the look-ahead stream.
 // ---------------------------------------------------------------------------------------------
+#ifdef EGX_POTF2_PROFILE
+__device__ long long g_potf2_stamps[4][5];
+#define EGX_STAMP(i) \
+    if (threadIdx.x == 0) g_potf2_stamps[s][i] = (long long)__builtin_readcyclecounter()
+#else
+#define EGX_STAMP(i)
+#endif
 constexpr int TS = 64;
-constexpr int TLD = 65;  // padded LDS row (doubles)
-constexpr int POTF2_LDS_BYTES = TS * TLD * 8 + GemmShape<64, 64, 16, 64>::LDS_BYTES;
+constexpr int TLD = 65;  // padded LDS row (doubles): per-lane row accesses are conflict free
+constexpr int POTF2_AUX = TS * TLD + 2 * TS + TS;  // tile + two broadcast lines + reciprocal diagonal (doubles)
+constexpr int POTF2_LDS_BYTES = POTF2_AUX * 8 + GemmShape<64, 64, 16, 64>::LDS_BYTES;
+static_assert((POTF2_AUX * 8) % 16 == 0, "MFMA staging must stay 16-byte aligned");
+static_assert(GemmShape<64, 64, 16, 64>::LDS_BYTES >= TS * TLD * 8, "inverse scratch aliases the MFMA staging");
 
 // sqrt(p) and 1/sqrt(p) for p > 0 (normal range): v_rsq_f64 seed + 2 Newton steps + 1 correction.
 // ~12 dependent ops instead of the ~50 of IEEE sqrt() followed by a division; error <= ~1 ulp.
@@ -250,89 +264,143 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double &d, double &r) {
     r = y;
 }
 
+// One wave: in-place lower Cholesky of the 64x64 tile T (LDS, row stride TLD), row `lane` per lane.
+__device__ __forceinline__ void wave_potf2_64(double *T, double *cb, double *rd, int lane, int *info, int gcol0,
+                                              int n_valid) {
+#pragma unroll 1
+    for (int jb = 0; jb < 4; jb++) {
+        double a[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) a[c] = T[lane * TLD + jb * 16 + c];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int gj = jb * 16 + j;
+            double piv = readlane_d(a[j], gj);
+            if (!(piv > 0.0) || !(piv < 1.0e300)) {  // wave-uniform: NaN, inf or non-positive pivot
+                if (lane == 0 && (gcol0 + gj) < n_valid) atomicCAS(info, 0, gcol0 + gj + 1);
+                piv = 1.0;
+            }
+            double dj, rinv;
+            sqrt_rsqrt(piv, dj, rinv);
+            const double lij = (lane == gj) ? dj : a[j] * rinv;
+            a[j] = lij;
+            double *colb = cb + (j & 1) * TS;  // two alternating broadcast lines (LDS is in-order per wave)
+            colb[lane] = lij;
+            if (lane == gj) rd[gj] = rinv;
+#pragma unroll
+            for (int c = j + 1; c < 16; c++) a[c] = __builtin_fma(-lij, colb[jb * 16 + c], a[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; c++) T[lane * TLD + jb * 16 + c] = ((jb * 16 + c) <= lane) ? a[c] : 0.0;
+#pragma unroll 1
+        for (int sb = jb + 1; sb < 4; sb++) {
+            double a2[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) a2[c] = T[lane * TLD + sb * 16 + c];
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+#pragma unroll
+                for (int c = 0; c < 16; c++)
+                    a2[c] = __builtin_fma(-a[k], T[(sb * 16 + c) * TLD + jb * 16 + k], a2[c]);
+#pragma unroll
+            for (int c = 0; c < 16; c++) T[lane * TLD + sb * 16 + c] = a2[c];
+        }
+    }
+}
+
+// One wave: X = L^-1 (lower) for the factored tile T; row `lane` of X per lane, into X (LDS, stride TLD).
+__device__ __forceinline__ void wave_inv_64(const double *T, const double *rd, double *X, int lane) {
+#pragma unroll 1
+    for (int cb = 3; cb >= 0; cb--) {
+        double x[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) x[c] = (lane == cb * 16 + c) ? 1.0 : 0.0;
+#pragma unroll 1
+        for (int kb = 3; kb > cb; kb--) {
+            double xk[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) xk[k] = X[lane * TLD + kb * 16 + k];
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+#pragma unroll
+                for (int c = 0; c < 16; c++)
+                    x[c] = __builtin_fma(-xk[k], T[(kb * 16 + k) * TLD + cb * 16 + c], x[c]);
+        }
+#pragma unroll
+        for (int c = 15; c >= 0; c--) {
+            double sacc = x[c];
+#pragma unroll
+            for (int k = c + 1; k < 16; k++) sacc = __builtin_fma(-x[k], T[(cb * 16 + k) * TLD + cb * 16 + c], sacc);
+            x[c] = sacc * rd[cb * 16 + c];
+        }
+#pragma unroll
+        for (int c = 0; c < 16; c++) X[lane * TLD + cb * 16 + c] = x[c];
+    }
+}
+
 __global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, int64_t ld, int nbk,
                                                         double *__restrict__ dinv, int *__restrict__ info,
                                                         int col0, int n_valid) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *Ls = sm;                // factor of the current diagonal tile, [64][65]
-    double *stage = sm + TS * TLD;  // MFMA staging (2 x (64+64) x 18 doubles)
+    double *Ls = sm;                 // current diagonal tile / its factor, [64][65]
+    double *cb = sm + TS * TLD;      // 2 x 64 broadcast lines
+    double *rd = cb + 2 * TS;        // 64 reciprocal diagonal entries
+    double *stage = sm + POTF2_AUX;  // MFMA staging; aliased by the inverse scratch X [64][65]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int nt = nbk / TS;
     for (int s = 0; s < nt; s++) {
-        // ---- step 1: wave 0 factors tile (s,s) in registers: lane i holds row i
-        if (wave == 0) {
-            double a[TS];
-            const double *src = D + (int64_t)(s * TS + lane) * ld + s * TS;
-#pragma unroll
-            for (int c = 0; c < TS; c++) a[c] = src[c];
-#pragma unroll
-            for (int j = 0; j < TS; j++) {
-                double piv = readlane_d(a[j], j);
-                if (!(piv > 0.0) || !(piv < 1.0e300)) {  // wave-uniform: NaN, inf or non-positive pivot
-                    if (lane == 0 && (col0 + s * TS + j) < n_valid) atomicCAS(info, 0, col0 + s * TS + j + 1);
-                    piv = 1.0;
-                }
-                double dj, rinv;
-                sqrt_rsqrt(piv, dj, rinv);
-                const double lij = (lane == j) ? dj : a[j] * rinv;
-                a[j] = lij;
-#pragma unroll
-                for (int c = j + 1; c < TS; c++) {
-                    const double lcj = readlane_d(lij, c);
-                    a[c] = __builtin_fma(-lij, lcj, a[c]);
-                }
-            }
-            double *dst = D + (int64_t)(s * TS + lane) * ld + s * TS;
-#pragma unroll
-            for (int c = 0; c < TS; c++) {
-                const double v = (c <= lane) ? a[c] : 0.0;
-                dst[c] = v;
-                Ls[lane * TLD + c] = v;
+        EGX_STAMP(0);
+        // ---- stage tile (s,s) into LDS (coalesced 16-byte pieces)
+        {
+            const double *src = D + (int64_t)(s * TS) * ld + s * TS;
+            for (int e = tid; e < TS * (TS / 2); e += 256) {
+                const int row = e >> 5, c2 = e & 31;
+                const d2_t v = *reinterpret_cast<const d2_t *>(src + (int64_t)row * ld + c2 * 2);
+                Ls[row * TLD + c2 * 2] = v[0];
+                Ls[row * TLD + c2 * 2 + 1] = v[1];
             }
         }
         __syncthreads();
-        // ---- step 2
-        if (wave == 3) {
-            double x[TS];
-#pragma unroll
-            for (int c = TS - 1; c >= 0; c--) {
-                // two interleaved partial sums halve the dependent-FMA chain
-                double s0 = (lane == c) ? 1.0 : 0.0, s1 = 0.0;
-#pragma unroll
-                for (int k = c + 1; k + 1 < TS; k += 2) {
-                    s0 = __builtin_fma(-x[k], Ls[k * TLD + c], s0);
-                    s1 = __builtin_fma(-x[k + 1], Ls[(k + 1) * TLD + c], s1);
-                }
-                if (((TS - 1 - c) & 1) != 0) s0 = __builtin_fma(-x[TS - 1], Ls[(TS - 1) * TLD + c], s0);
-                x[c] = (s0 + s1) / Ls[c * TLD + c];
-            }
-            double *dst = dinv + (int64_t)s * 4096 + lane * TS;
-#pragma unroll
-            for (int c = 0; c < TS; c++) dst[c] = x[c];
-        } else {
-            const int t = s + 1 + wave;
-            if (t < nt) {
-                double a[TS];
-                double *rowp = D + (int64_t)(t * TS + lane) * ld + s * TS;
-#pragma unroll
-                for (int c = 0; c < TS; c++) a[c] = rowp[c];
-#pragma unroll
-                for (int c = 0; c < TS; c++) {
-                    double v0 = a[c], v1 = 0.0;
-#pragma unroll
-                    for (int k = 0; k + 1 < c; k += 2) {
-                        v0 = __builtin_fma(-a[k], Ls[c * TLD + k], v0);
-                        v1 = __builtin_fma(-a[k + 1], Ls[c * TLD + k + 1], v1);
-                    }
-                    if ((c & 1) != 0) v0 = __builtin_fma(-a[c - 1], Ls[c * TLD + c - 1], v0);
-                    a[c] = (v0 + v1) / Ls[c * TLD + c];
-                }
-#pragma unroll
-                for (int c = 0; c < TS; c++) rowp[c] = a[c];
+        // ---- steps 1+2: wave 0 factors and inverts the tile
+        if (wave == 0) {
+            wave_potf2_64(Ls, cb, rd, lane, info, col0 + s * TS, n_valid);
+            wave_inv_64(Ls, rd, stage, lane);
+        }
+        __syncthreads();
+        EGX_STAMP(1);
+        // ---- write the factor back (upper part zeroed) and the inverse to dinv
+        {
+            double *dstL = D + (int64_t)(s * TS) * ld + s * TS;
+            double *dstI = dinv + (int64_t)s * 4096;
+            for (int e = tid; e < TS * (TS / 2); e += 256) {
+                const int row = e >> 5, c2 = e & 31;
+                d2_t v, w;
+                v[0] = Ls[row * TLD + c2 * 2];
+                v[1] = Ls[row * TLD + c2 * 2 + 1];
+                w[0] = stage[row * TLD + c2 * 2];
+                w[1] = stage[row * TLD + c2 * 2 + 1];
+                *reinterpret_cast<d2_t *>(dstL + (int64_t)row * ld + c2 * 2) = v;
+                *reinterpret_cast<d2_t *>(dstI + row * TS + c2 * 2) = w;
             }
         }
-        __syncthreads();  // X tiles visible (workgroup scope) before the MFMA core reads them from global
-        // ---- step 3: A(t,u) -= X_t X_u^T for s < u <= t < nt, all four waves per tile pair
+        __syncthreads();  // dinv visible (workgroup scope); the staging area is free again
+        EGX_STAMP(2);
+        // ---- step 3: tiles below:  X_t = A(t,s) Linv^T  (in place)
+        for (int t = s + 1; t < nt; t++) {
+            double4_t acc[1][4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+            double *At = D + (int64_t)t * TS * ld + s * TS;
+            gemm_core<64, 64, 16, 64>(At, ld, dinv + (int64_t)s * 4096, TS, TS, acc, stage, tid);
+            double *xt = At + (int64_t)(wave * 16 + (lane >> 4)) * ld + (lane & 15);
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) xt[(int64_t)(4 * r) * ld + ni * 16] = acc[0][ni][r];
+        }
+        __syncthreads();  // X tiles visible before they are re-read as MFMA operands
+        EGX_STAMP(3);
+        // ---- step 4: A(t,u) -= X_t X_u^T for s < u <= t < nt
         for (int t = s + 1; t < nt; t++)
             for (int u = s + 1; u <= t; u++) {
                 double4_t acc[1][4];
@@ -352,6 +420,7 @@ __global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, 
                     for (int r = 0; r < 4; r++) ct[(int64_t)(4 * r) * ld + ni * 16] = cv[ni][r] - acc[0][ni][r];
             }
         __syncthreads();
+        EGX_STAMP(4);
     }
 }
 

@@ -252,7 +252,7 @@ def test_config2_dense_sqexp_n4096_d8(egx, O):
         xq = np.random.default_rng(3).random((1000, 8))
         yr, vr = ref.predict(xq), ref.predict_var(xq)
         np.testing.assert_allclose(h.predict(xq), yr, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(yr).max())
-        np.testing.assert_allclose(h.predict_var(xq), vr, rtol=1e-5, atol=1e-5 * vr.max())
+        np.testing.assert_allclose(h.predict_var(xq), vr, rtol=100 * tol, atol=100 * tol * vr.max())
 
 
 def test_config2_size_well_conditioned_matern(egx, O):
