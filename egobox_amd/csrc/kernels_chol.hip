@@ -137,37 +137,38 @@ __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t 
 // C: trailing update / general  C -= A B^T.  grid = (M/128, N/128).
 // ---------------------------------------------------------------------------------------------
 using TrailShape = GemmShape<128, 128, 64, 64>;
+using SmallShape = GemmShape<64, 64, 32, 32>;  // 4x lower per-tile latency: look-ahead column + small trailing matrices
 
-template <bool LOWER>
+template <bool LOWER, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_sub(double *__restrict__ C, int64_t ldc,
                                                         const double *__restrict__ A, int64_t lda,
                                                         const double *__restrict__ B, int64_t ldb, int K) {
+    using S = GemmShape<BM, BN, WM, WN>;
     const int bx = blockIdx.x, by = blockIdx.y;
-    if (LOWER && bx < by) return;
+    if (LOWER && (bx + 1) * BM <= by * BN) return;  // tile entirely above the diagonal
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
-    double4_t acc[4][4];
+    double4_t acc[S::MT][S::NT];
 #pragma unroll
-    for (int mi = 0; mi < 4; mi++)
+    for (int mi = 0; mi < S::MT; mi++)
 #pragma unroll
-        for (int ni = 0; ni < 4; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-    gemm_core<128, 128, 64, 64>(A + (int64_t)bx * 128 * lda, lda, B + (int64_t)by * 128 * ldb, ldb, K,
-                                acc, smem, tid);
+        for (int ni = 0; ni < S::NT; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm_core<BM, BN, WM, WN>(A + (int64_t)bx * BM * lda, lda, B + (int64_t)by * BN * ldb, ldb, K, acc, smem, tid);
     const int wave = tid >> 6, lane = tid & 63;
-    const int r0 = bx * 128 + (wave >> 1) * 64 + (lane >> 4);
-    const int c0 = by * 128 + (wave & 1) * 64 + (lane & 15);
-    // read-modify-write of the C tile in batches of 16 independent loads (a naive `*p -= acc` chain
+    const int r0 = bx * BM + (wave / S::WAVES_N) * WM + (lane >> 4);
+    const int c0 = by * BN + (wave % S::WAVES_N) * WN + (lane & 15);
+    // read-modify-write of the C tile in batches of independent loads (a naive `*p -= acc` chain
     // serialises on vmcnt(0) per element: measured 2x on the whole kernel)
 #pragma unroll
-    for (int mi = 0; mi < 4; mi++) {
-        double cv[4][4];
+    for (int mi = 0; mi < S::MT; mi++) {
+        double cv[S::NT][4];
 #pragma unroll
-        for (int ni = 0; ni < 4; ni++)
+        for (int ni = 0; ni < S::NT; ni++)
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 cv[ni][r] = C[(int64_t)(r0 + mi * 16 + 4 * r) * ldc + (c0 + ni * 16)];
 #pragma unroll
-        for (int ni = 0; ni < 4; ni++)
+        for (int ni = 0; ni < S::NT; ni++)
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 C[(int64_t)(r0 + mi * 16 + 4 * r) * ldc + (c0 + ni * 16)] = cv[ni][r] - acc[mi][ni][r];
@@ -264,39 +265,48 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double &d, double &r) {
     r = y;
 }
 
-// One wave: in-place lower Cholesky of the 64x64 tile T (LDS, row stride TLD), row `lane` per lane.
-__device__ __forceinline__ void wave_potf2_64(double *T, double *cb, double *rd, int lane, int *info, int gcol0,
-                                              int n_valid) {
+// Workgroup (4 waves): in-place lower Cholesky of the 64x64 tile T (LDS, row stride TLD), matrix row `lane`
+// per lane.  Per 16-column strip: wave 0 factors the strip (sequential in the 16 columns: pivot by v_readlane,
+// multipliers through a broadcast LDS line), then waves 0..2 each update one of the remaining strips.
+__device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, int tid, int *info, int gcol0,
+                                            int n_valid) {
+    const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll 1
     for (int jb = 0; jb < 4; jb++) {
-        double a[16];
+        if (wave == 0) {
+            double a[16];
 #pragma unroll
-        for (int c = 0; c < 16; c++) a[c] = T[lane * TLD + jb * 16 + c];
+            for (int c = 0; c < 16; c++) a[c] = T[lane * TLD + jb * 16 + c];
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int gj = jb * 16 + j;
-            double piv = readlane_d(a[j], gj);
-            if (!(piv > 0.0) || !(piv < 1.0e300)) {  // wave-uniform: NaN, inf or non-positive pivot
-                if (lane == 0 && (gcol0 + gj) < n_valid) atomicCAS(info, 0, gcol0 + gj + 1);
-                piv = 1.0;
+            for (int j = 0; j < 16; j++) {
+                const int gj = jb * 16 + j;
+                double piv = readlane_d(a[j], gj);
+                if (!(piv > 0.0) || !(piv < 1.0e300)) {  // wave-uniform: NaN, inf or non-positive pivot
+                    if (lane == 0 && (gcol0 + gj) < n_valid) atomicCAS(info, 0, gcol0 + gj + 1);
+                    piv = 1.0;
+                }
+                double dj, rinv;
+                sqrt_rsqrt(piv, dj, rinv);
+                const double lij = (lane == gj) ? dj : a[j] * rinv;
+                a[j] = lij;
+                double *colb = cb + (j & 1) * TS;  // two alternating broadcast lines (LDS is in-order per wave)
+                colb[lane] = lij;
+                if (lane == gj) rd[gj] = rinv;
+#pragma unroll
+                for (int c = j + 1; c < 16; c++) a[c] = __builtin_fma(-lij, colb[jb * 16 + c], a[c]);
             }
-            double dj, rinv;
-            sqrt_rsqrt(piv, dj, rinv);
-            const double lij = (lane == gj) ? dj : a[j] * rinv;
-            a[j] = lij;
-            double *colb = cb + (j & 1) * TS;  // two alternating broadcast lines (LDS is in-order per wave)
-            colb[lane] = lij;
-            if (lane == gj) rd[gj] = rinv;
 #pragma unroll
-            for (int c = j + 1; c < 16; c++) a[c] = __builtin_fma(-lij, colb[jb * 16 + c], a[c]);
+            for (int c = 0; c < 16; c++) T[lane * TLD + jb * 16 + c] = ((jb * 16 + c) <= lane) ? a[c] : 0.0;
         }
+        __syncthreads();
+        const int sb = jb + 1 + wave;
+        if (sb < 4) {
+            double a[16], a2[16];
 #pragma unroll
-        for (int c = 0; c < 16; c++) T[lane * TLD + jb * 16 + c] = ((jb * 16 + c) <= lane) ? a[c] : 0.0;
-#pragma unroll 1
-        for (int sb = jb + 1; sb < 4; sb++) {
-            double a2[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) a2[c] = T[lane * TLD + sb * 16 + c];
+            for (int c = 0; c < 16; c++) {
+                a[c] = T[lane * TLD + jb * 16 + c];
+                a2[c] = T[lane * TLD + sb * 16 + c];
+            }
 #pragma unroll
             for (int k = 0; k < 16; k++)
 #pragma unroll
@@ -305,36 +315,52 @@ __device__ __forceinline__ void wave_potf2_64(double *T, double *cb, double *rd,
 #pragma unroll
             for (int c = 0; c < 16; c++) T[lane * TLD + sb * 16 + c] = a2[c];
         }
+        __syncthreads();
     }
 }
 
-// One wave: X = L^-1 (lower) for the factored tile T; row `lane` of X per lane, into X (LDS, stride TLD).
-__device__ __forceinline__ void wave_inv_64(const double *T, const double *rd, double *X, int lane) {
+// Workgroup: X = L^-1 (lower) for the factored tile T; row `lane` of X per lane, into X (LDS, stride TLD).
+// Strips of 16 columns from the right; the contributions of the already finished strips are split over the
+// four waves (4 columns each), the short in-strip back substitution is done by wave 0.
+__device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, double *X, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll 1
-    for (int cb = 3; cb >= 0; cb--) {
-        double x[16];
+    for (int cbk = 3; cbk >= 0; cbk--) {
+        {
+            double x4[4];
 #pragma unroll
-        for (int c = 0; c < 16; c++) x[c] = (lane == cb * 16 + c) ? 1.0 : 0.0;
+            for (int cc = 0; cc < 4; cc++) x4[cc] = (lane == cbk * 16 + wave * 4 + cc) ? 1.0 : 0.0;
 #pragma unroll 1
-        for (int kb = 3; kb > cb; kb--) {
-            double xk[16];
+            for (int kb = 3; kb > cbk; kb--) {
+                double xk[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) xk[k] = X[lane * TLD + kb * 16 + k];
+                for (int k = 0; k < 16; k++) xk[k] = X[lane * TLD + kb * 16 + k];
 #pragma unroll
-            for (int k = 0; k < 16; k++)
+                for (int k = 0; k < 16; k++)
 #pragma unroll
-                for (int c = 0; c < 16; c++)
-                    x[c] = __builtin_fma(-xk[k], T[(kb * 16 + k) * TLD + cb * 16 + c], x[c]);
+                    for (int cc = 0; cc < 4; cc++)
+                        x4[cc] = __builtin_fma(-xk[k], T[(kb * 16 + k) * TLD + cbk * 16 + wave * 4 + cc], x4[cc]);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) X[lane * TLD + cbk * 16 + wave * 4 + cc] = x4[cc];
         }
+        __syncthreads();
+        if (wave == 0) {
+            double x[16];
 #pragma unroll
-        for (int c = 15; c >= 0; c--) {
-            double sacc = x[c];
+            for (int c = 0; c < 16; c++) x[c] = X[lane * TLD + cbk * 16 + c];
 #pragma unroll
-            for (int k = c + 1; k < 16; k++) sacc = __builtin_fma(-x[k], T[(cb * 16 + k) * TLD + cb * 16 + c], sacc);
-            x[c] = sacc * rd[cb * 16 + c];
+            for (int c = 15; c >= 0; c--) {
+                double sacc = x[c];
+#pragma unroll
+                for (int k = c + 1; k < 16; k++)
+                    sacc = __builtin_fma(-x[k], T[(cbk * 16 + k) * TLD + cbk * 16 + c], sacc);
+                x[c] = sacc * rd[cbk * 16 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 16; c++) X[lane * TLD + cbk * 16 + c] = x[c];
         }
-#pragma unroll
-        for (int c = 0; c < 16; c++) X[lane * TLD + cb * 16 + c] = x[c];
+        __syncthreads();
     }
 }
 
@@ -361,12 +387,9 @@ __global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, 
             }
         }
         __syncthreads();
-        // ---- steps 1+2: wave 0 factors and inverts the tile
-        if (wave == 0) {
-            wave_potf2_64(Ls, cb, rd, lane, info, col0 + s * TS, n_valid);
-            wave_inv_64(Ls, rd, stage, lane);
-        }
-        __syncthreads();
+        // ---- steps 1+2: factor and invert the tile (all four waves, see wg_potf2_64 / wg_inv_64)
+        wg_potf2_64(Ls, cb, rd, tid, info, col0 + s * TS, n_valid);
+        wg_inv_64(Ls, rd, stage, tid);
         EGX_STAMP(1);
         // ---- write the factor back (upper part zeroed) and the inverse to dinv
         {
@@ -439,6 +462,7 @@ __global__ __launch_bounds__(256) void k_trsv_t_diag(const double *__restrict__ 
     for (int c = nt - 1; c >= 0; c--) {
         double part = 0.0;
         for (int t = c + 1; t < nt; t++)
+#pragma unroll
             for (int ii = 0; ii < 16; ii++) {
                 const int i = g + 4 * ii;
                 part = __builtin_fma(Dg[(int64_t)(t * 64 + i) * ld + c * 64 + j], xs[t * 64 + i], part);
@@ -449,6 +473,7 @@ __global__ __launch_bounds__(256) void k_trsv_t_diag(const double *__restrict__ 
         __syncthreads();
         part = 0.0;
         const double *li = dinv + (int64_t)c * 4096;
+#pragma unroll
         for (int ii = 0; ii < 16; ii++) {
             const int i = g + 4 * ii;
             part = __builtin_fma(li[i * 64 + j], ws[i], part);
@@ -472,7 +497,13 @@ __global__ __launch_bounds__(256) void k_gemv_t_update(const double *__restrict_
     if (tid < nbk) xs[tid] = x[tid];
     __syncthreads();
     double part = 0.0;
-    for (int i = g; i < nbk; i += 4) part = __builtin_fma(Mrow[(int64_t)i * ld + j], xs[i], part);
+    for (int i0 = g; i0 < nbk; i0 += 64) {  // nbk is a multiple of 64: 16 independent loads in flight
+        double mv[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) mv[u] = Mrow[(int64_t)(i0 + 4 * u) * ld + j];
+#pragma unroll
+        for (int u = 0; u < 16; u++) part = __builtin_fma(mv[u], xs[i0 + 4 * u], part);
+    }
     red[g][jl] = part;
     __syncthreads();
     if (g == 0) v[j] -= ((red[0][jl] + red[1][jl]) + red[2][jl]) + red[3][jl];
@@ -501,9 +532,9 @@ int chol_init() {
     if (g_init_done) return EGX_SUCCESS;
     EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2_block),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<true>),
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 128, 64, 64>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, TrailShape::LDS_BYTES));
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<false>),
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 128, 64, 64>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, TrailShape::LDS_BYTES));
     EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel_trsm),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, PanelShape::LDS_BYTES));
@@ -511,6 +542,8 @@ int chol_init() {
     return EGX_SUCCESS;
 }
 
+// Tile shape: 128x128 (64x64 per wave) when the launch fills the chip, 64x64 (32x32 per wave) otherwise: a
+// 128x128xK tile is one wave-chain of K/4*16 MFMAs (~43 us at K = 256), so small grids are latency bound.
 int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
                        const double *B, int64_t ldb, int M, int N, int K, int lower) {
     if (M <= 0 || N <= 0 || K <= 0) return EGX_SUCCESS;
@@ -518,11 +551,26 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         set_error("gemm_nt_sub: M,N must be multiples of 128 and K of 16");
         return EGX_ERR_INVALID_VALUE;
     }
-    dim3 grid(M / 128, N / 128);
-    if (lower)
-        hipLaunchKernelGGL(k_gemm_nt_sub<true>, grid, dim3(256), TrailShape::LDS_BYTES, s, C, ldc, A, lda, B, ldb, K);
-    else
-        hipLaunchKernelGGL(k_gemm_nt_sub<false>, grid, dim3(256), TrailShape::LDS_BYTES, s, C, ldc, A, lda, B, ldb, K);
+    const int64_t big_tiles = lower ? ((int64_t)(M / 128) * (N / 128) - (int64_t)(N / 128) * (N / 128 - 1) / 2)
+                                    : (int64_t)(M / 128) * (N / 128);
+    const bool small = big_tiles < 1024;  // fewer than 2 waves of workgroups over 256 CUs x 2
+    if (small) {
+        dim3 grid(M / 64, N / 64);
+        if (lower)
+            hipLaunchKernelGGL((k_gemm_nt_sub<true, 64, 64, 32, 32>), grid, dim3(256), SmallShape::LDS_BYTES, s, C, ldc, A,
+                               lda, B, ldb, K);
+        else
+            hipLaunchKernelGGL((k_gemm_nt_sub<false, 64, 64, 32, 32>), grid, dim3(256), SmallShape::LDS_BYTES, s, C, ldc,
+                               A, lda, B, ldb, K);
+    } else {
+        dim3 grid(M / 128, N / 128);
+        if (lower)
+            hipLaunchKernelGGL((k_gemm_nt_sub<true, 128, 128, 64, 64>), grid, dim3(256), TrailShape::LDS_BYTES, s, C, ldc,
+                               A, lda, B, ldb, K);
+        else
+            hipLaunchKernelGGL((k_gemm_nt_sub<false, 128, 128, 64, 64>), grid, dim3(256), TrailShape::LDS_BYTES, s, C, ldc,
+                               A, lda, B, ldb, K);
+    }
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }
@@ -552,13 +600,14 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
                                (const double *)dtiles, nbk);
     };
     auto blk = [&](int k0) { return (n_pad - k0 < kNB) ? (n_pad - k0) : kNB; };
-    const bool look = (s2 != nullptr);
     panel(s, 0, blk(0));
     for (int k0 = 0; k0 < n_pad; k0 += kNB) {
         const int nbk = blk(k0);
         const int r1 = k0 + nbk;  // first row/col of the trailing matrix
         if (r1 >= n_pad) break;   // (right-hand-side rows below the last block were solved by its panel)
         const int nb1 = blk(r1);
+        // the cross-stream hand-off costs ~2 x 10 us; below ~3k trailing columns RU_k is shorter than that
+        const bool look = (s2 != nullptr) && (n_pad - r1 - nb1 >= 3072);
         const double *pan = M + (int64_t)r1 * ld + k0;
         // LU_k: next block column only
         rc = launch_gemm_nt_sub(s, M + (int64_t)r1 * ld + r1, ld, pan, ld, pan, ld, m_tot - r1, nb1, nbk, 1);
