@@ -53,61 +53,64 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 constexpr int KC = 16;      // K chunk staged per iteration
 constexpr int LDS_LD = 18;  // doubles per staged tile row (16 + 2 pad): conflict-free ds_read_b64
 
-template <int ROWS>
+template <int ROWS, int NT>
 __device__ __forceinline__ void tile_load_regs(const double *__restrict__ g, int64_t ld, int k0,
-                                               d2_t (&r)[ROWS / 32], int tid) {
+                                               d2_t (&r)[ROWS * 8 / NT], int tid) {
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; i++) {
-        int p = tid + 256 * i;
+    for (int i = 0; i < ROWS * 8 / NT; i++) {
+        int p = tid + NT * i;
         int row = p >> 3, part = p & 7;
         r[i] = *reinterpret_cast<const d2_t *>(g + (int64_t)row * ld + k0 + part * 2);
     }
 }
-template <int ROWS>
-__device__ __forceinline__ void tile_store_lds(double *s, const d2_t (&r)[ROWS / 32], int tid) {
+template <int ROWS, int NT>
+__device__ __forceinline__ void tile_store_lds(double *s, const d2_t (&r)[ROWS * 8 / NT], int tid) {
 #pragma unroll
-    for (int i = 0; i < ROWS / 32; i++) {
-        int p = tid + 256 * i;
+    for (int i = 0; i < ROWS * 8 / NT; i++) {
+        int p = tid + NT * i;
         int row = p >> 3, part = p & 7;
         *reinterpret_cast<d2_t *>(s + row * LDS_LD + part * 2) = r[i];
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+// A single wave can issue v_mfma_f64_16x16x4_f64 only at ~46 % of the pipe rate; two MFMA-ready waves on a
+// SIMD reach 99 % (tools/fp64_peak.hip, profiles/r01_fp64_peak_microbench.txt).  The big trailing-update tile
+// therefore uses 8 waves per workgroup with 32x64 wave tiles (<= 128 VGPRs) so that 4 waves share a SIMD.
+template <int BM, int BN, int WM, int WN, int NTHREADS = 256>
 struct GemmShape {
     static constexpr int MT = WM / 16, NT = WN / 16;
     static constexpr int WAVES_N = BN / WN;
     static constexpr int A_TILE = BM * LDS_LD, B_TILE = BN * LDS_LD;
     static constexpr int STAGE = A_TILE + B_TILE;
     static constexpr int LDS_BYTES = 2 * STAGE * 8;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-    static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows per load pass");
+    static_assert((BM / WM) * (BN / WN) * 64 == NTHREADS, "one wave per wave tile");
+    static_assert((BM * 8) % NTHREADS == 0 && (BN * 8) % NTHREADS == 0, "tile rows per load pass");
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NTHREADS = 256>
 __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t lda,
                                           const double *__restrict__ B, int64_t ldb, int K,
                                           double4_t (&acc)[WM / 16][WN / 16], double *smem, int tid) {
-    using S = GemmShape<BM, BN, WM, WN>;
+    using S = GemmShape<BM, BN, WM, WN, NTHREADS>;
     const int nchunks = K / KC;
     if (nchunks <= 0) return;
     const int wave = tid >> 6, lane = tid & 63;
     const int wm0 = (wave / S::WAVES_N) * WM, wn0 = (wave % S::WAVES_N) * WN;
     const int frow = lane & 15, fk = lane >> 4;
 
-    d2_t ra[BM / 32], rb[BN / 32];
-    tile_load_regs<BM>(A, lda, 0, ra, tid);
-    tile_load_regs<BN>(B, ldb, 0, rb, tid);
-    tile_store_lds<BM>(smem, ra, tid);
-    tile_store_lds<BN>(smem + S::A_TILE, rb, tid);
+    d2_t ra[BM * 8 / NTHREADS], rb[BN * 8 / NTHREADS];
+    tile_load_regs<BM, NTHREADS>(A, lda, 0, ra, tid);
+    tile_load_regs<BN, NTHREADS>(B, ldb, 0, rb, tid);
+    tile_store_lds<BM, NTHREADS>(smem, ra, tid);
+    tile_store_lds<BN, NTHREADS>(smem + S::A_TILE, rb, tid);
     __syncthreads();
     for (int c = 0; c < nchunks; c++) {
         double *As = smem + (c & 1) * S::STAGE;
         double *Bs = As + S::A_TILE;
         const bool more = (c + 1 < nchunks);
         if (more) {
-            tile_load_regs<BM>(A, lda, (c + 1) * KC, ra, tid);
-            tile_load_regs<BN>(B, ldb, (c + 1) * KC, rb, tid);
+            tile_load_regs<BM, NTHREADS>(A, lda, (c + 1) * KC, ra, tid);
+            tile_load_regs<BN, NTHREADS>(B, ldb, (c + 1) * KC, rb, tid);
         }
 #pragma unroll
         for (int kk = 0; kk < KC / 4; kk++) {
@@ -126,8 +129,8 @@ __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t 
         }
         if (more) {
             double *An = smem + ((c + 1) & 1) * S::STAGE;
-            tile_store_lds<BM>(An, ra, tid);
-            tile_store_lds<BN>(An + S::A_TILE, rb, tid);
+            tile_store_lds<BM, NTHREADS>(An, ra, tid);
+            tile_store_lds<BN, NTHREADS>(An + S::A_TILE, rb, tid);
         }
         __syncthreads();
     }
@@ -136,14 +139,14 @@ __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t 
 // ---------------------------------------------------------------------------------------------
 // C: trailing update / general  C -= A B^T.  grid = (M/128, N/128).
 // ---------------------------------------------------------------------------------------------
-using TrailShape = GemmShape<128, 128, 64, 64>;
-using SmallShape = GemmShape<64, 64, 32, 32>;  // 4x lower per-tile latency: look-ahead column + small trailing matrices
+using TrailShape = GemmShape<128, 128, 32, 64, 512>;  // 8 waves, 2 workgroups per CU -> 4 MFMA waves per SIMD
+using SmallShape = GemmShape<64, 64, 32, 32, 256>;    // 4x lower per-tile latency: look-ahead column + small trailing matrices
 
-template <bool LOWER, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void k_gemm_nt_sub(double *__restrict__ C, int64_t ldc,
-                                                        const double *__restrict__ A, int64_t lda,
-                                                        const double *__restrict__ B, int64_t ldb, int K) {
-    using S = GemmShape<BM, BN, WM, WN>;
+template <bool LOWER, int BM, int BN, int WM, int WN, int NTHREADS>
+__global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt_sub(
+    double *__restrict__ C, int64_t ldc, const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
+    int64_t ldb, int K) {
+    using S = GemmShape<BM, BN, WM, WN, NTHREADS>;
     const int bx = blockIdx.x, by = blockIdx.y;
     if (LOWER && (bx + 1) * BM <= by * BN) return;  // tile entirely above the diagonal
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -153,7 +156,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_sub(double *__restrict__ C, 
     for (int mi = 0; mi < S::MT; mi++)
 #pragma unroll
         for (int ni = 0; ni < S::NT; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-    gemm_core<BM, BN, WM, WN>(A + (int64_t)bx * BM * lda, lda, B + (int64_t)by * BN * ldb, ldb, K, acc, smem, tid);
+    gemm_core<BM, BN, WM, WN, NTHREADS>(A + (int64_t)bx * BM * lda, lda, B + (int64_t)by * BN * ldb, ldb, K, acc, smem,
+                                        tid);
     const int wave = tid >> 6, lane = tid & 63;
     const int r0 = bx * BM + (wave / S::WAVES_N) * WM + (lane >> 4);
     const int c0 = by * BN + (wave % S::WAVES_N) * WN + (lane & 15);
@@ -532,9 +536,9 @@ int chol_init() {
     if (g_init_done) return EGX_SUCCESS;
     EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2_block),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 128, 64, 64>),
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 128, 32, 64, 512>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, TrailShape::LDS_BYTES));
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 128, 64, 64>),
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 128, 32, 64, 512>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, TrailShape::LDS_BYTES));
     EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel_trsm),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, PanelShape::LDS_BYTES));
@@ -557,18 +561,18 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
     if (small) {
         dim3 grid(M / 64, N / 64);
         if (lower)
-            hipLaunchKernelGGL((k_gemm_nt_sub<true, 64, 64, 32, 32>), grid, dim3(256), SmallShape::LDS_BYTES, s, C, ldc, A,
+            hipLaunchKernelGGL((k_gemm_nt_sub<true, 64, 64, 32, 32, 256>), grid, dim3(256), SmallShape::LDS_BYTES, s, C, ldc, A,
                                lda, B, ldb, K);
         else
-            hipLaunchKernelGGL((k_gemm_nt_sub<false, 64, 64, 32, 32>), grid, dim3(256), SmallShape::LDS_BYTES, s, C, ldc,
+            hipLaunchKernelGGL((k_gemm_nt_sub<false, 64, 64, 32, 32, 256>), grid, dim3(256), SmallShape::LDS_BYTES, s, C, ldc,
                                A, lda, B, ldb, K);
     } else {
         dim3 grid(M / 128, N / 128);
         if (lower)
-            hipLaunchKernelGGL((k_gemm_nt_sub<true, 128, 128, 64, 64>), grid, dim3(256), TrailShape::LDS_BYTES, s, C, ldc,
+            hipLaunchKernelGGL((k_gemm_nt_sub<true, 128, 128, 32, 64, 512>), grid, dim3(512), TrailShape::LDS_BYTES, s, C, ldc,
                                A, lda, B, ldb, K);
         else
-            hipLaunchKernelGGL((k_gemm_nt_sub<false, 128, 128, 64, 64>), grid, dim3(256), TrailShape::LDS_BYTES, s, C, ldc,
+            hipLaunchKernelGGL((k_gemm_nt_sub<false, 128, 128, 32, 64, 512>), grid, dim3(512), TrailShape::LDS_BYTES, s, C, ldc,
                                A, lda, B, ldb, K);
     }
     EGX_HIP_CHECK(hipGetLastError());

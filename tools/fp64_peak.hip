@@ -1,12 +1,14 @@
 // Micro-benchmark: sustained FP64 MFMA (v_mfma_f64_16x16x4_f64) and FP64 VALU FMA rate on gfx950.
 // Establishes the measured ceiling the Cholesky trailing update is priced against (the CDNA4 guide in this
 // image lists no FP64 matrix number; the public spec figure is 78.6 TFLOP/s for both vector and matrix FP64).
+// Every configuration is run repeatedly (>= 40 ms) after a warm-up: short runs right after idle measure the
+// DVFS ramp, not the pipe.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-template <int NACC>
-__global__ __launch_bounds__(256) void k_mfma(double *out, int iters, double a0, double b0) {
+template <int NACC, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_mfma(double *out, int iters, double a0, double b0) {
     double4_t acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; i++) acc[i] = double4_t{0, 0, 0, 0};
@@ -21,7 +23,8 @@ __global__ __launch_bounds__(256) void k_mfma(double *out, int iters, double a0,
     if (s == 12345.678) out[0] = s;
 }
 
-__global__ __launch_bounds__(256) void k_fma(double *out, int iters, double a0, double b0) {
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_fma(double *out, int iters, double a0, double b0) {
     double acc[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = i;
@@ -36,39 +39,86 @@ __global__ __launch_bounds__(256) void k_fma(double *out, int iters, double a0, 
     if (s == 12345.678) out[0] = s;
 }
 
+// half the waves of every SIMD run MFMA chains, the other half VALU FMA chains (are the two pipes additive?)
+__global__ __launch_bounds__(512) void k_mixed(double *out, int iters_mfma, int iters_fma, double a0, double b0) {
+    const int wave = threadIdx.x >> 6;
+    double s = 0;
+    if ((wave & 1) == 0) {
+        double4_t acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = double4_t{0, 0, 0, 0};
+        double a = a0 + threadIdx.x * 1e-9, b = b0;
+        for (int it = 0; it < iters_mfma; it++) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    } else {
+        double acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = i;
+        double a = a0 + threadIdx.x * 1e-9, b = b0;
+        for (int it = 0; it < iters_fma; it++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] = __builtin_fma(a, acc[i], b);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) s += acc[i];
+    }
+    if (s == 12345.678) out[0] = s;
+}
+
 template <typename F>
-static double time_ms(F f) {
+static double time_ms(F f, int reps) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    f();
+    for (int i = 0; i < reps; i++) f();  // warm-up (clock ramp)
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    f();
+    for (int i = 0; i < reps; i++) f();
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    return ms;
+    return ms / reps;
+}
+
+template <int NACC, int THREADS>
+static void run_mfma(double *out, int wg_per_cu) {
+    const int iters = 64000 / NACC;
+    const int grid = 256 * wg_per_cu;
+    double ms = time_ms([&] { hipLaunchKernelGGL((k_mfma<NACC, THREADS>), dim3(grid), dim3(THREADS), 0, 0, out, iters, 1.0, 1e-3); }, 8);
+    double flops = (double)grid * (THREADS / 64) * iters * NACC * 2048.0;
+    printf("mfma_f64_16x16x4 %2d acc, WG %3d threads, %d WG/CU (%d waves/SIMD): %6.2f TFLOP/s (%.3f ms/launch)\n", NACC, THREADS,
+           wg_per_cu, wg_per_cu * THREADS / 256, flops / ms / 1e9, ms);
 }
 
 int main() {
     double *out;
     hipMalloc(&out, 8);
-    const int iters = 4000;
-    for (int wg_per_cu = 1; wg_per_cu <= 2; wg_per_cu++) {
-        const int grid = 256 * wg_per_cu;
-        double ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<16>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0, 1e-3); });
-        double flops = (double)grid * 4 * iters * 16 * 2048.0;
-        printf("mfma_f64_16x16x4 16 acc, %d waves/SIMD: %.2f TFLOP/s (%.3f ms)\n", wg_per_cu, flops / ms / 1e9, ms);
-        ms = time_ms([&] { hipLaunchKernelGGL(k_mfma<4>, dim3(grid), dim3(256), 0, 0, out, iters * 4, 1.0, 1e-3); });
-        printf("mfma_f64_16x16x4  4 acc, %d waves/SIMD: %.2f TFLOP/s (%.3f ms)\n", wg_per_cu, flops / ms / 1e9, ms);
-    }
+    run_mfma<4, 256>(out, 1);
+    run_mfma<8, 256>(out, 1);
+    run_mfma<16, 256>(out, 1);
+    run_mfma<4, 256>(out, 2);
+    run_mfma<8, 256>(out, 2);
+    run_mfma<16, 256>(out, 2);
+    run_mfma<8, 512>(out, 1);
+    run_mfma<16, 512>(out, 1);
+    run_mfma<16, 256>(out, 1);
     for (int wg_per_cu = 1; wg_per_cu <= 4; wg_per_cu *= 2) {
-        const int grid = 256 * wg_per_cu;
-        double ms = time_ms([&] { hipLaunchKernelGGL(k_fma, dim3(grid), dim3(256), 0, 0, out, iters * 4, 1.0000001, 1e-3); });
-        double flops = (double)grid * 256 * (iters * 4.0) * 16 * 2.0;
-        printf("v_fma_f64 16 chains, %d waves/SIMD: %.2f TFLOP/s (%.3f ms)\n", wg_per_cu, flops / ms / 1e9, ms);
+        const int grid = 256 * wg_per_cu, iters = 40000;
+        double ms = time_ms([&] { hipLaunchKernelGGL(k_fma<256>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0000001, 1e-3); }, 8);
+        double flops = (double)grid * 256 * (double)iters * 16 * 2.0;
+        printf("v_fma_f64 16 chains, %d waves/SIMD: %6.2f TFLOP/s (%.3f ms/launch)\n", wg_per_cu, flops / ms / 1e9, ms);
+    }
+    {
+        const int im = 8000, iv = 16000;
+        double ms = time_ms([&] { hipLaunchKernelGGL(k_mixed, dim3(256), dim3(512), 0, 0, out, im, iv, 1.0000001, 1e-3); }, 8);
+        const double fm = 256.0 * 4 * im * 8 * 2048.0, fv = 256.0 * 4 * 64 * (double)iv * 16 * 2.0;
+        printf("mixed (4 MFMA + 4 VALU waves/CU, one of each per SIMD): %.3f ms -> mfma part %.2f + valu part %.2f TFLOP/s (upper bounds: each part "
+               "divided by the whole launch time)\n", ms, fm / ms / 1e9, fv / ms / 1e9);
     }
     return 0;
 }
