@@ -147,7 +147,34 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt
     double *__restrict__ C, int64_t ldc, const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
     int64_t ldb, int K) {
     using S = GemmShape<BM, BN, WM, WN, NTHREADS>;
-    const int bx = blockIdx.x, by = blockIdx.y;
+    // XCD-aware tile order.  Workgroup w lands on XCD w % 8 (observed dispatch order, used for speed only): give
+    // every XCD a contiguous run of the logical tile sequence, and order that sequence by 8x8 super-tiles, so
+    // the ~64 workgroups resident on one XCD share 8 A and 8 B panel blocks (4 MiB = its L2) instead of
+    // streaming the whole 33 MB panel through it (measured: 3.9 TB/s of fabric traffic, MFMA half idle).
+    int bx, by;
+    {
+        const int nbx = gridDim.x, nby = gridDim.y, nw = nbx * nby;
+        const int w = blockIdx.y * nbx + blockIdx.x;
+        const int xcd = w & 7, q = nw >> 3, r = nw & 7;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);  // bijective
+        const int nsx = (nbx + 7) >> 3, nsy = (nby + 7) >> 3;
+        const int full_rows = (nsx - 1) * 8 * nby;  // tiles in the full super-tile rows
+        int sxi, rem, h;
+        if (L < full_rows) {
+            sxi = L / (8 * nby);
+            rem = L - sxi * 8 * nby;
+            h = 8;
+        } else {
+            sxi = nsx - 1;
+            rem = L - full_rows;
+            h = nbx - 8 * (nsx - 1);
+        }
+        int syi = rem / (h * 8);
+        if (syi > nsy - 1) syi = nsy - 1;
+        const int lrem = rem - syi * h * 8;
+        bx = sxi * 8 + lrem % h;
+        by = syi * 8 + lrem / h;
+    }
     if (LOWER && (bx + 1) * BM <= by * BN) return;  // tile entirely above the diagonal
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
