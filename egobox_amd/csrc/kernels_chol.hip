@@ -142,38 +142,45 @@ __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t 
 using TrailShape = GemmShape<128, 128, 32, 64, 512>;  // 8 waves, 2 workgroups per CU -> 4 MFMA waves per SIMD
 using SmallShape = GemmShape<64, 64, 32, 32, 256>;    // 4x lower per-tile latency: look-ahead column + small trailing matrices
 
-template <bool LOWER, int BM, int BN, int WM, int WN, int NTHREADS>
+template <bool LOWER, int BM, int BN, int WM, int WN, int NTHREADS, bool SWZ>
 __global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt_sub(
     double *__restrict__ C, int64_t ldc, const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
-    int64_t ldb, int K) {
+    int64_t ldb, int K, int nbx, int nby) {
     using S = GemmShape<BM, BN, WM, WN, NTHREADS>;
-    // XCD-aware tile order.  Workgroup w lands on XCD w % 8 (observed dispatch order, used for speed only): give
-    // every XCD a contiguous run of the logical tile sequence, and order that sequence by 8x8 super-tiles, so
-    // the ~64 workgroups resident on one XCD share 8 A and 8 B panel blocks (4 MiB = its L2) instead of
-    // streaming the whole 33 MB panel through it (measured: 3.9 TB/s of fabric traffic, MFMA half idle).
+    // XCD-aware tile order (SWZ).  Workgroup w lands on XCD w % 8 (observed dispatch order, used for speed only,
+    // never for correctness).  Tiles are grouped in 8x8 super-tiles; super-tile ST goes to XCD ST % 8 and its 64
+    // tiles are the 64 workgroups resident on that XCD (2 per CU), which then share 8 A and 8 B panel blocks
+    // (4 MiB = the XCD's L2) instead of streaming the whole 33 MB panel through every L2.  For the lower-triangular
+    // update only super-tiles that touch the lower triangle are enumerated, so the eight XCDs stay balanced.
     int bx, by;
-    {
-        const int nbx = gridDim.x, nby = gridDim.y, nw = nbx * nby;
-        const int w = blockIdx.y * nbx + blockIdx.x;
-        const int xcd = w & 7, q = nw >> 3, r = nw & 7;
-        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);  // bijective
+    if (SWZ) {
+        const int w = blockIdx.x;
+        const int xcd = w & 7, q = w >> 3;
+        const int ST = (q >> 6) * 8 + xcd, local = q & 63;
         const int nsx = (nbx + 7) >> 3, nsy = (nby + 7) >> 3;
-        const int full_rows = (nsx - 1) * 8 * nby;  // tiles in the full super-tile rows
-        int sxi, rem, h;
-        if (L < full_rows) {
-            sxi = L / (8 * nby);
-            rem = L - sxi * 8 * nby;
-            h = 8;
+        int si, sj;
+        if (LOWER) {
+            const int ntri = nsy * (nsy + 1) / 2;  // rows si < nsy hold si + 1 super-tiles, later rows hold nsy
+            if (ST < ntri) {
+                si = (int)((sqrt(8.0 * ST + 1.0) - 1.0) * 0.5);
+                while (si * (si + 1) / 2 > ST) si--;
+                while ((si + 1) * (si + 2) / 2 <= ST) si++;
+                sj = ST - si * (si + 1) / 2;
+            } else {
+                si = nsy + (ST - ntri) / nsy;
+                sj = (ST - ntri) % nsy;
+            }
         } else {
-            sxi = nsx - 1;
-            rem = L - full_rows;
-            h = nbx - 8 * (nsx - 1);
+            si = ST / nsy;
+            sj = ST % nsy;
         }
-        int syi = rem / (h * 8);
-        if (syi > nsy - 1) syi = nsy - 1;
-        const int lrem = rem - syi * h * 8;
-        bx = sxi * 8 + lrem % h;
-        by = syi * 8 + lrem / h;
+        if (si >= nsx) return;
+        bx = si * 8 + (local & 7);
+        by = sj * 8 + (local >> 3);
+        if (bx >= nbx || by >= nby) return;
+    } else {
+        bx = blockIdx.x;
+        by = blockIdx.y;
     }
     if (LOWER && (bx + 1) * BM <= by * BN) return;  // tile entirely above the diagonal
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -563,9 +570,9 @@ int chol_init() {
     if (g_init_done) return EGX_SUCCESS;
     EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2_block),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 128, 32, 64, 512>),
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 128, 32, 64, 512, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, TrailShape::LDS_BYTES));
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 128, 32, 64, 512>),
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 128, 32, 64, 512, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, TrailShape::LDS_BYTES));
     EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel_trsm),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, PanelShape::LDS_BYTES));
@@ -588,19 +595,30 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
     if (small) {
         dim3 grid(M / 64, N / 64);
         if (lower)
-            hipLaunchKernelGGL((k_gemm_nt_sub<true, 64, 64, 32, 32, 256>), grid, dim3(256), SmallShape::LDS_BYTES, s, C, ldc, A,
-                               lda, B, ldb, K);
+            hipLaunchKernelGGL((k_gemm_nt_sub<true, 64, 64, 32, 32, 256, false>), grid, dim3(256), SmallShape::LDS_BYTES, s,
+                               C, ldc, A, lda, B, ldb, K, M / 64, N / 64);
         else
-            hipLaunchKernelGGL((k_gemm_nt_sub<false, 64, 64, 32, 32, 256>), grid, dim3(256), SmallShape::LDS_BYTES, s, C, ldc,
-                               A, lda, B, ldb, K);
+            hipLaunchKernelGGL((k_gemm_nt_sub<false, 64, 64, 32, 32, 256, false>), grid, dim3(256), SmallShape::LDS_BYTES,
+                               s, C, ldc, A, lda, B, ldb, K, M / 64, N / 64);
     } else {
-        dim3 grid(M / 128, N / 128);
+        const int nbx = M / 128, nby = N / 128;
+        const int nsx = (nbx + 7) / 8, nsy = (nby + 7) / 8;
+        int nst;
+        if (lower) {
+            const int tri_rows = nsx < nsy ? nsx : nsy;
+            nst = tri_rows * (tri_rows + 1) / 2 + (nsx > nsy ? (nsx - nsy) * nsy : 0);
+            if (nsx < nsy) nst = nsy * (nsy + 1) / 2;  // (not used by the factorisation: M >= N there)
+        } else {
+            nst = nsx * nsy;
+        }
+        const int per_xcd = (nst + 7) / 8;
+        dim3 grid(8 * per_xcd * 64);
         if (lower)
-            hipLaunchKernelGGL((k_gemm_nt_sub<true, 128, 128, 32, 64, 512>), grid, dim3(512), TrailShape::LDS_BYTES, s, C, ldc,
-                               A, lda, B, ldb, K);
+            hipLaunchKernelGGL((k_gemm_nt_sub<true, 128, 128, 32, 64, 512, true>), grid, dim3(512), TrailShape::LDS_BYTES, s,
+                               C, ldc, A, lda, B, ldb, K, nbx, nby);
         else
-            hipLaunchKernelGGL((k_gemm_nt_sub<false, 128, 128, 32, 64, 512>), grid, dim3(512), TrailShape::LDS_BYTES, s, C, ldc,
-                               A, lda, B, ldb, K);
+            hipLaunchKernelGGL((k_gemm_nt_sub<false, 128, 128, 32, 64, 512, true>), grid, dim3(512), TrailShape::LDS_BYTES,
+                               s, C, ldc, A, lda, B, ldb, K, nbx, nby);
     }
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
