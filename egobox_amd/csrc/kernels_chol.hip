@@ -53,14 +53,22 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 constexpr int KC = 16;      // K chunk staged per iteration
 constexpr int LDS_LD = 18;  // doubles per staged tile row (16 + 2 pad): conflict-free ds_read_b64
 
+// Global -> register staging of one K chunk of a tile.  `g` is the wave-uniform tile base (+ k0): the
+// per-thread part of the address is a 32-bit element offset so the loads use the SGPR-base + VGPR-offset form
+// (64-bit per-thread addresses cost 2 VGPRs per load and pushed the 128-VGPR trailing-update kernel into scratch).
 template <int ROWS, int NT>
-__device__ __forceinline__ void tile_load_regs(const double *__restrict__ g, int64_t ld, int k0,
-                                               d2_t (&r)[ROWS * 8 / NT], int tid) {
+__device__ __forceinline__ void tile_load_regs(const double *__restrict__ g, const unsigned (&off)[ROWS * 8 / NT],
+                                               d2_t (&r)[ROWS * 8 / NT]) {
+#pragma unroll
+    for (int i = 0; i < ROWS * 8 / NT; i++) r[i] = *reinterpret_cast<const d2_t *>(g + off[i]);
+}
+template <int ROWS, int NT>
+__device__ __forceinline__ void tile_offsets(int64_t ld, unsigned (&off)[ROWS * 8 / NT], int tid) {
 #pragma unroll
     for (int i = 0; i < ROWS * 8 / NT; i++) {
         int p = tid + NT * i;
         int row = p >> 3, part = p & 7;
-        r[i] = *reinterpret_cast<const d2_t *>(g + (int64_t)row * ld + k0 + part * 2);
+        off[i] = (unsigned)(row * (int)ld + part * 2);
     }
 }
 template <int ROWS, int NT>
@@ -99,8 +107,11 @@ __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t 
     const int frow = lane & 15, fk = lane >> 4;
 
     d2_t ra[BM * 8 / NTHREADS], rb[BN * 8 / NTHREADS];
-    tile_load_regs<BM, NTHREADS>(A, lda, 0, ra, tid);
-    tile_load_regs<BN, NTHREADS>(B, ldb, 0, rb, tid);
+    unsigned oa[BM * 8 / NTHREADS], ob[BN * 8 / NTHREADS];
+    tile_offsets<BM, NTHREADS>(lda, oa, tid);
+    tile_offsets<BN, NTHREADS>(ldb, ob, tid);
+    tile_load_regs<BM, NTHREADS>(A, oa, ra);
+    tile_load_regs<BN, NTHREADS>(B, ob, rb);
     tile_store_lds<BM, NTHREADS>(smem, ra, tid);
     tile_store_lds<BN, NTHREADS>(smem + S::A_TILE, rb, tid);
     __syncthreads();
@@ -109,8 +120,8 @@ __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t 
         double *Bs = As + S::A_TILE;
         const bool more = (c + 1 < nchunks);
         if (more) {
-            tile_load_regs<BM, NTHREADS>(A, lda, (c + 1) * KC, ra, tid);
-            tile_load_regs<BN, NTHREADS>(B, ldb, (c + 1) * KC, rb, tid);
+            tile_load_regs<BM, NTHREADS>(A + (c + 1) * KC, oa, ra);
+            tile_load_regs<BN, NTHREADS>(B + (c + 1) * KC, ob, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < KC / 4; kk++) {

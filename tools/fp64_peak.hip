@@ -98,15 +98,20 @@ static void run_mfma(double *out, int wg_per_cu) {
 int main() {
     double *out;
     hipMalloc(&out, 8);
-    run_mfma<4, 256>(out, 1);
     run_mfma<8, 256>(out, 1);
-    run_mfma<16, 256>(out, 1);
-    run_mfma<4, 256>(out, 2);
     run_mfma<8, 256>(out, 2);
-    run_mfma<16, 256>(out, 2);
+    run_mfma<8, 256>(out, 3);
+    run_mfma<8, 256>(out, 4);
+    run_mfma<8, 256>(out, 8);
     run_mfma<8, 512>(out, 1);
+    run_mfma<8, 512>(out, 2);
+    run_mfma<8, 512>(out, 4);
+    run_mfma<8, 1024>(out, 1);
+    run_mfma<8, 128>(out, 2);
+    run_mfma<8, 128>(out, 4);
+    run_mfma<8, 64>(out, 8);
     run_mfma<16, 512>(out, 1);
-    run_mfma<16, 256>(out, 1);
+    run_mfma<16, 512>(out, 2);
     for (int wg_per_cu = 1; wg_per_cu <= 4; wg_per_cu *= 2) {
         const int grid = 256 * wg_per_cu, iters = 40000;
         double ms = time_ms([&] { hipLaunchKernelGGL(k_fma<256>, dim3(grid), dim3(256), 0, 0, out, iters, 1.0000001, 1e-3); }, 8);
