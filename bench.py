@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--d", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=2,
+                    help="candidate thetas in flight per GPU and step (independent fits on separate workspaces/streams, "
+                         "like the reference's rayon multistart, crates/gp/src/algorithm.rs:928-945)")
     args = ap.parse_args()
 
     import torch
@@ -97,22 +100,33 @@ def main():
     # candidates of the theta sweep around the nominal theta (a different one every step and rank)
     base = workload.default_theta(d)
     rng = np.random.default_rng(1234)
-    total = (args.steps + args.warmup) * world
+    nb = max(1, args.batch)
+    total = (args.steps + args.warmup) * world * nb
     cands = base * 10.0 ** rng.uniform(-0.15, 0.15, size=(total, d))
 
-    gp = egx.GpHandle(x, y, mean=0, corr=0, device=local_rank, n_workspaces=1)  # uploads: inputs resident
+    # one handle (own workspace + stream pair) per in-flight candidate; uploads happen here: inputs resident
+    gps = [egx.GpHandle(x, y, mean=0, corr=0, device=local_rank, n_workspaces=1) for _ in range(nb)]
+    gp = gps[0]
     lkhs = np.zeros(total)
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(nb)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def one_fit(i, b):
+        idx = (i * world + rank) * nb + b
+        g = gps[b]
+        g.finalize(cands[idx])  # the fixed-theta fit (ctypes releases the GIL: the nb fits overlap on the GPU)
+        lkhs[idx] = g.fitted_scalars()[0]
+        return g.timings()  # struct copy of the HIP-event stage durations
+
     def step(i):
-        th = cands[i * world + rank]
-        gp.finalize(th)  # the fixed-theta fit
-        lkhs[i * world + rank] = gp.fitted_scalars()[0]
-        return gp.timings()  # struct copy of the HIP-event stage durations
+        if nb == 1:
+            return one_fit(i, 0)
+        return list(pool.map(lambda b: one_fit(i, b), range(nb)))[0]
 
     tim = []
     for i in range(args.warmup):
@@ -130,12 +144,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         from egobox_amd.sweep import sweep_likelihood
-        mine = lkhs[rank::world]
-        all_lk, _ = sweep_likelihood(lambda th: (mine, np.zeros(len(mine), dtype=np.int32)), cands, device=dev)
-        lkhs[:] = all_lk
+        lk2 = lkhs.reshape(-1, world, nb)  # (step, rank, in-flight slot)
+        rows = cands.reshape(-1, world, nb, d)
+        for b in range(nb):
+            mine = lk2[:, rank, b].copy()
+            all_lk, _ = sweep_likelihood(lambda th: (mine, np.zeros(len(mine), dtype=np.int32)),
+                                         rows[:, :, b, :].reshape(-1, d), device=dev)
+            lk2[:, :, b] = all_lk.reshape(-1, world)
 
     if rank == 0:
-        fits = args.steps * world
+        fits = args.steps * world * nb
         potrf_ms = float(np.mean([t["potrf_ms"] for t in tim]))
         corr_ms = float(np.mean([t["corr_build_ms"] for t in tim]))
         solve_ms = float(np.mean([t["solve_ms"] for t in tim]))
@@ -148,9 +166,9 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"dense GP fixed-theta fit, squared exponential, n={n} d={d}, classic LHS + "
-                                   "Griewank (BASELINE metric line / configs[2] size); one candidate theta per GPU per step",
+                                   "Griewank (BASELINE metric line / configs[2] size); --batch candidate thetas in flight per GPU per step",
                        "n": n, "d": d, "corr": "SquaredExponential", "mean": "Constant",
-                       "parallelism": f"sweep-dp{world}"},
+                       "parallelism": f"sweep-dp{world}", "fits_in_flight_per_gpu": nb},
             "cholesky_tflops": tflops,
             "stage_ms": {"corr_build": corr_ms, "potrf_fused_fwd_solve": potrf_ms, "gamma_solve": solve_ms,
                          "host_gls": host_ms},
@@ -159,13 +177,14 @@ def main():
                          "kernel": "blocked Cholesky (k_gemm_nt_sub trailing update + panel kernels), n^3/3 flops / "
                                    "HIP-event duration on the workspace stream"},
             "corr_build_gbps": tim[0]["corr_bytes"] / (corr_ms * 1e-3) / 1e9,
-            "likelihood_checksum": float(np.sum(lkhs[args.warmup * world:])),
+            "likelihood_checksum": float(np.sum(lkhs[args.warmup * world * nb:])),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, d)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    gp.close()
+    for g in gps:
+        g.close()
     if world > 1:
         dist.destroy_process_group()
 

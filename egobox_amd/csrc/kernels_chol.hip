@@ -150,6 +150,16 @@ __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t 
 // ---------------------------------------------------------------------------------------------
 // C: trailing update / general  C -= A B^T.  grid = (M/128, N/128).
 // ---------------------------------------------------------------------------------------------
+#ifdef EGX_GEMM_PROFILE
+__device__ long long g_gemm_stamps[1 << 16][4];
+#define EGX_GSTAMP(i)                                                                                     \
+    if (threadIdx.x == 0) {                                                                               \
+        g_gemm_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 0xffff][i] = (long long)wall_clock64();    \
+        if (i == 0) g_gemm_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 0xffff][3] = __smid();          \
+    }
+#else
+#define EGX_GSTAMP(i)
+#endif
 using TrailShape = GemmShape<128, 128, 32, 64, 512>;  // 8 waves, 2 workgroups per CU -> 4 MFMA waves per SIMD
 using SmallShape = GemmShape<64, 64, 32, 32, 256>;    // 4x lower per-tile latency: look-ahead column + small trailing matrices
 
@@ -196,6 +206,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt
     if (LOWER && (bx + 1) * BM <= by * BN) return;  // tile entirely above the diagonal
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
+    EGX_GSTAMP(0);
     double4_t acc[S::MT][S::NT];
 #pragma unroll
     for (int mi = 0; mi < S::MT; mi++)
@@ -203,6 +214,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt
         for (int ni = 0; ni < S::NT; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
     gemm_core<BM, BN, WM, WN, NTHREADS>(A + (int64_t)bx * BM * lda, lda, B + (int64_t)by * BN * ldb, ldb, K, acc, smem,
                                         tid);
+    EGX_GSTAMP(1);
     const int wave = tid >> 6, lane = tid & 63;
     const int r0 = bx * BM + (wave / S::WAVES_N) * WM + (lane >> 4);
     const int c0 = by * BN + (wave % S::WAVES_N) * WN + (lane & 15);
@@ -222,6 +234,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt
             for (int r = 0; r < 4; r++)
                 C[(int64_t)(r0 + mi * 16 + 4 * r) * ldc + (c0 + ni * 16)] = cv[ni][r] - acc[mi][ni][r];
     }
+    EGX_GSTAMP(2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -235,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, i
                                                        const double *__restrict__ L, int64_t ldl,
                                                        const double *__restrict__ dinv, int nbk) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double *Pw = P + (int64_t)blockIdx.x * 64 * ldp;  // this workgroup's 64 rows
     const int row = wave * 16 + (lane >> 4);          // + 4 r
@@ -417,6 +431,7 @@ __global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, 
                                                         double *__restrict__ dinv, int *__restrict__ info,
                                                         int col0, int n_valid) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    __builtin_amdgcn_s_setprio(3);   // on the look-ahead stream this workgroup shares its CU with trailing-update waves
     double *Ls = sm;                 // current diagonal tile / its factor, [64][65]
     double *cb = sm + TS * TLD;      // 2 x 64 broadcast lines
     double *rd = cb + 2 * TS;        // 64 reciprocal diagonal entries
