@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the BASELINE.json configs (bench.py stays the driver's contract).
+
+  config 2  n=4096  d=8   sq-exp      fixed-theta fits/s, Cholesky TFLOP/s, K1 GB/s
+  config 3  n=16384 d=32  Matern-5/2  likelihood evals/s, one likelihood+gradient evaluation
+  config 4  theta sweep (n=16384 d=32 sq-exp): evals/s of egx_gp_likelihood_batch on this GPU
+            (the 8-GPU run shards candidates k mod G and all-gathers, egobox_amd/sweep.py)
+  config 5  one expert n=8192 d=16: predict / predict_var on m=100000 query points
+
+Prints one JSON object per config.  Run on the GPU box:  python bench_configs.py [--quick]
+"""
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+
+
+def timeit(fn, reps):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", type=int, default=0)
+    args = ap.parse_args()
+    import egobox_amd as egx
+    from egobox_amd import workload
+    from concurrent.futures import ThreadPoolExecutor
+
+    def emit(d):
+        print(json.dumps(d), flush=True)
+
+    # ---------------- config 2
+    if args.only in (0, 2):
+        n, d = 4096, 8
+        x, y = workload.make_training_set(n, d, 42)
+        th = workload.default_theta(d)
+        hs = [egx.GpHandle(x, y) for _ in range(2)]
+        pool = ThreadPoolExecutor(2)
+        t1 = timeit(lambda: hs[0].finalize(th), 10)
+        tm = hs[0].timings()
+        t2 = timeit(lambda: list(pool.map(lambda h: h.finalize(th), hs)), 10) / 2
+        emit({"config": 2, "n": n, "d": d, "corr": "SquaredExponential", "fits_per_s_1_in_flight": 1 / t1,
+              "fits_per_s_2_in_flight": 1 / t2, "potrf_ms": tm["potrf_ms"],
+              "cholesky_tflops": tm["potrf_flops"] / tm["potrf_ms"] / 1e9, "corr_build_ms": tm["corr_build_ms"],
+              "corr_build_gbps": tm["corr_bytes"] / tm["corr_build_ms"] / 1e6})
+        for h in hs:
+            h.close()
+
+    # ---------------- config 3
+    if args.only in (0, 3):
+        n, d = 16384, 32
+        x, y = workload.make_training_set(n, d, 42)
+        th = workload.default_theta(d)
+        h = egx.GpHandle(x, y, corr=3, n_workspaces=2)
+        thetas = np.stack([th * (1 + 0.01 * i) for i in range(4)])
+        t = timeit(lambda: h.likelihood_batch(thetas), 2) / 4
+        tm = h.timings()
+        t0 = time.perf_counter()
+        lk, g, st = h.likelihood_grad(th)
+        tg = time.perf_counter() - t0
+        emit({"config": 3, "n": n, "d": d, "corr": "Matern52", "likelihood_evals_per_s_2_workspaces": 1 / t,
+              "corr_build_ms": tm["corr_build_ms"], "corr_build_gbps": tm["corr_bytes"] / tm["corr_build_ms"] / 1e6,
+              "potrf_ms": tm["potrf_ms"], "cholesky_tflops": tm["potrf_flops"] / tm["potrf_ms"] / 1e9,
+              "likelihood_plus_gradient_s": tg, "grad_status": int(st), "grad_norm": float(np.linalg.norm(g)),
+              "likelihood": lk})
+        h.close()
+
+    # ---------------- config 4
+    if args.only in (0, 4):
+        n, d = 16384, 32
+        x, y = workload.make_training_set(n, d, 42)
+        k = 16 if args.quick else 64
+        thetas = egx.theta_sweep_candidates(512, d)[:k]
+        h = egx.GpHandle(x, y, n_workspaces=2)
+        h.likelihood_batch(thetas[:2])
+        t0 = time.perf_counter()
+        lk, st = h.likelihood_batch(thetas)
+        t = time.perf_counter() - t0
+        emit({"config": 4, "n": n, "d": d, "candidates_timed": k, "of_sweep": 512, "evals_per_s_this_gpu": k / t,
+              "status_counts": {int(s): int((st == s).sum()) for s in np.unique(st)},
+              "best": float(np.max(lk[st == 0])) if (st == 0).any() else None,
+              "projected_512_evals_s_1gpu": 512 * t / k, "projected_512_evals_s_8gpu": 512 * t / k / 8})
+        h.close()
+
+    # ---------------- config 5
+    if args.only in (0, 5):
+        n, d, m = 8192, 16, (20000 if args.quick else 100000)
+        x, y = workload.make_training_set(n, d, 7)
+        th = workload.default_theta(d)
+        h = egx.GpHandle(x, y)
+        t0 = time.perf_counter()
+        h.finalize(th)
+        tfit = time.perf_counter() - t0
+        xq = np.random.default_rng(7).random((m, d))
+        h.predict(xq[:1000])
+        t0 = time.perf_counter()
+        yp = h.predict(xq)
+        tp = time.perf_counter() - t0
+        h.predict_var(xq[:1000])
+        t0 = time.perf_counter()
+        vp = h.predict_var(xq)
+        tv = time.perf_counter() - t0
+        emit({"config": 5, "n": n, "d": d, "m": m, "fit_s": tfit, "predict_points_per_s": m / tp,
+              "predict_var_points_per_s": m / tv, "predict_var_trsm_tflops": (float(n) * n * m) / tv / 1e12,
+              "var_min": float(vp.min()), "var_max": float(vp.max()), "y_mean": float(yp.mean()),
+              "projected_8_experts_8gpu_points_per_s": m / tv})
+        h.close()
+
+
+if __name__ == "__main__":
+    main()
