@@ -71,8 +71,10 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
 // rows [0, m) of RT (ld) are right-hand sides: RT <- RT * C^-T  (C = lower factor in M, n_pad cols)
 int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, const double *dinv,
                      double *RT, int64_t ldr, int m);
-// v (n_pad) <- C^-T v
-int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *dinv, double *v);
+// Wall ((n_pad/256) x 256 x 256) <- transposed inverses of the 256x256 diagonal blocks of the factor
+int launch_block_inverse(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *dinv, double *Wall);
+// v (n_pad) <- C^-T v   (needs launch_block_inverse first)
+int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *Wall, double *v);
 // C (M x N, ldc) -= A (M x K, lda) * B (N x K, ldb)^T ; lower != 0 skips tiles strictly above the diagonal
 int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
                        const double *B, int64_t ldb, int M, int N, int K, int lower);

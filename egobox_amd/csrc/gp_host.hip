@@ -31,6 +31,7 @@ struct Workspace {
     hipEvent_t ev_lu = nullptr, ev_panel = nullptr;
     double *M = nullptr;       // (m_tot x ld): correlation matrix / factor + appended RHS rows
     double *dinv = nullptr;    // (n_pad/64) x 64 x 64 inverses of the diagonal tiles
+    double *dW = nullptr;      // (n_pad/256) x 256 x 256 transposed inverses of the diagonal blocks (lazy)
     double *d_coef = nullptr;  // d x hcols
     double *d_diag = nullptr;  // n
     double *d_vec = nullptr;   // n_pad (rho -> gamma)
@@ -95,6 +96,7 @@ static int set_device(const egx_gp *gp) {
 static void free_workspace(Workspace &w) {
     if (w.M) hipFree(w.M);
     if (w.dinv) hipFree(w.dinv);
+    if (w.dW) hipFree(w.dW);
     if (w.d_coef) hipFree(w.d_coef);
     if (w.d_diag) hipFree(w.d_diag);
     if (w.d_vec) hipFree(w.d_vec);
@@ -329,6 +331,15 @@ static int eval_one(egx_gp *gp, int widx, const double *theta, int64_t theta_len
     return EGX_SUCCESS;
 }
 
+// w.d_vec <- C^-T w.d_vec  (block inverses are rebuilt: the factor in w.M has just changed)
+static int backward_solve(egx_gp *gp, Workspace &w) {
+    if (!w.dW)
+        EGX_HIP_CHECK(hipMalloc(&w.dW, sizeof(double) * (size_t)((gp->n_pad + kNB - 1) / kNB) * 65536));
+    EGX_RC(launch_block_inverse(w.stream, w.M, gp->ld, gp->n_pad, w.dinv, w.dW));
+    EGX_RC(launch_trsv_t(w.stream, w.M, gp->ld, gp->n_pad, w.dW, w.d_vec));
+    return EGX_SUCCESS;
+}
+
 static int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     std::vector<double> coef, thfull;
     int hcols = 1;
@@ -363,7 +374,7 @@ static int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     std::memcpy(w.h_vec, res.rho.data(), sizeof(double) * n);
     EGX_HIP_CHECK(hipMemcpyAsync(w.d_vec, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
     EGX_HIP_CHECK(hipEventRecord(w.ev[4], w.stream));
-    EGX_RC(launch_trsv_t(w.stream, w.M, gp->ld, n_pad, w.dinv, w.d_vec));
+    EGX_RC(backward_solve(gp, w));
     EGX_HIP_CHECK(hipMemcpyAsync(gp->d_gamma, w.d_vec, sizeof(double) * n_pad, hipMemcpyDeviceToDevice, w.stream));
     EGX_HIP_CHECK(hipMemcpyAsync(w.h_vec, w.d_vec, sizeof(double) * n_pad, hipMemcpyDeviceToHost, w.stream));
     EGX_HIP_CHECK(hipMemcpyAsync(gp->d_fit_coef, w.d_coef, sizeof(double) * coef.size(), hipMemcpyDeviceToDevice,
@@ -1051,7 +1062,7 @@ int32_t egx_gp_likelihood_grad(egx_gp *gp, const double *theta, int64_t theta_le
     std::memset(w.h_vec, 0, sizeof(double) * n_pad);
     std::memcpy(w.h_vec, res.rho.data(), sizeof(double) * n);
     EGX_HIP_CHECK(hipMemcpyAsync(w.d_vec, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
-    EGX_RC(launch_trsv_t(w.stream, w.M, gp->ld, n_pad, w.dinv, w.d_vec));
+    EGX_RC(backward_solve(gp, w));
     // W = I * C^-T  (rows of the identity as right-hand sides), then -R^-1 = 0 - W W^T (lower tiles)
     EGX_HIP_CHECK(hipMemsetAsync(gp->d_W, 0, sizeof(double) * sq, w.stream));
     {

@@ -311,9 +311,9 @@ __device__ long long g_potf2_stamps[4][5];
 constexpr int TS = 64;
 constexpr int TLD = 65;  // padded LDS row (doubles): per-lane row accesses are conflict free
 constexpr int POTF2_AUX = TS * TLD + 2 * TS + TS;  // tile + two broadcast lines + reciprocal diagonal (doubles)
-constexpr int POTF2_LDS_BYTES = POTF2_AUX * 8 + GemmShape<64, 64, 16, 64>::LDS_BYTES;
+constexpr int POTF2_LDS_BYTES = POTF2_AUX * 8 + GemmShape<64, 64, 16, 32, 512>::LDS_BYTES;
 static_assert((POTF2_AUX * 8) % 16 == 0, "MFMA staging must stay 16-byte aligned");
-static_assert(GemmShape<64, 64, 16, 64>::LDS_BYTES >= TS * TLD * 8, "inverse scratch aliases the MFMA staging");
+static_assert(GemmShape<64, 64, 16, 32, 512>::LDS_BYTES >= TS * TLD * 8, "inverse scratch aliases the MFMA staging");
 
 // sqrt(p) and 1/sqrt(p) for p > 0 (normal range): v_rsq_f64 seed + 2 Newton steps + 1 correction.
 // ~12 dependent ops instead of the ~50 of IEEE sqrt() followed by a division; error <= ~1 ulp.
@@ -328,9 +328,9 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double &d, double &r) {
     r = y;
 }
 
-// Workgroup (4 waves): in-place lower Cholesky of the 64x64 tile T (LDS, row stride TLD), matrix row `lane`
+// Workgroup (8 waves): in-place lower Cholesky of the 64x64 tile T (LDS, row stride TLD), matrix row `lane`
 // per lane.  Per 16-column strip: wave 0 factors the strip (sequential in the 16 columns: pivot by v_readlane,
-// multipliers through a broadcast LDS line), then waves 0..2 each update one of the remaining strips.
+// multipliers through a broadcast LDS line), then waves 0..5 each update half of one of the remaining strips.
 __device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, int tid, int *info, int gcol0,
                                             int n_valid) {
     const int wave = tid >> 6, lane = tid & 63;
@@ -362,21 +362,21 @@ __device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, i
             for (int c = 0; c < 16; c++) T[lane * TLD + jb * 16 + c] = ((jb * 16 + c) <= lane) ? a[c] : 0.0;
         }
         __syncthreads();
-        const int sb = jb + 1 + wave;
+        // trailing strips: wave w updates 8 columns (half a strip): strip jb + 1 + w/2, half w & 1
+        const int sb = jb + 1 + (wave >> 1), hb = (wave & 1) * 8;
         if (sb < 4) {
-            double a[16], a2[16];
+            double a[16], a2[8];
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                a[c] = T[lane * TLD + jb * 16 + c];
-                a2[c] = T[lane * TLD + sb * 16 + c];
-            }
+            for (int c = 0; c < 16; c++) a[c] = T[lane * TLD + jb * 16 + c];
+#pragma unroll
+            for (int c = 0; c < 8; c++) a2[c] = T[lane * TLD + sb * 16 + hb + c];
 #pragma unroll
             for (int k = 0; k < 16; k++)
 #pragma unroll
-                for (int c = 0; c < 16; c++)
-                    a2[c] = __builtin_fma(-a[k], T[(sb * 16 + c) * TLD + jb * 16 + k], a2[c]);
+                for (int c = 0; c < 8; c++)
+                    a2[c] = __builtin_fma(-a[k], T[(sb * 16 + hb + c) * TLD + jb * 16 + k], a2[c]);
 #pragma unroll
-            for (int c = 0; c < 16; c++) T[lane * TLD + sb * 16 + c] = a2[c];
+            for (int c = 0; c < 8; c++) T[lane * TLD + sb * 16 + hb + c] = a2[c];
         }
         __syncthreads();
     }
@@ -384,15 +384,15 @@ __device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, i
 
 // Workgroup: X = L^-1 (lower) for the factored tile T; row `lane` of X per lane, into X (LDS, stride TLD).
 // Strips of 16 columns from the right; the contributions of the already finished strips are split over the
-// four waves (4 columns each), the short in-strip back substitution is done by wave 0.
+// eight waves (2 columns each), the short in-strip back substitution is done by wave 0.
 __device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, double *X, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll 1
     for (int cbk = 3; cbk >= 0; cbk--) {
         {
-            double x4[4];
+            double x4[2];
 #pragma unroll
-            for (int cc = 0; cc < 4; cc++) x4[cc] = (lane == cbk * 16 + wave * 4 + cc) ? 1.0 : 0.0;
+            for (int cc = 0; cc < 2; cc++) x4[cc] = (lane == cbk * 16 + wave * 2 + cc) ? 1.0 : 0.0;
 #pragma unroll 1
             for (int kb = 3; kb > cbk; kb--) {
                 double xk[16];
@@ -401,11 +401,11 @@ __device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, dou
 #pragma unroll
                 for (int k = 0; k < 16; k++)
 #pragma unroll
-                    for (int cc = 0; cc < 4; cc++)
-                        x4[cc] = __builtin_fma(-xk[k], T[(kb * 16 + k) * TLD + cbk * 16 + wave * 4 + cc], x4[cc]);
+                    for (int cc = 0; cc < 2; cc++)
+                        x4[cc] = __builtin_fma(-xk[k], T[(kb * 16 + k) * TLD + cbk * 16 + wave * 2 + cc], x4[cc]);
             }
 #pragma unroll
-            for (int cc = 0; cc < 4; cc++) X[lane * TLD + cbk * 16 + wave * 4 + cc] = x4[cc];
+            for (int cc = 0; cc < 2; cc++) X[lane * TLD + cbk * 16 + wave * 2 + cc] = x4[cc];
         }
         __syncthreads();
         if (wave == 0) {
@@ -427,7 +427,7 @@ __device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, dou
     }
 }
 
-__global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, int64_t ld, int nbk,
+__global__ __launch_bounds__(512, 2) void k_potf2_block(double *__restrict__ D, int64_t ld, int nbk,
                                                         double *__restrict__ dinv, int *__restrict__ info,
                                                         int col0, int n_valid) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, 
         // ---- stage tile (s,s) into LDS (coalesced 16-byte pieces)
         {
             const double *src = D + (int64_t)(s * TS) * ld + s * TS;
-            for (int e = tid; e < TS * (TS / 2); e += 256) {
+            for (int e = tid; e < TS * (TS / 2); e += 512) {
                 const int row = e >> 5, c2 = e & 31;
                 const d2_t v = *reinterpret_cast<const d2_t *>(src + (int64_t)row * ld + c2 * 2);
                 Ls[row * TLD + c2 * 2] = v[0];
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, 
         {
             double *dstL = D + (int64_t)(s * TS) * ld + s * TS;
             double *dstI = dinv + (int64_t)s * 4096;
-            for (int e = tid; e < TS * (TS / 2); e += 256) {
+            for (int e = tid; e < TS * (TS / 2); e += 512) {
                 const int row = e >> 5, c2 = e & 31;
                 d2_t v, w;
                 v[0] = Ls[row * TLD + c2 * 2];
@@ -472,16 +472,17 @@ __global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, 
         }
         __syncthreads();  // dinv visible (workgroup scope); the staging area is free again
         EGX_STAMP(2);
-        // ---- step 3: tiles below:  X_t = A(t,s) Linv^T  (in place)
+        // ---- step 3: tiles below:  X_t = A(t,s) Linv^T  (in place); 8 waves of 16x32 (two MFMA waves per SIMD)
+        const int wrow = (wave >> 1) * 16 + (lane >> 4), wcol = (wave & 1) * 32 + (lane & 15);
         for (int t = s + 1; t < nt; t++) {
-            double4_t acc[1][4];
+            double4_t acc[1][2];
 #pragma unroll
-            for (int ni = 0; ni < 4; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+            for (int ni = 0; ni < 2; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
             double *At = D + (int64_t)t * TS * ld + s * TS;
-            gemm_core<64, 64, 16, 64>(At, ld, dinv + (int64_t)s * 4096, TS, TS, acc, stage, tid);
-            double *xt = At + (int64_t)(wave * 16 + (lane >> 4)) * ld + (lane & 15);
+            gemm_core<64, 64, 16, 32, 512>(At, ld, dinv + (int64_t)s * 4096, TS, TS, acc, stage, tid);
+            double *xt = At + (int64_t)wrow * ld + wcol;
 #pragma unroll
-            for (int ni = 0; ni < 4; ni++)
+            for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) xt[(int64_t)(4 * r) * ld + ni * 16] = acc[0][ni][r];
         }
@@ -490,19 +491,19 @@ __global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, 
         // ---- step 4: A(t,u) -= X_t X_u^T for s < u <= t < nt
         for (int t = s + 1; t < nt; t++)
             for (int u = s + 1; u <= t; u++) {
-                double4_t acc[1][4];
+                double4_t acc[1][2];
 #pragma unroll
-                for (int ni = 0; ni < 4; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-                gemm_core<64, 64, 16, 64>(D + (int64_t)t * TS * ld + s * TS, ld, D + (int64_t)u * TS * ld + s * TS, ld,
-                                          TS, acc, stage, tid);
-                double *ct = D + (int64_t)(t * TS + wave * 16 + (lane >> 4)) * ld + u * TS + (lane & 15);
-                double cv[4][4];
+                for (int ni = 0; ni < 2; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+                gemm_core<64, 64, 16, 32, 512>(D + (int64_t)t * TS * ld + s * TS, ld, D + (int64_t)u * TS * ld + s * TS,
+                                               ld, TS, acc, stage, tid);
+                double *ct = D + (int64_t)(t * TS + wrow) * ld + u * TS + wcol;
+                double cv[2][4];
 #pragma unroll
-                for (int ni = 0; ni < 4; ni++)
+                for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) cv[ni][r] = ct[(int64_t)(4 * r) * ld + ni * 16];
 #pragma unroll
-                for (int ni = 0; ni < 4; ni++)
+                for (int ni = 0; ni < 2; ni++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) ct[(int64_t)(4 * r) * ld + ni * 16] = cv[ni][r] - acc[0][ni][r];
             }
@@ -513,41 +514,79 @@ __global__ __launch_bounds__(256, 1) void k_potf2_block(double *__restrict__ D, 
 
 // ---------------------------------------------------------------------------------------------
 // Backward substitution  v <- C^-T v  (gamma = C^-T rho, algorithm.rs:1034), right-looking over
-// 256-row blocks from the bottom: diagonal block solve (one workgroup) + transposed GEMV update.
+// 256-row blocks from the bottom.  The 64-step dependency chain is kept short by precomputing, once per
+// fit and for all blocks in parallel, W_b = (L_bb^-1)^T of every 256x256 diagonal block (k_block_inv256,
+// MFMA), so that the per-block solve is a single 256x256 mat-vec (k_trsv_w) followed by the transposed
+// GEMV update of the rows above (k_gemv_t_update).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_trsv_t_diag(const double *__restrict__ Dg, int64_t ld,
-                                                     const double *__restrict__ dinv, int nbk,
-                                                     double *__restrict__ v) {
-    __shared__ double xs[256];
-    __shared__ double red[4][64];
-    __shared__ double ws[64];
-    const int tid = threadIdx.x, g = tid >> 6, j = tid & 63;
-    const int nt = nbk / 64;
-    for (int c = nt - 1; c >= 0; c--) {
-        double part = 0.0;
-        for (int t = c + 1; t < nt; t++)
-#pragma unroll
-            for (int ii = 0; ii < 16; ii++) {
-                const int i = g + 4 * ii;
-                part = __builtin_fma(Dg[(int64_t)(t * 64 + i) * ld + c * 64 + j], xs[t * 64 + i], part);
-            }
-        red[g][j] = part;
-        __syncthreads();
-        if (g == 0) ws[j] = v[c * 64 + j] - (((red[0][j] + red[1][j]) + red[2][j]) + red[3][j]);
-        __syncthreads();
-        part = 0.0;
-        const double *li = dinv + (int64_t)c * 4096;
-#pragma unroll
-        for (int ii = 0; ii < 16; ii++) {
-            const int i = g + 4 * ii;
-            part = __builtin_fma(li[i * 64 + j], ws[i], part);
-        }
-        __syncthreads();
-        red[g][j] = part;
-        __syncthreads();
-        if (g == 0) xs[c * 64 + j] = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
-        __syncthreads();
+// W (256 x 256 row-major per block, upper triangular) = Linv^T built from the 64x64 tile inverses:
+//   W(c,c) = dinv_c^T ;  W(c,t) = -[ W(c, c..t-1) L(t, c..t-1)^T ] dinv_t^T   for t > c
+__global__ __launch_bounds__(512, 2) void k_block_inv256(const double *__restrict__ M, int64_t ld, int n_pad,
+                                                         const double *__restrict__ dinv, double *__restrict__ Wall) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int b = blockIdx.x, k0 = b * 256;
+    const int nbk = (n_pad - k0 < 256) ? (n_pad - k0) : 256, nt = nbk / 64;
+    const double *D = M + (int64_t)k0 * ld + k0;
+    const double *di = dinv + (int64_t)(k0 / 64) * 4096;
+    double *W = Wall + (int64_t)b * 65536;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int e = tid; e < 65536; e += 512) {  // zero + transposed diagonal tiles
+        const int j = e >> 8, i = e & 255;
+        double v = 0.0;
+        if ((j >> 6) == (i >> 6) && j < nbk) v = di[(int64_t)(j >> 6) * 4096 + (i & 63) * 64 + (j & 63)];
+        W[e] = v;
     }
+    __syncthreads();
+    const int wrow = (wave >> 1) * 16 + (lane >> 4), wcol = (wave & 1) * 32 + (lane & 15);
+    for (int dist = 1; dist < nt; dist++)
+        for (int c = 0; c + dist < nt; c++) {
+            const int t = c + dist;
+            double4_t acc[1][2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+            gemm_core<64, 64, 16, 32, 512>(W + (int64_t)c * 64 * 256 + c * 64, 256, D + (int64_t)t * 64 * ld + c * 64, ld,
+                                           dist * 64, acc, smem, tid);
+            double *wt = W + (int64_t)(c * 64 + wrow) * 256 + t * 64 + wcol;
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) wt[(4 * r) * 256 + ni * 16] = acc[0][ni][r];
+            __syncthreads();
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+            gemm_core<64, 64, 16, 32, 512>(W + (int64_t)c * 64 * 256 + t * 64, 256, di + (int64_t)t * 4096, 64, 64, acc,
+                                           smem, tid);
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) wt[(4 * r) * 256 + ni * 16] = -acc[0][ni][r];
+            __syncthreads();
+        }
+}
+
+// x = W v for one 256-block (W upper triangular): one wave per row group, lanes stride the row (coalesced)
+__global__ __launch_bounds__(256) void k_trsv_w(const double *__restrict__ W, int nbk, double *__restrict__ v) {
+    __shared__ double vs[256];
+    __shared__ double xs[256];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    vs[tid] = (tid < nbk) ? v[tid] : 0.0;
+    __syncthreads();
+    const double v0 = vs[lane], v1 = vs[lane + 64], v2 = vs[lane + 128], v3 = vs[lane + 192];
+    for (int j0 = wave * 64; j0 < wave * 64 + 64; j0 += 4) {
+        double acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const double *row = W + (int64_t)(j0 + u) * 256;
+            acc[u] = row[lane] * v0 + row[lane + 64] * v1 + row[lane + 128] * v2 + row[lane + 192] * v3;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            double a = acc[u];
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            if (lane == 0) xs[j0 + u] = a;
+        }
+    }
+    __syncthreads();
     if (tid < nbk) v[tid] = xs[tid];
 }
 
@@ -666,7 +705,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     auto panel = [&](hipStream_t st, int k0, int nbk) {
         double *diag = M + (int64_t)k0 * ld + k0;
         double *dtiles = dinv + (int64_t)(k0 / 64) * 4096;
-        hipLaunchKernelGGL(k_potf2_block, dim3(1), dim3(256), POTF2_LDS_BYTES, st, diag, ld, nbk, dtiles, info, k0,
+        hipLaunchKernelGGL(k_potf2_block, dim3(1), dim3(512), POTF2_LDS_BYTES, st, diag, ld, nbk, dtiles, info, k0,
                            n_pad);
         const int below = m_tot - (k0 + nbk);
         if (below > 0)
@@ -735,13 +774,21 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
     return EGX_SUCCESS;
 }
 
-int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *dinv, double *v) {
+int launch_block_inverse(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *dinv, double *Wall) {
+    int rc = chol_init();
+    if (rc) return rc;
+    constexpr int lds = GemmShape<64, 64, 16, 32, 512>::LDS_BYTES;
+    hipLaunchKernelGGL(k_block_inv256, dim3((n_pad + kNB - 1) / kNB), dim3(512), lds, s, M, ld, n_pad, dinv, Wall);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *Wall, double *v) {
     const int nblocks = (n_pad + kNB - 1) / kNB;
     for (int b = nblocks - 1; b >= 0; b--) {
         const int k0 = b * kNB;
         const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;
-        hipLaunchKernelGGL(k_trsv_t_diag, dim3(1), dim3(256), 0, s, M + (int64_t)k0 * ld + k0, ld,
-                           dinv + (int64_t)(k0 / 64) * 4096, nbk, v + k0);
+        hipLaunchKernelGGL(k_trsv_w, dim3(1), dim3(256), 0, s, Wall + (int64_t)b * 65536, nbk, v + k0);
         if (k0 > 0)
             hipLaunchKernelGGL(k_gemv_t_update, dim3(k0 / 64), dim3(256), 0, s, M + (int64_t)k0 * ld, ld, nbk,
                                (const double *)(v + k0), v);
