@@ -73,8 +73,9 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
                      double *RT, int64_t ldr, int m);
 // Wall ((n_pad/256) x 256 x 256) <- transposed inverses of the 256x256 diagonal blocks of the factor
 int launch_block_inverse(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *dinv, double *Wall);
-// v (n_pad) <- C^-T v   (needs launch_block_inverse first)
-int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *Wall, double *v);
+// xout (n_pad) <- C^-T v ; v (n_pad) is destroyed   (needs launch_block_inverse first)
+int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *Wall, double *v,
+                  double *xout);
 // C (M x N, ldc) -= A (M x K, lda) * B (N x K, ldb)^T ; lower != 0 skips tiles strictly above the diagonal
 int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
                        const double *B, int64_t ldb, int M, int N, int K, int lower);

@@ -34,7 +34,8 @@ struct Workspace {
     double *dW = nullptr;      // (n_pad/256) x 256 x 256 transposed inverses of the diagonal blocks (lazy)
     double *d_coef = nullptr;  // d x hcols
     double *d_diag = nullptr;  // n
-    double *d_vec = nullptr;   // n_pad (rho -> gamma)
+    double *d_vec = nullptr;   // n_pad (gamma)
+    double *d_rhs = nullptr;   // n_pad (rho, destroyed by the back-substitution)
     int *d_info = nullptr;
     double *h_coef = nullptr;  // pinned
     double *h_rows = nullptr;  // pinned: q x n_pad solved RHS rows (ft^T, yt^T)
@@ -100,6 +101,7 @@ static void free_workspace(Workspace &w) {
     if (w.d_coef) hipFree(w.d_coef);
     if (w.d_diag) hipFree(w.d_diag);
     if (w.d_vec) hipFree(w.d_vec);
+    if (w.d_rhs) hipFree(w.d_rhs);
     if (w.d_info) hipFree(w.d_info);
     if (w.h_coef) hipHostFree(w.h_coef);
     if (w.h_rows) hipHostFree(w.h_rows);
@@ -133,6 +135,7 @@ static int alloc_workspace(egx_gp *gp, Workspace &w) {
     EGX_HIP_CHECK(hipMalloc(&w.d_coef, sizeof(double) * (size_t)gp->d * hmax));
     EGX_HIP_CHECK(hipMalloc(&w.d_diag, sizeof(double) * (size_t)gp->n_pad));
     EGX_HIP_CHECK(hipMalloc(&w.d_vec, sizeof(double) * (size_t)gp->n_pad));
+    EGX_HIP_CHECK(hipMalloc(&w.d_rhs, sizeof(double) * (size_t)gp->n_pad));
     EGX_HIP_CHECK(hipMalloc(&w.d_info, sizeof(int)));
     EGX_HIP_CHECK(hipHostMalloc(&w.h_coef, sizeof(double) * (size_t)gp->d * hmax, hipHostMallocDefault));
     EGX_HIP_CHECK(hipHostMalloc(&w.h_rows, sizeof(double) * (size_t)gp->q * gp->n_pad, hipHostMallocDefault));
@@ -331,12 +334,12 @@ static int eval_one(egx_gp *gp, int widx, const double *theta, int64_t theta_len
     return EGX_SUCCESS;
 }
 
-// w.d_vec <- C^-T w.d_vec  (block inverses are rebuilt: the factor in w.M has just changed)
+// w.d_vec <- C^-T w.d_rhs  (block inverses are rebuilt: the factor in w.M has just changed)
 static int backward_solve(egx_gp *gp, Workspace &w) {
     if (!w.dW)
         EGX_HIP_CHECK(hipMalloc(&w.dW, sizeof(double) * (size_t)((gp->n_pad + kNB - 1) / kNB) * 65536));
     EGX_RC(launch_block_inverse(w.stream, w.M, gp->ld, gp->n_pad, w.dinv, w.dW));
-    EGX_RC(launch_trsv_t(w.stream, w.M, gp->ld, gp->n_pad, w.dW, w.d_vec));
+    EGX_RC(launch_trsv_t(w.stream, w.M, gp->ld, gp->n_pad, w.dW, w.d_rhs, w.d_vec));
     return EGX_SUCCESS;
 }
 
@@ -372,7 +375,7 @@ static int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     const int n = gp->n, n_pad = gp->n_pad;
     std::memset(w.h_vec, 0, sizeof(double) * n_pad);
     std::memcpy(w.h_vec, res.rho.data(), sizeof(double) * n);
-    EGX_HIP_CHECK(hipMemcpyAsync(w.d_vec, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
+    EGX_HIP_CHECK(hipMemcpyAsync(w.d_rhs, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
     EGX_HIP_CHECK(hipEventRecord(w.ev[4], w.stream));
     EGX_RC(backward_solve(gp, w));
     EGX_HIP_CHECK(hipMemcpyAsync(gp->d_gamma, w.d_vec, sizeof(double) * n_pad, hipMemcpyDeviceToDevice, w.stream));
@@ -1061,7 +1064,7 @@ int32_t egx_gp_likelihood_grad(egx_gp *gp, const double *theta, int64_t theta_le
     // gamma = C^-T rho
     std::memset(w.h_vec, 0, sizeof(double) * n_pad);
     std::memcpy(w.h_vec, res.rho.data(), sizeof(double) * n);
-    EGX_HIP_CHECK(hipMemcpyAsync(w.d_vec, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
+    EGX_HIP_CHECK(hipMemcpyAsync(w.d_rhs, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
     EGX_RC(backward_solve(gp, w));
     // W = I * C^-T  (rows of the identity as right-hand sides), then -R^-1 = 0 - W W^T (lower tiles)
     EGX_HIP_CHECK(hipMemsetAsync(gp->d_W, 0, sizeof(double) * sq, w.stream));

@@ -564,30 +564,30 @@ __global__ __launch_bounds__(512, 2) void k_block_inv256(const double *__restric
         }
 }
 
-// x = W v for one 256-block (W upper triangular): one wave per row group, lanes stride the row (coalesced)
-__global__ __launch_bounds__(256) void k_trsv_w(const double *__restrict__ W, int nbk, double *__restrict__ v) {
-    __shared__ double vs[256];
-    __shared__ double xs[256];
+// x = W v for one 256-block (W upper triangular).  grid = 8 workgroups x 32 rows: each wave owns 8 rows and
+// streams them with all loads of 4 rows in flight (one workgroup alone is HBM-latency bound: 24 us).
+// x is written to xout (a separate buffer: other workgroups still read v).
+__global__ __launch_bounds__(256) void k_trsv_w(const double *__restrict__ W, int nbk, const double *__restrict__ v,
+                                                double *__restrict__ xout) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    vs[tid] = (tid < nbk) ? v[tid] : 0.0;
-    __syncthreads();
-    const double v0 = vs[lane], v1 = vs[lane + 64], v2 = vs[lane + 128], v3 = vs[lane + 192];
-    for (int j0 = wave * 64; j0 < wave * 64 + 64; j0 += 4) {
+    const double v0 = (lane < nbk) ? v[lane] : 0.0, v1 = (lane + 64 < nbk) ? v[lane + 64] : 0.0;
+    const double v2 = (lane + 128 < nbk) ? v[lane + 128] : 0.0, v3 = (lane + 192 < nbk) ? v[lane + 192] : 0.0;
+    const int jbase = blockIdx.x * 32 + wave * 8;
+#pragma unroll
+    for (int j0 = 0; j0 < 8; j0 += 4) {
         double acc[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const double *row = W + (int64_t)(j0 + u) * 256;
+            const double *row = W + (int64_t)(jbase + j0 + u) * 256;
             acc[u] = row[lane] * v0 + row[lane + 64] * v1 + row[lane + 128] * v2 + row[lane + 192] * v3;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             double a = acc[u];
             for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-            if (lane == 0) xs[j0 + u] = a;
+            if (lane == 0 && jbase + j0 + u < nbk) xout[jbase + j0 + u] = a;
         }
     }
-    __syncthreads();
-    if (tid < nbk) v[tid] = xs[tid];
 }
 
 // v[j] -= sum_i Mrow[i*ld + j] * x[i]  for j < ncols ; grid = ncols/64
@@ -783,15 +783,18 @@ int launch_block_inverse(hipStream_t s, const double *M, int64_t ld, int n_pad, 
     return EGX_SUCCESS;
 }
 
-int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *Wall, double *v) {
+int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *Wall, double *v,
+                  double *xout) {
+    // v holds the right-hand side and is updated in place above the current block; the solution goes to xout
     const int nblocks = (n_pad + kNB - 1) / kNB;
     for (int b = nblocks - 1; b >= 0; b--) {
         const int k0 = b * kNB;
         const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;
-        hipLaunchKernelGGL(k_trsv_w, dim3(1), dim3(256), 0, s, Wall + (int64_t)b * 65536, nbk, v + k0);
+        hipLaunchKernelGGL(k_trsv_w, dim3(8), dim3(256), 0, s, Wall + (int64_t)b * 65536, nbk,
+                           (const double *)(v + k0), xout + k0);
         if (k0 > 0)
             hipLaunchKernelGGL(k_gemv_t_update, dim3(k0 / 64), dim3(256), 0, s, M + (int64_t)k0 * ld, ld, nbk,
-                               (const double *)(v + k0), v);
+                               (const double *)(xout + k0), v);
     }
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
