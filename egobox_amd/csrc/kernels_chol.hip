@@ -25,6 +25,7 @@
 // flops with two 8-byte operands per lane, which keeps LDS and issue pressure negligible.
 #include "egx_internal.h"
 
+#include <cstdlib>
 #include <vector>
 
 namespace egx {
@@ -331,8 +332,11 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double &d, double &r) {
 // Workgroup (8 waves): in-place lower Cholesky of the 64x64 tile T (LDS, row stride TLD), matrix row `lane`
 // per lane.  Per 16-column strip: wave 0 factors the strip (sequential in the 16 columns: pivot by v_readlane,
 // multipliers through a broadcast LDS line), then waves 0..5 each update half of one of the remaining strips.
+template <int NW>
 __device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, int tid, int *info, int gcol0,
                                             int n_valid) {
+    constexpr int CW = (NW == 8) ? 8 : 16;   // columns of a trailing strip handled by one wave
+    constexpr int WPS = 16 / CW;             // waves per strip
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll 1
     for (int jb = 0; jb < 4; jb++) {
@@ -362,21 +366,21 @@ __device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, i
             for (int c = 0; c < 16; c++) T[lane * TLD + jb * 16 + c] = ((jb * 16 + c) <= lane) ? a[c] : 0.0;
         }
         __syncthreads();
-        // trailing strips: wave w updates 8 columns (half a strip): strip jb + 1 + w/2, half w & 1
-        const int sb = jb + 1 + (wave >> 1), hb = (wave & 1) * 8;
+        // trailing strips: wave w updates CW columns of strip jb + 1 + w / WPS
+        const int sb = jb + 1 + wave / WPS, hb = (wave % WPS) * CW;
         if (sb < 4) {
-            double a[16], a2[8];
+            double a[16], a2[CW];
 #pragma unroll
             for (int c = 0; c < 16; c++) a[c] = T[lane * TLD + jb * 16 + c];
 #pragma unroll
-            for (int c = 0; c < 8; c++) a2[c] = T[lane * TLD + sb * 16 + hb + c];
+            for (int c = 0; c < CW; c++) a2[c] = T[lane * TLD + sb * 16 + hb + c];
 #pragma unroll
             for (int k = 0; k < 16; k++)
 #pragma unroll
-                for (int c = 0; c < 8; c++)
+                for (int c = 0; c < CW; c++)
                     a2[c] = __builtin_fma(-a[k], T[(sb * 16 + hb + c) * TLD + jb * 16 + k], a2[c]);
 #pragma unroll
-            for (int c = 0; c < 8; c++) T[lane * TLD + sb * 16 + hb + c] = a2[c];
+            for (int c = 0; c < CW; c++) T[lane * TLD + sb * 16 + hb + c] = a2[c];
         }
         __syncthreads();
     }
@@ -385,14 +389,16 @@ __device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, i
 // Workgroup: X = L^-1 (lower) for the factored tile T; row `lane` of X per lane, into X (LDS, stride TLD).
 // Strips of 16 columns from the right; the contributions of the already finished strips are split over the
 // eight waves (2 columns each), the short in-strip back substitution is done by wave 0.
+template <int NW>
 __device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, double *X, int tid) {
+    constexpr int CPW = 16 / NW;  // columns of the current strip per wave in the bulk phase
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll 1
     for (int cbk = 3; cbk >= 0; cbk--) {
         {
-            double x4[2];
+            double x4[CPW];
 #pragma unroll
-            for (int cc = 0; cc < 2; cc++) x4[cc] = (lane == cbk * 16 + wave * 2 + cc) ? 1.0 : 0.0;
+            for (int cc = 0; cc < CPW; cc++) x4[cc] = (lane == cbk * 16 + wave * CPW + cc) ? 1.0 : 0.0;
 #pragma unroll 1
             for (int kb = 3; kb > cbk; kb--) {
                 double xk[16];
@@ -401,11 +407,11 @@ __device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, dou
 #pragma unroll
                 for (int k = 0; k < 16; k++)
 #pragma unroll
-                    for (int cc = 0; cc < 2; cc++)
-                        x4[cc] = __builtin_fma(-xk[k], T[(kb * 16 + k) * TLD + cbk * 16 + wave * 2 + cc], x4[cc]);
+                    for (int cc = 0; cc < CPW; cc++)
+                        x4[cc] = __builtin_fma(-xk[k], T[(kb * 16 + k) * TLD + cbk * 16 + wave * CPW + cc], x4[cc]);
             }
 #pragma unroll
-            for (int cc = 0; cc < 2; cc++) X[lane * TLD + cbk * 16 + wave * 2 + cc] = x4[cc];
+            for (int cc = 0; cc < CPW; cc++) X[lane * TLD + cbk * 16 + wave * CPW + cc] = x4[cc];
         }
         __syncthreads();
         if (wave == 0) {
@@ -427,9 +433,11 @@ __device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, dou
     }
 }
 
-__global__ __launch_bounds__(512, 2) void k_potf2_block(double *__restrict__ D, int64_t ld, int nbk,
-                                                        double *__restrict__ dinv, int *__restrict__ info,
-                                                        int col0, int n_valid) {
+template <int NT>
+__global__ __launch_bounds__(NT, NT / 256) void k_potf2_block(double *__restrict__ D, int64_t ld, int nbk,
+                                                              double *__restrict__ dinv, int *__restrict__ info,
+                                                              int col0, int n_valid) {
+    constexpr int NW = NT / 64, WN = 256 / NW;  // MFMA phases: NW waves of 16 x WN
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __builtin_amdgcn_s_setprio(3);   // on the look-ahead stream this workgroup shares its CU with trailing-update waves
     double *Ls = sm;                 // current diagonal tile / its factor, [64][65]
@@ -443,7 +451,7 @@ __global__ __launch_bounds__(512, 2) void k_potf2_block(double *__restrict__ D, 
         // ---- stage tile (s,s) into LDS (coalesced 16-byte pieces)
         {
             const double *src = D + (int64_t)(s * TS) * ld + s * TS;
-            for (int e = tid; e < TS * (TS / 2); e += 512) {
+            for (int e = tid; e < TS * (TS / 2); e += NT) {
                 const int row = e >> 5, c2 = e & 31;
                 const d2_t v = *reinterpret_cast<const d2_t *>(src + (int64_t)row * ld + c2 * 2);
                 Ls[row * TLD + c2 * 2] = v[0];
@@ -452,14 +460,14 @@ __global__ __launch_bounds__(512, 2) void k_potf2_block(double *__restrict__ D, 
         }
         __syncthreads();
         // ---- steps 1+2: factor and invert the tile (all four waves, see wg_potf2_64 / wg_inv_64)
-        wg_potf2_64(Ls, cb, rd, tid, info, col0 + s * TS, n_valid);
-        wg_inv_64(Ls, rd, stage, tid);
+        wg_potf2_64<NW>(Ls, cb, rd, tid, info, col0 + s * TS, n_valid);
+        wg_inv_64<NW>(Ls, rd, stage, tid);
         EGX_STAMP(1);
         // ---- write the factor back (upper part zeroed) and the inverse to dinv
         {
             double *dstL = D + (int64_t)(s * TS) * ld + s * TS;
             double *dstI = dinv + (int64_t)s * 4096;
-            for (int e = tid; e < TS * (TS / 2); e += 512) {
+            for (int e = tid; e < TS * (TS / 2); e += NT) {
                 const int row = e >> 5, c2 = e & 31;
                 d2_t v, w;
                 v[0] = Ls[row * TLD + c2 * 2];
@@ -473,16 +481,17 @@ __global__ __launch_bounds__(512, 2) void k_potf2_block(double *__restrict__ D, 
         __syncthreads();  // dinv visible (workgroup scope); the staging area is free again
         EGX_STAMP(2);
         // ---- step 3: tiles below:  X_t = A(t,s) Linv^T  (in place); 8 waves of 16x32 (two MFMA waves per SIMD)
-        const int wrow = (wave >> 1) * 16 + (lane >> 4), wcol = (wave & 1) * 32 + (lane & 15);
+        constexpr int WVN = 64 / WN;  // waves along the columns of a 64x64 tile
+        const int wrow = (wave / WVN) * 16 + (lane >> 4), wcol = (wave % WVN) * WN + (lane & 15);
         for (int t = s + 1; t < nt; t++) {
-            double4_t acc[1][2];
+            double4_t acc[1][WN / 16];
 #pragma unroll
-            for (int ni = 0; ni < 2; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+            for (int ni = 0; ni < WN / 16; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
             double *At = D + (int64_t)t * TS * ld + s * TS;
-            gemm_core<64, 64, 16, 32, 512>(At, ld, dinv + (int64_t)s * 4096, TS, TS, acc, stage, tid);
+            gemm_core<64, 64, 16, WN, NT>(At, ld, dinv + (int64_t)s * 4096, TS, TS, acc, stage, tid);
             double *xt = At + (int64_t)wrow * ld + wcol;
 #pragma unroll
-            for (int ni = 0; ni < 2; ni++)
+            for (int ni = 0; ni < WN / 16; ni++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) xt[(int64_t)(4 * r) * ld + ni * 16] = acc[0][ni][r];
         }
@@ -491,19 +500,19 @@ __global__ __launch_bounds__(512, 2) void k_potf2_block(double *__restrict__ D, 
         // ---- step 4: A(t,u) -= X_t X_u^T for s < u <= t < nt
         for (int t = s + 1; t < nt; t++)
             for (int u = s + 1; u <= t; u++) {
-                double4_t acc[1][2];
+                double4_t acc[1][WN / 16];
 #pragma unroll
-                for (int ni = 0; ni < 2; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-                gemm_core<64, 64, 16, 32, 512>(D + (int64_t)t * TS * ld + s * TS, ld, D + (int64_t)u * TS * ld + s * TS,
-                                               ld, TS, acc, stage, tid);
+                for (int ni = 0; ni < WN / 16; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+                gemm_core<64, 64, 16, WN, NT>(D + (int64_t)t * TS * ld + s * TS, ld, D + (int64_t)u * TS * ld + s * TS,
+                                              ld, TS, acc, stage, tid);
                 double *ct = D + (int64_t)(t * TS + wrow) * ld + u * TS + wcol;
-                double cv[2][4];
+                double cv[WN / 16][4];
 #pragma unroll
-                for (int ni = 0; ni < 2; ni++)
+                for (int ni = 0; ni < WN / 16; ni++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) cv[ni][r] = ct[(int64_t)(4 * r) * ld + ni * 16];
 #pragma unroll
-                for (int ni = 0; ni < 2; ni++)
+                for (int ni = 0; ni < WN / 16; ni++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) ct[(int64_t)(4 * r) * ld + ni * 16] = cv[ni][r] - acc[0][ni][r];
             }
@@ -630,10 +639,14 @@ __global__ void k_mfma_probe(const double *A, const double *B, double *C) {
 // host launchers
 // =============================================================================================
 static bool g_init_done = false;
+static int g_potf2_threads = 256;
 
 int chol_init() {
     if (g_init_done) return EGX_SUCCESS;
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2_block),
+    if (const char *e = std::getenv("EGX_POTF2_THREADS")) g_potf2_threads = (std::atoi(e) == 512) ? 512 : 256;
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2_block<256>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
+    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2_block<512>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
     EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 128, 32, 64, 512, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, TrailShape::LDS_BYTES));
@@ -705,8 +718,14 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     auto panel = [&](hipStream_t st, int k0, int nbk) {
         double *diag = M + (int64_t)k0 * ld + k0;
         double *dtiles = dinv + (int64_t)(k0 / 64) * 4096;
-        hipLaunchKernelGGL(k_potf2_block, dim3(1), dim3(512), POTF2_LDS_BYTES, st, diag, ld, nbk, dtiles, info, k0,
-                           n_pad);
+        // 256 threads (<= 232 VGPRs, 1 wave per SIMD) fit next to ONE resident trailing-update workgroup; the
+        // 512-thread variant is ~10 % faster alone but needs a CU that has drained both of them
+        if (g_potf2_threads == 512)
+            hipLaunchKernelGGL(k_potf2_block<512>, dim3(1), dim3(512), POTF2_LDS_BYTES, st, diag, ld, nbk, dtiles, info,
+                               k0, n_pad);
+        else
+            hipLaunchKernelGGL(k_potf2_block<256>, dim3(1), dim3(256), POTF2_LDS_BYTES, st, diag, ld, nbk, dtiles, info,
+                               k0, n_pad);
         const int below = m_tot - (k0 + nbk);
         if (below > 0)
             hipLaunchKernelGGL(k_panel_trsm, dim3(below / 64), dim3(256), PanelShape::LDS_BYTES, st,

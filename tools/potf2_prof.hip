@@ -19,7 +19,7 @@ int main() {
         hipMemset(info, 0, 4);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_potf2_block, dim3(1), dim3(512), POTF2_LDS_BYTES, 0, dA, (int64_t)ld, n, dinv, info, 0, n);
+        hipLaunchKernelGGL(k_potf2_block<256>, dim3(1), dim3(256), POTF2_LDS_BYTES, 0, dA, (int64_t)ld, n, dinv, info, 0, n);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         long long st[4][5];
