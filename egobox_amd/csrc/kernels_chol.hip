@@ -639,11 +639,11 @@ __global__ void k_mfma_probe(const double *A, const double *B, double *C) {
 // host launchers
 // =============================================================================================
 static bool g_init_done = false;
-static int g_potf2_threads = 256;
+static int g_potf2_threads = 512;
 
 int chol_init() {
     if (g_init_done) return EGX_SUCCESS;
-    if (const char *e = std::getenv("EGX_POTF2_THREADS")) g_potf2_threads = (std::atoi(e) == 512) ? 512 : 256;
+    if (const char *e = std::getenv("EGX_POTF2_THREADS")) g_potf2_threads = (std::atoi(e) == 256) ? 256 : 512;
     EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2_block<256>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
     EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2_block<512>),
@@ -718,8 +718,9 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     auto panel = [&](hipStream_t st, int k0, int nbk) {
         double *diag = M + (int64_t)k0 * ld + k0;
         double *dtiles = dinv + (int64_t)(k0 / 64) * 4096;
-        // 256 threads (<= 232 VGPRs, 1 wave per SIMD) fit next to ONE resident trailing-update workgroup; the
-        // 512-thread variant is ~10 % faster alone but needs a CU that has drained both of them
+        // 512 threads (two MFMA waves per SIMD) is ~10 % faster alone; the 256-thread variant (1 wave per SIMD) fits
+        // next to one resident trailing-update workgroup.  Measured end to end they are within 1.5 % (run 12);
+        // EGX_POTF2_THREADS=256 selects the latter for experiments.
         if (g_potf2_threads == 512)
             hipLaunchKernelGGL(k_potf2_block<512>, dim3(1), dim3(512), POTF2_LDS_BYTES, st, diag, ld, nbk, dtiles, info,
                                k0, n_pad);
