@@ -9,6 +9,8 @@
 #include <cstring>
 #include <limits>
 #include <mutex>
+#include <thread>
+#include <algorithm>
 #include <vector>
 
 #include "egx_internal.h"
@@ -850,33 +852,38 @@ int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int
     std::lock_guard<std::mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
     const int nws = (int)gp->ws.size();
-    // waves of nws candidates: every workspace has its own stream, so the serial panel
-    // factorisations of one candidate overlap the trailing updates of the others.
-    for (int64_t c0 = 0; c0 < k; c0 += nws) {
-        const int cnt = (int)((k - c0 < nws) ? (k - c0) : nws);
-        std::vector<int> launched(cnt, 0);
-        for (int i = 0; i < cnt; i++) {
-            const double *th = thetas + (c0 + i) * theta_len;
-            std::vector<double> coef;
-            int hcols = 1;
-            EGX_RC(make_coef(gp, th, theta_len, coef, hcols, nullptr));
-            if (has_nan(th, theta_len)) {
-                lkh[c0 + i] = -std::numeric_limits<double>::infinity();
-                status[c0 + i] = EGX_STATUS_NAN_THETA;
-                continue;
-            }
-            if (i == 0) gp->fitted = false;
-            EGX_RC(enqueue_eval(gp, gp->ws[i], coef, hcols));
-            launched[i] = 1;
+    // Software pipeline over the workspaces: every workspace has its own stream pair, so the serial panel
+    // factorisations of one candidate overlap the trailing updates of the others; as soon as a candidate has
+    // been read back its workspace is re-used for candidate c + nws.
+    std::vector<int> launched(nws, 0);
+    auto enqueue = [&](int64_t c) -> int {
+        const int wi = (int)(c % nws);
+        const double *th = thetas + c * theta_len;
+        std::vector<double> coef;
+        int hcols = 1;
+        EGX_RC(make_coef(gp, th, theta_len, coef, hcols, nullptr));
+        launched[wi] = 0;
+        if (has_nan(th, theta_len)) {
+            lkh[c] = -std::numeric_limits<double>::infinity();
+            status[c] = EGX_STATUS_NAN_THETA;
+            return EGX_SUCCESS;
         }
-        for (int i = 0; i < cnt; i++) {
-            if (!launched[i]) continue;
+        if (wi == 0) gp->fitted = false;
+        EGX_RC(enqueue_eval(gp, gp->ws[wi], coef, hcols));
+        launched[wi] = 1;
+        return EGX_SUCCESS;
+    };
+    for (int64_t c = 0; c < k && c < nws; c++) EGX_RC(enqueue(c));
+    for (int64_t c = 0; c < k; c++) {
+        const int wi = (int)(c % nws);
+        if (launched[wi]) {
             EvalResult res;
-            EGX_RC(finish_eval(gp, gp->ws[i], res, false));
-            lkh[c0 + i] = res.lkh;
-            status[c0 + i] = res.status;
-            if (i == 0) record_timings(gp, gp->ws[0], 0.0, 0.0);
+            EGX_RC(finish_eval(gp, gp->ws[wi], res, false));
+            lkh[c] = res.lkh;
+            status[c] = res.status;
+            if (wi == 0) record_timings(gp, gp->ws[0], 0.0, 0.0);
         }
+        if (c + nws < k) EGX_RC(enqueue(c + nws));
     }
     return EGX_SUCCESS;
 }
@@ -922,35 +929,62 @@ int32_t egx_gp_fit(egx_gp *gp, const double *theta0s, int64_t n_starts, const do
     double best_f = std::numeric_limits<double>::infinity();
     std::vector<double> best_x(h, 0.0);
     int64_t evals = 0;
-    int rc_inner = EGX_SUCCESS;
-    auto objective = [&](const std::vector<double> &x) -> double {
-        std::vector<double> th(h);
-        for (int i = 0; i < h; i++) th[i] = std::pow(10.0, x[i]);
-        EvalResult res;
-        int rc = eval_one(gp, 0, th.data(), h, res, false);
-        if (rc) {
-            rc_inner = rc;
-            return std::numeric_limits<double>::infinity();
+    for (int64_t s = 0; s < n_starts * h; s++)
+        if (!(theta0s[s] > 0.0)) {
+            set_error("theta start points must be > 0");
+            return EGX_ERR_INVALID_VALUE;
         }
-        if (res.status != EGX_STATUS_OK || std::isnan(res.lkh)) return std::numeric_limits<double>::infinity();
-        return -res.lkh;
-    };
-    for (int64_t s = 0; s < n_starts; s++) {
-        std::vector<double> x0(h);
-        for (int i = 0; i < h; i++) {
-            const double t = theta0s[s * h + i];
-            if (!(t > 0.0)) {
-                set_error("theta start points must be > 0");
-                return EGX_ERR_INVALID_VALUE;
+    // The starts are independent optimisations (rayon par_iter over theta_inits rows, algorithm.rs:928-945):
+    // one host thread per workspace, start s runs on workspace s % n_threads.
+    const int nthreads = (int)std::min<int64_t>((int64_t)gp->ws.size(), n_starts);
+    std::vector<NmResult> results((size_t)n_starts);
+    std::vector<int> rcs((size_t)nthreads, EGX_SUCCESS);
+    std::vector<std::string> errs((size_t)nthreads);
+    gp->fitted = false;
+    auto worker = [&](int t) {
+        if (hipSetDevice(gp->device) != hipSuccess) {
+            rcs[t] = EGX_ERR_HIP;
+            errs[t] = "hipSetDevice failed in optimiser thread";
+            return;
+        }
+        auto objective = [&](const std::vector<double> &x) -> double {
+            std::vector<double> th(h);
+            for (int i = 0; i < h; i++) th[i] = std::pow(10.0, x[i]);
+            EvalResult res;
+            int rc = eval_one(gp, t, th.data(), h, res, false);
+            if (rc) {
+                if (!rcs[t]) {
+                    rcs[t] = rc;
+                    errs[t] = g_last_error;
+                }
+                return std::numeric_limits<double>::infinity();
             }
-            x0[i] = std::log10(t);
+            if (res.status != EGX_STATUS_OK || std::isnan(res.lkh)) return std::numeric_limits<double>::infinity();
+            return -res.lkh;
+        };
+        for (int64_t s = t; s < n_starts; s += nthreads) {
+            std::vector<double> x0(h);
+            for (int i = 0; i < h; i++) x0[i] = std::log10(theta0s[s * h + i]);
+            results[(size_t)s] = nelder_mead(objective, x0, blo, bhi, per_start);
         }
-        NmResult r = nelder_mead(objective, x0, blo, bhi, per_start);
-        evals += r.evals;
-        if (rc_inner) return rc_inner;
-        if (r.f < best_f) {  // algorithm.rs:942-945 reduce to min
-            best_f = r.f;
-            best_x = r.x;
+    };
+    if (nthreads <= 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; t++) pool.emplace_back(worker, t);
+        for (auto &th : pool) th.join();
+    }
+    for (int t = 0; t < nthreads; t++)
+        if (rcs[t]) {
+            set_error(errs[t]);
+            return rcs[t];
+        }
+    for (int64_t s = 0; s < n_starts; s++) {
+        evals += results[(size_t)s].evals;
+        if (results[(size_t)s].f < best_f) {  // algorithm.rs:942-945 reduce to min (first wins ties)
+            best_f = results[(size_t)s].f;
+            best_x = results[(size_t)s].x;
         }
     }
     if (n_evals_out) *n_evals_out = evals;

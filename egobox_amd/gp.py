@@ -332,6 +332,7 @@ class GpParams:
         self._max_eval = GP_COBYLA_MAX_EVAL
         self._nugget = DEFAULT_NUGGET
         self._device = -1
+        self._n_workspaces = 2  # concurrent likelihood evaluations (multistart threads) during a tuned fit
         self._seed = 42  # optimization.rs:62: multistart LHS is seeded with 42
 
     # setters return self, like the Rust builder
@@ -389,6 +390,12 @@ class GpParams:
         self._device = int(device)
         return self
 
+    def n_workspaces(self, n):
+        """Extension: correlation-matrix workspaces = multistart optimisations run concurrently on the GPU
+        (the reference runs its starts on a rayon pool, algorithm.rs:928-945)."""
+        self._n_workspaces = max(1, int(n))
+        return self
+
     def check(self):  # ParamGuard::check_ref, parameters.rs:287-308
         d = self._kpls_dim
         if d is not None:
@@ -420,8 +427,9 @@ class GpParams:
                     "KPLS rotations come from linfa-pls in the reference (out of the accelerated path); "
                     "pass them with .kpls_weights(w_star)")
             w = self._kpls_weights
+        nws = 1 if self._theta_tuning.kind == "Fixed" else min(self._n_workspaces, self._n_start + 1)
         h = GpHandle(x, y, mean=self._mean.code, corr=self._corr.code, nugget=self._nugget, device=self._device,
-                     w_star=w)
+                     n_workspaces=max(1, nws), w_star=w)
         t = self._theta_tuning
         dim = h.h
         if t.init.size not in (1, dim):  # algorithm.rs:829-838 (a panic in the reference)

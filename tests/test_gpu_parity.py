@@ -369,6 +369,47 @@ def test_full_fit_improves_likelihood(egx):
     gp.close()
 
 
+def test_multistart_threads_are_deterministic(egx):
+    """Starts are independent optimisations reduced by min: running them on 1 or 3 workspaces (host threads +
+    streams) must give the same theta and likelihood."""
+    x, y = _data(300, 3, seed=12)
+    res = []
+    for nws in (1, 3):
+        gp = egx.GaussianProcess.params(egx.ConstantMean(), egx.Matern52Corr()).n_start(4).max_eval(40) \
+            .n_workspaces(nws).fit(x, y)
+        res.append((gp.theta().copy(), gp.likelihood(), gp.n_evals))
+        gp.close()
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+
+
+def test_api_state_semantics(egx):
+    x, y = _data(200, 2, seed=13)
+    with egx.GpHandle(x, y) as h:
+        assert (h.n, h.d, h.p, h.h) == (200, 2, 1, 2)
+        with pytest.raises(egx.NotFittedError):
+            h.inner()
+        h.finalize([0.8, 0.9])
+        y0 = h.predict(x[:3])
+        assert h.predict(np.zeros((0, 2))).shape == (0,)                # empty query batch
+        np.testing.assert_array_equal(h.predict(x[:1]), y0[:1])          # single point == batched
+        h.finalize([0.8, 0.9])                                            # re-fit is idempotent (bit identical)
+        np.testing.assert_array_equal(h.predict(x[:3]), y0)
+        h.likelihood([0.5, 0.5])                                          # re-uses workspace 0: the fit is gone
+        with pytest.raises(egx.NotFittedError):
+            h.predict(x[:3])
+        with pytest.raises(egx.InvalidValueError):
+            h.predict(np.zeros((3, 5)))
+    # concurrent calls on one handle from several host threads are serialised, not corrupted
+    from concurrent.futures import ThreadPoolExecutor
+    with egx.GpHandle(x, y, n_workspaces=2) as h:
+        ths = [np.array([0.3 + 0.1 * i, 0.7]) for i in range(6)]
+        want = [h.likelihood(t)[0] for t in ths]
+        with ThreadPoolExecutor(3) as pool:
+            got = list(pool.map(lambda t: h.likelihood(t)[0], ths))
+        assert got == want
+
+
 def test_gpx_save_load_roundtrip(egx, tmp_path):
     x, y = _data(50, 2, seed=11)
     gpx = egx.Gpx.builder(regr_spec=egx.RegressionSpec.LINEAR, corr_spec=egx.CorrelationSpec.MATERN52,
