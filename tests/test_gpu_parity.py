@@ -385,7 +385,7 @@ def test_multistart_threads_are_deterministic(egx):
 
 def test_api_state_semantics(egx):
     x, y = _data(200, 2, seed=13)
-    with egx.GpHandle(x, y) as h:
+    with egx.GpHandle(x, y, corr=3) as h:  # Matern-5/2: well conditioned at these thetas
         assert (h.n, h.d, h.p, h.h) == (200, 2, 1, 2)
         with pytest.raises(egx.NotFittedError):
             h.inner()
@@ -402,7 +402,7 @@ def test_api_state_semantics(egx):
             h.predict(np.zeros((3, 5)))
     # concurrent calls on one handle from several host threads are serialised, not corrupted
     from concurrent.futures import ThreadPoolExecutor
-    with egx.GpHandle(x, y, n_workspaces=2) as h:
+    with egx.GpHandle(x, y, corr=3, n_workspaces=2) as h:
         ths = [np.array([0.3 + 0.1 * i, 0.7]) for i in range(6)]
         want = [h.likelihood(t)[0] for t in ths]
         with ThreadPoolExecutor(3) as pool:
