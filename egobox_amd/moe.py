@@ -1,0 +1,143 @@
+"""Predict-side mixture-of-experts recombination around the GPU GP experts ("next").
+
+Mirrors what egobox-moe does AFTER its clustering has chosen and trained the experts:
+  GaussianMixture.predict_probas / predict        crates/moe/src/gaussian_mixture.rs:114-121, 231-283, 305-316
+  GpMixture.predict_smooth / predict_var_smooth   crates/moe/src/algorithm.rs:411-423, 670-685, 789-809
+  GpMixture.predict_hard  / predict_var_hard      crates/moe/src/algorithm.rs:879-935
+Clustering itself (GMM fitting, expert selection by cross-validation) stays in egobox-moe.
+
+Differences that matter on a GPU: the reference's hard recombination calls the expert ONCE PER ROW with a
+1 x nx batch (each a full n^2 triangular solve for the variance); here queries are routed once and every
+expert gets one batched call on its subset.  With several GPUs expert e lives on rank e mod G
+(BASELINE config 5) and one all-reduce of the weighted vectors replaces the fold over experts.
+The mixture algebra is k x nx x nx host arithmetic (numpy); every GP evaluation runs on the GPU.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+class GaussianMixture:
+    """Responsibilities of a fitted Gaussian mixture (weights (k,), means (k,nx), covariances (k,nx,nx))."""
+
+    def __init__(self, weights, means, covariances, heaviside_factor=1.0):
+        self.weights = np.asarray(weights, dtype=np.float64)
+        self.means = np.atleast_2d(np.asarray(means, dtype=np.float64))
+        self.covariances = np.asarray(covariances, dtype=np.float64)
+        k, nx = self.means.shape
+        if self.weights.shape != (k,) or self.covariances.shape != (k, nx, nx):
+            raise ValueError("weights (k,), means (k,nx), covariances (k,nx,nx) expected")
+        # precisions_chol[k] = (chol(cov_k)^-1)^T, gaussian_mixture.rs:182-205
+        self.precisions_chol = np.empty((k, nx, nx))
+        for i in range(k):
+            c = np.linalg.cholesky(self.covariances[i])
+            self.precisions_chol[i] = np.linalg.solve(c, np.eye(nx)).T
+        self.set_heaviside_factor(heaviside_factor)
+
+    def set_heaviside_factor(self, f):
+        """gaussian_mixture.rs:105-110: refresh the log-determinants."""
+        self.heaviside_factor = float(f)
+        precs = self.precisions_chol * self.heaviside_factor ** -0.5
+        self.log_det = np.log(np.einsum("kii->ki", precs)).sum(axis=1)
+        return self
+
+    @property
+    def n_clusters(self):
+        return self.means.shape[0]
+
+    def _log_gaussian_prob(self, x):
+        nx = self.means.shape[1]
+        precs = self.precisions_chol * self.heaviside_factor ** -0.5
+        diff = np.einsum("nkj,kjl->nkl", x[:, None, :] - self.means[None, :, :], precs)
+        q = (diff * diff).sum(axis=2)
+        return -0.5 * (q + nx * math.log(2.0 * math.pi)) + self.log_det
+
+    def _log_resp(self, x):
+        wlp = self._log_gaussian_prob(x) + np.log(self.weights)
+        e = np.where(wlp <= -307.0, 0.0, np.exp(wlp))
+        s = e.sum(axis=1)
+        norm = np.where(np.abs(s) < np.finfo(float).eps, 0.0, np.log(np.where(s > 0, s, 1.0)))
+        return wlp - norm[:, None]
+
+    def predict_probas(self, x):
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        if self.n_clusters == 1:
+            return np.ones((x.shape[0], 1))
+        return np.exp(self._log_resp(x))
+
+    def predict(self, x):
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        return np.argmax(np.exp(self._log_resp(x)), axis=1)
+
+    def pdfs(self, x):
+        return np.exp(self._log_gaussian_prob(np.asarray(x, dtype=np.float64).reshape(1, -1))[0])
+
+
+class GpMixture:
+    """Experts + mixture, predict side only.  `experts[i]` is None for experts that live on another rank."""
+
+    def __init__(self, experts, gmx, recombination="hard", rank=0, world=1, device=None):
+        self.experts, self.gmx = list(experts), gmx
+        self.recombination = recombination.lower()
+        if self.recombination not in ("hard", "smooth"):
+            raise ValueError("recombination must be 'hard' or 'smooth'")
+        if len(self.experts) != gmx.n_clusters:
+            raise ValueError("one expert per cluster expected")
+        self.rank, self.world, self.device = rank, world, device
+
+    def _mine(self, i):
+        return i % self.world == self.rank and self.experts[i] is not None
+
+    def _allreduce(self, *arrays):
+        if self.world == 1:
+            return arrays
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(np.stack(arrays))
+        if self.device is not None:
+            t = t.to(self.device)
+        dist.all_reduce(t)  # ncclAllReduce(sum) over xGMI; gloo in the CPU tests
+        out = t.cpu().numpy()
+        return tuple(out[i] for i in range(len(arrays)))
+
+    def predict_valvar(self, x, want_val=True, want_var=True):
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        m = x.shape[0]
+        val, var = np.zeros(m), np.zeros(m)
+        if self.recombination == "smooth":
+            p = self.gmx.predict_probas(x)
+            for i, e in enumerate(self.experts):
+                if not self._mine(i):
+                    continue
+                if want_val and want_var:
+                    y, v = e.predict_valvar(x)
+                    val += y * p[:, i]
+                    var += v * p[:, i] * p[:, i]
+                elif want_val:
+                    val += e.predict(x) * p[:, i]
+                else:
+                    var += e.predict_var(x) * p[:, i] * p[:, i]
+        else:
+            c = self.gmx.predict(x)
+            for i, e in enumerate(self.experts):
+                if not self._mine(i):
+                    continue
+                idx = np.flatnonzero(c == i)
+                if idx.size == 0:
+                    continue
+                if want_val and want_var:
+                    val[idx], var[idx] = e.predict_valvar(x[idx])
+                elif want_val:
+                    val[idx] = e.predict(x[idx])
+                else:
+                    var[idx] = e.predict_var(x[idx])
+        val, var = self._allreduce(val, var)
+        return val, var
+
+    def predict(self, x):
+        return self.predict_valvar(x, True, False)[0]
+
+    def predict_var(self, x):
+        return self.predict_valvar(x, False, True)[1]

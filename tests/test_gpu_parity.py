@@ -447,3 +447,34 @@ def test_full_size_properties_n16384_d32(egx, corr):
     with egx.GpHandle(x[perm], y[perm], corr=corr) as h2:
         lk2, st2 = h2.likelihood(theta)
         assert st2 == 0 and lk2 == pytest.approx(lk, rel=LK_RTOL)
+
+
+# ------------------------------------------------------------------ widening: mixture of GPU experts
+@pytest.mark.parametrize("recomb", ["smooth", "hard"])
+def test_mixture_of_gpu_experts_matches_oracle(egx, O, recomb):
+    from egobox_amd.moe import GaussianMixture, GpMixture
+    from oracle import moe_oracle as MO
+    rng = np.random.default_rng(1)
+    gpu_experts, cpu_experts = [], []
+    for c in range(3):
+        x = rng.random((300, 2)) + [c, 0.0]
+        y = np.sin(3 * x[:, 0]) + x[:, 1] * (c + 1)
+        theta = [1.5, 1.0]
+        gpu_experts.append(egx.GaussianProcess.params(egx.ConstantMean(), egx.Matern52Corr())
+                           .theta_tuning(egx.ThetaTuning.Fixed(theta)).fit(x, y))
+        cpu_experts.append(O.fit_fixed(x, y, theta, corr=O.MATERN52))
+    means = np.array([[0.5, 0.5], [1.5, 0.5], [2.5, 0.5]])
+    covs = np.array([np.eye(2) * 0.2] * 3)
+    w = np.array([0.3, 0.3, 0.4])
+    mix = GpMixture(gpu_experts, GaussianMixture(w, means, covs, 0.8), recomb)
+    gmo = MO.GaussianMixtureOracle(w, means, covs, 0.8)
+    xq = np.random.default_rng(2).random((500, 2)) * [3.0, 1.0]
+    val, var = mix.predict_valvar(xq)
+    if recomb == "smooth":
+        want_val, want_var = MO.predict_smooth(cpu_experts, gmo, xq), MO.predict_var_smooth(cpu_experts, gmo, xq)
+    else:
+        want_val, want_var = MO.predict_hard(cpu_experts, gmo, xq), MO.predict_var_hard(cpu_experts, gmo, xq)
+    np.testing.assert_allclose(val, want_val, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(want_val).max())
+    np.testing.assert_allclose(var, want_var, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(want_var).max() + 1e-12)
+    for e in gpu_experts:
+        e.close()
