@@ -71,6 +71,8 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
 // rows [0, m) of RT (ld) are right-hand sides: RT <- RT * C^-T  (C = lower factor in M, n_pad cols)
 int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, const double *dinv,
                      double *RT, int64_t ldr, int m);
+// dinv <- inverses of the 64x64 diagonal tiles of a given lower factor (model load path)
+int launch_diag_tile_inverses(hipStream_t s, const double *M, int64_t ld, int n_pad, double *dinv);
 // Wall ((n_pad/256) x 256 x 256) <- transposed inverses of the 256x256 diagonal blocks of the factor
 int launch_block_inverse(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *dinv, double *Wall);
 // xout (n_pad) <- C^-T v ; v (n_pad) is destroyed   (needs launch_block_inverse first)

@@ -1057,6 +1057,53 @@ int32_t egx_gp_get_inner(egx_gp *gp, const egx_gp_inner_view *v) {
     return EGX_SUCCESS;
 }
 
+int32_t egx_gp_set_inner(egx_gp *gp, const egx_gp_inner_view *v) {
+    if (!gp || !v || !v->theta || !v->likelihood || !v->sigma2 || !v->beta || !v->gamma || !v->r_chol || !v->ft ||
+        !v->ft_qr_r) {
+        set_error("egx_gp_set_inner: theta, likelihood, sigma2, beta, gamma, r_chol, ft and ft_qr_r are required");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::lock_guard<std::mutex> lock(gp->mu);
+    EGX_RC(set_device(gp));
+    const int n = gp->n, p = gp->p, n_pad = gp->n_pad;
+    for (int i = 0; i < n; i++)
+        if (!(v->r_chol[(size_t)i * n + i] > 0.0)) {
+            set_error("egx_gp_set_inner: r_chol must have a positive diagonal");
+            return EGX_ERR_INVALID_VALUE;
+        }
+    std::vector<double> coef, thfull;
+    int hcols = 1;
+    EGX_RC(make_coef(gp, v->theta, gp->h, coef, hcols, &thfull));
+    gp->fitted = false;
+    Workspace &w = gp->ws[0];
+    // factor (identity padded, lower) + ft^T rows below it, exactly the layout a factorisation leaves behind
+    std::vector<double> hm((size_t)gp->m_tot * gp->ld, 0.0);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j <= i; j++) hm[(size_t)i * gp->ld + j] = v->r_chol[(size_t)i * n + j];
+    for (int i = n; i < n_pad; i++) hm[(size_t)i * gp->ld + i] = 1.0;
+    for (int l = 0; l < p; l++)
+        for (int i = 0; i < n; i++) hm[(size_t)(n_pad + l) * gp->ld + i] = v->ft[(size_t)i * p + l];
+    EGX_HIP_CHECK(hipMemcpyAsync(w.M, hm.data(), sizeof(double) * hm.size(), hipMemcpyHostToDevice, w.stream));
+    EGX_RC(launch_diag_tile_inverses(w.stream, w.M, gp->ld, n_pad, w.dinv));
+    std::memset(w.h_vec, 0, sizeof(double) * n_pad);
+    std::memcpy(w.h_vec, v->gamma, sizeof(double) * n);
+    EGX_HIP_CHECK(hipMemcpyAsync(gp->d_gamma, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
+    std::memcpy(w.h_coef, coef.data(), sizeof(double) * coef.size());
+    EGX_HIP_CHECK(hipMemcpyAsync(gp->d_fit_coef, w.h_coef, sizeof(double) * coef.size(), hipMemcpyHostToDevice, w.stream));
+    EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+    gp->theta = thfull;
+    gp->likelihood = *v->likelihood;
+    gp->sigma2 = *v->sigma2;
+    gp->beta.assign(v->beta, v->beta + p);
+    gp->gamma.assign(v->gamma, v->gamma + n);
+    gp->ft.assign(v->ft, v->ft + (size_t)n * p);
+    gp->ft_qr_r.assign(v->ft_qr_r, v->ft_qr_r + (size_t)p * p);
+    gp->fit_coef = coef;
+    gp->fit_hcols = hcols;
+    gp->fitted = true;
+    return EGX_SUCCESS;
+}
+
 int32_t egx_gp_likelihood_grad(egx_gp *gp, const double *theta, int64_t theta_len, double *lkh, double *grad,
                                int32_t *status) {
     if (!gp || !theta || !lkh || !grad || !status) {

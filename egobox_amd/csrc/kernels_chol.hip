@@ -521,6 +521,27 @@ __global__ __launch_bounds__(NT, NT / 256) void k_potf2_block(double *__restrict
     }
 }
 
+// Inverses of all 64x64 diagonal tiles of a GIVEN lower factor (used when a fitted model is loaded instead of
+// factored here): one workgroup per tile, same row-per-lane strip algorithm as in k_potf2_block.
+__global__ __launch_bounds__(256, 1) void k_diag_tile_inverses(const double *__restrict__ M, int64_t ld,
+                                                               double *__restrict__ dinv) {
+    __shared__ double Ls[TS * TLD];
+    __shared__ double X[TS * TLD];
+    __shared__ double rd[TS];
+    const int tid = threadIdx.x, t = blockIdx.x;
+    const double *src = M + (int64_t)(t * TS) * ld + t * TS;
+    for (int e = tid; e < TS * TS; e += 256) {
+        const int row = e >> 6, c = e & 63;
+        Ls[row * TLD + c] = (c <= row) ? src[(int64_t)row * ld + c] : 0.0;
+    }
+    __syncthreads();
+    if (tid < TS) rd[tid] = 1.0 / Ls[tid * TLD + tid];
+    __syncthreads();
+    wg_inv_64<4>(Ls, rd, X, tid);
+    double *dst = dinv + (int64_t)t * 4096;
+    for (int e = tid; e < TS * TS; e += 256) dst[e] = X[(e >> 6) * TLD + (e & 63)];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Backward substitution  v <- C^-T v  (gamma = C^-T rho, algorithm.rs:1034), right-looking over
 // 256-row blocks from the bottom.  The 64-step dependency chain is kept short by precomputing, once per
@@ -790,6 +811,12 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
             if (rc) return rc;
         }
     }
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_diag_tile_inverses(hipStream_t s, const double *M, int64_t ld, int n_pad, double *dinv) {
+    hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64), dim3(256), 0, s, M, ld, dinv);
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }

@@ -249,6 +249,19 @@ class GpHandle:
         out["sigma2"] = float(out["sigma2"][0])
         return out
 
+    def set_inner(self, theta, likelihood, sigma2, beta, gamma, r_chol, ft, ft_qr_r):
+        """Install a fitted state produced elsewhere (deserialised model) without re-factoring."""
+        n, p, h = self.n, self.p, self.h
+        arrs = dict(theta=np.broadcast_to(L.as_f64(np.atleast_1d(theta)).ravel(), (h,)).copy(),
+                    likelihood=np.array([float(likelihood)]), sigma2=np.array([float(sigma2)]),
+                    beta=L.as_f64(beta).reshape(p).copy(), gamma=L.as_f64(gamma).reshape(n).copy(),
+                    r_chol=L.as_f64(r_chol).reshape(n, n).copy(), ft=L.as_f64(ft).reshape(n, p).copy(),
+                    ft_qr_r=L.as_f64(ft_qr_r).reshape(p, p).copy())
+        view = L.InnerView()
+        for k, a in arrs.items():
+            setattr(view, k, L.dptr(a))
+        L.check(self._lib.egx_gp_set_inner(self._h, C.byref(view)))
+
     def fitted_scalars(self):
         """(likelihood, sigma2) of the resident fit without downloading any array."""
         lk, s2 = np.empty(1), np.empty(1)

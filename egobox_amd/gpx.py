@@ -191,11 +191,16 @@ class Gpx:
         return True
 
     @staticmethod
-    def load(filename):
-        """Rebuild the model on the GPU from a JSON dump (ours or the reference's): the factor is recomputed
-        at the stored theta from the stored training data (the stored r_chol is not uploaded)."""
+    def load(filename, refit=False):
+        """Rebuild the model on the GPU from a JSON dump (ours or the reference's serde schema,
+        crates/moe/src/surrogates.rs:426-441).  The stored factor, gamma, beta, ft and ft_qr_r are uploaded as they
+        are (`egx_gp_set_inner`); `refit=True` re-factors at the stored theta from the stored training data instead."""
         with open(filename) as f:
             obj = json.load(f)
+        return Gpx.from_dict(obj, refit)
+
+    @staticmethod
+    def from_dict(obj, refit=False):
         experts = []
         for e in obj["experts"]:
             p = e["params"]
@@ -203,9 +208,17 @@ class Gpx:
             corr = G.CORRS[p["corr"]]()
             x, y = _from_nd(e["training_data"][0]), _from_nd(e["training_data"][1])
             w = _from_nd(e["w_star"])
-            params = G.GpParams(mean, corr).nugget(p["nugget"]).theta_tuning(
-                G.ThetaTuning.Fixed(_from_nd(e["theta"])))
+            theta = _from_nd(e["theta"])
+            params = G.GpParams(mean, corr).nugget(p["nugget"]).theta_tuning(G.ThetaTuning.Fixed(theta))
             if w.shape[0] != w.shape[1]:
                 params.kpls_weights(w)
-            experts.append(params.fit(x, y))
+            if refit:
+                experts.append(params.fit(x, y))
+                continue
+            h = G.GpHandle(x, y, mean=mean.code, corr=corr.code, nugget=p["nugget"],
+                           w_star=params._kpls_weights)
+            ip = e["inner_params"]
+            h.set_inner(theta, e["likelihood"], ip["sigma2"], _from_nd(ip["beta"]), _from_nd(ip["gamma"]),
+                        _from_nd(ip["r_chol"]), _from_nd(ip["ft"]), _from_nd(ip["ft_qr_r"]))
+            experts.append(G.GaussianProcess(h, params, n_evals=0))
         return Gpx(experts)

@@ -167,6 +167,12 @@ typedef struct {
     double *yt_norm;    /* n */
 } egx_gp_inner_view;
 int32_t egx_gp_get_inner(egx_gp *gp, const egx_gp_inner_view *view);
+/* Inverse of egx_gp_get_inner: install a fitted state produced elsewhere (e.g. deserialised from the
+ * reference's serde JSON, crates/moe/src/surrogates.rs:426-441 `load`) WITHOUT re-factoring: theta (h),
+ * likelihood, sigma2, beta (p), gamma (n), r_chol (n*n, lower), ft (n*p), ft_qr_r (p*p) are read;
+ * normalisation fields of the view are ignored (they are recomputed from the training data given to
+ * egx_gp_create and must agree).  All eight pointers are required. */
+int32_t egx_gp_set_inner(egx_gp *gp, const egx_gp_inner_view *view);
 
 /* ---- kernel-level entry points ---------------------------------------------
  * The CorrelationModel::value seam (correlation_models.rs:19-58) fused with

@@ -418,10 +418,46 @@ def test_gpx_save_load_roundtrip(egx, tmp_path):
     assert gpx.save(f)
     d = json.load(open(f))
     assert d["experts"][0]["type_fullgp"] == "GpLinearMatern52Surrogate"
-    gpx2 = egx.Gpx.load(f)
     xq = np.random.default_rng(0).random((20, 2))
-    np.testing.assert_allclose(gpx2.predict(xq), gpx.predict(xq), rtol=1e-12)
+    for refit in (False, True):  # upload the stored factor as is / re-factor at the stored theta
+        gpx2 = egx.Gpx.load(f, refit=refit)
+        np.testing.assert_allclose(gpx2.predict(xq), gpx.predict(xq), rtol=1e-12)
+        np.testing.assert_allclose(gpx2.predict_var(xq), gpx.predict_var(xq), rtol=1e-9, atol=1e-12 * gpx.variances()[0])
+        assert gpx2.likelihoods()[0] == pytest.approx(gpx.likelihoods()[0], rel=1e-12)
     assert "Mixture[Hard](Linear_Matern52GP(mean=LinearMean, corr=Matern52" in str(gpx)
+
+
+def test_load_reference_serialized_model(egx, O, golden_dir):
+    """A model serialized by the REFERENCE (egobox 0.32.0, doc/Gpx_Tutorial.ipynb cell 31; same serde schema as
+    crates/moe/src/surrogates.rs save/load) is ingested as is -- stored r_chol, gamma, beta, ft, ft_qr_r uploaded,
+    nothing re-factored -- and predicts like the oracle evaluated on the reference's own stored parameters."""
+    g = json.load(open(os.path.join(golden_dir, "golden_b.json")))
+    nd = lambda a: {"v": 1, "dim": list(np.shape(a)), "data": np.asarray(a, dtype=float).ravel().tolist()}
+    expert = {
+        "type_fullgp": g["type_fullgp"], "theta": nd(g["theta"]), "likelihood": g["likelihood"],
+        "inner_params": {"sigma2": g["sigma2"], "beta": nd(g["beta"]), "gamma": nd(g["gamma"]),
+                         "r_chol": nd(g["r_chol"]), "ft": nd(g["ft"]), "ft_qr_r": nd(g["ft_qr_r"])},
+        "w_star": nd(g["w_star"]),
+        "xt_norm": {k: nd(v) for k, v in g["xt_norm"].items()}, "yt_norm": {k: nd(v) for k, v in g["yt_norm"].items()},
+        "training_data": [nd(g["training_x"]), nd(g["training_y"])],
+        "params": {"theta_tuning": {"Full": {}}, "mean": "LinearMean", "corr": "Matern52", "kpls_dim": None,
+                   "n_start": 10, "max_eval": 1000, "nugget": g["nugget"]},
+    }
+    gpx = egx.Gpx.from_dict({"recombination": "Hard", "experts": [expert], "gp_type": "FullGp"})
+    assert gpx.likelihoods()[0] == g["likelihood"] and gpx.variances()[0] == g["sigma2"]
+    assert gpx.thetas()[0, 0] == g["theta"][0]
+    # oracle object carrying the reference's stored parameters (no fitting anywhere)
+    xn, ym, ys = np.array(g["xt_norm"]["data"]), np.array(g["yt_norm"]["mean"]), np.array(g["yt_norm"]["std"])
+    inner = O.GpInnerParams(sigma2=g["sigma2"], beta=np.array(g["beta"]), gamma=np.array(g["gamma"]),
+                            r_chol=np.array(g["r_chol"]), ft=np.array(g["ft"]), ft_qr_r=np.array(g["ft_qr_r"]))
+    ref = O.GaussianProcessOracle(theta=np.array(g["theta"]), likelihood=g["likelihood"], inner=inner,
+                                  w_star=np.eye(1), xt_norm=xn, x_mean=np.array(g["xt_norm"]["mean"]),
+                                  x_std=np.array(g["xt_norm"]["std"]), yt_norm=np.array(g["yt_norm"]["data"]),
+                                  y_mean=ym, y_std=ys, mean=O.LINEAR, corr=O.MATERN52, nugget=g["nugget"])
+    xq = np.linspace(-10, 10, 500).reshape(-1, 1)  # the notebook's own plotting grid (cell 37)
+    yr, vr = ref.predict(xq), ref.predict_var(xq)
+    np.testing.assert_allclose(gpx.predict(xq), yr, rtol=1e-9, atol=1e-9 * np.abs(yr).max())
+    np.testing.assert_allclose(gpx.predict_var(xq), vr, rtol=1e-7, atol=1e-9 * g["sigma2"])
 
 
 # ------------------------------------------------------------------ full size (BASELINE metric size): properties
