@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--n", type=int, default=16384)
     ap.add_argument("--d", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
+                    "gloo only for checking the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--batch", type=int, default=2,
                     help="candidate thetas in flight per GPU and step (independent fits on separate workspaces/streams, "
                          "like the reference's rayon multistart, crates/gp/src/algorithm.rs:928-945)")
@@ -83,14 +85,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    ndev = torch.cuda.device_count()
+    gpu = local_rank % max(1, ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        torch.cuda.set_device(gpu)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{gpu}"))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
-    dev = torch.device(f"cuda:{local_rank}")
+    # collective payloads live on the GPU under RCCL, on the host under gloo
+    dev = torch.device(f"cuda:{gpu}") if args.backend == "nccl" else None
+    local_rank = gpu
 
     import egobox_amd as egx
     from egobox_amd import workload
@@ -140,7 +149,7 @@ def main():
     if world > 1:
         # the one exchange of the sweep: all-gather of the per-candidate results (16 B each), and
         # the max-over-ranks clock
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dev is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         from egobox_amd.sweep import sweep_likelihood
