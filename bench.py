@@ -69,8 +69,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=16384)
-    ap.add_argument("--d", type=int, default=32)
+    ap.add_argument("--npoints", dest="n", type=int, default=16384)
+    ap.add_argument("--dim", dest="d", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; "
                     "gloo only for checking the multi-rank path on a box with fewer GPUs than ranks)")
