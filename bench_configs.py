@@ -44,13 +44,14 @@ def main():
         n, d = 4096, 8
         x, y = workload.make_training_set(n, d, 42)
         th = workload.default_theta(d)
-        hs = [egx.GpHandle(x, y) for _ in range(2)]
-        pool = ThreadPoolExecutor(2)
+        hs = [egx.GpHandle(x, y) for _ in range(8)]
+        pool = ThreadPoolExecutor(8)
         t1 = timeit(lambda: hs[0].finalize(th), 10)
         tm = hs[0].timings()
-        t2 = timeit(lambda: list(pool.map(lambda h: h.finalize(th), hs)), 10) / 2
+        tk = {k: timeit(lambda: list(pool.map(lambda h: h.finalize(th), hs[:k])), 10) / k for k in (2, 4, 8)}
         emit({"config": 2, "n": n, "d": d, "corr": "SquaredExponential", "fits_per_s_1_in_flight": 1 / t1,
-              "fits_per_s_2_in_flight": 1 / t2, "potrf_ms": tm["potrf_ms"],
+              "fits_per_s_2_in_flight": 1 / tk[2], "fits_per_s_4_in_flight": 1 / tk[4],
+              "fits_per_s_8_in_flight": 1 / tk[8], "potrf_ms": tm["potrf_ms"],
               "cholesky_tflops": tm["potrf_flops"] / tm["potrf_ms"] / 1e9, "corr_build_ms": tm["corr_build_ms"],
               "corr_build_gbps": tm["corr_bytes"] / tm["corr_build_ms"] / 1e6})
         for h in hs:

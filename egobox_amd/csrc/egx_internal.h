@@ -69,8 +69,9 @@ int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, in
 int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
                  hipStream_t s2 = nullptr, hipEvent_t ev_lu = nullptr, hipEvent_t ev_panel = nullptr);
 // rows [0, m) of RT (ld) are right-hand sides: RT <- RT * C^-T  (C = lower factor in M, n_pad cols)
+// tri_rows != 0: the rows are those of the identity (solution upper triangular): zero blocks are skipped
 int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, const double *dinv,
-                     double *RT, int64_t ldr, int m);
+                     double *RT, int64_t ldr, int m, int tri_rows = 0);
 // dinv <- inverses of the 64x64 diagonal tiles of a given lower factor (model load path)
 int launch_diag_tile_inverses(hipStream_t s, const double *M, int64_t ld, int n_pad, double *dinv);
 // Wall ((n_pad/256) x 256 x 256) <- transposed inverses of the 256x256 diagonal blocks of the factor
@@ -79,8 +80,9 @@ int launch_block_inverse(hipStream_t s, const double *M, int64_t ld, int n_pad, 
 int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *Wall, double *v,
                   double *xout);
 // C (M x N, ldc) -= A (M x K, lda) * B (N x K, ldb)^T ; lower != 0 skips tiles strictly above the diagonal
+// ktri != 0 (with lower): A and B are upper triangular, the K loop of tile (bx, by) starts at row bx*tile
 int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
-                       const double *B, int64_t ldb, int M, int N, int K, int lower);
+                       const double *B, int64_t ldb, int M, int N, int K, int lower, int ktri = 0);
 int mfma_probe(double *max_abs_err);
 int chol_init();  // one-time function attribute setup (dynamic LDS sizes)
 

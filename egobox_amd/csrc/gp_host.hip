@@ -1155,9 +1155,9 @@ int32_t egx_gp_likelihood_grad(egx_gp *gp, const double *theta, int64_t theta_le
                                        sizeof(double), n_pad, hipMemcpyHostToDevice, w.stream));
         EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
     }
-    EGX_RC(launch_trsm_rows(w.stream, w.M, gp->ld, n_pad, w.dinv, gp->d_W, n_pad, n_pad));
+    EGX_RC(launch_trsm_rows(w.stream, w.M, gp->ld, n_pad, w.dinv, gp->d_W, n_pad, n_pad, 1));
     EGX_HIP_CHECK(hipMemsetAsync(gp->d_Rinv, 0, sizeof(double) * sq, w.stream));
-    EGX_RC(launch_gemm_nt_sub(w.stream, gp->d_Rinv, n_pad, gp->d_W, n_pad, gp->d_W, n_pad, n_pad, n_pad, n_pad, 1));
+    EGX_RC(launch_gemm_nt_sub(w.stream, gp->d_Rinv, n_pad, gp->d_W, n_pad, gp->d_W, n_pad, n_pad, n_pad, n_pad, 1, 1));
     EGX_HIP_CHECK(hipMemcpyAsync(gp->d_theta, thfull.data(), sizeof(double) * d, hipMemcpyHostToDevice, w.stream));
     EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
     EGX_RC(launch_grad_accum(w.stream, gp->corr, gp->d_xT, n_pad, n, d, gp->d_theta, gp->d_Rinv, n_pad, w.d_vec,

@@ -167,7 +167,7 @@ using SmallShape = GemmShape<64, 64, 32, 32, 256>;    // 4x lower per-tile laten
 template <bool LOWER, int BM, int BN, int WM, int WN, int NTHREADS, bool SWZ>
 __global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt_sub(
     double *__restrict__ C, int64_t ldc, const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
-    int64_t ldb, int K, int nbx, int nby) {
+    int64_t ldb, int K, int nbx, int nby, int ktri) {
     using S = GemmShape<BM, BN, WM, WN, NTHREADS>;
     // XCD-aware tile order (SWZ).  Workgroup w lands on XCD w % 8 (observed dispatch order, used for speed only,
     // never for correctness).  Tiles are grouped in 8x8 super-tiles; super-tile ST goes to XCD ST % 8 and its 64
@@ -213,8 +213,11 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt
     for (int mi = 0; mi < S::MT; mi++)
 #pragma unroll
         for (int ni = 0; ni < S::NT; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-    gemm_core<BM, BN, WM, WN, NTHREADS>(A + (int64_t)bx * BM * lda, lda, B + (int64_t)by * BN * ldb, ldb, K, acc, smem,
-                                        tid);
+    // ktri: both operands are upper triangular (row i is zero left of column i), C lower: the K range of tile
+    // (bx, by), bx >= by, starts at the first row of the tile (used for R^-1 = C^-T C^-1 in the theta-gradient)
+    const int koff = ktri ? bx * BM : 0;
+    gemm_core<BM, BN, WM, WN, NTHREADS>(A + (int64_t)bx * BM * lda + koff, lda, B + (int64_t)by * BN * ldb + koff, ldb,
+                                        K - koff, acc, smem, tid);
     EGX_GSTAMP(1);
     const int wave = tid >> 6, lane = tid & 63;
     const int r0 = bx * BM + (wave / S::WAVES_N) * WM + (lane >> 4);
@@ -682,7 +685,7 @@ int chol_init() {
 // Tile shape: 128x128 (64x64 per wave) when the launch fills the chip, 64x64 (32x32 per wave) otherwise: a
 // 128x128xK tile is one wave-chain of K/4*16 MFMAs (~43 us at K = 256), so small grids are latency bound.
 int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
-                       const double *B, int64_t ldb, int M, int N, int K, int lower) {
+                       const double *B, int64_t ldb, int M, int N, int K, int lower, int ktri) {
     if (M <= 0 || N <= 0 || K <= 0) return EGX_SUCCESS;
     if (M % 128 || N % 128 || K % KC) {
         set_error("gemm_nt_sub: M,N must be multiples of 128 and K of 16");
@@ -695,10 +698,10 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         dim3 grid(M / 64, N / 64);
         if (lower)
             hipLaunchKernelGGL((k_gemm_nt_sub<true, 64, 64, 32, 32, 256, false>), grid, dim3(256), SmallShape::LDS_BYTES, s,
-                               C, ldc, A, lda, B, ldb, K, M / 64, N / 64);
+                               C, ldc, A, lda, B, ldb, K, M / 64, N / 64, ktri);
         else
             hipLaunchKernelGGL((k_gemm_nt_sub<false, 64, 64, 32, 32, 256, false>), grid, dim3(256), SmallShape::LDS_BYTES,
-                               s, C, ldc, A, lda, B, ldb, K, M / 64, N / 64);
+                               s, C, ldc, A, lda, B, ldb, K, M / 64, N / 64, ktri);
     } else {
         const int nbx = M / 128, nby = N / 128;
         const int nsx = (nbx + 7) / 8, nsy = (nby + 7) / 8;
@@ -714,10 +717,10 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         dim3 grid(8 * per_xcd * 64);
         if (lower)
             hipLaunchKernelGGL((k_gemm_nt_sub<true, 128, 128, 32, 64, 512, true>), grid, dim3(512), TrailShape::LDS_BYTES, s,
-                               C, ldc, A, lda, B, ldb, K, nbx, nby);
+                               C, ldc, A, lda, B, ldb, K, nbx, nby, ktri);
         else
             hipLaunchKernelGGL((k_gemm_nt_sub<false, 128, 128, 32, 64, 512, true>), grid, dim3(512), TrailShape::LDS_BYTES,
-                               s, C, ldc, A, lda, B, ldb, K, nbx, nby);
+                               s, C, ldc, A, lda, B, ldb, K, nbx, nby, ktri);
     }
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
@@ -765,7 +768,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         const bool look = (s2 != nullptr) && (n_pad - r1 - nb1 >= 3072);
         const double *pan = M + (int64_t)r1 * ld + k0;
         // LU_k: next block column only
-        rc = launch_gemm_nt_sub(s, M + (int64_t)r1 * ld + r1, ld, pan, ld, pan, ld, m_tot - r1, nb1, nbk, 1);
+        rc = launch_gemm_nt_sub(s, M + (int64_t)r1 * ld + r1, ld, pan, ld, pan, ld, m_tot - r1, nb1, nbk, 1, 0);
         if (rc) return rc;
         if (look) {
             EGX_HIP_CHECK(hipEventRecord(ev_lu, s));
@@ -778,7 +781,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         if (r2 < n_pad) {
             const double *pan2 = M + (int64_t)r2 * ld + k0;
             rc = launch_gemm_nt_sub(s, M + (int64_t)r2 * ld + r2, ld, pan2, ld, pan2, ld, m_tot - r2, n_pad - r2, nbk,
-                                    1);
+                                    1, 0);
             if (rc) return rc;
         }
         if (look)
@@ -791,7 +794,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
 }
 
 int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, const double *dinv, double *RT,
-                     int64_t ldr, int m) {
+                     int64_t ldr, int m, int tri_rows) {
     int rc = chol_init();
     if (rc) return rc;
     if (m % kTile || n_pad % kTile) {
@@ -802,12 +805,15 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
         const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;
         const double *diag = M + (int64_t)k0 * ldm + k0;
         const double *dtiles = dinv + (int64_t)(k0 / 64) * 4096;
-        hipLaunchKernelGGL(k_panel_trsm, dim3(m / 64), dim3(256), PanelShape::LDS_BYTES, s, RT + k0, ldr, diag, ldm,
+        // tri_rows: the right-hand sides are the rows of the identity, so the solution (C^-T) is upper triangular:
+        // rows below the current block are still zero in these columns and are skipped
+        const int m_eff = tri_rows ? ((k0 + nbk < m) ? (k0 + nbk) : m) : m;
+        hipLaunchKernelGGL(k_panel_trsm, dim3(m_eff / 64), dim3(256), PanelShape::LDS_BYTES, s, RT + k0, ldr, diag, ldm,
                            dtiles, nbk);
         const int ncols = n_pad - (k0 + nbk);
         if (ncols > 0) {
             rc = launch_gemm_nt_sub(s, RT + (k0 + nbk), ldr, RT + k0, ldr, M + (int64_t)(k0 + nbk) * ldm + k0, ldm,
-                                    m, ncols, nbk, 0);
+                                    m_eff, ncols, nbk, 0, 0);
             if (rc) return rc;
         }
     }
