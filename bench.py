@@ -175,6 +175,10 @@ def main():
         host_ms = float(np.mean([t["host_ms"] for t in tim1]))
         flops = tim1[0]["potrf_flops"]
         tflops = flops / (potrf_ms * 1e-3) / 1e12
+        syrk_ms = float(np.mean([t["potrf_syrk_ms"] for t in tim1]))
+        syrk_flops = float(np.mean([t["syrk_flops"] for t in tim1]))
+        syrk_launches = int(tim1[0]["syrk_launches"])
+        syrk_tflops = syrk_flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
         agg_tflops = fits * flops / elapsed / 1e12 / world
         out = {
             "metric": "gp_fixed_theta_fits_per_sec", "value": fits / elapsed, "unit": "fits/s",
@@ -190,14 +194,22 @@ def main():
             "cholesky_tflops_per_gpu_in_timed_region": agg_tflops,
             "stage_ms_single_fit": {"corr_build": corr_ms, "potrf_fused_fwd_solve": potrf_ms, "gamma_solve": solve_ms,
                                     "host_gls": host_ms},
-            "roofline": {"bound": "mfma", "achieved": tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "blocked FP64 Cholesky (k_gemm_nt_sub trailing update = 92% of its flops, + panel "
-                                   "kernels): n^3/3 flops / HIP-event duration of the factorisation on its stream, one "
-                                   "fit in flight (separate leg after the timed region)",
-                         "flops_per_launch": flops, "launch_ms": potrf_ms,
-                         "measured_mfma_f64_ceiling_tflops": "77.6 register-only (tools/fp64_peak.hip); ~46-56 in the "
-                                                             "LDS-fed kernel under DVFS (tools/gemm_prof.hip)"},
+            "cholesky_tflops_single_fit": tflops,
+            "roofline": {"bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "k_gemm_nt_sub<LOWER,128,128,32,64,512> (Cholesky trailing update C -= P P^T, K = 256: "
+                                   "92% of the factorisation's flops)",
+                         "launches_per_fit": syrk_launches, "launch_ms_avg": syrk_ms / max(1, syrk_launches),
+                         "flops_per_launch_avg": syrk_flops / max(1, syrk_launches),
+                         "how": "algorithmic flops (2*K*ncols*(ncols+1)/2 per launch) / HIP-event durations around every "
+                                "launch on the stream it is launched on, one fit in flight (separate leg after the timed "
+                                "region; in the timed region two candidates overlap and share the GPU)",
+                         "traffic_measured_offline": "rocprofv3 --pmc: 20.5 GB fetched + 22.1 GB written per fit over "
+                                                     "these launches (algorithmic C read+write 45.9 GB), L2 hit rate 0.74 "
+                                                     "-- profiles/r01_pmc_gemm_summary.txt",
+                         "measured_mfma_f64_ceiling_tflops": "77.6 register-only (tools/fp64_peak.hip); 43-49 (random "
+                                                             "operands) / 56 (zeros) for this kernel alone under DVFS "
+                                                             "(tools/gemm_prof.hip)"},
             "corr_build_gbps": tim1[0]["corr_bytes"] / (corr_ms * 1e-3) / 1e9,
             "likelihood_checksum": float(np.sum(lkhs[args.warmup * world * nb:])),
         }

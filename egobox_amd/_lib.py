@@ -37,7 +37,8 @@ class InnerView(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("corr_build_ms", C.c_double), ("potrf_ms", C.c_double), ("potrf_syrk_ms", C.c_double),
                 ("solve_ms", C.c_double), ("host_ms", C.c_double), ("total_ms", C.c_double),
-                ("potrf_flops", C.c_int64), ("corr_bytes", C.c_int64)]
+                ("potrf_flops", C.c_int64), ("corr_bytes", C.c_int64), ("syrk_launches", C.c_int64),
+                ("syrk_flops", C.c_int64)]
 
 
 #: every symbol include/egx_gp.h declares: (name, restype, argtypes)

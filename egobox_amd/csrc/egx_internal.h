@@ -64,10 +64,20 @@ int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, in
 // dinv receives the inverses of the 64x64 diagonal tiles ((n_pad/64) * 4096 doubles).
 // info (device int): 0 or 1-based index of the first non-positive pivot.
 // ev_syrk: optional accumulation of per-launch timings is done by the caller via events.
+// Optional per-launch timing of the big-tile trailing-update kernel (the dominant kernel): event pairs recorded on
+// the stream the kernel is launched on.  Filled by launch_potrf, read back by the caller after a stream sync.
+struct GemmTrace {
+    static constexpr int kMax = 192;
+    hipEvent_t e0[kMax], e1[kMax];
+    double flops[kMax];
+    int used = 0;
+    bool ready = false;
+};
 // s2 / ev_lu / ev_panel: auxiliary (high priority) stream and two events for the one-block look-ahead;
 // s2 == nullptr runs everything in order on s.
 int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
-                 hipStream_t s2 = nullptr, hipEvent_t ev_lu = nullptr, hipEvent_t ev_panel = nullptr);
+                 hipStream_t s2 = nullptr, hipEvent_t ev_lu = nullptr, hipEvent_t ev_panel = nullptr,
+                 GemmTrace *trace = nullptr);
 // rows [0, m) of RT (ld) are right-hand sides: RT <- RT * C^-T  (C = lower factor in M, n_pad cols)
 // tri_rows != 0: the rows are those of the identity (solution upper triangular): zero blocks are skipped
 int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, const double *dinv,
@@ -82,7 +92,8 @@ int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const d
 // C (M x N, ldc) -= A (M x K, lda) * B (N x K, ldb)^T ; lower != 0 skips tiles strictly above the diagonal
 // ktri != 0 (with lower): A and B are upper triangular, the K loop of tile (bx, by) starts at row bx*tile
 int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
-                       const double *B, int64_t ldb, int M, int N, int K, int lower, int ktri = 0);
+                       const double *B, int64_t ldb, int M, int N, int K, int lower, int ktri = 0,
+                       bool *used_big_tile = nullptr);
 int mfma_probe(double *max_abs_err);
 int chol_init();  // one-time function attribute setup (dynamic LDS sizes)
 

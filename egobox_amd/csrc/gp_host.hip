@@ -45,6 +45,7 @@ struct Workspace {
     double *h_vec = nullptr;   // pinned: n_pad
     int *h_info = nullptr;     // pinned
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    GemmTrace trace;
 };
 
 struct EvalResult {
@@ -112,6 +113,11 @@ static void free_workspace(Workspace &w) {
     if (w.h_info) hipHostFree(w.h_info);
     for (auto &e : w.ev)
         if (e) hipEventDestroy(e);
+    if (w.trace.ready)
+        for (int i = 0; i < GemmTrace::kMax; i++) {
+            hipEventDestroy(w.trace.e0[i]);
+            hipEventDestroy(w.trace.e1[i]);
+        }
     if (w.ev_lu) hipEventDestroy(w.ev_lu);
     if (w.ev_panel) hipEventDestroy(w.ev_panel);
     if (w.stream2) hipStreamDestroy(w.stream2);
@@ -145,6 +151,11 @@ static int alloc_workspace(egx_gp *gp, Workspace &w) {
     EGX_HIP_CHECK(hipHostMalloc(&w.h_vec, sizeof(double) * (size_t)gp->n_pad, hipHostMallocDefault));
     EGX_HIP_CHECK(hipHostMalloc(&w.h_info, sizeof(int), hipHostMallocDefault));
     for (auto &e : w.ev) EGX_HIP_CHECK(hipEventCreate(&e));
+    for (int i = 0; i < GemmTrace::kMax; i++) {
+        EGX_HIP_CHECK(hipEventCreate(&w.trace.e0[i]));
+        EGX_HIP_CHECK(hipEventCreate(&w.trace.e1[i]));
+    }
+    w.trace.ready = true;
     return EGX_SUCCESS;
 }
 
@@ -203,7 +214,7 @@ static int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coe
     EGX_RC(launch_fill_rows(w.stream, w.M, gp->ld, gp->n_pad, gp->rhs_pad, gp->d_rhsT, gp->n_pad, gp->q, gp->n_pad));
     EGX_HIP_CHECK(hipEventRecord(w.ev[1], w.stream));
     EGX_RC(launch_potrf(w.stream, w.M, gp->ld, gp->n_pad, gp->m_tot, w.dinv, w.d_info, w.stream2, w.ev_lu,
-                        w.ev_panel));
+                        w.ev_panel, &w.trace));
     EGX_HIP_CHECK(hipEventRecord(w.ev[2], w.stream));
     EGX_RC(launch_gather_diag(w.stream, w.M, gp->ld, gp->n, w.d_diag));
     EGX_HIP_CHECK(hipMemcpyAsync(w.h_diag, w.d_diag, sizeof(double) * gp->n, hipMemcpyDeviceToHost, w.stream));
@@ -298,6 +309,18 @@ static void record_timings(egx_gp *gp, Workspace &w, double host_ms, double solv
     t.corr_build_ms = t01;
     t.potrf_ms = t12;
     t.potrf_syrk_ms = 0.0;
+    t.syrk_launches = 0;
+    t.syrk_flops = 0;
+    double fl = 0.0;
+    for (int i = 0; i < w.trace.used; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, w.trace.e0[i], w.trace.e1[i]) == hipSuccess) {
+            t.potrf_syrk_ms += ms;
+            fl += w.trace.flops[i];
+            t.syrk_launches++;
+        }
+    }
+    t.syrk_flops = (int64_t)fl;
     t.solve_ms = solve_ms;
     t.host_ms = host_ms;
     t.total_ms = t03 + host_ms + solve_ms;

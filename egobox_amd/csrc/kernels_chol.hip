@@ -685,7 +685,8 @@ int chol_init() {
 // Tile shape: 128x128 (64x64 per wave) when the launch fills the chip, 64x64 (32x32 per wave) otherwise: a
 // 128x128xK tile is one wave-chain of K/4*16 MFMAs (~43 us at K = 256), so small grids are latency bound.
 int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
-                       const double *B, int64_t ldb, int M, int N, int K, int lower, int ktri) {
+                       const double *B, int64_t ldb, int M, int N, int K, int lower, int ktri, bool *used_big_tile) {
+    if (used_big_tile) *used_big_tile = false;
     if (M <= 0 || N <= 0 || K <= 0) return EGX_SUCCESS;
     if (M % 128 || N % 128 || K % KC) {
         set_error("gemm_nt_sub: M,N must be multiples of 128 and K of 16");
@@ -694,6 +695,7 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
     const int64_t big_tiles = lower ? ((int64_t)(M / 128) * (N / 128) - (int64_t)(N / 128) * (N / 128 - 1) / 2)
                                     : (int64_t)(M / 128) * (N / 128);
     const bool small = big_tiles < 1024;  // fewer than 2 waves of workgroups over 256 CUs x 2
+    if (used_big_tile) *used_big_tile = !small;
     if (small) {
         dim3 grid(M / 64, N / 64);
         if (lower)
@@ -732,7 +734,8 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
 // then latency-bound solves) is thereby hidden behind the MFMA-bound update for all but the last blocks.
 // s2 == nullptr disables the look-ahead (everything in order on `s`).
 int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
-                 hipStream_t s2, hipEvent_t ev_lu, hipEvent_t ev_panel) {
+                 hipStream_t s2, hipEvent_t ev_lu, hipEvent_t ev_panel, GemmTrace *trace) {
+    if (trace) trace->used = 0;
     int rc = chol_init();
     if (rc) return rc;
     if (n_pad % kTile || m_tot % kTile || m_tot < n_pad) {
@@ -780,9 +783,18 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         const int r2 = r1 + nb1;
         if (r2 < n_pad) {
             const double *pan2 = M + (int64_t)r2 * ld + k0;
+            const bool timed = trace && trace->ready && trace->used < GemmTrace::kMax;
+            if (timed) EGX_HIP_CHECK(hipEventRecord(trace->e0[trace->used], s));
+            bool big = false;
             rc = launch_gemm_nt_sub(s, M + (int64_t)r2 * ld + r2, ld, pan2, ld, pan2, ld, m_tot - r2, n_pad - r2, nbk,
-                                    1, 0);
+                                    1, 0, &big);
             if (rc) return rc;
+            if (timed && big) {
+                EGX_HIP_CHECK(hipEventRecord(trace->e1[trace->used], s));
+                const double nc = (double)(n_pad - r2);
+                trace->flops[trace->used] = 2.0 * nbk * nc * (nc + 1.0) / 2.0;
+                trace->used++;
+            }
         }
         if (look)
             EGX_HIP_CHECK(hipStreamWaitEvent(s, ev_panel, 0));

@@ -196,12 +196,14 @@ int32_t egx_potrf(double *a, int64_t n, int32_t *info);
 typedef struct {
     double corr_build_ms; /* K1 */
     double potrf_ms;      /* K3 incl. fused forward solves (K4) */
-    double potrf_syrk_ms; /* trailing-update launches only (when EGX_TIMING=2) */
+    double potrf_syrk_ms; /* sum of the HIP-event durations of the big-tile trailing-update launches */
     double solve_ms;      /* gamma back-substitution */
     double host_ms;       /* GLS / QR / reductions on the host */
     double total_ms;
     int64_t potrf_flops;  /* n^3/3 algorithmic */
     int64_t corr_bytes;   /* 8*n*d + 8*n(n+1)/2 algorithmic */
+    int64_t syrk_launches; /* number of big-tile (128x128, 512-thread) trailing-update launches timed */
+    int64_t syrk_flops;    /* their algorithmic flops: sum of 2*K*ncols*(ncols+1)/2 (lower triangle) */
 } egx_timings;
 int32_t egx_gp_last_timings(const egx_gp *gp, egx_timings *t);
 
