@@ -1,0 +1,13 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
+LOG=gpurun_out/run15.log
+{
+echo "=== bench default"; timeout 900 python bench.py --steps 6 --warmup 2
+echo "=== bench batch 1"; timeout 900 python bench.py --steps 6 --warmup 2 --batch 1 --no-cpu-baseline
+} > $LOG 2>&1
+for B in 1 2; do
+echo "=== rocprof batch $B" >> $LOG
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_r15_b$B" -o bench -- python "$GRAFT_REPO_ROOT/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --batch $B 2>&1 | grep -v "simple_timer\|generateRocpd" >> "$GRAFT_REPO_ROOT/$LOG")
+python tools/rocpd_stats.py gpurun_out/prof_r15_b$B/bench_results.db >> $LOG 2>&1
+done
+cat $LOG | cut -c1-3000
