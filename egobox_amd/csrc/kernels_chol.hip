@@ -153,9 +153,11 @@ __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t 
 // ---------------------------------------------------------------------------------------------
 #ifdef EGX_GEMM_PROFILE
 __device__ long long g_gemm_stamps[1 << 16][4];
+__device__ long long g_gemm_cycles[1 << 16][2];  // shader-clock ticks (s_memtime) at the K-loop boundaries
 #define EGX_GSTAMP(i)                                                                                     \
     if (threadIdx.x == 0) {                                                                               \
         g_gemm_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 0xffff][i] = (long long)wall_clock64();    \
+        if (i < 2) g_gemm_cycles[(blockIdx.y * gridDim.x + blockIdx.x) & 0xffff][i] = (long long)clock64(); \
         if (i == 0) g_gemm_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 0xffff][3] = __smid();          \
     }
 #else

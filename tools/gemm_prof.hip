@@ -39,6 +39,15 @@ int main(int argc, char **argv) {
         epi.push_back((st[i][2] - st[i][1]) / 100.0);
         tmin = std::min(tmin, st[i][0]); tmax = std::max(tmax, st[i][2]); cnt++;
     }
+    static long long cy[1 << 16][2];
+    hipMemcpyFromSymbol(cy, HIP_SYMBOL(g_gemm_cycles), sizeof cy);
+    std::vector<double> mhz;
+    for (int i = 0; i < (1 << 16); i++)
+        if (st[i][2] != 0 && st[i][1] > st[i][0]) mhz.push_back((cy[i][1] - cy[i][0]) / ((st[i][1] - st[i][0]) / 100.0));
+    std::sort(mhz.begin(), mhz.end());
+    if (!mhz.empty())
+        printf("shader clock during the K loop (s_memtime ticks / 100 MHz wall clock): p10 %.0f  p50 %.0f  p90 %.0f MHz\n",
+               mhz[(size_t)(0.1 * (mhz.size() - 1))], mhz[(size_t)(0.5 * (mhz.size() - 1))], mhz[(size_t)(0.9 * (mhz.size() - 1))]);
     std::sort(loop.begin(), loop.end()); std::sort(epi.begin(), epi.end());
     auto q = [](std::vector<double> &v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
     printf("%d tiles stamped; span %.1f us\n", cnt, (tmax - tmin) / 100.0);
