@@ -514,3 +514,60 @@ def test_mixture_of_gpu_experts_matches_oracle(egx, O, recomb):
     np.testing.assert_allclose(var, want_var, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(want_var).max() + 1e-12)
     for e in gpu_experts:
         e.close()
+
+
+# ------------------------------------------------------------------ more edge cases
+def test_quadratic_mean_with_more_than_128_basis_columns(egx, O):
+    """Quadratic mean at d = 15 has p = 136 basis columns: the appended right-hand-side block is 256 rows."""
+    rng = np.random.default_rng(21)
+    x = rng.random((700, 15))
+    y = np.sin(x).sum(axis=1) + (x[:, :3] ** 2).sum(axis=1)
+    theta = np.full(15, 0.6)
+    ref = O.fit_fixed(x, y, theta, mean="Quadratic", corr="Matern52")
+    with egx.GpHandle(x, y, mean=2, corr=3) as h:
+        assert h.p == 136
+        lk, st = h.likelihood(theta)
+        assert st == 0 and lk == pytest.approx(ref.likelihood, rel=1e-7)  # p x p GLS conditioning, not the kernels
+        h.finalize(theta)
+        xq = rng.random((200, 15))
+        np.testing.assert_allclose(h.predict(xq), ref.predict(xq), rtol=1e-6, atol=1e-7)
+        vr = ref.predict_var(xq)
+        np.testing.assert_allclose(h.predict_var(xq), vr, rtol=1e-5, atol=1e-6 * vr.max())
+
+
+def test_duplicate_training_points_follow_the_oracle_status(egx, O):
+    """Collisions: the reference only warns on duplicated rows (algorithm.rs:857-865); with the default nugget the
+    factorisation may or may not survive -- either way the status channel must agree with a LAPACK evaluation in
+    kind (0 or NOT_POSITIVE_DEFINITE) and never raise."""
+    rng = np.random.default_rng(5)
+    x = rng.random((300, 3))
+    x[17] = x[3]
+    x[250] = x[100]
+    y = x.sum(axis=1)
+    y[17], y[250] = y[3], y[100]
+    for corr in (0, 3):
+        lk_ref, st_ref = O.likelihood_at(x, y, [1.0, 1.0, 1.0], corr=KINDS[corr])
+        with egx.GpHandle(x, y, corr=corr) as h:
+            lk, st = h.likelihood([1.0, 1.0, 1.0])
+        assert st in (0, 1) and st_ref in (0, 1)
+        if st == 0:
+            assert np.isfinite(lk)
+
+
+def test_non_power_of_two_large_n_properties(egx):
+    """n = 20000 (n_pad = 20096, 3.2 GB workspace: byte offsets beyond 2^31): interpolation and zero variance at
+    training points, permutation invariance of the likelihood."""
+    n, d = 20000, 6
+    x, y = _data(n, d, seed=77)
+    theta = egx.workload.default_theta(d) * 2.0
+    with egx.GpHandle(x, y, corr=3) as h:
+        h.finalize(theta)
+        lk, s2 = h.fitted_scalars()
+        idx = np.arange(0, n, 401)
+        yp, vp = h.predict_valvar(x[idx])
+        np.testing.assert_allclose(yp, y[idx], rtol=1e-6, atol=1e-6 * np.abs(y).max())
+        assert np.all(vp >= 0) and np.all(vp <= 1e-6 * s2)
+    perm = np.random.default_rng(0).permutation(n)
+    with egx.GpHandle(x[perm], y[perm], corr=3) as h2:
+        lk2, st2 = h2.likelihood(theta)
+        assert st2 == 0 and lk2 == pytest.approx(lk, rel=LK_RTOL)
