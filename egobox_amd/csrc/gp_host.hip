@@ -1127,18 +1127,12 @@ int32_t egx_gp_set_inner(egx_gp *gp, const egx_gp_inner_view *v) {
     return EGX_SUCCESS;
 }
 
-int32_t egx_gp_likelihood_grad(egx_gp *gp, const double *theta, int64_t theta_len, double *lkh, double *grad,
-                               int32_t *status) {
-    if (!gp || !theta || !lkh || !grad || !status) {
-        set_error("NULL argument");
-        return EGX_ERR_INVALID_VALUE;
-    }
-    if (gp->has_w) {
-        set_error("likelihood gradient with KPLS weights is not implemented");
-        return EGX_ERR_UNSUPPORTED;
-    }
-    std::lock_guard<std::mutex> lock(gp->mu);
-    EGX_RC(set_device(gp));
+}  // extern "C"
+
+namespace egx {
+// likelihood and dL/dtheta on workspace 0 (caller holds gp->mu and has set the device)
+static int likelihood_grad_core(egx_gp *gp, const double *theta, int64_t theta_len, double *lkh, double *grad,
+                                int32_t *status) {
     const int n = gp->n, n_pad = gp->n_pad, d = gp->d;
     std::vector<double> coef, thfull;
     int hcols = 1;
@@ -1192,6 +1186,195 @@ int32_t egx_gp_likelihood_grad(egx_gp *gp, const double *theta, int64_t theta_le
     const double ln10 = std::log(10.0);
     for (int k = 0; k < d; k++) grad[k] = (gout[d + k] / res.sigma2n + gout[k]) / ln10;
     return EGX_SUCCESS;
+}
+}  // namespace egx
+
+extern "C" {
+
+int32_t egx_gp_likelihood_grad(egx_gp *gp, const double *theta, int64_t theta_len, double *lkh, double *grad,
+                               int32_t *status) {
+    if (!gp || !theta || !lkh || !grad || !status) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (gp->has_w) {
+        set_error("likelihood gradient with KPLS weights is not implemented");
+        return EGX_ERR_UNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> lock(gp->mu);
+    EGX_RC(set_device(gp));
+    return likelihood_grad_core(gp, theta, theta_len, lkh, grad, status);
+}
+
+/* Gradient-based alternative to egx_gp_fit (new: uses the theta-gradient the reference does not have).
+ * Projected L-BFGS on x = log10(theta) inside the box, one run per start (sequential: the gradient scratch
+ * is per handle), best start wins, then finalize.  max_iter bounds the iterations per start. */
+int32_t egx_gp_fit_lbfgs(egx_gp *gp, const double *theta0s, int64_t n_starts, const double *lo, const double *hi,
+                         int64_t bounds_len, int64_t max_iter, int64_t *n_evals_out) {
+    if (!gp || !theta0s || !lo || !hi || n_starts < 1) {
+        set_error("NULL argument / no start point");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (gp->has_w) {
+        set_error("likelihood gradient with KPLS weights is not implemented");
+        return EGX_ERR_UNSUPPORTED;
+    }
+    const int h = gp->h;
+    if (bounds_len != 1 && bounds_len != h) {
+        set_error("Bounds for theta should be either 1-dim or dim of xtrain (" + std::to_string(h) + "), got " +
+                  std::to_string(bounds_len));
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::vector<double> blo(h), bhi(h);
+    for (int i = 0; i < h; i++) {
+        const double l = lo[bounds_len == 1 ? 0 : i], u = hi[bounds_len == 1 ? 0 : i];
+        if (!(l > 0.0) || !(u >= l)) {
+            set_error("theta bounds must satisfy 0 < lo <= hi");
+            return EGX_ERR_INVALID_VALUE;
+        }
+        blo[i] = std::log10(l);
+        bhi[i] = std::log10(u);
+    }
+    for (int64_t s = 0; s < n_starts * h; s++)
+        if (!(theta0s[s] > 0.0)) {
+            set_error("theta start points must be > 0");
+            return EGX_ERR_INVALID_VALUE;
+        }
+    if (max_iter < 1) max_iter = 50;
+    std::lock_guard<std::mutex> lock(gp->mu);
+    EGX_RC(set_device(gp));
+    const double ln10 = std::log(10.0), inf = std::numeric_limits<double>::infinity();
+    int64_t evals = 0;
+    int rc_inner = EGX_SUCCESS;
+    // f(x) = -L(10^x), g = -dL/dx = -theta ln10 dL/dtheta
+    auto fg = [&](const std::vector<double> &x, std::vector<double> &g) -> double {
+        std::vector<double> th(h), gt(h);
+        for (int i = 0; i < h; i++) th[i] = std::pow(10.0, x[i]);
+        double lk = 0.0;
+        int32_t st = 0;
+        evals++;
+        int rc = likelihood_grad_core(gp, th.data(), h, &lk, gt.data(), &st);
+        if (rc) {
+            rc_inner = rc;
+            return inf;
+        }
+        if (st != EGX_STATUS_OK || !std::isfinite(lk)) return inf;
+        for (int i = 0; i < h; i++) g[i] = -th[i] * ln10 * gt[i];
+        return -lk;
+    };
+    auto clip = [&](std::vector<double> &x) {
+        for (int i = 0; i < h; i++) x[i] = std::fmin(bhi[i], std::fmax(blo[i], x[i]));
+    };
+    double best_f = inf;
+    std::vector<double> best_x(h, 0.0);
+    const int mem = 8;
+    for (int64_t s = 0; s < n_starts; s++) {
+        std::vector<double> x(h), g(h), pg(h), d(h), xn(h), gn(h);
+        for (int i = 0; i < h; i++) x[i] = std::log10(theta0s[s * h + i]);
+        clip(x);
+        double f = fg(x, g);
+        if (rc_inner) return rc_inner;
+        std::vector<std::vector<double>> S, Y;
+        std::vector<double> rho;
+        if (std::isfinite(f)) {
+            for (int64_t it = 0; it < max_iter; it++) {
+                double pgmax = 0.0;
+                for (int i = 0; i < h; i++) {
+                    const bool at_lo = x[i] <= blo[i] && g[i] > 0.0, at_hi = x[i] >= bhi[i] && g[i] < 0.0;
+                    pg[i] = (at_lo || at_hi) ? 0.0 : g[i];
+                    pgmax = std::fmax(pgmax, std::fabs(pg[i]));
+                }
+                if (pgmax <= 1e-5 * (1.0 + std::fabs(f))) break;
+                // two-loop recursion on the projected gradient
+                std::vector<double> q(pg), alpha(S.size());
+                for (int j = (int)S.size() - 1; j >= 0; j--) {
+                    double a = 0.0;
+                    for (int i = 0; i < h; i++) a += S[j][i] * q[i];
+                    a *= rho[j];
+                    alpha[j] = a;
+                    for (int i = 0; i < h; i++) q[i] -= a * Y[j][i];
+                }
+                if (!S.empty()) {
+                    double sy = 0.0, yy = 0.0;
+                    for (int i = 0; i < h; i++) {
+                        sy += S.back()[i] * Y.back()[i];
+                        yy += Y.back()[i] * Y.back()[i];
+                    }
+                    for (int i = 0; i < h; i++) q[i] *= sy / yy;
+                }
+                for (size_t j = 0; j < S.size(); j++) {
+                    double b = 0.0;
+                    for (int i = 0; i < h; i++) b += Y[j][i] * q[i];
+                    b *= rho[j];
+                    for (int i = 0; i < h; i++) q[i] += (alpha[j] - b) * S[j][i];
+                }
+                double dg = 0.0, dmax = 0.0;
+                for (int i = 0; i < h; i++) {
+                    d[i] = (pg[i] == 0.0) ? 0.0 : -q[i];
+                    dg += d[i] * pg[i];
+                    dmax = std::fmax(dmax, std::fabs(d[i]));
+                }
+                if (!(dg < 0.0)) {  // not a descent direction: steepest descent
+                    dg = 0.0;
+                    dmax = 0.0;
+                    for (int i = 0; i < h; i++) {
+                        d[i] = -pg[i];
+                        dg += d[i] * pg[i];
+                        dmax = std::fmax(dmax, std::fabs(d[i]));
+                    }
+                }
+                double t = S.empty() ? std::fmin(1.0, 0.5 / dmax) : std::fmin(1.0, 1.0 / dmax);  // <= 1 decade per step
+                double fnew = inf;
+                bool ok = false;
+                for (int ls = 0; ls < 12; ls++, t *= 0.5) {
+                    for (int i = 0; i < h; i++) xn[i] = x[i] + t * d[i];
+                    clip(xn);
+                    fnew = fg(xn, gn);
+                    if (rc_inner) return rc_inner;
+                    double dec = 0.0;
+                    for (int i = 0; i < h; i++) dec += pg[i] * (xn[i] - x[i]);
+                    if (std::isfinite(fnew) && fnew <= f + 1e-4 * dec) {
+                        ok = true;
+                        break;
+                    }
+                }
+                if (!ok) break;
+                std::vector<double> sv(h), yv(h);
+                double sy = 0.0;
+                for (int i = 0; i < h; i++) {
+                    sv[i] = xn[i] - x[i];
+                    yv[i] = gn[i] - g[i];
+                    sy += sv[i] * yv[i];
+                }
+                const double fprev = f;
+                x = xn;
+                g = gn;
+                f = fnew;
+                if (sy > 1e-12) {
+                    S.push_back(sv);
+                    Y.push_back(yv);
+                    rho.push_back(1.0 / sy);
+                    if ((int)S.size() > mem) {
+                        S.erase(S.begin());
+                        Y.erase(Y.begin());
+                        rho.erase(rho.begin());
+                    }
+                }
+                if (std::fabs(fprev - f) <= 1e-7 * (std::fabs(f) + 1e-300)) break;
+            }
+        }
+        if (f < best_f) {
+            best_f = f;
+            best_x = x;
+        }
+    }
+    if (n_evals_out) *n_evals_out = evals;
+    std::vector<double> th(h);
+    if (std::isfinite(best_f))
+        for (int i = 0; i < h; i++) th[i] = std::pow(10.0, best_x[i]);
+    else
+        for (int i = 0; i < h; i++) th[i] = theta0s[i];
+    return do_finalize(gp, th.data(), h);
 }
 
 // ---- kernel-level entry points ------------------------------------------------------------------

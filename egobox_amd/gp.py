@@ -204,6 +204,15 @@ class GpHandle:
                                      int(max_eval), C.byref(ne)))
         return ne.value
 
+    def fit_lbfgs(self, theta0s, lo, hi, max_iter=50):
+        theta0s = L.as_f64(theta0s, 2)
+        lo = L.as_f64(np.atleast_1d(lo), 1)
+        hi = L.as_f64(np.atleast_1d(hi), 1)
+        ne = C.c_int64()
+        L.check(self._lib.egx_gp_fit_lbfgs(self._h, L.dptr(theta0s), theta0s.shape[0], L.dptr(lo), L.dptr(hi), lo.size,
+                                           int(max_iter), C.byref(ne)))
+        return ne.value
+
     # -- predict
     def _q(self, x):
         x = L.as_f64(x)
@@ -346,6 +355,7 @@ class GpParams:
         self._nugget = DEFAULT_NUGGET
         self._device = -1
         self._n_workspaces = 2  # concurrent likelihood evaluations (multistart threads) during a tuned fit
+        self._optimizer = "nelder-mead"  # derivative-free like the reference's COBYLA; "lbfgs" uses the new gradient
         self._seed = 42  # optimization.rs:62: multistart LHS is seeded with 42
 
     # setters return self, like the Rust builder
@@ -401,6 +411,14 @@ class GpParams:
 
     def device(self, device):
         self._device = int(device)
+        return self
+
+    def optimizer(self, name):
+        """Extension: "nelder-mead" (derivative-free, the reference's COBYLA stand-in) or "lbfgs" (projected
+        L-BFGS on log10 theta driven by the new likelihood gradient)."""
+        if name not in ("nelder-mead", "lbfgs"):
+            raise ValueError("optimizer must be 'nelder-mead' or 'lbfgs'")
+        self._optimizer = name
         return self
 
     def n_workspaces(self, n):
@@ -463,7 +481,11 @@ class GpParams:
                     f"Bounds for theta should be either 1-dim or dim of xtrain ({dim}), got {len(b)}")
             b = b * dim if len(b) == 1 else b
             starts_log10, _ = prepare_multistart(self._n_start, theta0, b, seed=self._seed)
-            n_evals = h.fit(10.0 ** starts_log10, [lo for lo, _ in b], [hi for _, hi in b], self._max_eval)
+            if self._optimizer == "lbfgs":
+                n_evals = h.fit_lbfgs(10.0 ** starts_log10, [lo for lo, _ in b], [hi for _, hi in b],
+                                      max(5, min(100, self._max_eval // 4)))
+            else:
+                n_evals = h.fit(10.0 ** starts_log10, [lo for lo, _ in b], [hi for _, hi in b], self._max_eval)
         else:
             h.close()
             raise NotImplementedError("ThetaTuning.Partial is not on the accelerated path yet")

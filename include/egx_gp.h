@@ -140,6 +140,12 @@ int32_t egx_gp_finalize(egx_gp *gp, const double *theta, int64_t theta_len);
 int32_t egx_gp_fit(egx_gp *gp, const double *theta0s, int64_t n_starts, const double *lo,
                    const double *hi, int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out);
 
+/* Gradient-based variant (NEW: consumes egx_gp_likelihood_grad; same contract as egx_gp_fit otherwise):
+ * projected L-BFGS on log10(theta) per start, best start wins, then finalize.  max_iter bounds the
+ * iterations per start; *n_evals_out counts likelihood+gradient evaluations. */
+int32_t egx_gp_fit_lbfgs(egx_gp *gp, const double *theta0s, int64_t n_starts, const double *lo,
+                         const double *hi, int64_t bounds_len, int64_t max_iter, int64_t *n_evals_out);
+
 /* ---- prediction (GaussianProcess::{predict, predict_var, predict_valvar},
  * algorithm.rs:253-307).  xq is (m x d) in ORIGINAL units. */
 int32_t egx_gp_predict(egx_gp *gp, const double *xq, int64_t m, double *y /*m*/);
