@@ -119,3 +119,41 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "gp_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_header_is_valid_c_and_cpp(tmp_path):
+    """include/egx_gp.h must compile as plain C (the Rust/cgo-style FFI consumers see it as C) and as C++."""
+    c = tmp_path / "t.c"
+    c.write_text('#include "egx_gp.h"\nint main(void) { egx_gp_config c; egx_timings t; (void)c; (void)t; '
+                 'return EGX_GP_ABI_VERSION == 1 ? 0 : 1; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", f"-I{inc}", str(c)], check=True)
+    cpp = tmp_path / "t.cpp"
+    cpp.write_text(c.read_text())
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", f"-I{inc}", str(cpp)], check=True)
+
+
+def test_c_program_links_against_the_library(tmp_path):
+    """A C program using only the header links against libegx_gp_hip.so and can call the host-only entry points."""
+    src = tmp_path / "host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "egx_gp.h"
+int main(void) {
+    double x[4] = {1, 2, 3, 4}, xn[4], m[2], s[2];
+    if (egx_abi_version() != EGX_GP_ABI_VERSION) return 1;
+    if (egx_normalize(x, 2, 2, xn, m, s) != EGX_SUCCESS) return 2;
+    if (m[0] != 2.0 || m[1] != 3.0) return 3;
+    if (egx_regression_ncols(EGX_MEAN_QUADRATIC, 3) != 10) return 4;
+    if (egx_normalize(x, 1, 2, xn, m, s) != EGX_ERR_INVALID_VALUE) return 5;
+    printf("%s\n", egx_last_error());
+    return 0;
+}
+''')
+    exe = tmp_path / "host"
+    libdir = os.path.join(ROOT, "egobox_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", f"-I{os.path.join(ROOT, 'include')}", str(src), f"-L{libdir}", "-legx_gp_hip",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out
+    assert "n >= 2" in out.stdout

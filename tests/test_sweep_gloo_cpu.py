@@ -87,3 +87,59 @@ def test_sweep_single_process():
     th = np.arange(6.0).reshape(3, 2)
     lk, st = sweep_likelihood(lambda t: (t.sum(1), np.zeros(len(t), dtype=np.int32)), th)
     np.testing.assert_array_equal(lk, [1.0, 5.0, 9.0])
+
+
+def _moe_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from egobox_amd.moe import GaussianMixture, GpMixture
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(1)
+    experts = []
+    for c in range(3):
+        x = rng.random((30, 2)) + [c, 0.0]
+        y = np.sin(3 * x[:, 0]) + x[:, 1] * (c + 1)
+        # expert e lives on rank e mod G (BASELINE config 5); the others are absent on this rank
+        experts.append(O.fit_fixed(x, y, [1.5, 1.0], corr=O.MATERN52) if c % world == rank else None)
+    gmx = GaussianMixture([0.3, 0.3, 0.4], [[0.5, 0.5], [1.5, 0.5], [2.5, 0.5]], [np.eye(2) * 0.2] * 3, 0.8)
+    xq = np.random.default_rng(2).random((25, 2)) * [3.0, 1.0]
+    out = {}
+    for recomb in ("smooth", "hard"):
+        out[recomb] = GpMixture(experts, gmx, recomb, rank=rank, world=world).predict_valvar(xq)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_moe_experts_sharded_over_two_ranks_gloo():
+    """Config-5 shape on CPU: experts sharded e mod G over 2 gloo ranks, one all-reduce of the weighted vectors;
+    every rank ends with the single-process result."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_moe_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from egobox_amd.moe import GaussianMixture, GpMixture
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(1)
+    experts = []
+    for c in range(3):
+        x = rng.random((30, 2)) + [c, 0.0]
+        y = np.sin(3 * x[:, 0]) + x[:, 1] * (c + 1)
+        experts.append(O.fit_fixed(x, y, [1.5, 1.0], corr=O.MATERN52))
+    gmx = GaussianMixture([0.3, 0.3, 0.4], [[0.5, 0.5], [1.5, 0.5], [2.5, 0.5]], [np.eye(2) * 0.2] * 3, 0.8)
+    xq = np.random.default_rng(2).random((25, 2)) * [3.0, 1.0]
+    for recomb in ("smooth", "hard"):
+        want = GpMixture(experts, gmx, recomb).predict_valvar(xq)
+        for r in range(2):
+            np.testing.assert_allclose(res[r][recomb][0], want[0], rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(res[r][recomb][1], want[1], rtol=1e-12, atol=1e-13)
