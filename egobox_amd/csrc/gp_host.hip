@@ -27,6 +27,21 @@ void set_error(const std::string &msg) { g_last_error = msg; }
         if (_rc) return _rc;      \
     } while (0)
 
+// Scoped device allocation for the temporaries of one call (freed on every exit path).
+struct DevBuf {
+    double *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t n_doubles) {
+        EGX_HIP_CHECK(hipMalloc(&p, sizeof(double) * (n_doubles ? n_doubles : 1)));
+        return EGX_SUCCESS;
+    }
+};
+
 struct Workspace {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // look-ahead (panel) stream
@@ -428,27 +443,21 @@ static int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
 }
 
 // ---- prediction -------------------------------------------------------------------------------
-struct QueryChunk {
-    int m = 0, m_pad = 0;
-    std::vector<double> xn;  // m x d normalised
-    double *d_xqT = nullptr; // d x m_pad
-};
-
-static int upload_queries(egx_gp *gp, const double *xq, int64_t m0, int m, QueryChunk &qc, hipStream_t s) {
+// Normalise a chunk of query points (algorithm.rs:254) and upload it k-major (d x m_pad, zero padded).
+static int upload_queries(egx_gp *gp, const double *xq, int64_t m0, int m, int m_pad, std::vector<double> &xn,
+                          DevBuf &d_xqT, hipStream_t s) {
     const int d = gp->d;
-    qc.m = m;
-    qc.m_pad = (int)round_up(m, kTile);
-    qc.xn.resize((size_t)m * d);
-    std::vector<double> xt((size_t)d * qc.m_pad, 0.0);
+    xn.resize((size_t)m * d);
+    std::vector<double> xt((size_t)d * m_pad, 0.0);
     for (int a = 0; a < m; a++)
         for (int j = 0; j < d; j++) {
-            const double v = (xq[(size_t)(m0 + a) * d + j] - gp->x_mean[j]) / gp->x_std[j];  // algorithm.rs:254
-            qc.xn[(size_t)a * d + j] = v;
-            xt[(size_t)j * qc.m_pad + a] = v;
+            const double v = (xq[(size_t)(m0 + a) * d + j] - gp->x_mean[j]) / gp->x_std[j];
+            xn[(size_t)a * d + j] = v;
+            xt[(size_t)j * m_pad + a] = v;
         }
-    EGX_HIP_CHECK(hipMalloc(&qc.d_xqT, sizeof(double) * xt.size()));
-    EGX_HIP_CHECK(hipMemcpyAsync(qc.d_xqT, xt.data(), sizeof(double) * xt.size(), hipMemcpyHostToDevice, s));
-    EGX_HIP_CHECK(hipStreamSynchronize(s));  // xt is a stack-owned pageable buffer
+    EGX_RC(d_xqT.alloc(xt.size()));
+    EGX_HIP_CHECK(hipMemcpyAsync(d_xqT.p, xt.data(), sizeof(double) * xt.size(), hipMemcpyHostToDevice, s));
+    EGX_HIP_CHECK(hipStreamSynchronize(s));  // xt is a pageable buffer owned by this frame
     return EGX_SUCCESS;
 }
 
@@ -469,65 +478,39 @@ static int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, d
     if (cap < kTile) cap = kTile;
     if (cap > 16384) cap = 16384;
     if (!vout) cap = 65536;
-    std::vector<double> f(p), rhs(p), u(p);
+    std::vector<double> f(p), rhs(p), u(p), xn, racc, s0, sl;
     for (int64_t m0 = 0; m0 < m; m0 += cap) {
         const int mc = (int)((m - m0 < cap) ? (m - m0) : cap);
-        QueryChunk qc;
-        int rc = upload_queries(gp, xq, m0, mc, qc, w.stream);
-        if (rc) return rc;
-        double *d_racc = nullptr, *d_RT = nullptr, *d_s0 = nullptr, *d_sl = nullptr;
-        std::vector<double> racc, s0, sl;
-        auto cleanup = [&]() {
-            if (qc.d_xqT) hipFree(qc.d_xqT);
-            if (d_racc) hipFree(d_racc);
-            if (d_RT) hipFree(d_RT);
-            if (d_s0) hipFree(d_s0);
-            if (d_sl) hipFree(d_sl);
-        };
-#define EGX_RCC(call)           \
-    do {                        \
-        int _rc = (call);       \
-        if (_rc) {              \
-            cleanup();          \
-            return _rc;         \
-        }                       \
-    } while (0)
-#define EGX_HIPC(expr)                                                            \
-    do {                                                                          \
-        hipError_t _e = (expr);                                                   \
-        if (_e != hipSuccess) {                                                   \
-            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));         \
-            cleanup();                                                            \
-            return EGX_ERR_HIP;                                                   \
-        }                                                                         \
-    } while (0)
+        const int m_pad = (int)round_up(mc, kTile);
+        DevBuf d_xqT, d_racc, d_RT, d_s0, d_sl;
+        EGX_RC(upload_queries(gp, xq, m0, mc, m_pad, xn, d_xqT, w.stream));
         if (yout) {
-            racc.resize(qc.m_pad);
-            EGX_HIPC(hipMalloc(&d_racc, sizeof(double) * qc.m_pad));
-            EGX_RCC(launch_predict_mean(w.stream, gp->corr, qc.d_xqT, qc.m_pad, qc.m_pad, gp->d_xT, n_pad, n_pad, d,
-                                        gp->d_fit_coef, gp->fit_hcols, gp->d_gamma, d_racc));
-            EGX_HIPC(hipMemcpyAsync(racc.data(), d_racc, sizeof(double) * qc.m_pad, hipMemcpyDeviceToHost, w.stream));
+            racc.resize(m_pad);
+            EGX_RC(d_racc.alloc(m_pad));
+            EGX_RC(launch_predict_mean(w.stream, gp->corr, d_xqT.p, m_pad, m_pad, gp->d_xT, n_pad, n_pad, d,
+                                       gp->d_fit_coef, gp->fit_hcols, gp->d_gamma, d_racc.p));
+            EGX_HIP_CHECK(hipMemcpyAsync(racc.data(), d_racc.p, sizeof(double) * m_pad, hipMemcpyDeviceToHost, w.stream));
         }
         if (vout) {
-            s0.resize(qc.m_pad);
-            sl.resize((size_t)qc.m_pad * p);
-            EGX_HIPC(hipMalloc(&d_RT, sizeof(double) * (size_t)qc.m_pad * n_pad));
-            EGX_HIPC(hipMalloc(&d_s0, sizeof(double) * qc.m_pad));
-            EGX_HIPC(hipMalloc(&d_sl, sizeof(double) * (size_t)qc.m_pad * p));
+            s0.resize(m_pad);
+            sl.resize((size_t)m_pad * p);
+            EGX_RC(d_RT.alloc((size_t)m_pad * n_pad));
+            EGX_RC(d_s0.alloc(m_pad));
+            EGX_RC(d_sl.alloc((size_t)m_pad * p));
             // corr (m x n): algorithm.rs:372-380 ; rt = C^-1 corr^T: :337-350 (held transposed, row per query)
-            EGX_RCC(launch_cross_corr(w.stream, gp->corr, qc.d_xqT, qc.m_pad, qc.m_pad, gp->d_xT, n_pad, n_pad, d,
-                                      gp->d_fit_coef, gp->fit_hcols, d_RT, n_pad));
-            EGX_RCC(launch_trsm_rows(w.stream, w.M, gp->ld, n_pad, w.dinv, d_RT, n_pad, qc.m_pad));
+            EGX_RC(launch_cross_corr(w.stream, gp->corr, d_xqT.p, m_pad, m_pad, gp->d_xT, n_pad, n_pad, d,
+                                     gp->d_fit_coef, gp->fit_hcols, d_RT.p, n_pad));
+            EGX_RC(launch_trsm_rows(w.stream, w.M, gp->ld, n_pad, w.dinv, d_RT.p, n_pad, m_pad));
             // sum rt^2 and ft^T rt (:352): ft^T rows live below the factor in the workspace
-            EGX_RCC(launch_row_reduce(w.stream, d_RT, n_pad, qc.m_pad, n, w.M + (size_t)n_pad * gp->ld, gp->ld, p, d_s0,
-                                      d_sl));
-            EGX_HIPC(hipMemcpyAsync(s0.data(), d_s0, sizeof(double) * qc.m_pad, hipMemcpyDeviceToHost, w.stream));
-            EGX_HIPC(hipMemcpyAsync(sl.data(), d_sl, sizeof(double) * (size_t)qc.m_pad * p, hipMemcpyDeviceToHost,
-                                    w.stream));
+            EGX_RC(launch_row_reduce(w.stream, d_RT.p, n_pad, m_pad, n, w.M + (size_t)n_pad * gp->ld, gp->ld, p,
+                                     d_s0.p, d_sl.p));
+            EGX_HIP_CHECK(hipMemcpyAsync(s0.data(), d_s0.p, sizeof(double) * m_pad, hipMemcpyDeviceToHost, w.stream));
+            EGX_HIP_CHECK(hipMemcpyAsync(sl.data(), d_sl.p, sizeof(double) * (size_t)m_pad * p, hipMemcpyDeviceToHost,
+                                         w.stream));
         }
-        EGX_HIPC(hipStreamSynchronize(w.stream));
+        EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
         for (int a = 0; a < mc; a++) {
-            hm::regression_row(gp->mean, &qc.xn[(size_t)a * d], d, f.data());
+            hm::regression_row(gp->mean, &xn[(size_t)a * d], d, f.data());
             if (yout) {
                 double fb = 0.0;
                 for (int l = 0; l < p; l++) fb += f[l] * gp->beta[l];
@@ -547,7 +530,6 @@ static int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, d
                 vout[m0 + a] = (mse < 0.0) ? 0.0 : mse;         // :278
             }
         }
-        cleanup();
     }
     return EGX_SUCCESS;
 }
@@ -1378,14 +1360,27 @@ int32_t egx_gp_fit_lbfgs(egx_gp *gp, const double *theta0s, int64_t n_starts, co
 }
 
 // ---- kernel-level entry points ------------------------------------------------------------------
-static int upload_kmajor(const double *x, int64_t n, int64_t d, int n_pad, double **dptr) {
+}  // extern "C"
+
+namespace egx {
+static int upload_kmajor(const double *x, int64_t n, int64_t d, int n_pad, DevBuf &buf) {
     std::vector<double> xT((size_t)d * n_pad, 0.0);
     for (int64_t i = 0; i < n; i++)
         for (int64_t j = 0; j < d; j++) xT[(size_t)j * n_pad + i] = x[i * d + j];
-    EGX_HIP_CHECK(hipMalloc(dptr, sizeof(double) * xT.size()));
-    EGX_HIP_CHECK(hipMemcpy(*dptr, xT.data(), sizeof(double) * xT.size(), hipMemcpyHostToDevice));
+    EGX_RC(buf.alloc(xT.size()));
+    EGX_HIP_CHECK(hipMemcpy(buf.p, xT.data(), sizeof(double) * xT.size(), hipMemcpyHostToDevice));
     return EGX_SUCCESS;
 }
+static int require_device() {
+    if (egx_device_count() <= 0) {
+        set_error("no HIP device: libegx_gp_hip has no CPU fallback (needs an MI355X / gfx950 GPU)");
+        return EGX_ERR_NO_DEVICE;
+    }
+    return EGX_SUCCESS;
+}
+}  // namespace egx
+
+extern "C" {
 
 int32_t egx_corr_matrix(int32_t corr, const double *xnorm, int64_t n, int64_t d, const double *theta, double nugget,
                         double *r) {
@@ -1393,32 +1388,16 @@ int32_t egx_corr_matrix(int32_t corr, const double *xnorm, int64_t n, int64_t d,
         set_error("egx_corr_matrix: bad arguments");
         return EGX_ERR_INVALID_VALUE;
     }
-    if (egx_device_count() <= 0) {
-        set_error("no HIP device");
-        return EGX_ERR_NO_DEVICE;
-    }
+    EGX_RC(require_device());
     const int n_pad = (int)round_up(n, kTile);
-    double *d_xT = nullptr, *d_coef = nullptr, *d_M = nullptr;
-    int rc = upload_kmajor(xnorm, n, d, n_pad, &d_xT);
-    if (rc) return rc;
-    hipMalloc(&d_coef, sizeof(double) * d);
-    hipMemcpy(d_coef, theta, sizeof(double) * d, hipMemcpyHostToDevice);
-    if (hipMalloc(&d_M, sizeof(double) * (size_t)n_pad * n_pad) != hipSuccess) {
-        hipFree(d_xT);
-        hipFree(d_coef);
-        set_error("hipMalloc failed");
-        return EGX_ERR_HIP;
-    }
-    rc = launch_corr_sym(0, corr, d_xT, n_pad, (int)n, (int)d, d_coef, 1, nugget, d_M, n_pad, n_pad);
-    if (!rc && hipMemcpy2D(r, sizeof(double) * n, d_M, sizeof(double) * n_pad, sizeof(double) * n, n,
-                           hipMemcpyDeviceToHost) != hipSuccess) {
-        set_error("hipMemcpy2D failed");
-        rc = EGX_ERR_HIP;
-    }
-    hipFree(d_xT);
-    hipFree(d_coef);
-    hipFree(d_M);
-    if (rc) return rc;
+    DevBuf d_xT, d_coef, d_M;
+    EGX_RC(upload_kmajor(xnorm, n, d, n_pad, d_xT));
+    EGX_RC(d_coef.alloc(d));
+    EGX_HIP_CHECK(hipMemcpy(d_coef.p, theta, sizeof(double) * d, hipMemcpyHostToDevice));
+    EGX_RC(d_M.alloc((size_t)n_pad * n_pad));
+    EGX_RC(launch_corr_sym(0, corr, d_xT.p, n_pad, (int)n, (int)d, d_coef.p, 1, nugget, d_M.p, n_pad, n_pad));
+    EGX_HIP_CHECK(hipMemcpy2D(r, sizeof(double) * n, d_M.p, sizeof(double) * n_pad, sizeof(double) * n, n,
+                              hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; i++)  // mirror the lower triangle (the scatter loop writes both, algorithm.rs:999-1000)
         for (int64_t j = i + 1; j < n; j++) r[i * n + j] = r[j * n + i];
     return EGX_SUCCESS;
@@ -1430,33 +1409,18 @@ int32_t egx_cross_corr(int32_t corr, const double *xq_norm, int64_t m, const dou
         set_error("egx_cross_corr: bad arguments");
         return EGX_ERR_INVALID_VALUE;
     }
-    if (egx_device_count() <= 0) {
-        set_error("no HIP device");
-        return EGX_ERR_NO_DEVICE;
-    }
+    EGX_RC(require_device());
     const int n_pad = (int)round_up(n, kTile), m_pad = (int)round_up(m, kTile);
-    double *d_xT = nullptr, *d_qT = nullptr, *d_coef = nullptr, *d_R = nullptr;
-    int rc = upload_kmajor(xt_norm, n, d, n_pad, &d_xT);
-    if (!rc) rc = upload_kmajor(xq_norm, m, d, m_pad, &d_qT);
-    if (!rc) {
-        hipMalloc(&d_coef, sizeof(double) * d);
-        hipMemcpy(d_coef, theta, sizeof(double) * d, hipMemcpyHostToDevice);
-        if (hipMalloc(&d_R, sizeof(double) * (size_t)m_pad * n_pad) != hipSuccess) {
-            set_error("hipMalloc failed");
-            rc = EGX_ERR_HIP;
-        }
-    }
-    if (!rc) rc = launch_cross_corr(0, corr, d_qT, m_pad, m_pad, d_xT, n_pad, n_pad, (int)d, d_coef, 1, d_R, n_pad);
-    if (!rc && hipMemcpy2D(r, sizeof(double) * n, d_R, sizeof(double) * n_pad, sizeof(double) * n, m,
-                           hipMemcpyDeviceToHost) != hipSuccess) {
-        set_error("hipMemcpy2D failed");
-        rc = EGX_ERR_HIP;
-    }
-    if (d_xT) hipFree(d_xT);
-    if (d_qT) hipFree(d_qT);
-    if (d_coef) hipFree(d_coef);
-    if (d_R) hipFree(d_R);
-    return rc;
+    DevBuf d_xT, d_qT, d_coef, d_R;
+    EGX_RC(upload_kmajor(xt_norm, n, d, n_pad, d_xT));
+    EGX_RC(upload_kmajor(xq_norm, m, d, m_pad, d_qT));
+    EGX_RC(d_coef.alloc(d));
+    EGX_HIP_CHECK(hipMemcpy(d_coef.p, theta, sizeof(double) * d, hipMemcpyHostToDevice));
+    EGX_RC(d_R.alloc((size_t)m_pad * n_pad));
+    EGX_RC(launch_cross_corr(0, corr, d_qT.p, m_pad, m_pad, d_xT.p, n_pad, n_pad, (int)d, d_coef.p, 1, d_R.p, n_pad));
+    EGX_HIP_CHECK(hipMemcpy2D(r, sizeof(double) * n, d_R.p, sizeof(double) * n_pad, sizeof(double) * n, m,
+                              hipMemcpyDeviceToHost));
+    return EGX_SUCCESS;
 }
 
 int32_t egx_potrf(double *a, int64_t n, int32_t *info) {
@@ -1464,33 +1428,20 @@ int32_t egx_potrf(double *a, int64_t n, int32_t *info) {
         set_error("egx_potrf: bad arguments");
         return EGX_ERR_INVALID_VALUE;
     }
-    if (egx_device_count() <= 0) {
-        set_error("no HIP device");
-        return EGX_ERR_NO_DEVICE;
-    }
+    EGX_RC(require_device());
     const int n_pad = (int)round_up(n, kTile);
     std::vector<double> hp((size_t)n_pad * n_pad, 0.0);
     for (int64_t i = 0; i < n; i++) std::memcpy(&hp[(size_t)i * n_pad], a + i * n, sizeof(double) * n);
     for (int64_t i = n; i < n_pad; i++) hp[(size_t)i * n_pad + i] = 1.0;
-    double *d_M = nullptr, *d_dinv = nullptr;
-    int *d_info = nullptr;
-    EGX_HIP_CHECK(hipMalloc(&d_M, sizeof(double) * hp.size()));
-    hipMalloc(&d_dinv, sizeof(double) * (size_t)(n_pad / 64) * 4096);
-    hipMalloc(&d_info, sizeof(int));
-    hipMemset(d_info, 0, sizeof(int));
-    hipMemcpy(d_M, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice);
-    int rc = launch_potrf(0, d_M, n_pad, n_pad, n_pad, d_dinv, d_info);
-    if (!rc) {
-        if (hipMemcpy(hp.data(), d_M, sizeof(double) * hp.size(), hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(info, d_info, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) {
-            set_error("hipMemcpy failed");
-            rc = EGX_ERR_HIP;
-        }
-    }
-    hipFree(d_M);
-    hipFree(d_dinv);
-    hipFree(d_info);
-    if (rc) return rc;
+    DevBuf d_M, d_dinv, d_info;  // d_info: one int stored in a double-sized slot
+    EGX_RC(d_M.alloc(hp.size()));
+    EGX_RC(d_dinv.alloc((size_t)(n_pad / 64) * 4096));
+    EGX_RC(d_info.alloc(1));
+    EGX_HIP_CHECK(hipMemset(d_info.p, 0, sizeof(double)));
+    EGX_HIP_CHECK(hipMemcpy(d_M.p, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
+    EGX_RC(launch_potrf(0, d_M.p, n_pad, n_pad, n_pad, d_dinv.p, reinterpret_cast<int *>(d_info.p)));
+    EGX_HIP_CHECK(hipMemcpy(hp.data(), d_M.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost));
+    EGX_HIP_CHECK(hipMemcpy(info, d_info.p, sizeof(int), hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; i++)
         for (int64_t j = 0; j < n; j++) a[i * n + j] = (j <= i) ? hp[(size_t)i * n_pad + j] : 0.0;
     return EGX_SUCCESS;

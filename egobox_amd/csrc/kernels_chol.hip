@@ -26,6 +26,8 @@
 #include "egx_internal.h"
 
 #include <cstdlib>
+#include <mutex>
+#include <string>
 #include <vector>
 
 namespace egx {
@@ -664,24 +666,27 @@ __global__ void k_mfma_probe(const double *A, const double *B, double *C) {
 // =============================================================================================
 // host launchers
 // =============================================================================================
-static bool g_init_done = false;
 static int g_potf2_threads = 512;
 
 int chol_init() {
-    if (g_init_done) return EGX_SUCCESS;
-    if (const char *e = std::getenv("EGX_POTF2_THREADS")) g_potf2_threads = (std::atoi(e) == 256) ? 256 : 512;
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2_block<256>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potf2_block<512>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS_BYTES));
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 128, 32, 64, 512, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, TrailShape::LDS_BYTES));
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 128, 32, 64, 512, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, TrailShape::LDS_BYTES));
-    EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_panel_trsm),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, PanelShape::LDS_BYTES));
-    g_init_done = true;
-    return EGX_SUCCESS;
+    static std::once_flag once;
+    static int rc_once = EGX_SUCCESS;
+    std::call_once(once, [] {
+        if (const char *e = std::getenv("EGX_POTF2_THREADS")) g_potf2_threads = (std::atoi(e) == 256) ? 256 : 512;
+        auto set = [](const void *fn, int bytes) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess && rc_once == EGX_SUCCESS) {
+                set_error(std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+                rc_once = EGX_ERR_HIP;
+            }
+        };
+        set(reinterpret_cast<const void *>(&k_potf2_block<256>), POTF2_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_potf2_block<512>), POTF2_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 128, 32, 64, 512, true>), TrailShape::LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 128, 32, 64, 512, true>), TrailShape::LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_panel_trsm), PanelShape::LDS_BYTES);
+    });
+    return rc_once;
 }
 
 // Tile shape: 128x128 (64x64 per wave) when the launch fills the chip, 64x64 (32x32 per wave) otherwise: a
