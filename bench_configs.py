@@ -117,6 +117,37 @@ def main():
               "projected_8_experts_8gpu_points_per_s": m / tv})
         h.close()
 
+    # ---------------- config 5b: the whole mixture on ONE GPU (8 experts resident), smooth and hard recombination
+    if args.only in (0, 6):
+        from egobox_amd.moe import GaussianMixture, GpMixture
+        k, n, d, m = 8, 8192, 16, (20000 if args.quick else 100000)
+        rng = np.random.default_rng(11)
+        experts, means = [], []
+        t0 = time.perf_counter()
+        for e in range(k):
+            x = workload.lhs(n, d, 100 + e)
+            y = workload.griewank(x) * (1.0 + 0.1 * e)
+            experts.append(egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr())
+                           .theta_tuning(egx.ThetaTuning.Fixed(workload.default_theta(d))).fit(x, y))
+            means.append(rng.random(d))
+        tfit = time.perf_counter() - t0
+        gmx = GaussianMixture(np.full(k, 1.0 / k), np.array(means), np.array([np.eye(d) * 0.05] * k))
+        xq = rng.random((m, d))
+        out = {"config": "5-mixture-1gpu", "experts": k, "n_per_expert": n, "d": d, "m": m, "fit_all_experts_s": tfit}
+        for recomb in ("smooth", "hard"):
+            mix = GpMixture(experts, gmx, recomb)
+            mix.predict_var(xq[:2000])
+            t0 = time.perf_counter()
+            v = mix.predict_var(xq)
+            t = time.perf_counter() - t0
+            out[f"predict_var_{recomb}_points_per_s"] = m / t
+            out[f"predict_var_{recomb}_checksum"] = float(v.sum())
+        out["note"] = ("smooth = every expert sees all points (8 x n^2 m flops); hard = points routed once, ONE batched "
+                       "call per expert (the reference calls the expert once per row, crates/moe/src/algorithm.rs:894-910)")
+        emit(out)
+        for e in experts:
+            e.close()
+
 
 if __name__ == "__main__":
     main()
