@@ -50,8 +50,10 @@ class GaussianMixture:
     def _log_gaussian_prob(self, x):
         nx = self.means.shape[1]
         precs = self.precisions_chol * self.heaviside_factor ** -0.5
-        diff = np.einsum("nkj,kjl->nkl", x[:, None, :] - self.means[None, :, :], precs)
-        q = (diff * diff).sum(axis=2)
+        q = np.empty((x.shape[0], self.n_clusters))
+        for k in range(self.n_clusters):  # one (m,nx)x(nx,nx) product per cluster
+            diff = (x - self.means[k]) @ precs[k]
+            q[:, k] = np.einsum("ij,ij->i", diff, diff)
         return -0.5 * (q + nx * math.log(2.0 * math.pi)) + self.log_det
 
     def _log_resp(self, x):
@@ -86,6 +88,7 @@ class GpMixture:
         if len(self.experts) != gmx.n_clusters:
             raise ValueError("one expert per cluster expected")
         self.rank, self.world, self.device = rank, world, device
+        self.n_in_flight = 2
 
     def _mine(self, i):
         return i % self.world == self.rank and self.experts[i] is not None
@@ -106,33 +109,45 @@ class GpMixture:
         x = np.atleast_2d(np.asarray(x, dtype=np.float64))
         m = x.shape[0]
         val, var = np.zeros(m), np.zeros(m)
-        if self.recombination == "smooth":
+        smooth = self.recombination == "smooth"
+        if smooth:
             p = self.gmx.predict_probas(x)
-            for i, e in enumerate(self.experts):
-                if not self._mine(i):
-                    continue
-                if want_val and want_var:
-                    y, v = e.predict_valvar(x)
-                    val += y * p[:, i]
-                    var += v * p[:, i] * p[:, i]
-                elif want_val:
-                    val += e.predict(x) * p[:, i]
-                else:
-                    var += e.predict_var(x) * p[:, i] * p[:, i]
         else:
             c = self.gmx.predict(x)
-            for i, e in enumerate(self.experts):
-                if not self._mine(i):
-                    continue
-                idx = np.flatnonzero(c == i)
-                if idx.size == 0:
-                    continue
-                if want_val and want_var:
-                    val[idx], var[idx] = e.predict_valvar(x[idx])
-                elif want_val:
-                    val[idx] = e.predict(x[idx])
-                else:
-                    var[idx] = e.predict_var(x[idx])
+
+        def run(i):
+            e = self.experts[i]
+            idx = None if smooth else np.flatnonzero(c == i)
+            if idx is not None and idx.size == 0:
+                return i, idx, None, None
+            xi = x if smooth else x[idx]
+            if want_val and want_var:
+                y, v = e.predict_valvar(xi)
+            elif want_val:
+                y, v = e.predict(xi), None
+            else:
+                y, v = None, e.predict_var(xi)
+            return i, idx, y, v
+
+        mine = [i for i in range(len(self.experts)) if self._mine(i)]
+        # every expert owns a handle with its own HIP streams: a few in flight hide each other's launch gaps
+        if len(mine) > 1 and self.n_in_flight > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(min(self.n_in_flight, len(mine))) as pool:
+                results = list(pool.map(run, mine))
+        else:
+            results = [run(i) for i in mine]
+        for i, idx, y, v in results:
+            if smooth:
+                if y is not None:
+                    val += y * p[:, i]
+                if v is not None:
+                    var += v * p[:, i] * p[:, i]
+            elif idx.size:
+                if y is not None:
+                    val[idx] = y
+                if v is not None:
+                    var[idx] = v
         val, var = self._allreduce(val, var)
         return val, var
 
