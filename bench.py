@@ -197,8 +197,9 @@ def main():
             "cholesky_tflops_single_fit": tflops,
             "roofline": {"bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "k_gemm_nt_sub<LOWER,128,128,32,64,512> (Cholesky trailing update C -= P P^T, K = 256: "
-                                   "92% of the factorisation's flops)",
+                         "kernel": "k_gemm_nt_sub<LOWER,128,256,64,64,512> (Cholesky trailing update C -= P P^T once per "
+                                   "group of two 256-wide panels, K = 512; the launches that fill the chip, ~83% of the "
+                                   "factorisation's flops)",
                          "launches_per_fit": syrk_launches, "launch_ms_avg": syrk_ms / max(1, syrk_launches),
                          "flops_per_launch_avg": syrk_flops / max(1, syrk_launches),
                          "how": "algorithmic flops (2*K*ncols*(ncols+1)/2 per launch) / HIP-event durations around every "

@@ -169,7 +169,7 @@ using TrailShape = GemmShape<128, 128, 32, 64, 512>;  // 8 waves, 2 workgroups p
 using SmallShape = GemmShape<64, 64, 32, 32, 256>;    // 4x lower per-tile latency: look-ahead column + small trailing matrices
 
 template <bool LOWER, int BM, int BN, int WM, int WN, int NTHREADS, bool SWZ>
-__global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt_sub(
+__global__ __launch_bounds__(NTHREADS, (WM * WN > 2048 ? 2 : (NTHREADS == 512 ? 4 : 2))) void k_gemm_nt_sub(
     double *__restrict__ C, int64_t ldc, const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
     int64_t ldb, int K, int nbx, int nby, int ktri) {
     using S = GemmShape<BM, BN, WM, WN, NTHREADS>;
@@ -204,6 +204,22 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt
         bx = si * 8 + (local & 7);
         by = sj * 8 + (local >> 3);
         if (bx >= nbx || by >= nby) return;
+    } else if (LOWER && (ktri & 2)) {
+        // 1-D grid over the tiles that touch the lower triangle only (column `by` holds rows bx >= by * BN / BM):
+        // workgroups that exit at once would still be dealt round-robin to the XCDs / shader engines and leave the
+        // real tiles unevenly spread (measured 5..12 tiles per CU with a 2-D grid and early exits).
+        constexpr int R = BN / BM;
+        const int t = blockIdx.x;
+        // tiles before column c: c * nbx - R * c (c - 1) / 2
+        const double bq = nbx + 0.5 * R;
+        int c = (int)((bq - sqrt(bq * bq - 2.0 * R * t)) / R);
+        if (c < 0) c = 0;
+        if (c >= nby) c = nby - 1;
+        while (c > 0 && c * nbx - R * c * (c - 1) / 2 > t) c--;
+        while (c + 1 < nby && (c + 1) * nbx - R * (c + 1) * c / 2 <= t) c++;
+        by = c;
+        bx = R * c + (t - (c * nbx - R * c * (c - 1) / 2));
+        if (bx >= nbx) return;
     } else {
         bx = blockIdx.x;
         by = blockIdx.y;
@@ -219,7 +235,7 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt
         for (int ni = 0; ni < S::NT; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
     // ktri: both operands are upper triangular (row i is zero left of column i), C lower: the K range of tile
     // (bx, by), bx >= by, starts at the first row of the tile (used for R^-1 = C^-T C^-1 in the theta-gradient)
-    const int koff = ktri ? bx * BM : 0;
+    const int koff = (ktri & 1) ? bx * BM : 0;
     gemm_core<BM, BN, WM, WN, NTHREADS>(A + (int64_t)bx * BM * lda + koff, lda, B + (int64_t)by * BN * ldb + koff, ldb,
                                         K - koff, acc, smem, tid);
     EGX_GSTAMP(1);
@@ -667,12 +683,19 @@ __global__ void k_mfma_probe(const double *A, const double *B, double *C) {
 // host launchers
 // =============================================================================================
 static int g_potf2_threads = 512;
+static int g_potrf_group = 2;    // panels per trailing update (EGX_POTRF_GROUP, 1..8)
+static int g_gemm_wide_min = 512;  // EGX_GEMM_WIDE: minimum number of 128x256 tiles for the wide-tile kernel (0 = off)
 
 int chol_init() {
     static std::once_flag once;
     static int rc_once = EGX_SUCCESS;
     std::call_once(once, [] {
         if (const char *e = std::getenv("EGX_POTF2_THREADS")) g_potf2_threads = (std::atoi(e) == 256) ? 256 : 512;
+        if (const char *e = std::getenv("EGX_POTRF_GROUP")) {
+            const int g = std::atoi(e);
+            if (g >= 1 && g <= 8) g_potrf_group = g;
+        }
+        if (const char *e = std::getenv("EGX_GEMM_WIDE")) g_gemm_wide_min = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -684,6 +707,10 @@ int chol_init() {
         set(reinterpret_cast<const void *>(&k_potf2_block<512>), POTF2_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 128, 32, 64, 512, true>), TrailShape::LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 128, 32, 64, 512, true>), TrailShape::LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 256, 64, 64, 512, false>),
+            GemmShape<128, 256, 64, 64, 512>::LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 256, 64, 64, 512, false>),
+            GemmShape<128, 256, 64, 64, 512>::LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_panel_trsm), PanelShape::LDS_BYTES);
     });
     return rc_once;
@@ -703,6 +730,28 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
                                     : (int64_t)(M / 128) * (N / 128);
     const bool small = big_tiles < 1024;  // fewer than 2 waves of workgroups over 256 CUs x 2
     if (used_big_tile) *used_big_tile = !small;
+    int64_t wide_tiles = 0;
+    if (N % 256 == 0) {
+        if (lower)
+            for (int c = 0; c < N / 256; c++) wide_tiles += (M / 128 - 2 * c > 0) ? M / 128 - 2 * c : 0;
+        else
+            wide_tiles = (int64_t)(M / 128) * (N / 256);
+    }
+    if (g_gemm_wide_min > 0 && wide_tiles >= g_gemm_wide_min && !ktri && (!lower || M >= N)) {
+        if (used_big_tile) *used_big_tile = true;
+        // experiment: 128x256 workgroup tile, 64x64 wave tiles (LDS operand reads per MFMA 0.5 instead of 0.75)
+        using WideShape = GemmShape<128, 256, 64, 64, 512>;
+        dim3 grid(M / 128, N / 256);
+        if (lower) {
+            const int nbx = M / 128, nby = N / 256;  // column c holds nbx - 2 c tiles (M >= N in the factorisation)
+            hipLaunchKernelGGL((k_gemm_nt_sub<true, 128, 256, 64, 64, 512, false>), dim3((unsigned)wide_tiles), dim3(512),
+                               WideShape::LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx, nby, 2);
+        } else
+            hipLaunchKernelGGL((k_gemm_nt_sub<false, 128, 256, 64, 64, 512, false>), grid, dim3(512), WideShape::LDS_BYTES,
+                               s, C, ldc, A, lda, B, ldb, K, M / 128, N / 256, 0);
+        EGX_HIP_CHECK(hipGetLastError());
+        return EGX_SUCCESS;
+    }
     if (small) {
         dim3 grid(M / 64, N / 64);
         if (lower)
@@ -767,46 +816,69 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
                                M + (int64_t)(k0 + nbk) * ld + k0, ld, (const double *)diag, ld,
                                (const double *)dtiles, nbk);
     };
-    auto blk = [&](int k0) { return (n_pad - k0 < kNB) ? (n_pad - k0) : kNB; };
-    panel(s, 0, blk(0));
-    for (int k0 = 0; k0 < n_pad; k0 += kNB) {
-        const int nbk = blk(k0);
-        const int r1 = k0 + nbk;  // first row/col of the trailing matrix
-        if (r1 >= n_pad) break;   // (right-hand-side rows below the last block were solved by its panel)
-        const int nb1 = blk(r1);
-        // the cross-stream hand-off costs ~2 x 10 us; below ~3k trailing columns RU_k is shorter than that
-        const bool look = (s2 != nullptr) && (n_pad - r1 - nb1 >= 3072);
-        const double *pan = M + (int64_t)r1 * ld + k0;
-        // LU_k: next block column only
-        rc = launch_gemm_nt_sub(s, M + (int64_t)r1 * ld + r1, ld, pan, ld, pan, ld, m_tot - r1, nb1, nbk, 1, 0);
+    // Two-level blocking: kNB-wide panels are factored inside a group of `g_potrf_group` panels (right-looking within
+    // the group's columns), the trailing matrix is then updated once per GROUP with K = group width.  The C tile
+    // read-modify-write (and the tile prologue) is thereby paid once per K = 512 instead of once per K = 256:
+    // C traffic of the factorisation halves and the MFMA K loop is a larger share of every tile.
+    const int GW = g_potrf_group * kNB;
+    auto gwidth = [&](int g0) { return (n_pad - g0 < GW) ? (n_pad - g0) : GW; };
+    auto inner_factor = [&](hipStream_t st, int g0, int gw) -> int {
+        for (int k0 = g0; k0 < g0 + gw; k0 += kNB) {
+            const int nbk = (g0 + gw - k0 < kNB) ? (g0 + gw - k0) : kNB;
+            panel(st, k0, nbk);
+            const int r1 = k0 + nbk;
+            if (r1 < g0 + gw) {
+                const double *pan = M + (int64_t)r1 * ld + k0;
+                int rc2 = launch_gemm_nt_sub(st, M + (int64_t)r1 * ld + r1, ld, pan, ld, pan, ld, m_tot - r1, g0 + gw - r1,
+                                             nbk, 1, 0);
+                if (rc2) return rc2;
+            }
+        }
+        return EGX_SUCCESS;
+    };
+    rc = inner_factor(s, 0, gwidth(0));
+    if (rc) return rc;
+    for (int g0 = 0; g0 < n_pad; g0 += GW) {
+        const int gw = gwidth(g0);
+        const int r1 = g0 + gw;  // first row/col of the trailing matrix
+        if (r1 >= n_pad) break;  // (right-hand-side rows below the last block were solved by its panel)
+        const int gw1 = gwidth(r1);
+        // the cross-stream hand-off costs ~2 x 10 us; below ~3k trailing columns RU is shorter than that
+        const bool look = (s2 != nullptr) && (n_pad - r1 - gw1 >= 3072);
+        const double *pan = M + (int64_t)r1 * ld + g0;
+        // LU: the next group's columns only
+        rc = launch_gemm_nt_sub(s, M + (int64_t)r1 * ld + r1, ld, pan, ld, pan, ld, m_tot - r1, gw1, gw, 1, 0);
         if (rc) return rc;
         if (look) {
             EGX_HIP_CHECK(hipEventRecord(ev_lu, s));
             EGX_HIP_CHECK(hipStreamWaitEvent(s2, ev_lu, 0));
-            panel(s2, r1, nb1);
+            rc = inner_factor(s2, r1, gw1);
+            if (rc) return rc;
             EGX_HIP_CHECK(hipEventRecord(ev_panel, s2));
         }
-        // RU_k: the rest of the trailing matrix
-        const int r2 = r1 + nb1;
+        // RU: the rest of the trailing matrix
+        const int r2 = r1 + gw1;
         if (r2 < n_pad) {
-            const double *pan2 = M + (int64_t)r2 * ld + k0;
+            const double *pan2 = M + (int64_t)r2 * ld + g0;
             const bool timed = trace && trace->ready && trace->used < GemmTrace::kMax;
             if (timed) EGX_HIP_CHECK(hipEventRecord(trace->e0[trace->used], s));
             bool big = false;
-            rc = launch_gemm_nt_sub(s, M + (int64_t)r2 * ld + r2, ld, pan2, ld, pan2, ld, m_tot - r2, n_pad - r2, nbk,
-                                    1, 0, &big);
+            rc = launch_gemm_nt_sub(s, M + (int64_t)r2 * ld + r2, ld, pan2, ld, pan2, ld, m_tot - r2, n_pad - r2, gw, 1,
+                                    0, &big);
             if (rc) return rc;
             if (timed && big) {
                 EGX_HIP_CHECK(hipEventRecord(trace->e1[trace->used], s));
                 const double nc = (double)(n_pad - r2);
-                trace->flops[trace->used] = 2.0 * nbk * nc * (nc + 1.0) / 2.0;
+                trace->flops[trace->used] = 2.0 * gw * nc * (nc + 1.0) / 2.0;
                 trace->used++;
             }
         }
-        if (look)
+        if (look) {
             EGX_HIP_CHECK(hipStreamWaitEvent(s, ev_panel, 0));
-        else
-            panel(s, r1, nb1);
+        } else {
+            rc = inner_factor(s, r1, gw1);
+            if (rc) return rc;
+        }
     }
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
@@ -820,19 +892,33 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
         set_error("trsm_rows: sizes must be multiples of 128");
         return EGX_ERR_INVALID_VALUE;
     }
-    for (int k0 = 0; k0 < n_pad; k0 += kNB) {
-        const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;
-        const double *diag = M + (int64_t)k0 * ldm + k0;
-        const double *dtiles = dinv + (int64_t)(k0 / 64) * 4096;
-        // tri_rows: the right-hand sides are the rows of the identity, so the solution (C^-T) is upper triangular:
-        // rows below the current block are still zero in these columns and are skipped
-        const int m_eff = tri_rows ? ((k0 + nbk < m) ? (k0 + nbk) : m) : m;
-        hipLaunchKernelGGL(k_panel_trsm, dim3(m_eff / 64), dim3(256), PanelShape::LDS_BYTES, s, RT + k0, ldr, diag, ldm,
-                           dtiles, nbk);
-        const int ncols = n_pad - (k0 + nbk);
+    // same two-level blocking as launch_potrf: block forward substitution inside a group of panels, then ONE update
+    // of the remaining columns per group (K = group width)
+    const int GW = g_potrf_group * kNB;
+    for (int g0 = 0; g0 < n_pad; g0 += GW) {
+        const int gw = (n_pad - g0 < GW) ? (n_pad - g0) : GW;
+        const int gend = g0 + gw;
+        for (int k0 = g0; k0 < gend; k0 += kNB) {
+            const int nbk = (gend - k0 < kNB) ? (gend - k0) : kNB;
+            const double *diag = M + (int64_t)k0 * ldm + k0;
+            const double *dtiles = dinv + (int64_t)(k0 / 64) * 4096;
+            // tri_rows: the right-hand sides are the rows of the identity, so the solution (C^-T) is upper triangular:
+            // rows below the current block are still zero in these columns and are skipped
+            const int m_eff = tri_rows ? ((k0 + nbk < m) ? (k0 + nbk) : m) : m;
+            hipLaunchKernelGGL(k_panel_trsm, dim3(m_eff / 64), dim3(256), PanelShape::LDS_BYTES, s, RT + k0, ldr, diag,
+                               ldm, dtiles, nbk);
+            const int ncols = gend - (k0 + nbk);
+            if (ncols > 0) {
+                rc = launch_gemm_nt_sub(s, RT + (k0 + nbk), ldr, RT + k0, ldr, M + (int64_t)(k0 + nbk) * ldm + k0, ldm,
+                                        m_eff, ncols, nbk, 0, 0);
+                if (rc) return rc;
+            }
+        }
+        const int ncols = n_pad - gend;
         if (ncols > 0) {
-            rc = launch_gemm_nt_sub(s, RT + (k0 + nbk), ldr, RT + k0, ldr, M + (int64_t)(k0 + nbk) * ldm + k0, ldm,
-                                    m_eff, ncols, nbk, 0, 0);
+            const int m_eff = tri_rows ? ((gend < m) ? gend : m) : m;
+            rc = launch_gemm_nt_sub(s, RT + gend, ldr, RT + g0, ldr, M + (int64_t)gend * ldm + g0, ldm, m_eff, ncols, gw, 0,
+                                    0);
             if (rc) return rc;
         }
     }

@@ -5,6 +5,7 @@
 // DVFS ramp, not the pipe.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 template <int NACC, int THREADS>
@@ -21,6 +22,35 @@ __global__ __launch_bounds__(THREADS) void k_mfma(double *out, int iters, double
 #pragma unroll
     for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 12345.678) out[0] = s;
+}
+
+// the same chains fed with random operands (hash of lane / register index in [-1,1]): the data-dependent switching
+// power moves the sustained clock, so this -- not the constant-operand figure -- is what a GEMM on real data sees.
+// out[1], out[2] = shader clocks / 100 MHz wall ticks of one wave -> sustained shader clock.
+template <int NACC, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_mfma_rand(double *out, int iters, unsigned seed) {
+    double4_t acc[NACC];
+    double a[NACC], b[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) {
+        acc[i] = double4_t{0, 0, 0, 0};
+        unsigned h = (threadIdx.x * 2654435761u) ^ (i * 40503u + seed) ^ (blockIdx.x * 97u);
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        a[i] = (double)(int)h * (1.0 / 2147483648.0);
+        h *= 3266489917u; h ^= h >> 16;
+        b[i] = (double)(int)h * (1.0 / 2147483648.0);
+    }
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[i], acc[i], 0, 0, 0);
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) out[0] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[1] = (double)(c1 - c0); out[2] = (double)(w1 - w0); }
 }
 
 template <int THREADS>
@@ -95,9 +125,22 @@ static void run_mfma(double *out, int wg_per_cu) {
            wg_per_cu, wg_per_cu * THREADS / 256, flops / ms / 1e9, ms);
 }
 
+template <int NACC, int THREADS>
+static void run_mfma_rand(double *out, int wg_per_cu) {
+    const int iters = 64000 / NACC;
+    const int grid = 256 * wg_per_cu;
+    double ms = time_ms([&] { hipLaunchKernelGGL((k_mfma_rand<NACC, THREADS>), dim3(grid), dim3(THREADS), 0, 0, out, iters, 12345u); }, 8);
+    double flops = (double)grid * (THREADS / 64) * iters * NACC * 2048.0;
+    double h[3];
+    hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+    printf("mfma_f64_16x16x4 RANDOM operands %2d acc, WG %3d threads, %d WG/CU: %6.2f TFLOP/s (%.3f ms/launch), clock64/wall ratio %.3f "
+           "(x100 MHz if clock64 ticks at the shader clock)\n", NACC, THREADS, wg_per_cu, flops / ms / 1e9, ms, h[1] / h[2]);
+}
+
 int main() {
     double *out;
-    hipMalloc(&out, 8);
+    hipMalloc(&out, 64);
+    if (getenv("EGX_PEAK_RANDOM_ONLY") == nullptr) {
     run_mfma<8, 256>(out, 1);
     run_mfma<8, 256>(out, 2);
     run_mfma<8, 256>(out, 3);
@@ -125,5 +168,11 @@ int main() {
         printf("mixed (4 MFMA + 4 VALU waves/CU, one of each per SIMD): %.3f ms -> mfma part %.2f + valu part %.2f TFLOP/s (upper bounds: each part "
                "divided by the whole launch time)\n", ms, fm / ms / 1e9, fv / ms / 1e9);
     }
+    }
+    run_mfma<8, 512>(out, 2);
+    run_mfma_rand<8, 512>(out, 1);
+    run_mfma_rand<8, 512>(out, 2);
+    run_mfma_rand<16, 512>(out, 2);
+    run_mfma<8, 512>(out, 2);
     return 0;
 }
