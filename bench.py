@@ -196,7 +196,9 @@ def main():
                                     "host_gls": host_ms},
             "cholesky_tflops_single_fit": tflops,
             "roofline": {"bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS,
+                         # HBM/fabric bytes per launch from the PMC passes of this very command (n = 16384, d = 32 only)
+                         "traffic": (1.30e9 if (n, d) == (16384, 32) else None),
                          "kernel": "k_gemm_nt_sub<LOWER,128,256,64,64,512> (Cholesky trailing update C -= P P^T once per "
                                    "group of two 256-wide panels, K = 512; the launches that fill the chip, ~83% of the "
                                    "factorisation's flops)",
@@ -205,9 +207,10 @@ def main():
                          "how": "algorithmic flops (2*K*ncols*(ncols+1)/2 per launch) / HIP-event durations around every "
                                 "launch on the stream it is launched on, one fit in flight (separate leg after the timed "
                                 "region; in the timed region two candidates overlap and share the GPU)",
-                         "traffic_measured_offline": "rocprofv3 --pmc: 20.5 GB fetched + 22.1 GB written per fit over "
-                                                     "these launches (algorithmic C read+write 45.9 GB), L2 hit rate 0.74 "
-                                                     "-- profiles/r01_pmc_gemm_summary.txt",
+                         "traffic_measured_offline": "rocprofv3 --pmc (separate passes, same command): FETCH_SIZE 0.817 GB + "
+                                                     "WRITE_SIZE 0.485 GB per launch = 1.30 GB against ~1.0 GB algorithmic "
+                                                     "(C tile read + write + panel), L2 hit rate 0.62, MFMA busy 0.71 -- "
+                                                     "profiles/r01_run19_pmc_wide_kernel_summary.txt",
                          "measured_mfma_f64_ceiling_tflops": "77.6 register-only (tools/fp64_peak.hip); 43-49 (random "
                                                              "operands) / 56 (zeros) for this kernel alone under DVFS "
                                                              "(tools/gemm_prof.hip)"},

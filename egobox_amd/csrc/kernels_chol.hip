@@ -684,7 +684,8 @@ __global__ void k_mfma_probe(const double *A, const double *B, double *C) {
 // =============================================================================================
 static int g_potf2_threads = 512;
 static int g_potrf_group = 2;    // panels per trailing update (EGX_POTRF_GROUP, 1..8)
-static int g_gemm_wide_min = 512;  // EGX_GEMM_WIDE: minimum number of 128x256 tiles for the wide-tile kernel (0 = off)
+static int g_gemm_wide_min = 512;
+static int g_gemm_small_max = 1024;  // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used  // EGX_GEMM_WIDE: minimum number of 128x256 tiles for the wide-tile kernel (0 = off)
 
 int chol_init() {
     static std::once_flag once;
@@ -696,6 +697,7 @@ int chol_init() {
             if (g >= 1 && g <= 8) g_potrf_group = g;
         }
         if (const char *e = std::getenv("EGX_GEMM_WIDE")) g_gemm_wide_min = std::atoi(e);
+        if (const char *e = std::getenv("EGX_GEMM_SMALL")) g_gemm_small_max = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -728,7 +730,7 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
     }
     const int64_t big_tiles = lower ? ((int64_t)(M / 128) * (N / 128) - (int64_t)(N / 128) * (N / 128 - 1) / 2)
                                     : (int64_t)(M / 128) * (N / 128);
-    const bool small = big_tiles < 1024;  // fewer than 2 waves of workgroups over 256 CUs x 2
+    const bool small = big_tiles < g_gemm_small_max;  // fewer than 2 waves of workgroups over 256 CUs x 2
     if (used_big_tile) *used_big_tile = !small;
     int64_t wide_tiles = 0;
     if (N % 256 == 0) {
