@@ -150,6 +150,88 @@ __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t 
     }
 }
 
+// EXPERIMENT, off by default (EGX_GEMM_PIPE=1): measured 140.6 vs 136.1 us per 128x256x512 tile against the
+// compiler's own schedule of gemm_core (profiles/r01_run20_pipe_ab.txt).
+// Software-pipelined variant for the 64x64 wave tile (2 waves per SIMD, so nothing else hides LDS latency): the
+// K chunk is consumed as two fragment sets of two k-steps each; the reads of a set are always issued one set ahead
+// of the MFMAs that use it, and the chunk barrier sits in the middle of the second set's MFMAs:
+//   [read set1(c)] [32 MFMA set0(c)] [LDS store chunk c+1] [16 MFMA set1(c)] [barrier] [read set0(c+1)] [16 MFMA set1(c)]
+// sched_barrier(0) pins this order (the scheduler otherwise sinks the reads right in front of their first use).
+template <int BM, int BN, int WM, int WN, int NTHREADS>
+__device__ __forceinline__ void gemm_core_pipe(const double *__restrict__ A, int64_t lda,
+                                               const double *__restrict__ B, int64_t ldb, int K,
+                                               double4_t (&acc)[WM / 16][WN / 16], double *smem, int tid) {
+    using S = GemmShape<BM, BN, WM, WN, NTHREADS>;
+    static_assert(KC == 16, "two fragment sets of two k-steps");
+    const int nchunks = K / KC;
+    if (nchunks <= 0) return;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm0 = (wave / S::WAVES_N) * WM, wn0 = (wave % S::WAVES_N) * WN;
+    const int frow = lane & 15, fk = lane >> 4;
+
+    d2_t ra[BM * 8 / NTHREADS], rb[BN * 8 / NTHREADS];
+    unsigned oa[BM * 8 / NTHREADS], ob[BN * 8 / NTHREADS];
+    tile_offsets<BM, NTHREADS>(lda, oa, tid);
+    tile_offsets<BN, NTHREADS>(ldb, ob, tid);
+    tile_load_regs<BM, NTHREADS>(A, oa, ra);
+    tile_load_regs<BN, NTHREADS>(B, ob, rb);
+    tile_store_lds<BM, NTHREADS>(smem, ra, tid);
+    tile_store_lds<BN, NTHREADS>(smem + S::A_TILE, rb, tid);
+    __syncthreads();
+
+    double a0[S::MT][2], b0[S::NT][2], a1[S::MT][2], b1[S::NT][2];
+    const int aoff = (wm0 + frow) * LDS_LD + fk, boff = S::A_TILE + (wn0 + frow) * LDS_LD + fk;
+#define EGX_READ_SET(stage, kk0, a, b)                                                           \
+    {                                                                                            \
+        _Pragma("unroll") for (int mi = 0; mi < S::MT; mi++) {                                   \
+            a[mi][0] = (stage)[aoff + mi * 16 * LDS_LD + (kk0) * 4];                             \
+            a[mi][1] = (stage)[aoff + mi * 16 * LDS_LD + (kk0) * 4 + 4];                         \
+        }                                                                                        \
+        _Pragma("unroll") for (int ni = 0; ni < S::NT; ni++) {                                   \
+            b[ni][0] = (stage)[boff + ni * 16 * LDS_LD + (kk0) * 4];                             \
+            b[ni][1] = (stage)[boff + ni * 16 * LDS_LD + (kk0) * 4 + 4];                         \
+        }                                                                                        \
+    }
+#define EGX_MMA(a, b, j)                                                                         \
+    {                                                                                            \
+        _Pragma("unroll") for (int mi = 0; mi < S::MT; mi++)                                     \
+            _Pragma("unroll") for (int ni = 0; ni < S::NT; ni++)                                 \
+                acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0); \
+    }
+    EGX_READ_SET(smem, 0, a0, b0);
+    for (int c = 0; c < nchunks; c++) {
+        const double *cur = smem + (c & 1) * S::STAGE;
+        double *nxt = smem + ((c + 1) & 1) * S::STAGE;
+        const bool more = (c + 1 < nchunks);
+        if (more) {
+            tile_load_regs<BM, NTHREADS>(A + (c + 1) * KC, oa, ra);
+            tile_load_regs<BN, NTHREADS>(B + (c + 1) * KC, ob, rb);
+        }
+        EGX_READ_SET(cur, 2, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        EGX_MMA(a0, b0, 0);
+        EGX_MMA(a0, b0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            tile_store_lds<BM, NTHREADS>(nxt, ra, tid);
+            tile_store_lds<BN, NTHREADS>(nxt + S::A_TILE, rb, tid);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        EGX_MMA(a1, b1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            __syncthreads();
+            EGX_READ_SET(nxt, 0, a0, b0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        EGX_MMA(a1, b1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef EGX_READ_SET
+#undef EGX_MMA
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------------------------
 // C: trailing update / general  C -= A B^T.  grid = (M/128, N/128).
 // ---------------------------------------------------------------------------------------------
@@ -168,7 +250,7 @@ __device__ long long g_gemm_cycles[1 << 16][2];  // shader-clock ticks (s_memtim
 using TrailShape = GemmShape<128, 128, 32, 64, 512>;  // 8 waves, 2 workgroups per CU -> 4 MFMA waves per SIMD
 using SmallShape = GemmShape<64, 64, 32, 32, 256>;    // 4x lower per-tile latency: look-ahead column + small trailing matrices
 
-template <bool LOWER, int BM, int BN, int WM, int WN, int NTHREADS, bool SWZ>
+template <bool LOWER, int BM, int BN, int WM, int WN, int NTHREADS, bool SWZ, bool PIPE = false>
 __global__ __launch_bounds__(NTHREADS, (WM * WN > 2048 ? 2 : (NTHREADS == 512 ? 4 : 2))) void k_gemm_nt_sub(
     double *__restrict__ C, int64_t ldc, const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
     int64_t ldb, int K, int nbx, int nby, int ktri) {
@@ -236,8 +318,12 @@ __global__ __launch_bounds__(NTHREADS, (WM * WN > 2048 ? 2 : (NTHREADS == 512 ? 
     // ktri: both operands are upper triangular (row i is zero left of column i), C lower: the K range of tile
     // (bx, by), bx >= by, starts at the first row of the tile (used for R^-1 = C^-T C^-1 in the theta-gradient)
     const int koff = (ktri & 1) ? bx * BM : 0;
-    gemm_core<BM, BN, WM, WN, NTHREADS>(A + (int64_t)bx * BM * lda + koff, lda, B + (int64_t)by * BN * ldb + koff, ldb,
-                                        K - koff, acc, smem, tid);
+    if constexpr (PIPE)
+        gemm_core_pipe<BM, BN, WM, WN, NTHREADS>(A + (int64_t)bx * BM * lda + koff, lda, B + (int64_t)by * BN * ldb + koff,
+                                                 ldb, K - koff, acc, smem, tid);
+    else
+        gemm_core<BM, BN, WM, WN, NTHREADS>(A + (int64_t)bx * BM * lda + koff, lda, B + (int64_t)by * BN * ldb + koff, ldb,
+                                            K - koff, acc, smem, tid);
     EGX_GSTAMP(1);
     const int wave = tid >> 6, lane = tid & 63;
     const int r0 = bx * BM + (wave / S::WAVES_N) * WM + (lane >> 4);
@@ -685,6 +771,7 @@ __global__ void k_mfma_probe(const double *A, const double *B, double *C) {
 static int g_potf2_threads = 512;
 static int g_potrf_group = 2;    // panels per trailing update (EGX_POTRF_GROUP, 1..8)
 static int g_gemm_wide_min = 512;
+static int g_gemm_pipe = 0;          // EGX_GEMM_PIPE=1: hand software-pipelined K loop (measured 3 % SLOWER, run 20)
 static int g_gemm_small_max = 1024;  // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used  // EGX_GEMM_WIDE: minimum number of 128x256 tiles for the wide-tile kernel (0 = off)
 
 int chol_init() {
@@ -698,6 +785,7 @@ int chol_init() {
         }
         if (const char *e = std::getenv("EGX_GEMM_WIDE")) g_gemm_wide_min = std::atoi(e);
         if (const char *e = std::getenv("EGX_GEMM_SMALL")) g_gemm_small_max = std::atoi(e);
+        if (const char *e = std::getenv("EGX_GEMM_PIPE")) g_gemm_pipe = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -709,10 +797,11 @@ int chol_init() {
         set(reinterpret_cast<const void *>(&k_potf2_block<512>), POTF2_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 128, 32, 64, 512, true>), TrailShape::LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 128, 32, 64, 512, true>), TrailShape::LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 256, 64, 64, 512, false>),
-            GemmShape<128, 256, 64, 64, 512>::LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 256, 64, 64, 512, false>),
-            GemmShape<128, 256, 64, 64, 512>::LDS_BYTES);
+        constexpr int wide_lds = GemmShape<128, 256, 64, 64, 512>::LDS_BYTES;
+        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 256, 64, 64, 512, false, false>), wide_lds);
+        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 256, 64, 64, 512, false, false>), wide_lds);
+        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 256, 64, 64, 512, false, true>), wide_lds);
+        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 256, 64, 64, 512, false, true>), wide_lds);
         set(reinterpret_cast<const void *>(&k_panel_trsm), PanelShape::LDS_BYTES);
     });
     return rc_once;
@@ -743,14 +832,16 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         if (used_big_tile) *used_big_tile = true;
         // experiment: 128x256 workgroup tile, 64x64 wave tiles (LDS operand reads per MFMA 0.5 instead of 0.75)
         using WideShape = GemmShape<128, 256, 64, 64, 512>;
-        dim3 grid(M / 128, N / 256);
-        if (lower) {
-            const int nbx = M / 128, nby = N / 256;  // column c holds nbx - 2 c tiles (M >= N in the factorisation)
-            hipLaunchKernelGGL((k_gemm_nt_sub<true, 128, 256, 64, 64, 512, false>), dim3((unsigned)wide_tiles), dim3(512),
-                               WideShape::LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx, nby, 2);
-        } else
-            hipLaunchKernelGGL((k_gemm_nt_sub<false, 128, 256, 64, 64, 512, false>), grid, dim3(512), WideShape::LDS_BYTES,
-                               s, C, ldc, A, lda, B, ldb, K, M / 128, N / 256, 0);
+        const int nbx = M / 128, nby = N / 256;  // LOWER: column c holds nbx - 2 c tiles (M >= N in the factorisation)
+        const dim3 g1((unsigned)wide_tiles), g2(M / 128, N / 256);
+#define EGX_WIDE(LOW, PIPE, GRID, FLAG)                                                                             \
+    hipLaunchKernelGGL((k_gemm_nt_sub<LOW, 128, 256, 64, 64, 512, false, PIPE>), GRID, dim3(512), WideShape::LDS_BYTES, s, \
+                       C, ldc, A, lda, B, ldb, K, nbx, nby, FLAG)
+        if (lower && g_gemm_pipe) EGX_WIDE(true, true, g1, 2);
+        else if (lower) EGX_WIDE(true, false, g1, 2);
+        else if (g_gemm_pipe) EGX_WIDE(false, true, g2, 0);
+        else EGX_WIDE(false, false, g2, 0);
+#undef EGX_WIDE
         EGX_HIP_CHECK(hipGetLastError());
         return EGX_SUCCESS;
     }

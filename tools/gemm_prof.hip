@@ -8,7 +8,7 @@
 namespace egx { void set_error(const std::string &m) { fprintf(stderr, "error: %s\n", m.c_str()); } }
 using namespace egx;
 int main(int argc, char **argv) {
-    const int n = argc > 1 ? atoi(argv[1]) : 8192, K = 256;
+    const int n = argc > 1 ? atoi(argv[1]) : 8192, K = argc > 3 ? atoi(argv[3]) : 256;
     const int64_t ld = n + K;
     double *M;
     hipMalloc(&M, sizeof(double) * (size_t)n * ld);
