@@ -751,7 +751,8 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
     gp->h = gp->has_w ? (int)cfg.kpls_dim : (int)d;
     if (gp->has_w) gp->w_star.assign(cfg.w_star, cfg.w_star + d * cfg.kpls_dim);
     gp->q = gp->p + 1;
-    gp->n_pad = (int)round_up(n, kTile);
+    // 256-column granularity lets every trailing update of a large fit use the 128x256 tile (N % 256 == 0)
+    gp->n_pad = (int)round_up(n, n >= 4096 ? kNB : kTile);
     gp->rhs_pad = (int)round_up(gp->q, kRhsPad);
     gp->m_tot = gp->n_pad + gp->rhs_pad;
     gp->ld = gp->n_pad;
