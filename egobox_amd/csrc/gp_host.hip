@@ -8,7 +8,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <algorithm>
 #include <vector>
@@ -90,7 +92,13 @@ struct egx_gp {
     double *d_xT = nullptr;    // d x n_pad (k-major normalised inputs, zero padded)
     double *d_rhsT = nullptr;  // q x n_pad: columns of F then y (normalised), as rows
     std::vector<Workspace> ws;
-    std::mutex mu;
+    // exclusive for everything that touches the fitted state or all workspaces; SHARED for egx_gp_likelihood, whose
+    // concurrent callers (the reference's rayon multistart closures, algorithm.rs:928-945) each take a workspace
+    // from the pool below
+    std::shared_mutex mu;
+    std::mutex pool_mu;
+    std::condition_variable pool_cv;
+    std::vector<char> ws_busy;
     // fitted state (lives in ws[0])
     bool fitted = false;
     std::vector<double> theta;  // h
@@ -840,10 +848,29 @@ int32_t egx_gp_likelihood(egx_gp *gp, const double *theta, int64_t theta_len, do
         set_error("NULL argument");
         return EGX_ERR_INVALID_VALUE;
     }
-    std::lock_guard<std::mutex> lock(gp->mu);
+    std::shared_lock<std::shared_mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
+    // take a free workspace; workspace 0 (where a fitted factor lives) is the last choice
+    int wi = -1;
+    {
+        std::unique_lock<std::mutex> pl(gp->pool_mu);
+        if (gp->ws_busy.size() != gp->ws.size()) gp->ws_busy.assign(gp->ws.size(), 0);
+        for (;;) {
+            for (int i = (int)gp->ws.size() - 1; i >= 0 && wi < 0; i--)
+                if (!gp->ws_busy[i]) wi = i;
+            if (wi >= 0) break;
+            gp->pool_cv.wait(pl);
+        }
+        gp->ws_busy[wi] = 1;
+    }
     EvalResult res;
-    EGX_RC(eval_one(gp, 0, theta, theta_len, res, false));
+    const int rc = eval_one(gp, wi, theta, theta_len, res, false);
+    {
+        std::lock_guard<std::mutex> pl(gp->pool_mu);
+        gp->ws_busy[wi] = 0;
+    }
+    gp->pool_cv.notify_one();
+    if (rc) return rc;
     *lkh = res.lkh;
     *status = res.status;
     return EGX_SUCCESS;
@@ -855,7 +882,7 @@ int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int
         set_error("NULL argument");
         return EGX_ERR_INVALID_VALUE;
     }
-    std::lock_guard<std::mutex> lock(gp->mu);
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
     const int nws = (int)gp->ws.size();
     // Software pipeline over the workspaces: every workspace has its own stream pair, so the serial panel
@@ -899,7 +926,7 @@ int32_t egx_gp_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
         set_error("NULL argument");
         return EGX_ERR_INVALID_VALUE;
     }
-    std::lock_guard<std::mutex> lock(gp->mu);
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
     return do_finalize(gp, theta, theta_len);
 }
@@ -926,7 +953,7 @@ int32_t egx_gp_fit(egx_gp *gp, const double *theta0s, int64_t n_starts, const do
         blo[i] = std::log10(l);  // optimization.rs:32-35
         bhi[i] = std::log10(u);
     }
-    std::lock_guard<std::mutex> lock(gp->mu);
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
     // maxeval = clamp(10 h, GP_COBYLA_MIN_EVAL = 25, max_eval)  algorithm.rs:933-936
     int64_t per_start = 10 * (int64_t)h;
@@ -1007,7 +1034,7 @@ int32_t egx_gp_predict(egx_gp *gp, const double *xq, int64_t m, double *y) {
         set_error("NULL argument");
         return EGX_ERR_INVALID_VALUE;
     }
-    std::lock_guard<std::mutex> lock(gp->mu);
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
     return predict_impl(gp, xq, m, y, nullptr);
 }
 int32_t egx_gp_predict_var(egx_gp *gp, const double *xq, int64_t m, double *var) {
@@ -1015,7 +1042,7 @@ int32_t egx_gp_predict_var(egx_gp *gp, const double *xq, int64_t m, double *var)
         set_error("NULL argument");
         return EGX_ERR_INVALID_VALUE;
     }
-    std::lock_guard<std::mutex> lock(gp->mu);
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
     return predict_impl(gp, xq, m, nullptr, var);
 }
 int32_t egx_gp_predict_valvar(egx_gp *gp, const double *xq, int64_t m, double *y, double *var) {
@@ -1023,7 +1050,7 @@ int32_t egx_gp_predict_valvar(egx_gp *gp, const double *xq, int64_t m, double *y
         set_error("NULL argument");
         return EGX_ERR_INVALID_VALUE;
     }
-    std::lock_guard<std::mutex> lock(gp->mu);
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
     return predict_impl(gp, xq, m, y, var);
 }
 
@@ -1032,7 +1059,7 @@ int32_t egx_gp_get_inner(egx_gp *gp, const egx_gp_inner_view *v) {
         set_error("NULL argument");
         return EGX_ERR_INVALID_VALUE;
     }
-    std::lock_guard<std::mutex> lock(gp->mu);
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
     if (!gp->fitted) {
         set_error("model is not fitted");
         return EGX_ERR_NOT_FITTED;
@@ -1069,7 +1096,7 @@ int32_t egx_gp_set_inner(egx_gp *gp, const egx_gp_inner_view *v) {
         set_error("egx_gp_set_inner: theta, likelihood, sigma2, beta, gamma, r_chol, ft and ft_qr_r are required");
         return EGX_ERR_INVALID_VALUE;
     }
-    std::lock_guard<std::mutex> lock(gp->mu);
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
     const int n = gp->n, p = gp->p, n_pad = gp->n_pad;
     for (int i = 0; i < n; i++)
@@ -1184,7 +1211,7 @@ int32_t egx_gp_likelihood_grad(egx_gp *gp, const double *theta, int64_t theta_le
         set_error("likelihood gradient with KPLS weights is not implemented");
         return EGX_ERR_UNSUPPORTED;
     }
-    std::lock_guard<std::mutex> lock(gp->mu);
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
     return likelihood_grad_core(gp, theta, theta_len, lkh, grad, status);
 }
@@ -1224,7 +1251,7 @@ int32_t egx_gp_fit_lbfgs(egx_gp *gp, const double *theta0s, int64_t n_starts, co
             return EGX_ERR_INVALID_VALUE;
         }
     if (max_iter < 1) max_iter = 50;
-    std::lock_guard<std::mutex> lock(gp->mu);
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
     const double ln10 = std::log(10.0), inf = std::numeric_limits<double>::infinity();
     int64_t evals = 0;

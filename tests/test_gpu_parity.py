@@ -335,6 +335,26 @@ def test_batch_equals_single_and_uses_workspaces(egx):
                 assert lk == lkb[i]  # same kernels, same order: bit identical
 
 
+def test_concurrent_likelihood_calls_on_one_handle(egx):
+    """SURVEY 8b threading: the objective closure is called concurrently from rayon workers on the same training
+    set -> egx_gp_likelihood from many threads must overlap on the workspace pool and return what the serial
+    calls return; a fitted model in workspace 0 survives as long as another workspace is free."""
+    from concurrent.futures import ThreadPoolExecutor
+    x, y = _data(900, 5, seed=21)
+    thetas = egx.theta_sweep_candidates(24, 5, seed=5)
+    with egx.GpHandle(x, y, corr=2, n_workspaces=3) as h:
+        serial = [h.likelihood(t) for t in thetas]
+        h.finalize(thetas[0])
+        yfit = h.predict(x[:5])
+        with ThreadPoolExecutor(2) as pool:  # 2 threads, workspaces 2 and 1: workspace 0 (the fit) is never taken
+            par = list(pool.map(h.likelihood, thetas))
+        assert par == serial
+        np.testing.assert_array_equal(h.predict(x[:5]), yfit)
+        with ThreadPoolExecutor(6) as pool:  # more threads than workspaces: callers queue on the pool
+            par = list(pool.map(h.likelihood, thetas))
+        assert par == serial
+
+
 # ------------------------------------------------------------------ new capability: theta gradient
 @pytest.mark.parametrize("corr", range(4))
 def test_likelihood_gradient(egx, O, corr):
