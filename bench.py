@@ -64,6 +64,31 @@ def cpu_baseline(n_full, d, seconds_budget=30.0):
     }
 
 
+def cpu_baseline_reference_shaped(n_full, d):
+    """SURVEY 8d baseline (i): the C restatement in the shape of the reference's DEFAULT build (single thread,
+    materialised difference table, unblocked Cholesky; oracle/ref_shaped.c) on two bounded samples, extrapolated
+    with a fitted a n^2 + b n^3.  Reported next to `cpu_baseline`, never the target."""
+    from oracle import gp_oracle as O
+    from oracle import ref_shaped
+    if not ref_shaped.available():
+        return None
+    ts, ns = [], (1024, 2048)
+    for n_s in ns:
+        x = O.lhs_classic(n_s, d, 42)
+        y = O.griewank(x)
+        t0 = time.perf_counter()
+        r = ref_shaped.likelihood(x, y, np.full(d, 0.5 / np.sqrt(d)))
+        ts.append(time.perf_counter() - t0)
+    a, b = np.linalg.solve(np.array([[ns[0] ** 2, ns[0] ** 3], [ns[1] ** 2, ns[1] ** 3]], dtype=float), np.array(ts))
+    a, b = max(a, 0.0), max(b, 0.0)
+    t_full = a * n_full ** 2 + b * n_full ** 3
+    return {"value": 1.0 / t_full, "unit": "fits/s", "cores": 1, "kind": "port",
+            "sample": (f"oracle/ref_shaped.c (single thread, (pairs,d) table + unblocked Cholesky) at n={ns[0]} "
+                       f"({ts[0]:.2f}s) and n={ns[1]} ({ts[1]:.2f}s), d={d}; a n^2 + b n^3 extrapolated to n={n_full} "
+                       f"({t_full:.0f}s per fit; the table alone would need {n_full * (n_full - 1) // 2 * d * 8 / 1e9:.1f} GB)"),
+            "sample_seconds": float(sum(ts)), "sample_status": int(r["status"])}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +245,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, d)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            rs = cpu_baseline_reference_shaped(n, d)
+            if rs is not None:
+                out["cpu_baseline_reference_shaped"] = rs
         print(json.dumps(out), flush=True)
     for g in gps:
         g.close()

@@ -155,3 +155,47 @@ def test_gradient_matches_finite_differences(corr):
         tm[k] -= h
         fd = (O.likelihood_at(x, y, tp, corr=corr)[0] - O.likelihood_at(x, y, tm, corr=corr)[0]) / (2 * h)
         assert g[k] == pytest.approx(fd, rel=2e-5, abs=1e-6)
+
+
+# ---------------------------------------------------------------- the C "reference-shaped" restatement (oracle/ref_shaped.c)
+@pytest.fixture(scope="module")
+def RS():
+    import subprocess
+    from oracle import ref_shaped
+    if not ref_shaped.available():
+        subprocess.run(["make", "-C", os.path.dirname(ref_shaped.__file__)], check=True)
+    return ref_shaped
+
+
+def test_ref_shaped_reproduces_golden_a(golden_dir, RS):
+    """The single-thread, LAPACK-free restatement hits the reference's own notebook values too."""
+    g = _load(golden_dir, "golden_a.json")
+    r = RS.likelihood(np.array(g["xt"]), np.array(g["yt"]), [g["theta_printed_8_digits"]], corr="squared_exponential")
+    assert r["status"] == 0
+    assert r["likelihood"] == pytest.approx(g["likelihood"], abs=1e-12)
+    assert r["sigma2"] == pytest.approx(g["variance"], rel=1e-8)
+
+
+@pytest.mark.parametrize("kind,name", [(O.SQEXP, "squared_exponential"), (O.ABSEXP, "absolute_exponential"),
+                                       (O.MATERN32, "matern32"), (O.MATERN52, "matern52")])
+def test_ref_shaped_agrees_with_numpy_oracle(RS, kind, name):
+    """Two independent restatements (numpy + LAPACK vs plain C, unblocked) of the same reference lines."""
+    rng = np.random.default_rng(17)
+    x = rng.random((150, 3))
+    y = np.sin(3 * x[:, 0]) + x[:, 1] ** 2 - 0.5 * x[:, 2]
+    theta = np.array([1.5, 2.0, 1.0])
+    ref = O.fit_fixed(x, y, theta, mean=O.CONSTANT, corr=kind)
+    r = RS.likelihood(x, y, theta, corr=name, want_factor=True)
+    assert r["status"] == 0
+    assert r["likelihood"] == pytest.approx(ref.likelihood, rel=1e-9)
+    assert r["sigma2"] == pytest.approx(ref.inner.sigma2, rel=1e-9)
+    assert r["beta"] == pytest.approx(float(ref.inner.beta.ravel()[0]), rel=1e-9, abs=1e-12)
+    np.testing.assert_allclose(r["r_chol"], ref.inner.r_chol, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(r["gamma"], ref.inner.gamma.ravel(), rtol=1e-6, atol=1e-6 * np.abs(ref.inner.gamma).max())
+
+
+def test_ref_shaped_not_positive_definite(RS):
+    x = np.array([[0.0], [1.0], [1.0], [2.0]])  # duplicate row, negative nugget -> exact singularity and below
+    r = RS.likelihood(x, np.array([0.0, 1.0, 1.0, 0.5]), [1.0], nugget=-1e-3)
+    assert r["status"] == 1
+    assert O.likelihood_at(x, np.array([0.0, 1.0, 1.0, 0.5]), [1.0], nugget=-1e-3)[1] == 1
