@@ -111,6 +111,21 @@ def main():
         t0 = time.perf_counter()
         vp = h.predict_var(xq)
         tv = time.perf_counter() - t0
+        h.predict_gradients(xq[:1000])
+        t0 = time.perf_counter()
+        h.predict_gradients(xq)
+        tgy = time.perf_counter() - t0
+        h.predict_var_gradients(xq[:1000])
+        mg = m // 4
+        t0 = time.perf_counter()
+        h.predict_var_gradients(xq[:mg])
+        tgv = time.perf_counter() - t0
+        t1 = timeit(lambda: h.predict_valvar_gradients(xq[:1]), 20)
+        emit({"config": "5-x-gradients", "n": n, "d": d, "predict_gradients_points_per_s": m / tgy,
+              "predict_var_gradients_points_per_s": mg / tgv, "m_var_gradients": mg,
+              "one_point_valvar_gradients_ms": t1 * 1e3,
+              "note": "batched; the reference evaluates point by point with two n^2 triangular solves plus "
+                      "R^-1 F and chol(F^T R^-1 F) per point (algorithm.rs:555-617)"})
         emit({"config": 5, "n": n, "d": d, "m": m, "fit_s": tfit, "predict_points_per_s": m / tp,
               "predict_var_points_per_s": m / tv, "predict_var_trsm_tflops": (float(n) * n * m) / tv / 1e12,
               "var_min": float(vp.min()), "var_max": float(vp.max()), "y_mean": float(yp.mean()),

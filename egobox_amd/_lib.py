@@ -65,6 +65,9 @@ SIGNATURES = [
     ("egx_gp_predict", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
     ("egx_gp_predict_var", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
     ("egx_gp_predict_valvar", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
+    ("egx_gp_predict_gradients", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
+    ("egx_gp_predict_var_gradients", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
+    ("egx_gp_predict_valvar_gradients", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p]),
     ("egx_gp_get_inner", C.c_int32, [C.c_void_p, C.POINTER(InnerView)]),
     ("egx_gp_set_inner", C.c_int32, [C.c_void_p, C.POINTER(InnerView)]),
     ("egx_corr_matrix", C.c_int32, [C.c_int32, c_double_p, C.c_int64, C.c_int64, c_double_p, C.c_double, c_double_p]),

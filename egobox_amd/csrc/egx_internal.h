@@ -43,6 +43,11 @@ int launch_cross_corr(hipStream_t s, int corr, const double *xqT, int64_t ldq, i
 int launch_predict_mean(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad,
                         const double *xT, int64_t ldx, int n_pad, int d, const double *coef,
                         int hcols, const double *gamma, double *racc);
+// x-gradient contraction out[split][a][k] = sum_j w(j, a) d r(x_a, x_j) / d x_ak over the split's training range;
+// Wt = gamma (vec != 0, ldw ignored) or the transposed (n x m_pad) weight matrix; m_pad multiple of 128
+int launch_xgrad(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad, const double *xT, int64_t ldx,
+                 int n, int d, const double *coef, int hcols, const double *Wt, int64_t ldw, int vec, int nsplit,
+                 double *out);
 // dst[(r0 + l) * ld + i] = src[l * lds + i] for l < nrows, i < ncols; rest of [r0, r0+rows_pad) x [0, ld) zeroed
 int launch_fill_rows(hipStream_t s, double *M, int64_t ld, int r0, int rows_pad, const double *src,
                      int64_t lds, int nrows, int ncols);

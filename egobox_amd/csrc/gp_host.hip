@@ -110,6 +110,10 @@ struct egx_gp {
     double *d_fit_coef = nullptr;
     // gradient scratch (allocated on first use)
     double *d_W = nullptr, *d_Rinv = nullptr, *d_gout = nullptr, *d_theta = nullptr;
+    // x-gradient state (lazy, per fitted factor): d_W = C^-T (shared with the theta-gradient scratch) and
+    // -R^-1 F = -C^-T ft as an (n_pad x rhs_pad) matrix
+    double *d_neg_invkf = nullptr;
+    uint64_t fit_epoch = 0, winv_epoch = ~(uint64_t)0;
     egx_timings timings{};
 };
 
@@ -442,6 +446,7 @@ static int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     gp->fit_coef = coef;
     gp->fit_hcols = hcols;
     gp->fitted = true;
+    gp->fit_epoch++;
     float gpu = 0;
     hipEventElapsedTime(&gpu, w.ev[0], w.ev[3]);
     double host_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() - gpu;
@@ -536,6 +541,141 @@ static int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, d
                 }
                 double mse = gp->sigma2 * (1.0 - s0[a] + usq);  // algorithm.rs:272-274
                 vout[m0 + a] = (mse < 0.0) ? 0.0 : mse;         // :278
+            }
+        }
+    }
+    return EGX_SUCCESS;
+}
+
+// d_W <- C^-T (upper triangular, rows of the identity through the forward block substitution) and
+// d_neg_invkf <- -C^-T [ft | yt] for the factor resident in workspace 0; cached per fitted state.
+static int ensure_winv(egx_gp *gp) {
+    if (gp->winv_epoch == gp->fit_epoch && gp->d_W && gp->d_neg_invkf) return EGX_SUCCESS;
+    Workspace &w = gp->ws[0];
+    const int n_pad = gp->n_pad;
+    const size_t sq = (size_t)n_pad * n_pad;
+    if (!gp->d_W) EGX_HIP_CHECK(hipMalloc(&gp->d_W, sizeof(double) * sq));
+    if (!gp->d_neg_invkf) EGX_HIP_CHECK(hipMalloc(&gp->d_neg_invkf, sizeof(double) * (size_t)n_pad * gp->rhs_pad));
+    EGX_HIP_CHECK(hipMemsetAsync(gp->d_W, 0, sizeof(double) * sq, w.stream));
+    {
+        std::vector<double> ones(n_pad, 1.0);
+        EGX_HIP_CHECK(hipMemcpy2DAsync(gp->d_W, sizeof(double) * (n_pad + 1), ones.data(), sizeof(double),
+                                       sizeof(double), n_pad, hipMemcpyHostToDevice, w.stream));
+        EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+    }
+    EGX_RC(launch_trsm_rows(w.stream, w.M, gp->ld, n_pad, w.dinv, gp->d_W, n_pad, n_pad, 1));
+    EGX_HIP_CHECK(hipMemsetAsync(gp->d_neg_invkf, 0, sizeof(double) * (size_t)n_pad * gp->rhs_pad, w.stream));
+    // 0 - W [ft | yt]: the rows [ft | yt]^T sit below the factor; W upper triangular -> K range starts at the row tile
+    EGX_RC(launch_gemm_nt_sub(w.stream, gp->d_neg_invkf, gp->rhs_pad, gp->d_W, n_pad, w.M + (size_t)n_pad * gp->ld,
+                              gp->ld, n_pad, gp->rhs_pad, n_pad, 0, 1));
+    EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+    gp->winv_epoch = gp->fit_epoch;
+    return EGX_SUCCESS;
+}
+
+// predict_gradients / predict_var_gradients (algorithm.rs:510-549, 555-617, 702-727), batched over the queries:
+//   d mean / d x_k = (dF beta + sum_i gamma_i dr_i/dx_k) y_std / x_std_k
+//   d var  / d x_k = 2 sigma2 / x_std_k * ( D^T dF_k - sum_i (R^-1 r + R^-1 F D)_i dr_i/dx_k ),  D = B^-1 A^T,
+//   A = f(x)^T - r^T R^-1 F = f^T - rt^T ft,  B = F^T R^-1 F = Rq^T Rq   (Rq = ft_qr_r, so D = Rq^-1 Rq^-T A^T)
+// The reference redoes R^-1 F and chol(B) for every query point; here they are per-fit state, the per-query
+// R^-1 r = C^-T (C^-1 r) is the predict_var solve followed by one GEMM with the cached C^-T.
+static int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv) {
+    if (!gp->fitted) {
+        set_error("model is not fitted (call egx_gp_finalize or egx_gp_fit first)");
+        return EGX_ERR_NOT_FITTED;
+    }
+    if (m < 0 || (m > 0 && !xq)) {
+        set_error("bad query array");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    EGX_RC(set_device(gp));
+    Workspace &w = gp->ws[0];
+    const int n = gp->n, n_pad = gp->n_pad, d = gp->d, p = gp->p, rp = gp->rhs_pad;
+    if (gv) EGX_RC(ensure_winv(gp));
+    int64_t cap = ((int64_t)1 << 27) / n_pad / kTile * kTile;
+    if (cap < kTile) cap = kTile;
+    if (cap > 16384) cap = 16384;
+    if (!gv) cap = 65536;
+    std::vector<double> xn, part, sl, f(p), a_vec(p), u(p), dd(p), dneg, df(d);
+    for (int64_t m0 = 0; m0 < m; m0 += cap) {
+        const int mc = (int)((m - m0 < cap) ? (m - m0) : cap);
+        const int m_pad = (int)round_up(mc, kTile);
+        // enough workgroups for small batches: split the training range (partial sums added on the host)
+        int nsplit = 1;
+        const int wgs = m_pad / 128;
+        if (wgs < 512) nsplit = (512 + wgs - 1) / wgs;
+        const int slabs = (n + 63) / 64;
+        if (nsplit > slabs) nsplit = slabs;
+        const int per = (slabs + nsplit - 1) / nsplit;
+        nsplit = (slabs + per - 1) / per;
+        DevBuf d_xqT, d_out, d_RT, d_s0, d_sl, d_Wt, d_D;
+        EGX_RC(upload_queries(gp, xq, m0, mc, m_pad, xn, d_xqT, w.stream));
+        const size_t out_sz = (size_t)nsplit * m_pad * d;
+        EGX_RC(d_out.alloc(out_sz));
+        part.resize(out_sz);
+        auto reduce_out = [&](int a, int k) {
+            double sacc = 0.0;
+            for (int sidx = 0; sidx < nsplit; sidx++) sacc += part[((size_t)sidx * m_pad + a) * d + k];
+            return sacc;
+        };
+        if (gy) {
+            EGX_RC(launch_xgrad(w.stream, gp->corr, d_xqT.p, m_pad, m_pad, gp->d_xT, n_pad, n, d, gp->d_fit_coef,
+                                gp->fit_hcols, gp->d_gamma, 0, 1, nsplit, d_out.p));
+            EGX_HIP_CHECK(hipMemcpyAsync(part.data(), d_out.p, sizeof(double) * out_sz, hipMemcpyDeviceToHost, w.stream));
+            EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+            for (int a = 0; a < mc; a++) {
+                hm::regression_jac_dot(gp->mean, &xn[(size_t)a * d], d, gp->beta.data(), df.data());
+                for (int k = 0; k < d; k++)
+                    gy[(size_t)(m0 + a) * d + k] = (df[k] + reduce_out(a, k)) * gp->y_std / gp->x_std[k];
+            }
+        }
+        if (gv) {
+            sl.resize((size_t)m_pad * p);
+            EGX_RC(d_RT.alloc((size_t)m_pad * n_pad));
+            EGX_RC(d_s0.alloc(m_pad));
+            EGX_RC(d_sl.alloc((size_t)m_pad * p));
+            EGX_RC(d_Wt.alloc((size_t)n_pad * m_pad));
+            EGX_RC(d_D.alloc((size_t)m_pad * rp));
+            EGX_RC(launch_cross_corr(w.stream, gp->corr, d_xqT.p, m_pad, m_pad, gp->d_xT, n_pad, n_pad, d,
+                                     gp->d_fit_coef, gp->fit_hcols, d_RT.p, n_pad));
+            EGX_RC(launch_trsm_rows(w.stream, w.M, gp->ld, n_pad, w.dinv, d_RT.p, n_pad, m_pad));
+            EGX_RC(launch_row_reduce(w.stream, d_RT.p, n_pad, m_pad, n, w.M + (size_t)n_pad * gp->ld, gp->ld, p,
+                                     d_s0.p, d_sl.p));
+            EGX_HIP_CHECK(hipMemcpyAsync(sl.data(), d_sl.p, sizeof(double) * (size_t)m_pad * p, hipMemcpyDeviceToHost,
+                                         w.stream));
+            // -Z^T = 0 - C^-T rt  as an (n_pad x m_pad) matrix (W upper triangular: K range starts at the row tile)
+            EGX_HIP_CHECK(hipMemsetAsync(d_Wt.p, 0, sizeof(double) * (size_t)n_pad * m_pad, w.stream));
+            EGX_RC(launch_gemm_nt_sub(w.stream, d_Wt.p, m_pad, gp->d_W, n_pad, d_RT.p, n_pad, n_pad, m_pad, n_pad, 0, 1));
+            EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+            // D = B^-1 A^T per query (p x p work on the host), uploaded negated and zero padded to rhs_pad columns
+            dneg.assign((size_t)m_pad * rp, 0.0);
+            for (int a = 0; a < mc; a++) {
+                hm::regression_row(gp->mean, &xn[(size_t)a * d], d, f.data());
+                for (int l = 0; l < p; l++) a_vec[l] = f[l] - sl[(size_t)a * p + l];
+                for (int i = 0; i < p; i++) {  // Rq^T u = A^T (Rq^T lower)
+                    double sacc = a_vec[i];
+                    for (int l = 0; l < i; l++) sacc -= gp->ft_qr_r[(size_t)l * p + i] * u[l];
+                    u[i] = sacc / gp->ft_qr_r[(size_t)i * p + i];
+                }
+                for (int i = p - 1; i >= 0; i--) {  // Rq D = u (Rq upper)
+                    double sacc = u[i];
+                    for (int l = i + 1; l < p; l++) sacc -= gp->ft_qr_r[(size_t)i * p + l] * dd[l];
+                    dd[i] = sacc / gp->ft_qr_r[(size_t)i * p + i];
+                }
+                for (int l = 0; l < p; l++) dneg[(size_t)a * rp + l] = -dd[l];
+            }
+            EGX_HIP_CHECK(hipMemcpyAsync(d_D.p, dneg.data(), sizeof(double) * dneg.size(), hipMemcpyHostToDevice, w.stream));
+            // -(Z + E)^T : Wt -= (-R^-1 F) (-D)^T
+            EGX_RC(launch_gemm_nt_sub(w.stream, d_Wt.p, m_pad, gp->d_neg_invkf, rp, d_D.p, rp, n_pad, m_pad, rp, 0, 0));
+            EGX_RC(launch_xgrad(w.stream, gp->corr, d_xqT.p, m_pad, m_pad, gp->d_xT, n_pad, n, d, gp->d_fit_coef,
+                                gp->fit_hcols, d_Wt.p, m_pad, 0, nsplit, d_out.p));
+            EGX_HIP_CHECK(hipMemcpyAsync(part.data(), d_out.p, sizeof(double) * out_sz, hipMemcpyDeviceToHost, w.stream));
+            EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+            for (int a = 0; a < mc; a++) {
+                for (int l = 0; l < p; l++) dd[l] = -dneg[(size_t)a * rp + l];
+                hm::regression_jac_dot(gp->mean, &xn[(size_t)a * d], d, dd.data(), df.data());
+                for (int k = 0; k < d; k++)
+                    gv[(size_t)(m0 + a) * d + k] = 2.0 * gp->sigma2 * (df[k] + reduce_out(a, k)) / gp->x_std[k];
             }
         }
     }
@@ -825,6 +965,7 @@ void egx_gp_destroy(egx_gp *gp) {
     if (gp->d_gamma) hipFree(gp->d_gamma);
     if (gp->d_fit_coef) hipFree(gp->d_fit_coef);
     if (gp->d_W) hipFree(gp->d_W);
+    if (gp->d_neg_invkf) hipFree(gp->d_neg_invkf);
     if (gp->d_Rinv) hipFree(gp->d_Rinv);
     if (gp->d_gout) hipFree(gp->d_gout);
     if (gp->d_theta) hipFree(gp->d_theta);
@@ -1054,6 +1195,33 @@ int32_t egx_gp_predict_valvar(egx_gp *gp, const double *xq, int64_t m, double *y
     return predict_impl(gp, xq, m, y, var);
 }
 
+int32_t egx_gp_predict_gradients(egx_gp *gp, const double *x, int64_t m, double *grad) {
+    if (!gp || (m > 0 && !grad)) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
+    return xgrad_impl(gp, x, m, grad, nullptr);
+}
+
+int32_t egx_gp_predict_var_gradients(egx_gp *gp, const double *x, int64_t m, double *grad) {
+    if (!gp || (m > 0 && !grad)) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
+    return xgrad_impl(gp, x, m, nullptr, grad);
+}
+
+int32_t egx_gp_predict_valvar_gradients(egx_gp *gp, const double *x, int64_t m, double *grad_y, double *grad_var) {
+    if (!gp || (m > 0 && (!grad_y || !grad_var))) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
+    return xgrad_impl(gp, x, m, grad_y, grad_var);
+}
+
 int32_t egx_gp_get_inner(egx_gp *gp, const egx_gp_inner_view *v) {
     if (!gp || !v) {
         set_error("NULL argument");
@@ -1134,6 +1302,7 @@ int32_t egx_gp_set_inner(egx_gp *gp, const egx_gp_inner_view *v) {
     gp->fit_coef = coef;
     gp->fit_hcols = hcols;
     gp->fitted = true;
+    gp->fit_epoch++;
     return EGX_SUCCESS;
 }
 
@@ -1175,6 +1344,7 @@ static int likelihood_grad_core(egx_gp *gp, const double *theta, int64_t theta_l
     EGX_HIP_CHECK(hipMemcpyAsync(w.d_rhs, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
     EGX_RC(backward_solve(gp, w));
     // W = I * C^-T  (rows of the identity as right-hand sides), then -R^-1 = 0 - W W^T (lower tiles)
+    gp->winv_epoch = ~(uint64_t)0;
     EGX_HIP_CHECK(hipMemsetAsync(gp->d_W, 0, sizeof(double) * sq, w.stream));
     {
         std::vector<double> ones(n_pad, 1.0);

@@ -49,6 +49,22 @@ inline void regression_row(int mean, const double *x, int64_t d, double *f) {
             for (int64_t j = k; j < d; j++) f[c++] = x[j] * x[k];
 }
 
+// out[k] = sum_j v[j] * d f_j(x) / d x_k : RegressionModel::jacobian (mean_models.rs:50-52, 76-81, 110-128)
+// contracted with a coefficient vector v (beta for the mean gradient, B^-1 A^T for the variance gradient).
+inline void regression_jac_dot(int mean, const double *x, int64_t d, const double *v, double *out) {
+    for (int64_t k = 0; k < d; k++) out[k] = 0.0;
+    if (mean >= 1)
+        for (int64_t k = 0; k < d; k++) out[k] = v[1 + k];
+    if (mean >= 2) {
+        int64_t c = 1 + d;
+        for (int64_t k = 0; k < d; k++)
+            for (int64_t j = k; j < d; j++, c++) {  // column x_j * x_k
+                out[k] += v[c] * x[j];
+                out[j] += v[c] * x[k];
+            }
+    }
+}
+
 // Householder QR of a (n x p, column-major: a[l*n + i]) in place; b (length n) receives Q^T b.
 // On return the upper p x p of `a` (a[l*n + i], i <= l) is R.  Rows of R are then sign-flipped so
 // that diag(R) > 0 (the convention of the reference's serialized models).

@@ -176,6 +176,85 @@ __global__ __launch_bounds__(256) void k_predict_mean(const double *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// x-gradients of the predictions (CorrelationModel::jacobian, correlation_models.rs:106-123, 198-214,
+// 355-413, 524-586, contracted as predict_jacobian / predict_var_gradients_single do, algorithm.rs:523-617):
+//     out[a][k] = sum_j w(j, a) * d r(x_a, x_j) / d x_ak
+// with w = gamma_j (mean, VEC) or a per-(j, a) weight matrix held TRANSPOSED (n x m: lanes <-> queries, coalesced).
+// The (n, d) jacobian of one query never exists: one lane per query, training slabs broadcast from LDS, the d
+// partial sums of a lane live in registers (DK at a time).  grid.y splits the training range for small batches
+// (EGO asks for one point at a time); the partial sums of the splits are added on the host.
+// d r / d x_k = r * g_k(x_ak - x_jk):
+//   sq-exp   g = -c_k^2 diff                      abs-exp  g = -c_k sign(diff)
+//   Matern   g = sign(diff) sum_l c_kl (f'(t_l) / f(t_l) - q),  t_l = c_kl |diff|,  f = 1 + q t [+ 5/3 t^2]
+// (the closed form of the reference's product-over-all-but-one loops; sign(+0) = +1 like f64::signum).
+// ---------------------------------------------------------------------------------------------
+template <int CORR>
+__device__ __forceinline__ double xgrad_factor(double diff, const double *__restrict__ c, int hcols) {
+    if (CORR == EGX_CORR_SQUARED_EXPONENTIAL) return -(c[0] * c[0]) * diff;
+    if (CORR == EGX_CORR_ABSOLUTE_EXPONENTIAL) return -copysign(c[0], diff);
+    const double ad = fabs(diff);
+    double sacc = 0.0;
+    for (int l = 0; l < hcols; l++) {
+        const double t = c[l] * ad;
+        if (CORR == EGX_CORR_MATERN32)
+            sacc += c[l] * (kSqrt3 / __builtin_fma(kSqrt3, t, 1.0) - kSqrt3);
+        else
+            sacc += c[l] * ((kSqrt5 + 2.0 * k5over3 * t) / (1.0 + kSqrt5 * t + k5over3 * (t * t)) - kSqrt5);
+    }
+    return copysign(1.0, diff) * sacc;
+}
+
+constexpr int kXgThreads = 128;
+
+template <int CORR, int DK, bool VEC>
+__global__ __launch_bounds__(kXgThreads) void k_xgrad(const double *__restrict__ xqT, int64_t ldq,
+                                                      const double *__restrict__ xT, int64_t ldx, int n, int d,
+                                                      const double *__restrict__ coef, int hcols,
+                                                      const double *__restrict__ Wt, int64_t ldw, int slabs_per_split,
+                                                      double *__restrict__ out, int m_pad) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *xa = sm;                    // [d][kXgThreads]
+    double *xj = sm + d * kXgThreads;   // [d][64]
+    double *cs = xj + d * 64;           // [d * hcols]
+    const int tid = threadIdx.x;
+    const int a = blockIdx.x * kXgThreads + tid;
+    for (int k = 0; k < d; k++) xa[k * kXgThreads + tid] = xqT[(int64_t)k * ldq + a];
+    for (int e = tid; e < d * hcols; e += kXgThreads) cs[e] = coef[e];
+    const int j_lo = blockIdx.y * slabs_per_split * 64;
+    int j_hi = j_lo + slabs_per_split * 64;
+    if (j_hi > n) j_hi = n;
+    double *o = out + ((int64_t)blockIdx.y * m_pad + a) * d;
+    for (int k0 = 0; k0 < d; k0 += DK) {
+        double acc[DK], xr[DK];
+#pragma unroll
+        for (int kk = 0; kk < DK; kk++) {
+            acc[kk] = 0.0;
+            xr[kk] = (k0 + kk < d) ? xa[(k0 + kk) * kXgThreads + tid] : 0.0;
+        }
+        for (int j0 = j_lo; j0 < j_hi; j0 += 64) {
+            __syncthreads();
+            for (int e = tid; e < d * 64; e += kXgThreads) xj[e] = xT[(int64_t)(e >> 6) * ldx + j0 + (e & 63)];
+            __syncthreads();
+            const int jn = (j_hi - j0 < 64) ? (j_hi - j0) : 64;
+            for (int jj = 0; jj < jn; jj++) {
+                PairAcc<CORR> pa;
+                for (int k = 0; k < d; k++) pa.add(xa[k * kXgThreads + tid] - xj[k * 64 + jj], cs + k * hcols, hcols);
+                const double wv = VEC ? Wt[j0 + jj] : Wt[(int64_t)(j0 + jj) * ldw + a];
+                const double rw = pa.value() * wv;
+#pragma unroll
+                for (int kk = 0; kk < DK; kk++)
+                    if (k0 + kk < d)
+                        acc[kk] = __builtin_fma(rw, xgrad_factor<CORR>(xr[kk] - xj[(k0 + kk) * 64 + jj],
+                                                                       cs + (k0 + kk) * hcols, hcols), acc[kk]);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < DK; kk++)
+            if (k0 + kk < d) o[k0 + kk] = acc[kk];
+    }
+}
+
 __global__ void k_fill_rows(double *__restrict__ M, int64_t ld, int r0, int rows_pad, const double *__restrict__ src,
                             int64_t lds, int nrows, int ncols) {
     const int64_t total = (int64_t)rows_pad * ld;
@@ -320,6 +399,42 @@ int launch_predict_mean(hipStream_t s, int corr, const double *xqT, int64_t ldq,
     const size_t lds = (size_t)(2 * d * 64 + 64) * sizeof(double);
     EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_predict_mean<C_>, dim3(m_pad / 64), dim3(256), lds, s, xqT, ldq, xT,
                                                ldx, n_pad, d, coef, hcols, gamma, racc));
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+// out: nsplit x m_pad x d partial sums (nsplit returned); Wt = gamma (vec != 0) or the (n x m_pad) weight matrix
+int launch_xgrad(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad, const double *xT, int64_t ldx,
+                 int n, int d, const double *coef, int hcols, const double *Wt, int64_t ldw, int vec, int nsplit,
+                 double *out) {
+    const int slabs = (n + 63) / 64;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > slabs) nsplit = slabs;
+    const int per = (slabs + nsplit - 1) / nsplit;
+    dim3 grid(m_pad / kXgThreads, nsplit);
+    const size_t lds = (size_t)(d * kXgThreads + d * 64 + d * hcols) * sizeof(double);
+#define EGX_XG(C_, DK_)                                                                                              \
+    if (vec) {                                                                                                       \
+        if (lds > 65536)                                                                                             \
+            EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xgrad<C_, DK_, true>),               \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+        hipLaunchKernelGGL((k_xgrad<C_, DK_, true>), grid, dim3(kXgThreads), lds, s, xqT, ldq, xT, ldx, n, d, coef,  \
+                           hcols, Wt, ldw, per, out, m_pad);                                                         \
+    } else {                                                                                                         \
+        if (lds > 65536)                                                                                             \
+            EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xgrad<C_, DK_, false>),              \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
+        hipLaunchKernelGGL((k_xgrad<C_, DK_, false>), grid, dim3(kXgThreads), lds, s, xqT, ldq, xT, ldx, n, d, coef, \
+                           hcols, Wt, ldw, per, out, m_pad);                                                         \
+    }
+    if (d <= 8) {
+        EGX_DISPATCH_CORR(corr, EGX_XG(C_, 8));
+    } else if (d <= 16) {
+        EGX_DISPATCH_CORR(corr, EGX_XG(C_, 16));
+    } else {
+        EGX_DISPATCH_CORR(corr, EGX_XG(C_, 32));
+    }
+#undef EGX_XG
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }

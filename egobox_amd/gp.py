@@ -241,6 +241,26 @@ class GpHandle:
         L.check(self._lib.egx_gp_predict_valvar(self._h, L.dptr(x), x.shape[0], L.dptr(y), L.dptr(v)))
         return y, v
 
+    # -- x-gradients (m, d): d prediction / d x in original units
+    def predict_gradients(self, x):
+        x = self._q(x)
+        out = np.empty((x.shape[0], self.d))
+        L.check(self._lib.egx_gp_predict_gradients(self._h, L.dptr(x), x.shape[0], L.dptr(out)))
+        return out
+
+    def predict_var_gradients(self, x):
+        x = self._q(x)
+        out = np.empty((x.shape[0], self.d))
+        L.check(self._lib.egx_gp_predict_var_gradients(self._h, L.dptr(x), x.shape[0], L.dptr(out)))
+        return out
+
+    def predict_valvar_gradients(self, x):
+        x = self._q(x)
+        gy = np.empty((x.shape[0], self.d))
+        gv = np.empty((x.shape[0], self.d))
+        L.check(self._lib.egx_gp_predict_valvar_gradients(self._h, L.dptr(x), x.shape[0], L.dptr(gy), L.dptr(gv)))
+        return gy, gv
+
     # -- state
     def inner(self, with_chol=False):
         n, d, p, h = self.n, self.d, self.p, self.h
@@ -513,6 +533,18 @@ class GaussianProcess:
 
     def predict_valvar(self, x):
         return self._h.predict_valvar(x)
+
+    def predict_gradients(self, x):
+        """algorithm.rs:510-519 -> (m, nx)."""
+        return self._h.predict_gradients(x)
+
+    def predict_var_gradients(self, x):
+        """algorithm.rs:702-709 -> (m, nx)."""
+        return self._h.predict_var_gradients(x)
+
+    def predict_valvar_gradients(self, x):
+        """algorithm.rs:711-727 -> ((m, nx), (m, nx))."""
+        return self._h.predict_valvar_gradients(x)
 
     def inner_params(self, with_chol=False):
         if self._inner is None or (with_chol and "r_chol" not in self._inner):

@@ -126,6 +126,14 @@ class Gpx:
     def predict_valvar(self, x):
         return self._experts[0].predict_valvar(x)
 
+    def predict_gradients(self, x):
+        """python/src/gp_mix.rs `predict_gradients`: (m, nx) derivatives of the mean."""
+        return self._experts[0].predict_gradients(x)
+
+    def predict_var_gradients(self, x):
+        """python/src/gp_mix.rs `predict_var_gradients`: (m, nx) derivatives of the variance."""
+        return self._experts[0].predict_var_gradients(x)
+
     def thetas(self):
         return np.stack([e.theta() for e in self._experts])
 

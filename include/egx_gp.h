@@ -152,6 +152,17 @@ int32_t egx_gp_predict(egx_gp *gp, const double *xq, int64_t m, double *y /*m*/)
 int32_t egx_gp_predict_var(egx_gp *gp, const double *xq, int64_t m, double *var /*m*/);
 int32_t egx_gp_predict_valvar(egx_gp *gp, const double *xq, int64_t m, double *y, double *var);
 
+/* ---- x-gradients of the predictions (what EGO's infill optimiser asks per point):
+ * GaussianProcess::predict_gradients algorithm.rs:510-549, predict_var_gradients(_single) :555-617, 702-709,
+ * predict_valvar_gradients :711-727; kernels' jacobian correlation_models.rs:106-123, 198-214, 355-413, 524-586,
+ * trend jacobian mean_models.rs:50-52, 76-81, 110-128.  xq is (m x d) in ORIGINAL units, grad is (m x d)
+ * row-major, d out / d xq_k in original units.  Batched over m (the reference loops point by point and redoes
+ * R^-1 F and chol(F^T R^-1 F) for every point); the first variance-gradient call after a fit caches C^-T. */
+int32_t egx_gp_predict_gradients(egx_gp *gp, const double *xq, int64_t m, double *grad /*m*d*/);
+int32_t egx_gp_predict_var_gradients(egx_gp *gp, const double *xq, int64_t m, double *grad /*m*d*/);
+int32_t egx_gp_predict_valvar_gradients(egx_gp *gp, const double *xq, int64_t m, double *grad_y /*m*d*/,
+                                        double *grad_var /*m*d*/);
+
 /* ---- fitted state download (GpInnerParams algorithm.rs:47-60 + accessors
  * theta()/variance()/likelihood() :413-431), for serde parity.  Any pointer may
  * be NULL (skipped).  r_chol is (n x n) lower with zero upper triangle;

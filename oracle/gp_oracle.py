@@ -163,6 +163,83 @@ def regression_value(kind, x):
     raise ValueError(f"unknown regression kind {kind!r}")
 
 
+def _signum(v):
+    """Rust f64::signum: +1 for +0.0 and positives, -1 for -0.0 and negatives (numpy sign(0) would be 0)."""
+    return np.copysign(1.0, v)
+
+
+def corr_jacobian(kind, x, xtrain, theta, weights):
+    """CorrelationModel::jacobian(x (nx,), xtrain (n,nx), theta, weights) -> (n,nx): d r(x, X_i) / d x_k.
+
+    sq-exp :106-123, abs-exp :198-214, Matern32 `_jac_helper` :355-413, Matern52 `_jac_helper` :524-586
+    (crates/gp/src/correlation_models.rs).  `differences(x, xtrain)` = x - xtrain rows (utils.rs).
+    """
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    xt = np.asarray(xtrain, dtype=np.float64)
+    theta = np.asarray(theta, dtype=np.float64).reshape(-1)
+    w = np.asarray(weights, dtype=np.float64)
+    d = x[None, :] - xt
+    r = corr_value(kind, d, theta, w)  # (n,1)
+    if kind == SQEXP:
+        dtheta_w = -((theta * w) ** 2).sum(axis=1)
+        return d * dtheta_w * r
+    if kind == ABSEXP:
+        dtheta_w = _signum(d) * (-(theta * np.abs(w)).sum(axis=1))
+        return dtheta_w * r
+    if kind in (MATERN32, MATERN52):
+        q = math.sqrt(3.0) if kind == MATERN32 else math.sqrt(5.0)
+        theta_w = theta * np.abs(w)  # (nx,h)
+        abs_d, sign_d = np.abs(d), _signum(d)
+        n, nx = d.shape
+
+        def factor(v):
+            return 1.0 + q * v if kind == MATERN32 else 1.0 + q * v + (5.0 / 3.0) * v * v
+
+        a = np.ones(n)
+        for j in range(nx):
+            for l in range(theta_w.shape[1]):
+                a = a * factor(theta_w[j, l] * abs_d[:, j])
+        b = np.exp(-q * abs_d.dot(theta_w).sum(axis=1))
+        db = -q * np.abs(w).dot(theta)[None, :] * sign_d * (a * b)[:, None]
+        da = np.zeros((n, nx))
+        for j in range(nx):
+            for k in range(theta_w.shape[1]):
+                if kind == MATERN32:
+                    deriv = q * theta_w[j, k] * sign_d[:, j]
+                else:
+                    deriv = (q * theta_w[j, k] * sign_d[:, j]
+                             + (10.0 / 3.0) * theta_w[j, k] ** 2 * sign_d[:, j] * abs_d[:, j])
+                term = np.ones(n)
+                for p in range(nx):
+                    for l in range(theta_w.shape[1]):
+                        if l != k or p != j:
+                            term = term * factor(theta_w[p, l] * abs_d[:, p])
+                da[:, j] += deriv * term
+        return db + da * b[:, None]
+    raise ValueError(f"unknown correlation kind {kind!r}")
+
+
+def regression_jacobian(kind, x):
+    """RegressionModel::jacobian(x (nx,)) -> (p,nx): Constant :50-52, Linear :76-81, Quadratic :110-128
+    (crates/gp/src/mean_models.rs); row order = the columns of `regression_value`."""
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    nx = x.size
+    if kind == CONSTANT:
+        return np.zeros((1, nx))
+    if kind == LINEAR:
+        return np.concatenate([np.zeros((1, nx)), np.eye(nx)], axis=0)
+    if kind == QUADRATIC:
+        rows = [np.zeros((1, nx)), np.eye(nx)]
+        for i in range(nx):  # columns x_i * x_j, j >= i
+            blk = np.zeros((nx - i, nx))
+            for c, j in enumerate(range(i, nx)):
+                blk[c, i] += x[j]
+                blk[c, j] += x[i]
+            rows.append(blk)
+        return np.concatenate(rows, axis=0)
+    raise ValueError(f"unknown regression kind {kind!r}")
+
+
 # --------------------------------------------------------------------------
 # crates/gp/src/algorithm.rs
 # --------------------------------------------------------------------------
@@ -322,6 +399,47 @@ class GaussianProcessOracle:
     def predict_valvar(self, x, chunk=1024):
         """algorithm.rs:282-307."""
         return self.predict(x, chunk), self.predict_var(x, chunk)
+
+    def predict_gradients(self, x):
+        """algorithm.rs:510-549 (`predict_jacobian` per row): d mean / d x, (m, nx)."""
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        out = np.empty((x.shape[0], self.xt_norm.shape[1]))
+        for a in range(x.shape[0]):
+            xnorm = (x[a] - self.x_mean) / self.x_std
+            df_dx = regression_jacobian(self.mean, xnorm).T.dot(self.inner.beta)           # (nx,1)
+            dr = corr_jacobian(self.corr, xnorm, self.xt_norm, self.theta, self.w_star)    # (n,nx)
+            out[a] = ((df_dx + dr.T.dot(self.inner.gamma))[:, 0]) * self.y_std[0] / self.x_std
+        return out
+
+    def predict_var_gradients(self, x):
+        """algorithm.rs:555-617 (`predict_var_gradients_single` per row): d variance / d x, (m, nx)."""
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        inn = self.inner
+        f_mean = regression_value(self.mean, self.xt_norm)
+        rho2 = sla.solve_triangular(inn.r_chol, f_mean, lower=True, check_finite=False)
+        inv_kf = sla.solve_triangular(inn.r_chol.T, rho2, lower=False, check_finite=False)
+        b_mat = f_mean.T.dot(inv_kf)
+        rho3 = np.linalg.cholesky(b_mat)
+        out = np.empty((x.shape[0], self.xt_norm.shape[1]))
+        for a in range(x.shape[0]):
+            xnorm = ((x[a] - self.x_mean) / self.x_std).reshape(1, -1)
+            r = self._compute_correlation(xnorm).T                                          # (n,1)
+            dr = corr_jacobian(self.corr, xnorm[0], self.xt_norm, self.theta, self.w_star)  # (n,nx)
+            rho1 = sla.solve_triangular(inn.r_chol, r, lower=True, check_finite=False)
+            inv_kr = sla.solve_triangular(inn.r_chol.T, rho1, lower=False, check_finite=False)
+            p2 = inv_kr.T.dot(dr)                                                           # (1,nx)
+            f_x = regression_value(self.mean, xnorm).T                                      # (p,1)
+            a_mat = f_x.T - r.T.dot(inv_kf)                                                 # (1,p)
+            inv_bat = sla.solve_triangular(rho3, a_mat.T, lower=True, check_finite=False)
+            d_mat = sla.solve_triangular(rho3.T, inv_bat, lower=False, check_finite=False)  # (p,1)
+            d_a = regression_jacobian(self.mean, xnorm[0]).T - dr.T.dot(inv_kf)             # (nx,p)
+            p4 = d_mat.T.dot(d_a.T)                                                         # (1,nx)
+            out[a] = (2.0 * (p4 - p2) / self.x_std * inn.sigma2)[0]
+        return out
+
+    def predict_valvar_gradients(self, x):
+        """algorithm.rs:711-727."""
+        return self.predict_gradients(x), self.predict_var_gradients(x)
 
 
 def expand_theta(theta, dim):

@@ -13,7 +13,7 @@ literals the reference's unit tests assert against (test data).
              mean + squared exponential (n=5), theta printed to 8 digits
   kat      : numeric literals of crates/gp/src/utils.rs:151-242,
              crates/gp/src/correlation_models.rs:598-641,719-726,
-             crates/gp/src/mean_models.rs:170-178 and
+             crates/gp/src/mean_models.rs:170-178,196-214, crates/gp/src/algorithm.rs:1723-1797 and
              python/egobox/tests/test_gpmix.py:37-53
 """
 import json
@@ -112,6 +112,18 @@ def main():
         "quadratic2": {  # mean_models.rs:181-186
             "x": [[0.0], [7.0], [25.0]],
             "expected": [[1.0, 0.0, 0.0], [1.0, 7.0, 49.0], [1.0, 25.0, 625.0]]},
+        "quadratic_jac": {  # mean_models.rs:196-214
+            "x": [1.0, 2.0, 3.0],
+            "expected": [[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [2.0, 0.0, 0.0],
+                         [2.0, 1.0, 0.0], [3.0, 0.0, 1.0], [0.0, 4.0, 0.0], [0.0, 3.0, 2.0], [0.0, 0.0, 6.0]]},
+        "bug_var_derivatives": {  # algorithm.rs:1723-1797: fixed data set + fixed theta, d var / dx vs central differences
+            "xt": [[6.875, -4.375], [-3.125, 1.875], [1.875, -1.875], [-4.375, 3.125], [8.125, 9.375],
+                   [4.375, 4.375], [0.625, 0.625], [9.375, 6.875], [5.625, 8.125], [-0.625, -3.125],
+                   [3.125, 5.625], [-1.875, -0.625]],
+            "yt": [2.43286801, 13.10840811, 5.32908578, 17.81862219, 74.08849877, 39.68137781, 14.96009727,
+                   63.17475741, 61.26331775, -7.46009727, 44.39159189, 2.17091422],
+            "theta_sq_half": [0.0437386, 0.00697978],  # theta = sqrt(2 * .)
+            "x": [-1.3, 2.5], "e": 5e-6, "epsilon": 1e-5},
         "python_kriging": {  # python/egobox/tests/test_gpmix.py:24-53 (default fit => theta* of golden A)
             "xt": [0.0, 1.0, 2.0, 3.0, 4.0], "yt": [0.0, 1.0, 1.5, 0.9, 1.0],
             "predict_1.0": 1.0, "var_1.0": 0.0, "places": 7,

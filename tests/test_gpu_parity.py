@@ -624,3 +624,97 @@ def test_lbfgs_fit_improves_on_start_and_on_derivative_free(egx):
         assert pg1 <= 0.5 * pg0
     g1.close()
     g2.close()
+
+
+# ------------------------------------------------------------------ x-gradients of the predictions
+def _grad_tol(ref):
+    return dict(rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("mean", range(3))
+@pytest.mark.parametrize("corr", range(4))
+def test_prediction_gradients_vs_oracle(egx, O, mean, corr):
+    x, y = _data(300, 3, seed=31)
+    theta = np.array([0.8, 1.3, 0.6]) * (4.0 if corr == 0 else 1.0)
+    ref = O.fit_fixed(x, y, theta, mean=MEANS[mean], corr=KINDS[corr])
+    xq = np.random.default_rng(3).random((37, 3))
+    with egx.GpHandle(x, y, mean=mean, corr=corr) as h:
+        h.finalize(theta)
+        gy, gv = h.predict_gradients(xq), h.predict_var_gradients(xq)
+        ry, rv = ref.predict_valvar_gradients(xq)
+        np.testing.assert_allclose(gy, ry, **_grad_tol(ry))
+        np.testing.assert_allclose(gv, rv, **_grad_tol(rv))
+        gy2, gv2 = h.predict_valvar_gradients(xq)
+        np.testing.assert_array_equal(gy2, gy)
+        np.testing.assert_array_equal(gv2, gv)
+        assert h.predict_gradients(np.zeros((0, 3))).shape == (0, 3)
+
+
+def test_reference_bug_var_derivatives_kat_through_cabi(egx, golden_dir):
+    """algorithm.rs:1723-1797: the reference's fixed data set, d var / d x vs central differences of predict_var."""
+    import json
+    b = json.load(open(os.path.join(golden_dir, "kat.json")))["bug_var_derivatives"]
+    gp = egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr()) \
+        .theta_tuning(egx.ThetaTuning.Fixed(np.sqrt(2.0 * np.array(b["theta_sq_half"])))) \
+        .fit(np.array(b["xt"]), np.array(b["yt"]))
+    xa, xb = b["x"]
+    e = b["e"]
+    v = gp.predict_var(np.array([[xa + e, xb], [xa - e, xb], [xa, xb + e], [xa, xb - e]]))
+    g = gp.predict_var_gradients(np.array([[xa, xb]]))
+    assert g[0, 0] == pytest.approx((v[0] - v[1]) / (2 * e), abs=b["epsilon"])
+    assert g[0, 1] == pytest.approx((v[2] - v[3]) / (2 * e), abs=b["epsilon"])
+    gp.close()
+
+
+def test_prediction_gradients_kpls_weights(egx, O):
+    x, y = _data(250, 5, seed=33)
+    rng = np.random.default_rng(2)
+    w = rng.standard_normal((5, 2))
+    theta = np.array([0.7, 0.4])
+    xq = rng.random((20, 5))
+    for corr in range(4):
+        ref = O.fit_fixed(x, y, theta, corr=KINDS[corr], w_star=w)
+        with egx.GpHandle(x, y, corr=corr, w_star=w) as h:
+            h.finalize(theta)
+            ry, rv = ref.predict_valvar_gradients(xq)
+            np.testing.assert_allclose(h.predict_gradients(xq), ry, **_grad_tol(ry))
+            np.testing.assert_allclose(h.predict_var_gradients(xq), rv, **_grad_tol(rv))
+
+
+def test_prediction_gradients_medium_size_and_state(egx, O):
+    """n = 2000, d = 8 (one pass of 8 register sums), m spanning several workgroups; one point (EGO's use: the training
+    range is split over workgroups); the cached C^-T is rebuilt after a refit at another theta."""
+    x, y = _data(2000, 8, seed=35)
+    theta = np.full(8, 0.9)
+    xq = np.random.default_rng(4).random((300, 8))
+    with egx.GpHandle(x, y, corr=3) as h:
+        for th in (theta, theta * 1.7):
+            ref = O.fit_fixed(x, y, th, corr=KINDS[3])
+            h.finalize(th)
+            ry, rv = ref.predict_valvar_gradients(xq[:40])
+            gy, gv = h.predict_valvar_gradients(xq)
+            np.testing.assert_allclose(gy[:40], ry, **_grad_tol(ry))
+            np.testing.assert_allclose(gv[:40], rv, **_grad_tol(rv))
+            g1 = h.predict_var_gradients(xq[7:8])
+            np.testing.assert_allclose(g1, gv[7:8], rtol=1e-9, atol=1e-12 * np.abs(gv).max())
+        with pytest.raises(egx.NotFittedError):
+            h.likelihood(theta)  # single workspace: the evaluation takes workspace 0 and un-fits the model
+            h.predict_gradients(xq[:1])
+
+
+def test_prediction_gradients_d32_two_chunks_of_registers(egx):
+    """d = 40 > 32: two register passes; checked against central differences of the GPU's own predictions."""
+    x, y = _data(500, 40, seed=37)
+    theta = np.full(40, 0.35)
+    xq = np.random.default_rng(6).random((3, 40))
+    with egx.GpHandle(x, y, corr=2) as h:
+        h.finalize(theta)
+        gy, gv = h.predict_valvar_gradients(xq)
+        e = 1e-6
+        for k in (0, 17, 33, 39):
+            dq = np.zeros(40)
+            dq[k] = e
+            fy = (h.predict(xq + dq) - h.predict(xq - dq)) / (2 * e)
+            fv = (h.predict_var(xq + dq) - h.predict_var(xq - dq)) / (2 * e)
+            np.testing.assert_allclose(gy[:, k], fy, rtol=1e-5, atol=1e-6 * np.abs(gy).max())
+            np.testing.assert_allclose(gv[:, k], fv, rtol=1e-5, atol=1e-6 * np.abs(gv).max())

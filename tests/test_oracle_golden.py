@@ -199,3 +199,56 @@ def test_ref_shaped_not_positive_definite(RS):
     r = RS.likelihood(x, np.array([0.0, 1.0, 1.0, 0.5]), [1.0], nugget=-1e-3)
     assert r["status"] == 1
     assert O.likelihood_at(x, np.array([0.0, 1.0, 1.0, 0.5]), [1.0], nugget=-1e-3)[1] == 1
+
+
+# ---------------------------------------------------------------- x-gradients of the predictions
+def test_quadratic_jacobian_kat(golden_dir):
+    k = _load(golden_dir, "kat.json")["quadratic_jac"]  # mean_models.rs:196-214
+    np.testing.assert_array_equal(O.regression_jacobian(O.QUADRATIC, k["x"]), np.array(k["expected"]))
+
+
+def test_bug_var_derivatives_kat(golden_dir):
+    """The reference's own fixed data set (algorithm.rs:1723-1797): d var / d x against central differences."""
+    b = _load(golden_dir, "kat.json")["bug_var_derivatives"]
+    gp = O.fit_fixed(np.array(b["xt"]), np.array(b["yt"]), np.sqrt(2.0 * np.array(b["theta_sq_half"])))
+    xa, xb = b["x"]
+    e = b["e"]
+    v = gp.predict_var(np.array([[xa + e, xb], [xa - e, xb], [xa, xb + e], [xa, xb - e]]))
+    g = gp.predict_var_gradients(np.array([[xa, xb]]))
+    assert g[0, 0] == pytest.approx((v[0] - v[1]) / (2 * e), abs=b["epsilon"])
+    assert g[0, 1] == pytest.approx((v[2] - v[3]) / (2 * e), abs=b["epsilon"])
+
+
+@pytest.mark.parametrize("mean", [O.CONSTANT, O.LINEAR, O.QUADRATIC])
+@pytest.mark.parametrize("corr", [O.SQEXP, O.ABSEXP, O.MATERN32, O.MATERN52])
+def test_prediction_gradients_match_finite_differences(mean, corr):
+    """What the reference's test_gp_derivatives / test_gp_variance_derivatives macros assert (algorithm.rs:1458-1660)."""
+    rng = np.random.default_rng(0)
+    x = rng.random((30, 3)) * 4 - 2
+    y = np.sin(x[:, 0]) + x[:, 1] ** 2 + np.abs(x[:, 2])
+    gp = O.fit_fixed(x, y, np.array([0.7, 1.1, 0.9]), mean=mean, corr=corr)
+    q = rng.random((4, 3)) * 3 - 1.5
+    e = 1e-6
+    gm, gv = gp.predict_valvar_gradients(q)
+    for k in range(3):
+        dq = np.zeros(3)
+        dq[k] = e
+        fm = (gp.predict(q + dq) - gp.predict(q - dq)) / (2 * e)
+        fv = (gp.predict_var(q + dq) - gp.predict_var(q - dq)) / (2 * e)
+        np.testing.assert_allclose(gm[:, k], fm, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(gv[:, k], fv, rtol=1e-6, atol=1e-7)
+
+
+def test_jacobian_with_kpls_weights_matches_finite_differences():
+    rng = np.random.default_rng(5)
+    xt = rng.standard_normal((12, 4))
+    w = rng.standard_normal((4, 2))
+    theta = np.array([0.6, 1.3])
+    x = rng.standard_normal(4)
+    for kind in (O.SQEXP, O.ABSEXP, O.MATERN32, O.MATERN52):
+        jac = O.corr_jacobian(kind, x, xt, theta, w)
+        for k in range(4):
+            dx = np.zeros(4)
+            dx[k] = 1e-6
+            fd = (O.corr_value(kind, (x + dx)[None, :] - xt, theta, w) - O.corr_value(kind, (x - dx)[None, :] - xt, theta, w)) / 2e-6
+            np.testing.assert_allclose(jac[:, k], fd[:, 0], rtol=1e-6, atol=1e-9)
