@@ -329,20 +329,27 @@ __global__ __launch_bounds__(NTHREADS, (WM * WN > 2048 ? 2 : (NTHREADS == 512 ? 
     const int r0 = bx * BM + (wave / S::WAVES_N) * WM + (lane >> 4);
     const int c0 = by * BN + (wave % S::WAVES_N) * WN + (lane & 15);
     // read-modify-write of the C tile in batches of independent loads (a naive `*p -= acc` chain
-    // serialises on vmcnt(0) per element: measured 2x on the whole kernel)
+    // serialises on vmcnt(0) per element: measured 2x on the whole kernel); the loads of batch mi + 1 are issued
+    // before batch mi is stored, so the epilogue pays one memory latency plus issue time instead of MT latencies
+    double cv[2][S::NT][4];
+#pragma unroll
+    for (int ni = 0; ni < S::NT; ni++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) cv[0][ni][r] = C[(int64_t)(r0 + 4 * r) * ldc + (c0 + ni * 16)];
 #pragma unroll
     for (int mi = 0; mi < S::MT; mi++) {
-        double cv[S::NT][4];
+        if (mi + 1 < S::MT) {
+#pragma unroll
+            for (int ni = 0; ni < S::NT; ni++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    cv[(mi + 1) & 1][ni][r] = C[(int64_t)(r0 + (mi + 1) * 16 + 4 * r) * ldc + (c0 + ni * 16)];
+        }
 #pragma unroll
         for (int ni = 0; ni < S::NT; ni++)
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                cv[ni][r] = C[(int64_t)(r0 + mi * 16 + 4 * r) * ldc + (c0 + ni * 16)];
-#pragma unroll
-        for (int ni = 0; ni < S::NT; ni++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                C[(int64_t)(r0 + mi * 16 + 4 * r) * ldc + (c0 + ni * 16)] = cv[ni][r] - acc[mi][ni][r];
+                C[(int64_t)(r0 + mi * 16 + 4 * r) * ldc + (c0 + ni * 16)] = cv[mi & 1][ni][r] - acc[mi][ni][r];
     }
     EGX_GSTAMP(2);
 }
