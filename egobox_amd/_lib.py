@@ -60,6 +60,8 @@ SIGNATURES = [
     ("egx_gp_finalize", C.c_int32, [C.c_void_p, c_double_p, C.c_int64]),
     ("egx_gp_fit", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_int64, C.c_int64,
                                c_int64_p]),
+    ("egx_gp_fit_partial", C.c_int32, [C.c_void_p, c_double_p, c_int64_p, C.c_int64, c_double_p, C.c_int64, c_double_p,
+                                       c_double_p, C.c_int64, C.c_int64, c_int64_p]),
     ("egx_gp_fit_lbfgs", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_int64, C.c_int64,
                                      c_int64_p]),
     ("egx_gp_predict", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),

@@ -1072,13 +1072,17 @@ int32_t egx_gp_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     return do_finalize(gp, theta, theta_len);
 }
 
-int32_t egx_gp_fit(egx_gp *gp, const double *theta0s, int64_t n_starts, const double *lo, const double *hi,
-                   int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out) {
-    if (!gp || !theta0s || !lo || !hi || n_starts < 1) {
+// Multistart derivative-free fit over the ACTIVE theta components (all of them for ThetaTuning::Full; a subset for
+// ThetaTuning::Partial, algorithm.rs:822-826, 873-960: the inactive components stay at theta_base).
+static int32_t fit_nm_core(egx_gp *gp, const double *theta_base /*h*/, const std::vector<int> &active,
+                           const double *theta0s /*n_starts x k*/, int64_t n_starts, const double *lo,
+                           const double *hi, int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out) {
+    if (!theta0s || !lo || !hi || n_starts < 1 || active.empty()) {
         set_error("NULL argument / no start point");
         return EGX_ERR_INVALID_VALUE;
     }
-    const int h = gp->h;
+    const int hfull = gp->h;
+    const int h = (int)active.size();  // optimised dimensions
     if (bounds_len != 1 && bounds_len != h) {  // algorithm.rs:901-912
         set_error("Bounds for theta should be either 1-dim or dim of xtrain (" + std::to_string(h) + "), got " +
                   std::to_string(bounds_len));
@@ -1122,10 +1126,10 @@ int32_t egx_gp_fit(egx_gp *gp, const double *theta0s, int64_t n_starts, const do
             return;
         }
         auto objective = [&](const std::vector<double> &x) -> double {
-            std::vector<double> th(h);
-            for (int i = 0; i < h; i++) th[i] = std::pow(10.0, x[i]);
+            std::vector<double> th(theta_base, theta_base + hfull);
+            for (int i = 0; i < h; i++) th[active[i]] = std::pow(10.0, x[i]);
             EvalResult res;
-            int rc = eval_one(gp, t, th.data(), h, res, false);
+            int rc = eval_one(gp, t, th.data(), hfull, res, false);
             if (rc) {
                 if (!rcs[t]) {
                     rcs[t] = rc;
@@ -1162,12 +1166,46 @@ int32_t egx_gp_fit(egx_gp *gp, const double *theta0s, int64_t n_starts, const do
         }
     }
     if (n_evals_out) *n_evals_out = evals;
-    std::vector<double> th(h);
+    std::vector<double> th(theta_base, theta_base + hfull);
     if (std::isfinite(best_f))
-        for (int i = 0; i < h; i++) th[i] = std::pow(10.0, best_x[i]);
+        for (int i = 0; i < h; i++) th[active[i]] = std::pow(10.0, best_x[i]);
     else  // every start failed: the reference falls through with ones (algorithm.rs:943) -> 10^1... keep start 0
-        for (int i = 0; i < h; i++) th[i] = theta0s[i];
-    return do_finalize(gp, th.data(), h);
+        for (int i = 0; i < h; i++) th[active[i]] = theta0s[i];
+    return do_finalize(gp, th.data(), hfull);
+}
+
+int32_t egx_gp_fit(egx_gp *gp, const double *theta0s, int64_t n_starts, const double *lo, const double *hi,
+                   int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out) {
+    if (!gp || !theta0s || n_starts < 1) {
+        set_error("NULL argument / no start point");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::vector<int> active(gp->h);
+    for (int i = 0; i < gp->h; i++) active[i] = i;
+    return fit_nm_core(gp, theta0s, active, theta0s, n_starts, lo, hi, bounds_len, max_eval, n_evals_out);
+}
+
+int32_t egx_gp_fit_partial(egx_gp *gp, const double *theta_init, const int64_t *active_idx, int64_t n_active,
+                           const double *theta0s, int64_t n_starts, const double *lo, const double *hi,
+                           int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out) {
+    if (!gp || !theta_init || !active_idx || n_active < 1 || n_active > gp->h) {
+        set_error("NULL argument / bad active set");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::vector<int> active((size_t)n_active);
+    for (int64_t i = 0; i < n_active; i++) {
+        if (active_idx[i] < 0 || active_idx[i] >= gp->h || (i > 0 && active_idx[i] <= active_idx[i - 1])) {
+            set_error("active theta components must be strictly increasing indices in [0, h)");
+            return EGX_ERR_INVALID_VALUE;
+        }
+        active[(size_t)i] = (int)active_idx[i];
+    }
+    for (int i = 0; i < gp->h; i++)
+        if (!(theta_init[i] > 0.0)) {
+            set_error("theta_init must be > 0");
+            return EGX_ERR_INVALID_VALUE;
+        }
+    return fit_nm_core(gp, theta_init, active, theta0s, n_starts, lo, hi, bounds_len, max_eval, n_evals_out);
 }
 
 int32_t egx_gp_predict(egx_gp *gp, const double *xq, int64_t m, double *y) {

@@ -204,6 +204,18 @@ class GpHandle:
                                      int(max_eval), C.byref(ne)))
         return ne.value
 
+    def fit_partial(self, theta_init, active, theta0s, lo, hi, max_eval=GP_COBYLA_MAX_EVAL):
+        theta_init = L.as_f64(theta_init, 1)
+        act = np.ascontiguousarray(active, dtype=np.int64)
+        theta0s = L.as_f64(theta0s, 2)
+        lo = L.as_f64(np.atleast_1d(lo), 1)
+        hi = L.as_f64(np.atleast_1d(hi), 1)
+        ne = C.c_int64()
+        L.check(self._lib.egx_gp_fit_partial(self._h, L.dptr(theta_init), act.ctypes.data_as(L.c_int64_p), act.size,
+                                             L.dptr(theta0s), theta0s.shape[0], L.dptr(lo), L.dptr(hi), lo.size,
+                                             int(max_eval), C.byref(ne)))
+        return ne.value
+
     def fit_lbfgs(self, theta0s, lo, hi, max_iter=50):
         theta0s = L.as_f64(theta0s, 2)
         lo = L.as_f64(np.atleast_1d(lo), 1)
@@ -506,9 +518,23 @@ class GpParams:
                                       max(5, min(100, self._max_eval // 4)))
             else:
                 n_evals = h.fit(10.0 ** starts_log10, [lo for lo, _ in b], [hi for _, hi in b], self._max_eval)
-        else:
-            h.close()
-            raise NotImplementedError("ThetaTuning.Partial is not on the accelerated path yet")
+        else:  # ThetaTuning::Partial, algorithm.rs:822-826, 873-960: only the active components move
+            theta0 = np.full(dim, t.init[0]) if t.init.size == 1 else np.array(t.init, dtype=np.float64)
+            b = t.bounds
+            if len(b) not in (1, dim):
+                h.close()
+                raise L.InvalidValueError(
+                    L.ERR_INVALID_VALUE,
+                    f"Bounds for theta should be either 1-dim or dim of xtrain ({dim}), got {len(b)}")
+            b = b * dim if len(b) == 1 else b
+            active = sorted(set(int(i) for i in t.active))
+            if not active or active[0] < 0 or active[-1] >= dim:
+                h.close()
+                raise L.InvalidValueError(L.ERR_INVALID_VALUE, f"active components must be indices in [0, {dim})")
+            ab = [b[i] for i in active]
+            starts_log10, _ = prepare_multistart(self._n_start, theta0[active], ab, seed=self._seed)
+            n_evals = h.fit_partial(theta0, active, 10.0 ** starts_log10, [lo for lo, _ in ab], [hi for _, hi in ab],
+                                    self._max_eval)
         return GaussianProcess(h, self, n_evals)
 
 

@@ -140,6 +140,14 @@ int32_t egx_gp_finalize(egx_gp *gp, const double *theta, int64_t theta_len);
 int32_t egx_gp_fit(egx_gp *gp, const double *theta0s, int64_t n_starts, const double *lo,
                    const double *hi, int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out);
 
+/* ThetaTuning::Partial (parameters.rs:24-32, algorithm.rs:822-826, 873-960): only the components listed in
+ * active_idx (strictly increasing, n_active of them) are optimised, the others stay at theta_init (h values).
+ * theta0s is (n_starts x n_active) in theta space, lo/hi have 1 or n_active entries;
+ * maxeval per start = clamp(10 n_active, 25, max_eval). */
+int32_t egx_gp_fit_partial(egx_gp *gp, const double *theta_init, const int64_t *active_idx, int64_t n_active,
+                           const double *theta0s, int64_t n_starts, const double *lo, const double *hi,
+                           int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out);
+
 /* Gradient-based variant (NEW: consumes egx_gp_likelihood_grad; same contract as egx_gp_fit otherwise):
  * projected L-BFGS on log10(theta) per start, best start wins, then finalize.  max_iter bounds the
  * iterations per start; *n_evals_out counts likelihood+gradient evaluations. */

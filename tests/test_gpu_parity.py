@@ -718,3 +718,22 @@ def test_prediction_gradients_d32_two_chunks_of_registers(egx):
             fv = (h.predict_var(xq + dq) - h.predict_var(xq - dq)) / (2 * e)
             np.testing.assert_allclose(gy[:, k], fy, rtol=1e-5, atol=1e-6 * np.abs(gy).max())
             np.testing.assert_allclose(gv[:, k], fv, rtol=1e-5, atol=1e-6 * np.abs(gv).max())
+
+
+def test_partial_theta_tuning(egx, O):
+    """ThetaTuning::Partial (algorithm.rs:822-826, 873-960): inactive components keep their initial value, the
+    active ones move and the likelihood at the result is what the oracle computes there."""
+    x, y = _data(300, 3, seed=41)
+    init = np.array([0.7, 1.1, 0.9])
+    gp = egx.GaussianProcess.params(egx.ConstantMean(), egx.Matern52Corr()) \
+        .theta_tuning(egx.ThetaTuning.Partial(init, [(1e-2, 1e1)], [0, 2])).n_start(2).max_eval(40).fit(x, y)
+    th = gp.theta()
+    assert th[1] == init[1] and (th[0] != init[0] or th[2] != init[2])
+    lk0, st0 = O.likelihood_at(x, y, init, corr=KINDS[3])[:2]
+    ref = O.fit_fixed(x, y, th, corr=KINDS[3])
+    assert gp.likelihood() == pytest.approx(ref.likelihood, rel=LK_RTOL)
+    assert gp.likelihood() >= lk0  # start 0 is the user's theta: the optimum cannot be worse
+    gp.close()
+    with pytest.raises(egx.InvalidValueError):
+        egx.GaussianProcess.params(egx.ConstantMean(), egx.Matern52Corr()) \
+            .theta_tuning(egx.ThetaTuning.Partial(init, [(1e-2, 1e1)], [0, 5])).fit(x, y)
