@@ -4,6 +4,8 @@ Mirrors what egobox-moe does AFTER its clustering has chosen and trained the exp
   GaussianMixture.predict_probas / predict        crates/moe/src/gaussian_mixture.rs:114-121, 231-283, 305-316
   GpMixture.predict_smooth / predict_var_smooth   crates/moe/src/algorithm.rs:411-423, 670-685, 789-809
   GpMixture.predict_hard  / predict_var_hard      crates/moe/src/algorithm.rs:879-935
+  GpMixture.predict_(var_)gradients smooth / hard crates/moe/src/algorithm.rs:691-783, 942-1010;
+  GaussianMixture.predict_probas_derivatives      crates/moe/src/gaussian_mixture.rs:127-170
 Clustering itself (GMM fitting, expert selection by cross-validation) stays in egobox-moe.
 
 Differences that matter on a GPU: the reference's hard recombination calls the expert ONCE PER ROW with a
@@ -75,6 +77,18 @@ class GaussianMixture:
 
     def pdfs(self, x):
         return np.exp(self._log_gaussian_prob(np.asarray(x, dtype=np.float64).reshape(1, -1))[0])
+
+    def predict_probas_derivatives(self, x):
+        """gaussian_mixture.rs:127-170, all points at once -> (m, k, nx): d p_i(x) / d x with p_i = u_i / v,
+        u_i = w_i pdf_i(x), v = sum_i u_i."""
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        u = self.weights * np.exp(self._log_gaussian_prob(x))                      # (m, k)
+        v = u.sum(axis=1)                                                          # (m,)
+        precs = np.einsum("kij,klj->kil", self.precisions_chol, self.precisions_chol) / self.heaviside_factor
+        deriv = np.einsum("mkj,kjl->mkl", x[:, None, :] - self.means[None, :, :], precs)
+        uprime = -deriv * u[:, :, None]                                            # (m, k, nx)
+        vprime = uprime.sum(axis=1)                                                # (m, nx)
+        return (uprime * v[:, None, None] - u[:, :, None] * vprime[:, None, :]) / (v * v)[:, None, None]
 
 
 class GpMixture:
@@ -156,3 +170,44 @@ class GpMixture:
 
     def predict_var(self, x):
         return self.predict_valvar(x, False, True)[1]
+
+    def predict_valvar_gradients(self, x, want_val=True, want_var=True):
+        """crates/moe/src/algorithm.rs:691-783 (smooth), :942-1010 (hard) -> ((m, nx), (m, nx)).
+        smooth:  d mean = sum_i p_i grad y_i + p'_i y_i ;  d var = sum_i p_i^2 grad v_i + 2 p_i p'_i v_i.
+        Every expert gets ONE batched call per quantity (the reference calls it once per row)."""
+        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        m, nx = x.shape
+        gy, gv = np.zeros((m, nx)), np.zeros((m, nx))
+        smooth = self.recombination == "smooth"
+        if smooth:
+            p = self.gmx.predict_probas(x)
+            pp = self.gmx.predict_probas_derivatives(x) if self.gmx.n_clusters > 1 else np.zeros((m, 1, nx))
+        else:
+            c = self.gmx.predict(x)
+        for i, e in enumerate(self.experts):
+            if not self._mine(i):
+                continue
+            idx = None if smooth else np.flatnonzero(c == i)
+            if idx is not None and idx.size == 0:
+                continue
+            xi = x if smooth else x[idx]
+            if want_val:
+                g = e.predict_gradients(xi)
+                if smooth:
+                    gy += g * p[:, i:i + 1] + pp[:, i, :] * e.predict(xi)[:, None]
+                else:
+                    gy[idx] = g
+            if want_var:
+                g = e.predict_var_gradients(xi)
+                if smooth:
+                    gv += g * (p[:, i:i + 1] ** 2) + 2.0 * p[:, i:i + 1] * pp[:, i, :] * e.predict_var(xi)[:, None]
+                else:
+                    gv[idx] = g
+        gy, gv = self._allreduce(gy, gv)
+        return gy, gv
+
+    def predict_gradients(self, x):
+        return self.predict_valvar_gradients(x, True, False)[0]
+
+    def predict_var_gradients(self, x):
+        return self.predict_valvar_gradients(x, False, True)[1]

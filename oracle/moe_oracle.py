@@ -69,6 +69,27 @@ class GaussianMixtureOracle:
         # :172-176
         return np.exp(self.log_gaussian_prob(np.asarray(x, dtype=np.float64).reshape(1, -1))[0])
 
+    def precisions(self):
+        # compute_precisions :207-215
+        return np.array([pc.dot(pc.T) for pc in self.precisions_chol])
+
+    def predict_single_probas_derivatives(self, x):
+        # :127-153 -> (k, nx)
+        x = np.asarray(x, dtype=np.float64).reshape(-1)
+        pdfs = self.pdfs(x)
+        v = self.weights.dot(pdfs)
+        precs = self.precisions() / self.heaviside_factor
+        deriv = np.array([(x - mu).dot(prec) for mu, prec in zip(self.means, precs)])
+        vprime = (deriv * (-self.weights * pdfs)[:, None]).sum(axis=0)
+        u = (self.weights * pdfs)[:, None]
+        uprime = -(deriv * u)
+        return (uprime * v - u * vprime[None, :]) / (v * v)
+
+    def predict_probas_derivatives(self, x):
+        # :158-170 -> (m, k, nx)
+        x = np.asarray(x, dtype=np.float64)
+        return np.array([self.predict_single_probas_derivatives(xi) for xi in x])
+
 
 # ---- recombination, crates/moe/src/algorithm.rs ------------------------------------------------
 def predict_smooth(experts, gmx, x):
@@ -95,3 +116,43 @@ def predict_var_hard(experts, gmx, x):
     x = np.asarray(x, dtype=np.float64)
     c = gmx.predict(x)
     return np.array([experts[c[i]].predict_var(x[i:i + 1])[0] for i in range(x.shape[0])])
+
+
+def predict_gradients_smooth(experts, gmx, x):
+    """:691-733  sum_i p_i grad y_i + sum_i p'_i y_i, point by point."""
+    x = np.asarray(x, dtype=np.float64)
+    p, pp = gmx.predict_probas(x), gmx.predict_probas_derivatives(x)
+    out = np.zeros_like(x)
+    for a in range(x.shape[0]):
+        xa = x[a:a + 1]
+        preds = np.array([e.predict(xa)[0] for e in experts])
+        drvs = np.array([e.predict_gradients(xa)[0] for e in experts])
+        out[a] = (drvs * p[a][:, None]).sum(axis=0) + (pp[a] * preds[:, None]).sum(axis=0)
+    return out
+
+
+def predict_var_gradients_smooth(experts, gmx, x):
+    """:739-783  sum_i p_i^2 grad v_i + 2 sum_i p_i p'_i v_i."""
+    x = np.asarray(x, dtype=np.float64)
+    p, pp = gmx.predict_probas(x), gmx.predict_probas_derivatives(x)
+    out = np.zeros_like(x)
+    for a in range(x.shape[0]):
+        xa = x[a:a + 1]
+        preds = np.array([e.predict_var(xa)[0] for e in experts])
+        drvs = np.array([e.predict_var_gradients(xa)[0] for e in experts])
+        out[a] = (drvs * (p[a] ** 2)[:, None]).sum(axis=0) + (2.0 * p[a][:, None] * pp[a] * preds[:, None]).sum(axis=0)
+    return out
+
+
+def predict_gradients_hard(experts, gmx, x):
+    """:942-960."""
+    x = np.asarray(x, dtype=np.float64)
+    c = gmx.predict(x)
+    return np.array([experts[c[i]].predict_gradients(x[i:i + 1])[0] for i in range(x.shape[0])])
+
+
+def predict_var_gradients_hard(experts, gmx, x):
+    """:965-983."""
+    x = np.asarray(x, dtype=np.float64)
+    c = gmx.predict(x)
+    return np.array([experts[c[i]].predict_var_gradients(x[i:i + 1])[0] for i in range(x.shape[0])])

@@ -737,3 +737,33 @@ def test_partial_theta_tuning(egx, O):
     with pytest.raises(egx.InvalidValueError):
         egx.GaussianProcess.params(egx.ConstantMean(), egx.Matern52Corr()) \
             .theta_tuning(egx.ThetaTuning.Partial(init, [(1e-2, 1e1)], [0, 5])).fit(x, y)
+
+
+@pytest.mark.parametrize("recomb", ["smooth", "hard"])
+def test_mixture_gradients_of_gpu_experts_match_oracle(egx, O, recomb):
+    from egobox_amd.moe import GaussianMixture, GpMixture
+    from oracle import moe_oracle as MO
+    rng = np.random.default_rng(1)
+    gpu_experts, cpu_experts = [], []
+    for c in range(3):
+        x = rng.random((200, 2)) + [c, 0.0]
+        y = np.sin(3 * x[:, 0]) + x[:, 1] * (c + 1)
+        theta = [1.5, 1.0]
+        gpu_experts.append(egx.GaussianProcess.params(egx.ConstantMean(), egx.Matern52Corr())
+                           .theta_tuning(egx.ThetaTuning.Fixed(theta)).fit(x, y))
+        cpu_experts.append(O.fit_fixed(x, y, theta, corr=O.MATERN52))
+    means = np.array([[0.5, 0.5], [1.5, 0.5], [2.5, 0.5]])
+    covs = np.array([np.eye(2) * 0.2] * 3)
+    w = np.array([0.3, 0.3, 0.4])
+    mix = GpMixture(gpu_experts, GaussianMixture(w, means, covs, 0.8), recomb)
+    gmo = MO.GaussianMixtureOracle(w, means, covs, 0.8)
+    xq = np.random.default_rng(2).random((60, 2)) * [3.0, 1.0]
+    gy, gv = mix.predict_valvar_gradients(xq)
+    if recomb == "smooth":
+        wy, wv = MO.predict_gradients_smooth(cpu_experts, gmo, xq), MO.predict_var_gradients_smooth(cpu_experts, gmo, xq)
+    else:
+        wy, wv = MO.predict_gradients_hard(cpu_experts, gmo, xq), MO.predict_var_gradients_hard(cpu_experts, gmo, xq)
+    np.testing.assert_allclose(gy, wy, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(wy).max())
+    np.testing.assert_allclose(gv, wv, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(wv).max())
+    for e in gpu_experts:
+        e.close()

@@ -99,3 +99,51 @@ def test_expert_sharding_covers_all_experts():
             parts.append(m.predict_valvar(xq))
         np.testing.assert_allclose(parts[0][0] + parts[1][0], full[0], rtol=1e-13)
         np.testing.assert_allclose(parts[0][1] + parts[1][1], full[1], rtol=1e-13)
+
+
+# ---------------------------------------------------------------- gradients of the mixture (algorithm.rs:691-783, 942-1010)
+def test_probas_derivatives_match_oracle_and_finite_differences():
+    _, means, covs = _experts()
+    w = np.array([0.3, 0.3, 0.4])
+    covs = covs.copy()
+    covs[1] = [[0.3, 0.05], [0.05, 0.15]]
+    gmx, gmo = GaussianMixture(w, means, covs, 0.8), MO.GaussianMixtureOracle(w, means, covs, 0.8)
+    xq = np.random.default_rng(3).random((11, 2)) * [3.0, 1.0]
+    pd = gmx.predict_probas_derivatives(xq)
+    np.testing.assert_allclose(pd, gmo.predict_probas_derivatives(xq), rtol=1e-10, atol=1e-13)
+    e = 1e-6
+    for k in range(2):
+        dq = np.zeros(2)
+        dq[k] = e
+        fd = (gmo.predict_probas(xq + dq) - gmo.predict_probas(xq - dq)) / (2 * e)
+        np.testing.assert_allclose(pd[:, :, k], fd, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(pd.sum(axis=1), 0.0, atol=1e-12)  # responsibilities sum to one
+
+
+@pytest.mark.parametrize("recomb", ["smooth", "hard"])
+def test_gradient_recombination_with_oracle_experts(recomb):
+    """Batched product logic vs the reference-shaped point-by-point recombination, and (smooth) vs central
+    differences of the mixture's own predictions -- what the reference's test_variance_derivatives asserts."""
+    experts, means, covs = _experts()
+    w = np.array([0.3, 0.3, 0.4])
+    gmx, gmo = GaussianMixture(w, means, covs, 0.8), MO.GaussianMixtureOracle(w, means, covs, 0.8)
+    xq = np.random.default_rng(2).random((23, 2)) * [3.0, 1.0]
+    mix = GpMixture(experts, gmx, recomb)
+    gy, gv = mix.predict_valvar_gradients(xq)
+    if recomb == "smooth":
+        wy, wv = MO.predict_gradients_smooth(experts, gmo, xq), MO.predict_var_gradients_smooth(experts, gmo, xq)
+    else:
+        wy, wv = MO.predict_gradients_hard(experts, gmo, xq), MO.predict_var_gradients_hard(experts, gmo, xq)
+    np.testing.assert_allclose(gy, wy, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(gv, wv, rtol=1e-8, atol=1e-11)
+    np.testing.assert_array_equal(mix.predict_gradients(xq), gy)
+    np.testing.assert_array_equal(mix.predict_var_gradients(xq), gv)
+    if recomb == "smooth":
+        e = 1e-6
+        for k in range(2):
+            dq = np.zeros(2)
+            dq[k] = e
+            fy = (mix.predict(xq + dq) - mix.predict(xq - dq)) / (2 * e)
+            fv = (mix.predict_var(xq + dq) - mix.predict_var(xq - dq)) / (2 * e)
+            np.testing.assert_allclose(gy[:, k], fy, rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(gv[:, k], fv, rtol=1e-5, atol=1e-7)
