@@ -767,3 +767,15 @@ def test_mixture_gradients_of_gpu_experts_match_oracle(egx, O, recomb):
     np.testing.assert_allclose(gv, wv, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(wv).max())
     for e in gpu_experts:
         e.close()
+
+
+def test_likelihood_gradient_several_panel_groups(egx, O):
+    """n_pad = 1536 = three groups of two 256-wide panels: the two-level blocking of the triangular solves
+    (identity right-hand sides, rows skipped below the current block) and the ktri GEMM behind the theta-gradient."""
+    x, y = _data(1500, 4, seed=43)
+    theta = np.array([0.9, 1.2, 0.7, 1.0])
+    lk_ref, g_ref = O.likelihood_grad(x, y, theta, corr=KINDS[3])
+    with egx.GpHandle(x, y, corr=3) as h:
+        lk, g, st = h.likelihood_grad(theta)
+        assert st == 0 and lk == pytest.approx(lk_ref, rel=LK_RTOL)
+        np.testing.assert_allclose(g, g_ref, rtol=1e-6, atol=1e-6 * np.abs(g_ref).max())
