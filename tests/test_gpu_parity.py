@@ -779,3 +779,52 @@ def test_likelihood_gradient_several_panel_groups(egx, O):
         lk, g, st = h.likelihood_grad(theta)
         assert st == 0 and lk == pytest.approx(lk_ref, rel=LK_RTOL)
         np.testing.assert_allclose(g, g_ref, rtol=1e-6, atol=1e-6 * np.abs(g_ref).max())
+
+
+# ------------------------------------------------------------------ exact closed form at ANY size (no oracle run needed)
+def _ou_closed_form(x, y, theta):
+    """Constant-mean kriging with the absolute-exponential kernel in ONE dimension is an Ornstein-Uhlenbeck process:
+    on the sorted points C^-1 v is the innovations transform  w_1 = v_1, w_{i+1} = (v_{i+1} - rho_i v_i) / sqrt(1 - rho_i^2),
+    rho_i = exp(-theta dx_i), and diag C = (1, sqrt(1 - rho_i^2)).  O(n), exact -> likelihood, sigma2, beta as the
+    reference defines them (algorithm.rs:1006-1048) at sizes no dense CPU factorisation reaches in a test."""
+    x = np.asarray(x, dtype=np.float64).ravel()
+    xs, ys = x.std(ddof=1), y.std(ddof=1)
+    order = np.argsort(x)
+    xn = ((x - x.mean()) / xs)[order].astype(np.longdouble)
+    yn = ((y - y.mean()) / ys)[order].astype(np.longdouble)
+    rho = np.exp(-np.longdouble(theta) * np.diff(xn))
+    s = np.sqrt(1.0 - rho * rho)
+
+    def whiten(v):
+        return np.concatenate([v[:1], (v[1:] - rho * v[:-1]) / s])
+
+    ft, yt = whiten(np.ones_like(xn)), whiten(yn)
+    beta = ft.dot(yt) / ft.dot(ft)
+    r = yt - ft * beta
+    n = x.size
+    sigma2 = r.dot(r) / n
+    lk = -n * (np.log10(sigma2) + 2.0 / n * np.log10(s).sum())
+    return float(lk), float(sigma2 * ys * ys), float(beta), float(s.min())
+
+
+@pytest.mark.parametrize("n", [5000, 16384, 49152, 98304])
+def test_ornstein_uhlenbeck_closed_form_any_size(egx, n):
+    """n = 98304 is a 77 GB correlation matrix (the handle is sized for the 288 GB of an MI355X; 131072 = 137 GB runs
+    too, tools/ou_capacity.py): likelihood, variance and beta against the exact O(n) closed form, rows shuffled."""
+    rng = np.random.default_rng(n)
+    x = np.sort(rng.random(n)) + np.arange(n) * (0.5 / n)  # strictly increasing, gaps >= 0.5 / n
+    y = np.sin(7.0 * x) + 0.3 * np.cos(23.0 * x) + 0.05 * rng.standard_normal(n)
+    theta = 40.0
+    lk, s2, beta, min_pivot = _ou_closed_form(x, y, theta)
+    assert min_pivot > 1e-3
+    perm = rng.permutation(n)
+    with egx.GpHandle(x[perm].reshape(-1, 1), y[perm], corr=1, nugget=0.0) as h:
+        h.finalize([theta])
+        lk_gpu, s2_gpu = h.fitted_scalars()
+        assert lk_gpu == pytest.approx(lk, rel=LK_RTOL)
+        assert s2_gpu == pytest.approx(s2, rel=1e-7)
+        assert float(h.inner()["beta"][0, 0]) == pytest.approx(beta, rel=1e-6, abs=1e-9)
+        idx = np.arange(0, n, 997)
+        yp, vp = h.predict_valvar(x[idx].reshape(-1, 1))
+        np.testing.assert_allclose(yp, y[idx], rtol=1e-6, atol=1e-6 * np.abs(y).max())
+        assert np.all(vp >= 0) and np.all(vp <= 1e-6 * s2)
