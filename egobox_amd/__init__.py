@@ -15,6 +15,8 @@ from .gp import (AbsoluteExponentialCorr, ConstantMean, GaussianProcess, GpHandl
                  corr_matrix, cross_corr, mfma_probe, normalize, potrf, regression_basis)
 from .gpx import CorrelationSpec, GpMix, Gpx, Recombination, RegressionSpec  # noqa: E402
 from .multistart import prepare_multistart, theta_sweep_candidates  # noqa: E402
+from .sgp import (Inducings, ParamTuning, SgpHandle, SgpParams, SparseGaussianProcess, SparseGpMix, SparseGpx,  # noqa: E402
+                  SparseMethod)
 from . import workload  # noqa: E402
 from .sweep import best_candidate, shard_indices, sweep_likelihood  # noqa: E402
 

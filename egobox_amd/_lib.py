@@ -34,6 +34,10 @@ class InnerView(C.Structure):
         "y_mean", "y_std", "xt_norm", "yt_norm")]
 
 
+class SgpConfig(C.Structure):
+    _fields_ = [("corr", C.c_int32), ("method", C.c_int32), ("nugget", C.c_double), ("device", C.c_int32)]
+
+
 class Timings(C.Structure):
     _fields_ = [("corr_build_ms", C.c_double), ("potrf_ms", C.c_double), ("potrf_syrk_ms", C.c_double),
                 ("solve_ms", C.c_double), ("host_ms", C.c_double), ("total_ms", C.c_double),
@@ -78,6 +82,18 @@ SIGNATURES = [
     ("egx_potrf", C.c_int32, [c_double_p, C.c_int64, c_int32_p]),
     ("egx_gp_last_timings", C.c_int32, [C.c_void_p, C.POINTER(Timings)]),
     ("egx_mfma_probe", C.c_int32, [c_double_p]),
+    ("egx_sgp_config_default", None, [C.POINTER(SgpConfig)]),
+    ("egx_sgp_create", C.c_int32, [C.POINTER(SgpConfig), c_double_p, c_double_p, C.c_int64, C.c_int64, c_double_p,
+                                   C.c_int64, C.POINTER(C.c_void_p)]),
+    ("egx_sgp_destroy", None, [C.c_void_p]),
+    ("egx_sgp_dims", C.c_int32, [C.c_void_p, c_int64_p, c_int64_p, c_int64_p]),
+    ("egx_sgp_likelihood", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, C.c_double, C.c_double, c_double_p, c_int32_p]),
+    ("egx_sgp_finalize", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, C.c_double, C.c_double]),
+    ("egx_sgp_fit", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_int32, C.c_double,
+                                C.c_int64, c_int64_p]),
+    ("egx_sgp_predict", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
+    ("egx_sgp_predict_var", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
+    ("egx_sgp_get_state", C.c_int32, [C.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]),
 ]
 
 

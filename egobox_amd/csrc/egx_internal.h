@@ -99,6 +99,10 @@ int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const d
 int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
                        const double *B, int64_t ldb, int M, int N, int K, int lower, int ktri = 0,
                        bool *used_big_tile = nullptr);
+// Gneg (rows x rows, ldg; lower 64x64 tiles) <- -(W W^T) for a small output and a long contraction (split-K, partial
+// tiles in the scratch P of gram_scratch_doubles(rows, K) doubles, summed in a fixed order)
+size_t gram_scratch_doubles(int rows, int K);
+int launch_gram_lower(hipStream_t s, const double *W, int64_t ldw, int rows, int K, double *Gneg, int64_t ldg, double *P);
 int mfma_probe(double *max_abs_err);
 int chol_init();  // one-time function attribute setup (dynamic LDS sizes)
 

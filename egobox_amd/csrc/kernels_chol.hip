@@ -772,6 +772,52 @@ __global__ void k_mfma_probe(const double *A, const double *B, double *C) {
     for (int r = 0; r < 4; r++) C[((lane >> 4) + 4 * r) * 16 + (lane & 15)] = acc[r];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Split-K Gram matrix (sparse GP: G = W W^T with a SMALL output, rows x rows, and a HUGE contraction length K = n):
+// grid.x enumerates the lower 64x64 tiles, grid.y the K splits; every workgroup writes its partial tile to
+// P[split] (no read-modify-write, deterministic), k_gram_reduce sums the splits into Gneg = -sum_s P[s].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_gram_splitk(const double *__restrict__ W, int64_t ldw, int rows, int kc,
+                                                        int K, double *__restrict__ P) {
+    using S = GemmShape<64, 64, 32, 32, 256>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int t = blockIdx.x;
+    int bx = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while (bx * (bx + 1) / 2 > t) bx--;
+    while ((bx + 1) * (bx + 2) / 2 <= t) bx++;
+    const int by = t - bx * (bx + 1) / 2;
+    const int k0 = blockIdx.y * kc;
+    int klen = K - k0;
+    if (klen > kc) klen = kc;
+    const int tid = threadIdx.x;
+    double4_t acc[S::MT][S::NT];
+#pragma unroll
+    for (int mi = 0; mi < S::MT; mi++)
+#pragma unroll
+        for (int ni = 0; ni < S::NT; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+    if (klen > 0)
+        gemm_core<64, 64, 32, 32, 256>(W + (int64_t)bx * 64 * ldw + k0, ldw, W + (int64_t)by * 64 * ldw + k0, ldw, klen,
+                                       acc, smem, tid);
+    const int wave = tid >> 6, lane = tid & 63;
+    const int r0 = bx * 64 + (wave / S::WAVES_N) * 32 + (lane >> 4);
+    const int c0 = by * 64 + (wave % S::WAVES_N) * 32 + (lane & 15);
+    double *out = P + (int64_t)blockIdx.y * rows * rows;
+#pragma unroll
+    for (int mi = 0; mi < S::MT; mi++)
+#pragma unroll
+        for (int ni = 0; ni < S::NT; ni++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[(int64_t)(r0 + mi * 16 + 4 * r) * rows + (c0 + ni * 16)] = acc[mi][ni][r];
+}
+
+__global__ void k_gram_reduce(const double *__restrict__ P, int rows, int nsplit, double *__restrict__ Gneg, int64_t ldg) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= rows || (j >> 6) > (i >> 6)) return;  // lower 64x64 tiles only
+    double sacc = 0.0;
+    for (int sp = 0; sp < nsplit; sp++) sacc += P[((int64_t)sp * rows + i) * rows + j];
+    Gneg[(int64_t)i * ldg + j] = -sacc;
+}
+
 // =============================================================================================
 // host launchers
 // =============================================================================================
@@ -880,6 +926,33 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
             hipLaunchKernelGGL((k_gemm_nt_sub<false, 128, 128, 32, 64, 512, true>), grid, dim3(512), TrailShape::LDS_BYTES,
                                s, C, ldc, A, lda, B, ldb, K, nbx, nby, ktri);
     }
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+// Gneg (rows x rows, ldg; lower 64-tiles) <- -(W W^T), W (rows x K, ldw) K-contiguous; rows % 64 == 0, K % 128 == 0.
+// P is scratch for the K splits: gram_scratch_doubles(rows, K) doubles.
+static int gram_nsplit(int rows, int K) {
+    const int nt = rows / 64, tiles = nt * (nt + 1) / 2;
+    int nsplit = (2048 + tiles - 1) / tiles;
+    const int maxs = K / 512 > 0 ? K / 512 : 1;
+    if (nsplit > maxs) nsplit = maxs;
+    if (nsplit < 1) nsplit = 1;
+    return nsplit;
+}
+size_t gram_scratch_doubles(int rows, int K) { return (size_t)gram_nsplit(rows, K) * rows * rows; }
+int launch_gram_lower(hipStream_t s, const double *W, int64_t ldw, int rows, int K, double *Gneg, int64_t ldg, double *P) {
+    if (rows % 64 || K % KC) {
+        set_error("gram: rows must be a multiple of 64 and K of 16");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    const int nt = rows / 64, tiles = nt * (nt + 1) / 2;
+    int nsplit = gram_nsplit(rows, K);
+    int kc = (int)round_up((K + nsplit - 1) / nsplit, 128);
+    nsplit = (K + kc - 1) / kc;
+    hipLaunchKernelGGL(k_gram_splitk, dim3(tiles, nsplit), dim3(256), SmallShape::LDS_BYTES, s, W, ldw, rows, kc, K, P);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((rows + 255) / 256, rows), dim3(256), 0, s, (const double *)P, rows, nsplit, Gneg,
+                       ldg);
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }

@@ -236,6 +236,42 @@ int32_t egx_gp_last_timings(const egx_gp *gp, egx_timings *t);
  * a 16x16x16 product computed with v_mfma_f64_16x16x4_f64 vs the host. */
 int32_t egx_mfma_probe(double *max_abs_err);
 
+
+/* ==== sparse Gaussian process (FITC / VFE), SURVEY 8f rank 4 =================================
+ * SparseGaussianProcess / SgpValidParams, crates/gp/src/sparse_algorithm.rs:145-168, 422-831 and
+ * sparse_parameters.rs.  Works on RAW x / y (the reference does not normalise here) with a zero trend;
+ * parameters are theta (d, or 1 broadcast), the process variance sigma2 and the homoscedastic noise variance.
+ * z are the nz inducing points (Inducings::Located; a Randomized(n) draw is the caller's shuffle of x). */
+typedef struct egx_sgp egx_sgp;
+typedef enum { EGX_SGP_FITC = 0, EGX_SGP_VFE = 1 } egx_sgp_method; /* SparseMethod, sparse_parameters.rs:59-67 */
+typedef struct {
+    int32_t corr;   /* egx_corr */
+    int32_t method; /* egx_sgp_method */
+    double nugget;  /* added to diag(Kmm); default 100 * f64::EPSILON */
+    int32_t device; /* HIP ordinal, -1 = current */
+} egx_sgp_config;
+void egx_sgp_config_default(egx_sgp_config *cfg);
+int32_t egx_sgp_create(const egx_sgp_config *cfg, const double *x /*n*d*/, const double *y /*n*/, int64_t n, int64_t d,
+                       const double *z /*nz*d*/, int64_t nz, egx_sgp **out);
+void egx_sgp_destroy(egx_sgp *sgp);
+int32_t egx_sgp_dims(const egx_sgp *sgp, int64_t *n, int64_t *d, int64_t *nz);
+/* reduced_likelihood (fitc :695-766 / vfe :769-831) at given parameters; status as for egx_gp_likelihood
+ * (1: Kmm or I + V diag(beta) V^T not positive definite -- the reference unwraps; 4: NaN / non-positive parameters) */
+int32_t egx_sgp_likelihood(egx_sgp *sgp, const double *theta, int64_t theta_len, double sigma2, double noise,
+                           double *lkh, int32_t *status);
+/* keep the state of one evaluation resident = a fit at fixed parameters */
+int32_t egx_sgp_finalize(egx_sgp *sgp, const double *theta, int64_t theta_len, double sigma2, double noise);
+/* SgpValidParams::fit :488-650: multistart derivative-free maximisation over log10 [theta.., sigma2, (noise)];
+ * params0s (n_starts x np), lo / hi (np), np = d + 1 + (estimate_noise != 0); maxeval = clamp(10 d, 25, max_eval) */
+int32_t egx_sgp_fit(egx_sgp *sgp, const double *params0s, int64_t n_starts, const double *lo, const double *hi,
+                    int32_t estimate_noise, double noise_fixed, int64_t max_eval, int64_t *n_evals_out);
+/* SparseGaussianProcess::predict :237-241, predict_var :245-257 (clamp at 1e-15, + noise) */
+int32_t egx_sgp_predict(egx_sgp *sgp, const double *xq, int64_t m, double *y /*m*/);
+int32_t egx_sgp_predict_var(egx_sgp *sgp, const double *xq, int64_t m, double *var /*m*/);
+/* fitted state: theta (d), sigma2, noise, likelihood, WoodburyData vec (nz) and inv (nz*nz) :32-36; NULL = skip */
+int32_t egx_sgp_get_state(egx_sgp *sgp, double *theta, double *sigma2, double *noise, double *likelihood,
+                          double *w_vec, double *w_inv);
+
 #ifdef __cplusplus
 }
 #endif
