@@ -182,6 +182,39 @@ def main():
         for e in experts:
             e.close()
 
+    if args.only in (0, 8):
+        sgp_bench(emit, args.quick)
+
+
+def sgp_bench(emit, quick):
+    """Sparse GP: one FITC / VFE likelihood evaluation = R_nz (ALU/HBM) + trsm (n nz^2 MFMA) +
+    split-K Gram product (n nz^2 MFMA) + two nz^3/3 factorisations."""
+    import egobox_amd as egx
+    for n, nz, d in ((200_000, 256, 8),) if quick else ((200_000, 256, 8), (1_000_000, 512, 8)):
+        rng = np.random.default_rng(3)
+        x = rng.random((n, d)) * 2 - 1
+        y = np.sin(3 * x[:, 0]) + 0.5 * np.cos(2 * x[:, 1]) * x[:, 2] + 0.1 * rng.standard_normal(n)
+        z = x[rng.permutation(n)[:nz]].copy()
+        theta = np.full(d, 0.8)
+        out = {"config": "sgp", "n": n, "nz": nz, "d": d}
+        for method, name in ((0, "fitc"), (1, "vfe")):
+            h = egx.SgpHandle(x, y, z, corr=0, method=method)
+            t = timeit(lambda: h.likelihood(theta, 1.0, 0.01), 5)
+            out[f"{name}_likelihood_ms"] = t * 1e3
+            out[f"{name}_mfma_tflops"] = 4.0 * n * nz * nz / 2 / t / 1e12  # trsm n nz^2 / 2 MACs + Gram n nz^2 / 2 MACs, x 2 flop
+            h.finalize(theta, 1.0, 0.01)
+            xq = rng.random((200_000, d)) * 2 - 1
+            h.predict(xq[:1000])
+            t0 = time.perf_counter()
+            h.predict(xq)
+            out[f"{name}_predict_points_per_s"] = xq.shape[0] / (time.perf_counter() - t0)
+            h.predict_var(xq[:1000])
+            t0 = time.perf_counter()
+            h.predict_var(xq)
+            out[f"{name}_predict_var_points_per_s"] = xq.shape[0] / (time.perf_counter() - t0)
+            h.close()
+        emit(out)
+
 
 if __name__ == "__main__":
     main()
