@@ -249,6 +249,25 @@ class SparseGaussianProcess:
     def predict_var(self, x):
         return self._h.predict_var(x)
 
+    def _central_diff(self, fn, x):
+        """sparse_algorithm.rs:298-336: the reference differentiates the sparse predictions NUMERICALLY
+        (finitediff's central_diff, step sqrt(f64::EPSILON)); here all 2 nx shifted batches go to the GPU at once."""
+        x = self._h._q(x)
+        m, nx = x.shape
+        h = float(np.sqrt(np.finfo(float).eps))
+        shifted = np.repeat(x[None, :, :], 2 * nx, axis=0)
+        for k in range(nx):
+            shifted[2 * k, :, k] += h
+            shifted[2 * k + 1, :, k] -= h
+        v = fn(shifted.reshape(-1, nx)).reshape(2 * nx, m)
+        return ((v[0::2] - v[1::2]) / (2.0 * h)).T.copy()
+
+    def predict_gradients(self, x):
+        return self._central_diff(self._h.predict, x)
+
+    def predict_var_gradients(self, x):
+        return self._central_diff(self._h.predict_var, x)
+
     def theta(self):
         return self._h.state()["theta"]
 
@@ -328,6 +347,12 @@ class SparseGpx:
 
     def predict_var(self, x):
         return self._sgp.predict_var(x)
+
+    def predict_gradients(self, x):
+        return self._sgp.predict_gradients(x)
+
+    def predict_var_gradients(self, x):
+        return self._sgp.predict_var_gradients(x)
 
     def thetas(self):
         return self._sgp.theta()[None, :]
