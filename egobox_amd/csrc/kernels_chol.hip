@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, i
 //    LDS: 70 KB, so the kernel can share a CU with one trailing-update workgroup on the look-ahead stream.
 // ---------------------------------------------------------------------------------------------
 #ifdef EGX_POTF2_PROFILE
-__device__ long long g_potf2_stamps[4][5];
+__device__ long long g_potf2_stamps[4][6];
 #define EGX_STAMP(i) \
     if (threadIdx.x == 0) g_potf2_stamps[s][i] = (long long)__builtin_readcyclecounter()
 #else
@@ -428,9 +428,9 @@ __device__ long long g_potf2_stamps[4][5];
 constexpr int TS = 64;
 constexpr int TLD = 65;  // padded LDS row (doubles): per-lane row accesses are conflict free
 constexpr int POTF2_AUX = TS * TLD + 2 * TS + TS;  // tile + two broadcast lines + reciprocal diagonal (doubles)
-constexpr int POTF2_LDS_BYTES = POTF2_AUX * 8 + GemmShape<64, 64, 16, 32, 512>::LDS_BYTES;
+constexpr int POTF2_LDS_BYTES = POTF2_AUX * 8 + GemmShape<192, 64, 48, 32, 512>::LDS_BYTES;  // staging of the 192-row phases
 static_assert((POTF2_AUX * 8) % 16 == 0, "MFMA staging must stay 16-byte aligned");
-static_assert(GemmShape<64, 64, 16, 32, 512>::LDS_BYTES >= TS * TLD * 8, "inverse scratch aliases the MFMA staging");
+static_assert(GemmShape<192, 64, 48, 32, 512>::LDS_BYTES >= TS * TLD * 8, "inverse scratch aliases the MFMA staging");
 
 // sqrt(p) and 1/sqrt(p) for p > 0 (normal range): v_rsq_f64 seed + 2 Newton steps + 1 correction.
 // ~12 dependent ops instead of the ~50 of IEEE sqrt() followed by a division; error <= ~1 ulp.
@@ -475,6 +475,8 @@ __device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, i
                 double *colb = cb + (j & 1) * TS;  // two alternating broadcast lines (LDS is in-order per wave)
                 colb[lane] = lij;
                 if (lane == gj) rd[gj] = rinv;
+                // (v_readlane of the multipliers instead of this LDS broadcast was measured 14 % SLOWER: 38.6k vs 33.8k
+                //  cycles per 64x64 tile, tools/potf2_prof)
 #pragma unroll
                 for (int c = j + 1; c < 16; c++) a[c] = __builtin_fma(-lij, colb[jb * 16 + c], a[c]);
             }
@@ -549,18 +551,66 @@ __device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, dou
     }
 }
 
+// In-block MFMA phases of k_potf2_block on 64 R rows at once (R = 1..3 tiles below / at the current tile column):
+// 8 waves of (16 R) x 32 (4 waves: (16 R) x 64).  One staging pass per phase instead of one per 64x64 tile.
+template <int NT, int R>
+__device__ __forceinline__ void potf2_trsm_rows(double *A, int64_t ld, const double *linv, double *stage, int tid) {
+    constexpr int WN = 256 / (NT / 64);
+    using S = GemmShape<64 * R, 64, 16 * R, WN, NT>;
+    double4_t acc[R][WN / 16];
+#pragma unroll
+    for (int mi = 0; mi < R; mi++)
+#pragma unroll
+        for (int ni = 0; ni < WN / 16; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm_core<64 * R, 64, 16 * R, WN, NT>(A, ld, linv, TS, TS, acc, stage, tid);
+    const int wave = tid >> 6, lane = tid & 63;
+    double *xt = A + (int64_t)((wave / S::WAVES_N) * 16 * R + (lane >> 4)) * ld + (wave % S::WAVES_N) * WN + (lane & 15);
+#pragma unroll
+    for (int mi = 0; mi < R; mi++)
+#pragma unroll
+        for (int ni = 0; ni < WN / 16; ni++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) xt[(int64_t)(mi * 16 + 4 * r) * ld + ni * 16] = acc[mi][ni][r];
+}
+
+template <int NT, int R>
+__device__ __forceinline__ void potf2_syrk_col(double *C, const double *X, int64_t ld, double *stage, int tid) {
+    constexpr int WN = 256 / (NT / 64);
+    using S = GemmShape<64 * R, 64, 16 * R, WN, NT>;
+    double4_t acc[R][WN / 16];
+#pragma unroll
+    for (int mi = 0; mi < R; mi++)
+#pragma unroll
+        for (int ni = 0; ni < WN / 16; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm_core<64 * R, 64, 16 * R, WN, NT>(X, ld, X, ld, TS, acc, stage, tid);  // rows u.. times tile u (the first 64 rows)
+    const int wave = tid >> 6, lane = tid & 63;
+    double *ct = C + (int64_t)((wave / S::WAVES_N) * 16 * R + (lane >> 4)) * ld + (wave % S::WAVES_N) * WN + (lane & 15);
+#pragma unroll
+    for (int mi = 0; mi < R; mi++) {
+        double cv[WN / 16][4];
+#pragma unroll
+        for (int ni = 0; ni < WN / 16; ni++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) cv[ni][r] = ct[(int64_t)(mi * 16 + 4 * r) * ld + ni * 16];
+#pragma unroll
+        for (int ni = 0; ni < WN / 16; ni++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) ct[(int64_t)(mi * 16 + 4 * r) * ld + ni * 16] = cv[ni][r] - acc[mi][ni][r];
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT, NT / 256) void k_potf2_block(double *__restrict__ D, int64_t ld, int nbk,
                                                               double *__restrict__ dinv, int *__restrict__ info,
                                                               int col0, int n_valid) {
-    constexpr int NW = NT / 64, WN = 256 / NW;  // MFMA phases: NW waves of 16 x WN
+    constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __builtin_amdgcn_s_setprio(3);   // on the look-ahead stream this workgroup shares its CU with trailing-update waves
     double *Ls = sm;                 // current diagonal tile / its factor, [64][65]
     double *cb = sm + TS * TLD;      // 2 x 64 broadcast lines
     double *rd = cb + 2 * TS;        // 64 reciprocal diagonal entries
     double *stage = sm + POTF2_AUX;  // MFMA staging; aliased by the inverse scratch X [64][65]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int nt = nbk / TS;
     for (int s = 0; s < nt; s++) {
         EGX_STAMP(0);
@@ -577,6 +627,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_potf2_block(double *__restrict
         __syncthreads();
         // ---- steps 1+2: factor and invert the tile (all four waves, see wg_potf2_64 / wg_inv_64)
         wg_potf2_64<NW>(Ls, cb, rd, tid, info, col0 + s * TS, n_valid);
+        EGX_STAMP(5);
         wg_inv_64<NW>(Ls, rd, stage, tid);
         EGX_STAMP(1);
         // ---- write the factor back (upper part zeroed) and the inverse to dinv
@@ -596,42 +647,22 @@ __global__ __launch_bounds__(NT, NT / 256) void k_potf2_block(double *__restrict
         }
         __syncthreads();  // dinv visible (workgroup scope); the staging area is free again
         EGX_STAMP(2);
-        // ---- step 3: tiles below:  X_t = A(t,s) Linv^T  (in place); 8 waves of 16x32 (two MFMA waves per SIMD)
-        constexpr int WVN = 64 / WN;  // waves along the columns of a 64x64 tile
-        const int wrow = (wave / WVN) * 16 + (lane >> 4), wcol = (wave % WVN) * WN + (lane & 15);
-        for (int t = s + 1; t < nt; t++) {
-            double4_t acc[1][WN / 16];
-#pragma unroll
-            for (int ni = 0; ni < WN / 16; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-            double *At = D + (int64_t)t * TS * ld + s * TS;
-            gemm_core<64, 64, 16, WN, NT>(At, ld, dinv + (int64_t)s * 4096, TS, TS, acc, stage, tid);
-            double *xt = At + (int64_t)wrow * ld + wcol;
-#pragma unroll
-            for (int ni = 0; ni < WN / 16; ni++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) xt[(int64_t)(4 * r) * ld + ni * 16] = acc[0][ni][r];
-        }
+        // ---- step 3: ALL tiles below in one MFMA pass:  X = A(s+1.., s) Linv^T  (in place, 64 R rows)
+        const int rb = nt - s - 1;
+        if (rb == 3) potf2_trsm_rows<NT, 3>(D + (int64_t)(s + 1) * TS * ld + s * TS, ld, dinv + (int64_t)s * 4096, stage, tid);
+        else if (rb == 2) potf2_trsm_rows<NT, 2>(D + (int64_t)(s + 1) * TS * ld + s * TS, ld, dinv + (int64_t)s * 4096, stage, tid);
+        else if (rb == 1) potf2_trsm_rows<NT, 1>(D + (int64_t)(s + 1) * TS * ld + s * TS, ld, dinv + (int64_t)s * 4096, stage, tid);
         __syncthreads();  // X tiles visible before they are re-read as MFMA operands
         EGX_STAMP(3);
-        // ---- step 4: A(t,u) -= X_t X_u^T for s < u <= t < nt
-        for (int t = s + 1; t < nt; t++)
-            for (int u = s + 1; u <= t; u++) {
-                double4_t acc[1][WN / 16];
-#pragma unroll
-                for (int ni = 0; ni < WN / 16; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-                gemm_core<64, 64, 16, WN, NT>(D + (int64_t)t * TS * ld + s * TS, ld, D + (int64_t)u * TS * ld + s * TS,
-                                              ld, TS, acc, stage, tid);
-                double *ct = D + (int64_t)(t * TS + wrow) * ld + u * TS + wcol;
-                double cv[WN / 16][4];
-#pragma unroll
-                for (int ni = 0; ni < WN / 16; ni++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) cv[ni][r] = ct[(int64_t)(4 * r) * ld + ni * 16];
-#pragma unroll
-                for (int ni = 0; ni < WN / 16; ni++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) ct[(int64_t)(4 * r) * ld + ni * 16] = cv[ni][r] - acc[0][ni][r];
-            }
+        // ---- step 4: per tile column u: A(u.., u) -= X(u..) X_u^T  (64 (nt - u) rows in one MFMA pass)
+        for (int u = s + 1; u < nt; u++) {
+            double *Cu = D + (int64_t)u * TS * ld + u * TS;
+            const double *Xu = D + (int64_t)u * TS * ld + s * TS;
+            const int ru = nt - u;
+            if (ru == 3) potf2_syrk_col<NT, 3>(Cu, Xu, ld, stage, tid);
+            else if (ru == 2) potf2_syrk_col<NT, 2>(Cu, Xu, ld, stage, tid);
+            else potf2_syrk_col<NT, 1>(Cu, Xu, ld, stage, tid);
+        }
         __syncthreads();
         EGX_STAMP(4);
     }

@@ -19,16 +19,16 @@ int main() {
         hipMemset(info, 0, 4);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipEventRecord(e0);
-        hipLaunchKernelGGL(k_potf2_block<256>, dim3(1), dim3(256), POTF2_LDS_BYTES, 0, dA, (int64_t)ld, n, dinv, info, 0, n);
+        hipLaunchKernelGGL(k_potf2_block<512>, dim3(1), dim3(512), POTF2_LDS_BYTES, 0, dA, (int64_t)ld, n, dinv, info, 0, n);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        long long st[4][5];
+        long long st[4][6];
         hipMemcpyFromSymbol(st, HIP_SYMBOL(g_potf2_stamps), sizeof st);
         int hinfo; hipMemcpy(&hinfo, info, 4, hipMemcpyDeviceToHost);
         printf("rep %d: kernel %.1f us, info %d\n", rep, ms * 1e3, hinfo);
         for (int s = 0; s < 4; s++)
-            printf("  s=%d: load+potf2+inv %lld  writeback %lld  mfma trsm %lld  mfma syrk %lld cycles\n", s,
-                   st[s][1] - st[s][0], st[s][2] - st[s][1], st[s][3] - st[s][2], st[s][4] - st[s][3]);
+            printf("  s=%d: load+potf2 %lld  inv %lld  writeback %lld  mfma trsm %lld  mfma syrk %lld cycles\n", s,
+                   st[s][5] - st[s][0], st[s][1] - st[s][5], st[s][2] - st[s][1], st[s][3] - st[s][2], st[s][4] - st[s][3]);
     }
     return 0;
 }
