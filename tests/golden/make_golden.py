@@ -127,7 +127,8 @@ def main():
         "python_kriging": {  # python/egobox/tests/test_gpmix.py:24-53 (default fit => theta* of golden A)
             "xt": [0.0, 1.0, 2.0, 3.0, 4.0], "yt": [0.0, 1.0, 1.5, 0.9, 1.0],
             "predict_1.0": 1.0, "var_1.0": 0.0, "places": 7,
-            "predict_1.1": 1.1163, "var_1.1": 0.0, "delta": 1e-3},
+            "predict_1.1": 1.1163, "var_1.1": 0.0, "delta": 1e-3,
+            "predict_gradients_1.1": 1.1204, "predict_var_gradients_1.1": 0.0145},  # test_gpmix.py:47-52
     }
     json.dump(kat, open(os.path.join(HERE, "kat.json"), "w"), indent=1)
     print("wrote golden_a.json golden_b.json kat.json")

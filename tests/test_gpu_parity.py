@@ -140,6 +140,9 @@ def test_golden_a_and_python_pins_through_gpx(egx, golden_dir):
     assert gpx.predict_var(np.array([[1.0]]))[0] == pytest.approx(k["var_1.0"], abs=1e-7)
     assert gpx.predict(np.array([[1.1]]))[0] == pytest.approx(k["predict_1.1"], abs=k["delta"])
     assert gpx.predict_var(np.array([[1.1]]))[0] == pytest.approx(k["var_1.1"], abs=k["delta"])
+    # python/egobox/tests/test_gpmix.py:47-52
+    assert gpx.predict_gradients(np.array([[1.1]]))[0, 0] == pytest.approx(k["predict_gradients_1.1"], abs=k["delta"])
+    assert gpx.predict_var_gradients(np.array([[1.1]]))[0, 0] == pytest.approx(k["predict_var_gradients_1.1"], abs=k["delta"])
     xd, yd = gpx.training_data()
     np.testing.assert_array_equal(xd[:, 0], g["xt"])
     np.testing.assert_array_equal(yd, g["yt"])

@@ -114,6 +114,8 @@ def test_golden_a_and_python_pins(golden_dir):
     assert gp.predict_var(np.array([[1.0]]))[0] == pytest.approx(k["var_1.0"], abs=10 ** -k["places"])
     assert gp.predict(np.array([[1.1]]))[0] == pytest.approx(k["predict_1.1"], abs=k["delta"])
     assert gp.predict_var(np.array([[1.1]]))[0] == pytest.approx(k["var_1.1"], abs=k["delta"])
+    assert gp.predict_gradients(np.array([[1.1]]))[0, 0] == pytest.approx(k["predict_gradients_1.1"], abs=k["delta"])
+    assert gp.predict_var_gradients(np.array([[1.1]]))[0, 0] == pytest.approx(k["predict_var_gradients_1.1"], abs=k["delta"])
     yv, vv = gp.predict_valvar(np.array([[1.1], [2.5]]))
     np.testing.assert_array_equal(yv, gp.predict(np.array([[1.1], [2.5]])))
     np.testing.assert_array_equal(vv, gp.predict_var(np.array([[1.1], [2.5]])))
