@@ -236,12 +236,27 @@ def main():
                                                      "WRITE_SIZE 0.485 GB per launch = 1.30 GB against ~1.0 GB algorithmic "
                                                      "(C tile read + write + panel), L2 hit rate 0.62, MFMA busy 0.71 -- "
                                                      "profiles/r01_run19_pmc_wide_kernel_summary.txt",
-                         "measured_mfma_f64_ceiling_tflops": "77.6 register-only (tools/fp64_peak.hip); 43-49 (random "
-                                                             "operands) / 56 (zeros) for this kernel alone under DVFS "
-                                                             "(tools/gemm_prof.hip)"},
+                         "measured_mfma_f64_ceiling_tflops": "77.6 register-only, 77.3 with random operands "
+                                                             "(tools/fp64_peak.hip); this LDS-fed kernel sustains "
+                                                             "2.1-2.25 GHz instead of 2.4 on real data "
+                                                             "(tools/gemm_prof.hip, profiles/r01_run20_pipe_ab.txt)"},
             "corr_build_gbps": tim1[0]["corr_bytes"] / (corr_ms * 1e-3) / 1e9,
             "likelihood_checksum": float(np.sum(lkhs[args.warmup * world * nb:])),
         }
+        if world == 1:
+            # the boundary hands over HOST buffers: one cold call sequence including the device allocation (2 GiB
+            # workspace), the upload of x / y over PCIe, the fit and the download of its scalars -- never `value`
+            t0 = time.perf_counter()
+            hcold = egx.GpHandle(x, y, mean=0, corr=0, device=local_rank, n_workspaces=1)
+            t1 = time.perf_counter()
+            hcold.finalize(cands[0])
+            hcold.fitted_scalars()
+            t2 = time.perf_counter()
+            hcold.close()
+            out["pcie_inclusive"] = {"create_alloc_upload_s": t1 - t0, "fit_and_download_s": t2 - t1,
+                                     "fits_per_s_cold_handle": 1.0 / (t2 - t0),
+                                     "note": "x, y (4 MiB) cross PCIe once per handle; every further fit on the handle "
+                                             "moves (p + 2) n doubles back (0.4 MB)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, d)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
