@@ -129,6 +129,7 @@ int sgp_eval(egx_sgp *g, const double *theta, int64_t theta_len, double sigma2, 
     }
     hipStream_t s = g->stream;
     const double sigma = std::sqrt(sigma2);
+    g->fitted = false;  // the resident factors are about to be overwritten; set again below when `keep`
     EGX_HIP_CHECK(hipMemcpyAsync(g->coef.p, th.data(), sizeof(double) * d, hipMemcpyHostToDevice, s));
     EGX_HIP_CHECK(hipStreamSynchronize(s));  // th is a local
     EGX_HIP_CHECK(hipMemsetAsync(g->d_info, 0, 2 * sizeof(int), s));
@@ -226,8 +227,6 @@ int sgp_eval(egx_sgp *g, const double *theta, int64_t theta_len, double sigma2, 
         g->noise = noise;
         g->likelihood = lkh;
         g->fitted = true;
-    } else {
-        g->fitted = false;
     }
     return EGX_SUCCESS;
 }

@@ -87,6 +87,12 @@ def test_no_cpu_fallback(egx):
         egx.potrf(np.eye(3))
     with pytest.raises(egx.NoDeviceError):
         egx.Kriging.params().fit(np.random.rand(10, 2), np.random.rand(10))
+    with pytest.raises(egx.NoDeviceError):
+        egx.SgpHandle(np.random.rand(10, 2), np.random.rand(10), np.random.rand(3, 2))
+    with pytest.raises(egx.InvalidValueError):  # validated before the device is touched
+        egx.SgpHandle(np.random.rand(10, 2), np.random.rand(10), np.random.rand(11, 2))
+    with pytest.raises(egx.InvalidValueError):
+        egx.SgpHandle(np.random.rand(10, 2), np.random.rand(10), np.random.rand(3, 2), method=7)
 
 
 def test_argument_validation_before_device(egx):
