@@ -831,3 +831,18 @@ def test_ornstein_uhlenbeck_closed_form_any_size(egx, n):
         yp, vp = h.predict_valvar(x[idx].reshape(-1, 1))
         np.testing.assert_allclose(yp, y[idx], rtol=1e-6, atol=1e-6 * np.abs(y).max())
         assert np.all(vp >= 0) and np.all(vp <= 1e-6 * s2)
+
+
+def test_plain_c_host_drives_the_boundary(tmp_path):
+    """tests/c_host/golden_a_driver.c: a C99 program (no Python, no torch) links libegx_gp_hip.so and reproduces the
+    reference's notebook / Python-test values through the C ABI -- the drop-in boundary as a compiled host sees it."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "golden_a_driver"
+    libdir = os.path.join(root, "egobox_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{os.path.join(root, 'include')}",
+                    os.path.join(root, "tests", "c_host", "golden_a_driver.c"), f"-L{libdir}", "-legx_gp_hip", "-lm",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert out.stdout.startswith("OK")
