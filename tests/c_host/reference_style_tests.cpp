@@ -1,0 +1,111 @@
+// C++17 host tests written the way the reference writes its own (crates/gp/src/algorithm.rs):
+//   test_gp!($regr, $corr)        :1239-1303   default fit on 5 points, predict / predict_var within epsilon = 0.5
+//   test_bug_var_derivatives      :1723-1797   fixed theta, d var / dx against central differences (1e-5)
+//   golden A                      doc/Gpx_Tutorial.ipynb cell 14 (theta printed, likelihood / variance to full precision)
+//   theta0 length check           :829-838     (a panic in the reference, InvalidValueError here)
+// through include/egx_gp.hpp -> C ABI -> GPU.  Exit code = number of failed checks.
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "egx_gp.hpp"
+
+using namespace egobox;
+static int failures = 0;
+#define EXPECT(cond)                                                        \
+    do {                                                                    \
+        if (!(cond)) {                                                      \
+            std::fprintf(stderr, "%s:%d: EXPECT(%s) failed\n", __FILE__, __LINE__, #cond); \
+            failures++;                                                     \
+        }                                                                   \
+    } while (0)
+
+static void test_gp(Mean regr, Corr corr) {
+    const double xt[5] = {0.0, 1.0, 2.0, 3.0, 4.0}, yt[5] = {0.0, 1.0, 1.5, 0.9, 1.0};
+    if (regr == Mean::Quadratic) {
+        // p = 3 basis columns on 5 points is fine; the reference runs it too
+    }
+    auto gp = GaussianProcess::params(regr, corr).theta_init({0.1}).fit(xt, 5, 1, yt);
+    const double xq[2] = {1.0, 3.5};
+    auto yvals = gp.predict(xq, 2);
+    EXPECT(std::fabs(yvals[0] - 1.0) <= 0.5 && std::fabs(yvals[1] - 0.9) <= 0.5);
+    auto yvars = gp.predict_var(xq, 2);
+    EXPECT(std::fabs(yvars[0] - 0.0) <= 0.5 && std::fabs(yvars[1] - 0.1) <= 0.5);
+    std::vector<double> xplot(100);
+    for (int i = 0; i < 100; i++) xplot[i] = 4.0 * i / 99.0;
+    auto vals = gp.predict(xplot.data(), 100);
+    auto vars = gp.predict_var(xplot.data(), 100);
+    for (int i = 0; i < 100; i++) EXPECT(std::isfinite(vals[i]) && vars[i] >= 0.0);
+    EXPECT(gp.theta().size() == 1 && gp.theta()[0] >= 1e-2 && gp.theta()[0] <= 1e1);
+    EXPECT(gp.dims().first == 1 && gp.dims().second == 1);
+}
+
+static void test_golden_a() {
+    const double xt[5] = {0.0, 1.0, 2.0, 3.0, 4.0}, yt[5] = {0.0, 1.0, 1.5, 0.9, 1.0};
+    auto gp = Kriging::params().theta_tuning(ThetaTuning::Fixed({1.83209405})).fit(xt, 5, 1, yt);
+    EXPECT(std::fabs(gp.likelihood() - 0.5781740714613353) <= 1e-12);
+    EXPECT(std::fabs(gp.variance() - 0.30494058899172644) <= 1e-8 * 0.305);
+    const double x11 = 1.1;
+    EXPECT(std::fabs(gp.predict(&x11, 1)[0] - 1.1163) <= 1e-3);
+    EXPECT(std::fabs(gp.predict_gradients(&x11, 1)[0] - 1.1204) <= 1e-3);
+    EXPECT(std::fabs(gp.predict_var_gradients(&x11, 1)[0] - 0.0145) <= 1e-3);
+    // the tuned default fit must do at least as well as the reference's printed optimum
+    auto tuned = Kriging::params().fit(xt, 5, 1, yt);
+    EXPECT(tuned.likelihood() >= 0.5781740714613353 - 1e-3);
+}
+
+static void test_bug_var_derivatives() {
+    const double xt[24] = {6.875, -4.375, -3.125, 1.875, 1.875, -1.875, -4.375, 3.125, 8.125, 9.375, 4.375, 4.375,
+                           0.625, 0.625,  9.375,  6.875, 5.625, 8.125,  -0.625, -3.125, 3.125, 5.625, -1.875, -0.625};
+    const double yt[12] = {2.43286801,  13.10840811, 5.32908578,  17.81862219, 74.08849877, 39.68137781,
+                           14.96009727, 63.17475741, 61.26331775, -7.46009727, 44.39159189, 2.17091422};
+    auto gp = Kriging::params()
+                  .theta_tuning(ThetaTuning::Fixed({std::sqrt(2. * 0.0437386), std::sqrt(2. * 0.00697978)}))
+                  .fit(xt, 12, 2, yt);
+    const double e = 5e-6, xa = -1.3, xb = 2.5;
+    const double x[10] = {xa, xb, xa + e, xb, xa - e, xb, xa, xb + e, xa, xb - e};
+    auto y_pred = gp.predict_var(x, 5);
+    auto y_deriv = gp.predict_var_gradients(x, 1);
+    EXPECT(std::fabs(y_deriv[0] - (y_pred[1] - y_pred[2]) / (2. * e)) <= 1e-5);
+    EXPECT(std::fabs(y_deriv[1] - (y_pred[3] - y_pred[4]) / (2. * e)) <= 1e-5);
+}
+
+static void test_errors() {
+    const double xt[5] = {0.0, 1.0, 2.0, 3.0, 4.0}, yt[5] = {0.0, 1.0, 1.5, 0.9, 1.0};
+    bool thrown = false;
+    try {
+        Kriging::params().theta_init({0.1, 0.2}).fit(xt, 5, 1, yt);
+    } catch (const InvalidValueError &) {
+        thrown = true;
+    }
+    EXPECT(thrown);
+    thrown = false;
+    try {
+        Kriging::params().fit(xt, 1, 1, yt);  // one training point
+    } catch (const InvalidValueError &) {
+        thrown = true;
+    }
+    EXPECT(thrown);
+    // ThetaTuning::Partial keeps the inactive component
+    const double x2[12] = {0.1, 0.9, 0.4, 0.2, 0.8, 0.7, 0.3, 0.5, 0.95, 0.05, 0.6, 0.35};
+    const double y2[6] = {0.3, 0.1, 0.9, 0.4, 0.7, 0.5};
+    auto gp = GaussianProcess::params(Mean::Constant, Corr::Matern52)
+                  .theta_tuning(ThetaTuning::Partial({0.7, 1.3}, {{1e-2, 1e1}}, {0}))
+                  .n_start(2)
+                  .fit(x2, 6, 2, y2);
+    EXPECT(gp.theta()[1] == 1.3);
+}
+
+int main() {
+    if (egx_device_count() < 1) {
+        std::fprintf(stderr, "no HIP device\n");
+        return 99;
+    }
+    for (Mean m : {Mean::Constant, Mean::Linear, Mean::Quadratic})
+        for (Corr c : {Corr::SquaredExponential, Corr::AbsoluteExponential, Corr::Matern32, Corr::Matern52}) test_gp(m, c);
+    test_golden_a();
+    test_bug_var_derivatives();
+    test_errors();
+    std::printf("%s (%d failed checks)\n", failures ? "FAILED" : "OK", failures);
+    return failures;
+}

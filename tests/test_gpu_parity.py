@@ -846,3 +846,18 @@ def test_plain_c_host_drives_the_boundary(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, (out.stdout, out.stderr)
     assert out.stdout.startswith("OK")
+
+
+def test_reference_style_cpp_host_tests(tmp_path):
+    """tests/c_host/reference_style_tests.cpp: the reference's own test shapes (test_gp! over 3 means x 4 kernels,
+    golden A, test_bug_var_derivatives, the theta0-length check) in C++ through include/egx_gp.hpp."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "reference_style_tests"
+    libdir = os.path.join(root, "egobox_amd", "lib")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", f"-I{os.path.join(root, 'include')}",
+                    os.path.join(root, "tests", "c_host", "reference_style_tests.cpp"), f"-L{libdir}", "-legx_gp_hip",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert out.stdout.startswith("OK")
