@@ -15,7 +15,6 @@ computes a correlation, a factorisation or a solve.
 from __future__ import annotations
 
 import ctypes as C
-import math
 
 import numpy as np
 
