@@ -42,7 +42,7 @@ struct Dev {
 // RT is (n_pad x z_pad) row-major, W is (zext x n_pad) row-major; 32x32 LDS transpose tiles.
 __global__ __launch_bounds__(256) void k_sgp_transpose_scale(const double *__restrict__ RT, int z_pad, int n, int nz,
                                                              const double *__restrict__ sb, const double *__restrict__ y,
-                                                             double scale, double *__restrict__ W, int n_pad, int zext) {
+                                                             double scale, double *__restrict__ W, int n_pad) {
     __shared__ double tile[32][33];
     const int t0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -148,7 +148,7 @@ int sgp_eval(egx_sgp *g, const double *theta, int64_t theta_len, double sigma2, 
     hipLaunchKernelGGL(k_sgp_sqrt_beta, dim3((n + 255) / 256), dim3(256), 0, s, g->s0.p, n, sigma2, noise, g->nugget,
                        g->method, g->sb.p);
     hipLaunchKernelGGL(k_sgp_transpose_scale, dim3(n_pad / 32, zext / 32), dim3(256), 0, s, g->RT.p, z_pad, n, nz, g->sb.p,
-                       g->y.p, sigma, g->W.p, n_pad, zext);
+                       g->y.p, sigma, g->W.p, n_pad);
     // Gneg = 0 - W W^T (lower tiles): G, V (beta o y) in row z_pad, y^T diag(beta) y in the corner
     rc = launch_gram_lower(s, g->W.p, n_pad, zext, n_pad, g->G.p, zext, g->P.p);
     if (rc) return rc;
@@ -243,7 +243,6 @@ int sgp_predict(egx_sgp *g, const double *xq, int64_t m, double *yout, double *v
     const int d = g->d, nz = g->nz, z_pad = g->z_pad;
     hipStream_t s = g->stream;
     const int64_t cap = 65536;
-    const double sigma = std::sqrt(g->sigma2);
     for (int64_t m0 = 0; m0 < m; m0 += cap) {
         const int mc = (int)((m - m0 < cap) ? (m - m0) : cap);
         const int m_pad = (int)round_up(mc, kTile);
@@ -295,7 +294,6 @@ int sgp_predict(egx_sgp *g, const double *xq, int64_t m, double *yout, double *v
             }
         }
     }
-    (void)sigma;
     return EGX_SUCCESS;
 }
 
