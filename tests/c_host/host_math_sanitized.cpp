@@ -1,0 +1,106 @@
+// Host-side pieces of the library (egobox_amd/csrc/host_math.h, nelder_mead.h) under AddressSanitizer + UBSan
+// (the reference relies on Rust for memory safety; here the host C++ gets sanitizer coverage on the CPU).
+// Checks values against independent formulas; exit code = number of failed checks.
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#include "../../egobox_amd/csrc/host_math.h"
+#include "../../egobox_amd/csrc/nelder_mead.h"
+
+using namespace egx;
+static int failures = 0;
+#define EXPECT(c)                                                                \
+    do {                                                                         \
+        if (!(c)) {                                                              \
+            std::fprintf(stderr, "%s:%d: EXPECT(%s)\n", __FILE__, __LINE__, #c); \
+            failures++;                                                          \
+        }                                                                        \
+    } while (0)
+
+int main() {
+    std::mt19937_64 rng(3);
+    std::normal_distribution<double> g(0.0, 1.0);
+    // normalize: sample std (ddof = 1), zero std -> 1
+    {
+        const int n = 7, d = 3;
+        std::vector<double> x(n * d), xn(n * d), m(d), s(d);
+        for (int i = 0; i < n; i++) {
+            x[i * d + 0] = g(rng) * 5 + 2;
+            x[i * d + 1] = 4.0;
+            x[i * d + 2] = i;
+        }
+        hm::normalize(x.data(), n, d, xn.data(), m.data(), s.data());
+        EXPECT(s[1] == 1.0 && m[1] == 4.0 && std::fabs(m[2] - 3.0) < 1e-15 && std::fabs(s[2] - std::sqrt(28.0 / 6.0)) < 1e-14);
+        double chk = 0;
+        for (int i = 0; i < n; i++) chk += xn[i * d] * xn[i * d];
+        EXPECT(std::fabs(chk - (n - 1)) < 1e-12);
+    }
+    // regression basis and its jacobian contraction vs central differences
+    for (int mean = 0; mean < 3; mean++) {
+        const int d = 4;
+        const int64_t p = hm::regression_ncols(mean, d);
+        EXPECT(p == (mean == 0 ? 1 : mean == 1 ? 5 : 15));
+        std::vector<double> x(d), v(p), f1(p), f2(p), jd(d);
+        for (auto &e : x) e = g(rng);
+        for (auto &e : v) e = g(rng);
+        hm::regression_jac_dot(mean, x.data(), d, v.data(), jd.data());
+        for (int k = 0; k < d; k++) {
+            std::vector<double> xp(x), xm(x);
+            xp[k] += 1e-6;
+            xm[k] -= 1e-6;
+            hm::regression_row(mean, xp.data(), d, f1.data());
+            hm::regression_row(mean, xm.data(), d, f2.data());
+            double fd = 0;
+            for (int64_t j = 0; j < p; j++) fd += v[j] * (f1[j] - f2[j]) / 2e-6;
+            EXPECT(std::fabs(fd - jd[k]) < 1e-7);
+        }
+    }
+    // Householder QR with a positive diagonal: R^T R = A^T A, Q^T b consistent with least squares
+    {
+        const int64_t n = 30, p = 4;
+        std::vector<double> a(n * p), a0, b(n), b0;
+        for (auto &e : a) e = g(rng);
+        for (auto &e : b) e = g(rng);
+        a0 = a;
+        b0 = b;
+        hm::qr_apply(a, n, p, &b);
+        for (int64_t i = 0; i < p; i++) {
+            EXPECT(a[i * n + i] > 0.0);
+            for (int64_t j = i; j < p; j++) {
+                double rtr = 0, ata = 0;
+                for (int64_t k = 0; k <= i; k++) rtr += a[i * n + k] * a[j * n + k];
+                for (int64_t k = 0; k < n; k++) ata += a0[i * n + k] * a0[j * n + k];
+                EXPECT(std::fabs(rtr - ata) < 1e-10);
+            }
+        }
+        // singular values of R: product = |det R|, max >= min > 0
+        std::vector<double> r(p * p, 0.0);
+        double det = 1.0;
+        for (int64_t i = 0; i < p; i++) {
+            det *= a[i * n + i];
+            for (int64_t j = i; j < p; j++) r[i * p + j] = a[j * n + i];
+        }
+        auto sv = hm::singular_values(r, p);
+        double prod = 1.0;
+        for (double s : sv) prod *= s;
+        EXPECT(sv.size() == (size_t)p && sv.front() >= sv.back() && sv.back() > 0.0 && std::fabs(prod - std::fabs(det)) < 1e-9 * prod);
+    }
+    // Nelder-Mead inside a box, budgeted
+    {
+        int calls = 0;
+        auto rosen = [&](const std::vector<double> &x) {
+            calls++;
+            return 100.0 * (x[1] - x[0] * x[0]) * (x[1] - x[0] * x[0]) + (1 - x[0]) * (1 - x[0]);
+        };
+        NmResult r = nelder_mead(rosen, {-1.0, 1.5}, {-2.0, -2.0}, {2.0, 2.0}, 400);
+        EXPECT(r.evals <= 400 && r.evals == calls && r.f < 1e-3 && std::fabs(r.x[0] - 1.0) < 0.1);
+        NmResult edge = nelder_mead([](const std::vector<double> &x) { return x[0] + x[1]; }, {0.5, 0.5}, {0.0, 0.0}, {1.0, 1.0}, 200);
+        EXPECT(edge.x[0] >= 0.0 && edge.x[1] >= 0.0 && edge.f < 0.05);
+        NmResult inf = nelder_mead([](const std::vector<double> &) { return INFINITY; }, {0.5}, {0.0}, {1.0}, 30);
+        EXPECT(std::isinf(inf.f) && inf.evals <= 30);
+    }
+    std::printf("%s (%d)\n", failures ? "FAILED" : "OK", failures);
+    return failures;
+}

@@ -95,3 +95,19 @@ def test_workload_generators(egx):
     from oracle import gp_oracle as O
     np.testing.assert_array_equal(O.lhs_classic(50, 2, 7), egx.workload.lhs(50, 2, 7))
     np.testing.assert_allclose(O.griewank(x), egx.workload.griewank(x))
+
+
+def test_host_cpp_under_address_and_ub_sanitizers(tmp_path):
+    """egobox_amd/csrc/host_math.h + nelder_mead.h (normalisation, trend basis and its jacobian, Householder QR with
+    positive diagonal, Jacobi singular values, the box-constrained Nelder-Mead) built with -fsanitize=address,undefined
+    and checked against independent formulas (tests/c_host/host_math_sanitized.cpp)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "host_math_sanitized"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Werror", "-fsanitize=address,undefined",
+                    "-fno-omit-frame-pointer", os.path.join(root, "tests", "c_host", "host_math_sanitized.cpp"),
+                    "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert out.stdout.startswith("OK") and "runtime error" not in out.stderr
