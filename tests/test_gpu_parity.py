@@ -861,3 +861,31 @@ def test_reference_style_cpp_host_tests(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, (out.stdout, out.stderr)
     assert out.stdout.startswith("OK")
+
+
+def test_no_device_memory_leak_over_handle_lifecycles(egx, O):
+    """Create / fit / predict / gradients / destroy many handles (dense and sparse): free device memory returns to its
+    level (every hipMalloc of a handle is owned by it)."""
+    import torch
+    x, y = _data(1500, 4, seed=51)
+    z = x[:40].copy()
+    theta = np.full(4, 0.9)
+
+    def cycle():
+        with egx.GpHandle(x, y, corr=3, n_workspaces=2) as h:
+            h.finalize(theta)
+            h.predict_valvar(x[:10])
+            h.predict_valvar_gradients(x[:3])
+            h.likelihood_grad(theta)
+        with egx.SgpHandle(x, y, z) as s:
+            s.finalize(theta, 1.0, 0.01)
+            s.predict_var(x[:10])
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(25):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) < 64 << 20, (free0, free1)
