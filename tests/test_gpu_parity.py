@@ -889,3 +889,44 @@ def test_no_device_memory_leak_over_handle_lifecycles(egx, O):
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert abs(free0 - free1) < 64 << 20, (free0, free1)
+
+
+def test_randomised_parity_sweep(egx, O):
+    """40 seeded random configurations (n around the 64 / 128 / 256 tile edges, d 1..12, every mean x kernel, with and
+    without KPLS weights): likelihood, beta, predictions, variances and x-gradients against the oracle wherever the
+    oracle's smallest Cholesky pivot says the problem is well posed."""
+    rng = np.random.default_rng(2024)
+    edges = [63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 300, 383, 385, 511, 513]
+    checked = 0
+    for case in range(40):
+        n = int(rng.choice(edges)) + int(rng.integers(0, 3))
+        d = int(rng.integers(1, 13))
+        mean = int(rng.integers(0, 3)) if d <= 6 else int(rng.integers(0, 2))
+        corr = int(rng.integers(0, 4))
+        if O.regression_value(MEANS[mean], np.zeros((1, d))).shape[1] >= n // 2:
+            mean = 0
+        x = rng.random((n, d)) * rng.uniform(0.5, 20.0, size=d) + rng.uniform(-5, 5, size=d)
+        y = np.sin(x @ rng.standard_normal(d) / np.sqrt(d)) + 0.1 * (x[:, 0] - x[:, 0].mean()) ** 2
+        use_w = d >= 3 and case % 4 == 0
+        h_dim = int(rng.integers(1, d)) if use_w else d
+        w = rng.standard_normal((d, h_dim)) if use_w else None
+        theta = rng.uniform(0.5, 2.0, size=h_dim) * (3.0 if corr == 0 else 1.0)
+        ref = O.fit_fixed(x, y, theta, mean=MEANS[mean], corr=KINDS[corr], w_star=w)
+        if np.min(np.diag(ref.inner.r_chol)) < 1e-3:
+            continue
+        checked += 1
+        xq = rng.random((17, d)) * (x.max(axis=0) - x.min(axis=0)) + x.min(axis=0)
+        with egx.GpHandle(x, y, mean=mean, corr=corr, w_star=w) as h:
+            lk, st = h.likelihood(theta)
+            assert st == 0 and lk == pytest.approx(ref.likelihood, rel=LK_RTOL), (case, n, d, mean, corr)
+            h.finalize(theta)
+            np.testing.assert_allclose(h.inner()["beta"], ref.inner.beta, rtol=1e-6, atol=1e-8 * np.abs(ref.inner.beta).max())
+            yv, vv = h.predict_valvar(xq)
+            ry, rv = ref.predict(xq), ref.predict_var(xq)
+            np.testing.assert_allclose(yv, ry, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(ry).max())
+            np.testing.assert_allclose(vv, rv, rtol=PRED_RTOL, atol=PRED_RTOL * ref.inner.sigma2)
+            gy, gv = h.predict_valvar_gradients(xq[:5])
+            wy, wv = ref.predict_valvar_gradients(xq[:5])
+            np.testing.assert_allclose(gy, wy, rtol=1e-5, atol=1e-5 * np.abs(wy).max())
+            np.testing.assert_allclose(gv, wv, rtol=1e-5, atol=1e-5 * max(np.abs(wv).max(), 1e-12))
+    assert checked >= 25
