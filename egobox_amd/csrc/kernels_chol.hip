@@ -451,8 +451,6 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double &d, double &r) {
 template <int NW>
 __device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, int tid, int *info, int gcol0,
                                             int n_valid) {
-    constexpr int CW = (NW == 8) ? 8 : 16;   // columns of a trailing strip handled by one wave
-    constexpr int WPS = 16 / CW;             // waves per strip
     const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll 1
     for (int jb = 0; jb < 4; jb++) {
@@ -460,10 +458,11 @@ __device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, i
             double a[16];
 #pragma unroll
             for (int c = 0; c < 16; c++) a[c] = T[lane * TLD + jb * 16 + c];
+            double pnext = a[0];  // lane gj holds the pivot of the coming column
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int gj = jb * 16 + j;
-                double piv = readlane_d(a[j], gj);
+                double piv = readlane_d(pnext, gj);
                 if (!(piv > 0.0) || !(piv < 1.0e300)) {  // wave-uniform: NaN, inf or non-positive pivot
                     if (lane == 0 && (gcol0 + gj) < n_valid) atomicCAS(info, 0, gcol0 + gj + 1);
                     piv = 1.0;
@@ -472,6 +471,10 @@ __device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, i
                 sqrt_rsqrt(piv, dj, rinv);
                 const double lij = (lane == gj) ? dj : a[j] * rinv;
                 a[j] = lij;
+                // the NEXT pivot a[j+1] - l^2 of lane gj + 1 needs only that lane's own multiplier: it is formed here, off
+                // the LDS broadcast below, so the rsqrt chain of column j + 1 overlaps the broadcast round trip of column j
+                // (same operands as the regular update of a[j + 1] in that lane -> the same bits)
+                if (j + 1 < 16) pnext = __builtin_fma(-lij, lij, a[j + 1]);
                 double *colb = cb + (j & 1) * TS;  // two alternating broadcast lines (LDS is in-order per wave)
                 colb[lane] = lij;
                 if (lane == gj) rd[gj] = rinv;
@@ -484,21 +487,26 @@ __device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, i
             for (int c = 0; c < 16; c++) T[lane * TLD + jb * 16 + c] = ((jb * 16 + c) <= lane) ? a[c] : 0.0;
         }
         __syncthreads();
-        // trailing strips: wave w updates CW columns of strip jb + 1 + w / WPS
-        const int sb = jb + 1 + wave / WPS, hb = (wave % WPS) * CW;
-        if (sb < 4) {
-            double a[16], a2[CW];
+        // trailing strips on the matrix cores: 16x16 tile (rt, sb), jb < sb <= rt, -= L(rt, jb) L(sb, jb)^T (K = 16);
+        // at most six tiles, one per wave (two per wave with four waves).  Tiles above the diagonal are never read.
+        {
+            const int frow = lane & 15, fk = lane >> 4;
+            int tcount = 0;
+            for (int sb = jb + 1; sb < 4; sb++)
+                for (int rt = sb; rt < 4; rt++, tcount++) {
+                    if (tcount % NW != wave) continue;
+                    const double *arow = T + (rt * 16 + frow) * TLD + jb * 16 + fk;
+                    const double *brow = T + (sb * 16 + frow) * TLD + jb * 16 + fk;
+                    double *ct = T + (rt * 16 + fk) * TLD + sb * 16 + frow;
+                    double4_t acc;
 #pragma unroll
-            for (int c = 0; c < 16; c++) a[c] = T[lane * TLD + jb * 16 + c];
+                    for (int r = 0; r < 4; r++) acc[r] = ct[(4 * r) * TLD];
 #pragma unroll
-            for (int c = 0; c < CW; c++) a2[c] = T[lane * TLD + sb * 16 + hb + c];
+                    for (int kk = 0; kk < 4; kk++)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-arow[kk * 4], brow[kk * 4], acc, 0, 0, 0);
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-#pragma unroll
-                for (int c = 0; c < CW; c++)
-                    a2[c] = __builtin_fma(-a[k], T[(sb * 16 + hb + c) * TLD + jb * 16 + k], a2[c]);
-#pragma unroll
-            for (int c = 0; c < CW; c++) T[lane * TLD + sb * 16 + hb + c] = a2[c];
+                    for (int r = 0; r < 4; r++) ct[(4 * r) * TLD] = acc[r];
+                }
         }
         __syncthreads();
     }
@@ -509,27 +517,29 @@ __device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, i
 // eight waves (2 columns each), the short in-strip back substitution is done by wave 0.
 template <int NW>
 __device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, double *X, int tid) {
-    constexpr int CPW = 16 / NW;  // columns of the current strip per wave in the bulk phase
     const int wave = tid >> 6, lane = tid & 63;
+    const int frow = lane & 15, fk = lane >> 4;
 #pragma unroll 1
     for (int cbk = 3; cbk >= 0; cbk--) {
-        {
-            double x4[CPW];
+        // bulk on the matrix cores: 16x16 tile (rt, cbk), rt > cbk:  - sum_{cbk < kb <= rt} X(rt, kb) L(kb, cbk);
+        // the diagonal tile starts as the identity, tiles above it are zero
+        for (int rt = wave; rt < 4; rt += NW) {
+            double *xt = X + (rt * 16 + fk) * TLD + cbk * 16 + frow;
+            double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+            if (rt == cbk) {
 #pragma unroll
-            for (int cc = 0; cc < CPW; cc++) x4[cc] = (lane == cbk * 16 + wave * CPW + cc) ? 1.0 : 0.0;
-#pragma unroll 1
-            for (int kb = 3; kb > cbk; kb--) {
-                double xk[16];
+                for (int r = 0; r < 4; r++) acc[r] = (fk + 4 * r == frow) ? 1.0 : 0.0;
+            } else if (rt > cbk) {
+                for (int kb = cbk + 1; kb <= rt; kb++) {
+                    const double *arow = X + (rt * 16 + frow) * TLD + kb * 16 + fk;   // A[i][k] = X(rt*16+i, kb*16+k)
+                    const double *bcol = T + (kb * 16 + fk) * TLD + cbk * 16 + frow;  // B[k][j] = L(kb*16+k, cbk*16+j)
 #pragma unroll
-                for (int k = 0; k < 16; k++) xk[k] = X[lane * TLD + kb * 16 + k];
-#pragma unroll
-                for (int k = 0; k < 16; k++)
-#pragma unroll
-                    for (int cc = 0; cc < CPW; cc++)
-                        x4[cc] = __builtin_fma(-xk[k], T[(kb * 16 + k) * TLD + cbk * 16 + wave * CPW + cc], x4[cc]);
+                    for (int kk = 0; kk < 4; kk++)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-arow[kk * 4], bcol[(kk * 4) * TLD], acc, 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int cc = 0; cc < CPW; cc++) X[lane * TLD + cbk * 16 + wave * CPW + cc] = x4[cc];
+            for (int r = 0; r < 4; r++) xt[(4 * r) * TLD] = acc[r];
         }
         __syncthreads();
         if (wave == 0) {
