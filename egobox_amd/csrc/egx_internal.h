@@ -39,15 +39,22 @@ int launch_corr_sym(hipStream_t s, int corr, const double *xT, int64_t ldx, int 
 int launch_cross_corr(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad,
                       const double *xT, int64_t ldx, int n_pad, int d, const double *coef,
                       int hcols, double *R, int64_t ld);
-// racc[q] = sum_i k(xq, x_i) * gamma[i]   (gamma zero padded to n_pad)
+// racc[split * m_pad + q] = partial sum_i k(xq, x_i) * gamma[i] over the split's training range (gamma zero padded to
+// n_pad); nsplit > 1 spreads a few queries over the chip, the caller adds the partial sums (racc: nsplit * m_pad)
 int launch_predict_mean(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad,
                         const double *xT, int64_t ldx, int n_pad, int d, const double *coef,
-                        int hcols, const double *gamma, double *racc);
+                        int hcols, const double *gamma, double *racc, int nsplit = 1);
 // x-gradient contraction out[split][a][k] = sum_j w(j, a) d r(x_a, x_j) / d x_ak over the split's training range;
 // Wt = gamma (vec != 0, ldw ignored) or the transposed (n x m_pad) weight matrix; m_pad multiple of 128
 int launch_xgrad(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad, const double *xT, int64_t ldx,
                  int n, int d, const double *coef, int hcols, const double *Wt, int64_t ldw, int vec, int nsplit,
                  double *out);
+// few-query form of launch_xgrad with a weight VECTOR: out (ceil(n / 256) x m x d) partial sums, lanes over training points
+int launch_xgrad_point(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m, const double *xT, int64_t ldx, int n,
+                       int d, const double *coef, int hcols, const double *wvec, double *out);
+// single right-hand side through the cached W = C^-T: y <- W^T r (= C^-1 r), z <- W y (= R^-1 r); P scratch 32 * n_pad
+int launch_uptri_solve_pair(hipStream_t s, const double *W, int64_t ld, int n, int n_pad, const double *r, double *P,
+                            double *y, double *z);
 // dst[(r0 + l) * ld + i] = src[l * lds + i] for l < nrows, i < ncols; rest of [r0, r0+rows_pad) x [0, ld) zeroed
 int launch_fill_rows(hipStream_t s, double *M, int64_t ld, int r0, int rows_pad, const double *src,
                      int64_t lds, int nrows, int ncols);

@@ -114,6 +114,12 @@ struct egx_gp {
     // x-gradient state (lazy, per fitted factor): d_W = C^-T (shared with the theta-gradient scratch) and
     // -R^-1 F = -C^-T ft as an (n_pad x rhs_pad) matrix
     double *d_neg_invkf = nullptr;
+    std::vector<double> h_neg_invkf;  // host copy (n x p) for the single-point path
+    // device scratch of the single-point path, allocated once (a hipMalloc per call would cost more than the kernels)
+    double *sp_R = nullptr, *sp_P = nullptr, *sp_y = nullptr, *sp_z = nullptr, *sp_wt = nullptr, *sp_out = nullptr,
+           *sp_xq = nullptr;
+    int sp_nsplit = 0;
+    int small_var_calls = 0;  // single-point predict_var calls since the fit: the third one builds W = C^-T
     uint64_t fit_epoch = 0, winv_epoch = ~(uint64_t)0;
     egx_timings timings{};
 };
@@ -448,6 +454,7 @@ static int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     gp->fit_hcols = hcols;
     gp->fitted = true;
     gp->fit_epoch++;
+    gp->small_var_calls = 0;
     float gpu = 0;
     hipEventElapsedTime(&gpu, w.ev[0], w.ev[3]);
     double host_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() - gpu;
@@ -475,6 +482,8 @@ static int upload_queries(egx_gp *gp, const double *xq, int64_t m0, int m, int m
     return EGX_SUCCESS;
 }
 
+static int predict_var_small(egx_gp *gp, const double *xq, int64_t m, double *vout);
+
 static int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *vout) {
     if (!gp->fitted) {
         set_error("model is not fitted (call egx_gp_finalize or egx_gp_fit first)");
@@ -485,6 +494,10 @@ static int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, d
         return EGX_ERR_INVALID_VALUE;
     }
     EGX_RC(set_device(gp));
+    if (vout && !yout && m > 0 && m <= 8) {  // a few points at a time: EGO's inner loop
+        const bool have_w = gp->winv_epoch == gp->fit_epoch && gp->d_W && gp->d_neg_invkf;
+        if (have_w || ++gp->small_var_calls >= 3) return predict_var_small(gp, xq, m, vout);
+    }
     Workspace &w = gp->ws[0];
     const int n = gp->n, n_pad = gp->n_pad, d = gp->d, p = gp->p;
     // chunk so that the (m_tile x n_pad) block of predict_var stays <= 1 GiB
@@ -498,12 +511,21 @@ static int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, d
         const int m_pad = (int)round_up(mc, kTile);
         DevBuf d_xqT, d_racc, d_RT, d_s0, d_sl;
         EGX_RC(upload_queries(gp, xq, m0, mc, m_pad, xn, d_xqT, w.stream));
+        // few queries: split the training range so that ~1024 workgroups exist (partial sums added below)
+        int msplit = 1;
+        if (m_pad / 64 < 1024) msplit = (1024 + m_pad / 64 - 1) / (m_pad / 64);
+        if (msplit > n_pad / 64) msplit = n_pad / 64;
+        {
+            const int per = (n_pad / 64 + msplit - 1) / msplit;
+            msplit = (n_pad / 64 + per - 1) / per;
+        }
         if (yout) {
-            racc.resize(m_pad);
-            EGX_RC(d_racc.alloc(m_pad));
+            racc.resize((size_t)msplit * m_pad);
+            EGX_RC(d_racc.alloc((size_t)msplit * m_pad));
             EGX_RC(launch_predict_mean(w.stream, gp->corr, d_xqT.p, m_pad, m_pad, gp->d_xT, n_pad, n_pad, d,
-                                       gp->d_fit_coef, gp->fit_hcols, gp->d_gamma, d_racc.p));
-            EGX_HIP_CHECK(hipMemcpyAsync(racc.data(), d_racc.p, sizeof(double) * m_pad, hipMemcpyDeviceToHost, w.stream));
+                                       gp->d_fit_coef, gp->fit_hcols, gp->d_gamma, d_racc.p, msplit));
+            EGX_HIP_CHECK(hipMemcpyAsync(racc.data(), d_racc.p, sizeof(double) * (size_t)msplit * m_pad,
+                                         hipMemcpyDeviceToHost, w.stream));
         }
         if (vout) {
             s0.resize(m_pad);
@@ -526,9 +548,10 @@ static int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, d
         for (int a = 0; a < mc; a++) {
             hm::regression_row(gp->mean, &xn[(size_t)a * d], d, f.data());
             if (yout) {
-                double fb = 0.0;
+                double fb = 0.0, rg = 0.0;
                 for (int l = 0; l < p; l++) fb += f[l] * gp->beta[l];
-                yout[m0 + a] = (fb + racc[a]) * gp->y_std + gp->y_mean;  // algorithm.rs:260-262
+                for (int sp = 0; sp < msplit; sp++) rg += racc[(size_t)sp * m_pad + a];
+                yout[m0 + a] = (fb + rg) * gp->y_std + gp->y_mean;  // algorithm.rs:260-262
             }
             if (vout) {
                 // u = (Rq^T)^-1 (ft^T rt - f^T)   algorithm.rs:352-367 ; Rq^T lower triangular
@@ -569,8 +592,150 @@ static int ensure_winv(egx_gp *gp) {
     // 0 - W [ft | yt]: the rows [ft | yt]^T sit below the factor; W upper triangular -> K range starts at the row tile
     EGX_RC(launch_gemm_nt_sub(w.stream, gp->d_neg_invkf, gp->rhs_pad, gp->d_W, n_pad, w.M + (size_t)n_pad * gp->ld,
                               gp->ld, n_pad, gp->rhs_pad, n_pad, 0, 1));
-    EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+    {
+        std::vector<double> tmp((size_t)n_pad * gp->rhs_pad);
+        EGX_HIP_CHECK(hipMemcpyAsync(tmp.data(), gp->d_neg_invkf, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, w.stream));
+        EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+        gp->h_neg_invkf.resize((size_t)gp->n * gp->p);
+        for (int i = 0; i < gp->n; i++)
+            for (int l = 0; l < gp->p; l++) gp->h_neg_invkf[(size_t)i * gp->p + l] = tmp[(size_t)i * gp->rhs_pad + l];
+    }
     gp->winv_epoch = gp->fit_epoch;
+    return EGX_SUCCESS;
+}
+
+// Small batches (EGO's infill optimiser asks for one point at a time): per query two memory-bound passes over the cached
+// W = C^-T instead of the batched block solves, then the x-gradient contraction with a per-training-point weight VECTOR.
+static int small_path_buffers(egx_gp *gp) {
+    if (gp->sp_R) return EGX_SUCCESS;
+    const int n = gp->n, n_pad = gp->n_pad, d = gp->d;
+    int nsplit = (n + 63) / 64;
+    if (nsplit > 512) nsplit = 512;
+    const int slabs = (n + 63) / 64, per = (slabs + nsplit - 1) / nsplit;
+    gp->sp_nsplit = (slabs + per - 1) / per;
+    EGX_HIP_CHECK(hipMalloc(&gp->sp_R, sizeof(double) * (size_t)kTile * n_pad));
+    EGX_HIP_CHECK(hipMalloc(&gp->sp_P, sizeof(double) * (size_t)32 * n_pad));
+    EGX_HIP_CHECK(hipMalloc(&gp->sp_y, sizeof(double) * n_pad));
+    EGX_HIP_CHECK(hipMalloc(&gp->sp_z, sizeof(double) * n_pad));
+    EGX_HIP_CHECK(hipMalloc(&gp->sp_wt, sizeof(double) * n_pad));
+    EGX_HIP_CHECK(hipMalloc(&gp->sp_out, sizeof(double) * (size_t)gp->sp_nsplit * kTile * d));
+    EGX_HIP_CHECK(hipMalloc(&gp->sp_xq, sizeof(double) * (size_t)d * kTile));
+    return EGX_SUCCESS;
+}
+
+// normalised query a of xq, k-major with the other 127 slots zero, into the cached device slab; xn (d) on the host
+static int small_path_query(egx_gp *gp, const double *xq, int64_t a, std::vector<double> &xn, std::vector<double> &slab) {
+    const int d = gp->d;
+    xn.resize(d);
+    slab.assign((size_t)d * kTile, 0.0);
+    for (int j = 0; j < d; j++) {
+        xn[j] = (xq[(size_t)a * d + j] - gp->x_mean[j]) / gp->x_std[j];
+        slab[(size_t)j * kTile] = xn[j];
+    }
+    EGX_HIP_CHECK(hipMemcpyAsync(gp->sp_xq, slab.data(), sizeof(double) * slab.size(), hipMemcpyHostToDevice, gp->ws[0].stream));
+    return EGX_SUCCESS;
+}
+
+// y = C^-1 r, z = R^-1 r of ONE query (already in sp_xq) on the host; needs ensure_winv
+static int small_path_solve(egx_gp *gp, std::vector<double> &y, std::vector<double> &z, bool want_z) {
+    Workspace &w = gp->ws[0];
+    const int n = gp->n, n_pad = gp->n_pad, d = gp->d;
+    EGX_RC(launch_cross_corr(w.stream, gp->corr, gp->sp_xq, kTile, kTile, gp->d_xT, n_pad, n_pad, d, gp->d_fit_coef,
+                             gp->fit_hcols, gp->sp_R, n_pad));
+    EGX_RC(launch_uptri_solve_pair(w.stream, gp->d_W, n_pad, n, n_pad, gp->sp_R, gp->sp_P, gp->sp_y, gp->sp_z));
+    y.resize(n_pad);
+    EGX_HIP_CHECK(hipMemcpyAsync(y.data(), gp->sp_y, sizeof(double) * n_pad, hipMemcpyDeviceToHost, w.stream));
+    if (want_z) {
+        z.resize(n_pad);
+        EGX_HIP_CHECK(hipMemcpyAsync(z.data(), gp->sp_z, sizeof(double) * n_pad, hipMemcpyDeviceToHost, w.stream));
+    }
+    EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+    return EGX_SUCCESS;
+}
+
+static int xgrad_small(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv) {
+    Workspace &w = gp->ws[0];
+    const int n = gp->n, n_pad = gp->n_pad, d = gp->d, p = gp->p;
+    if (gv) EGX_RC(ensure_winv(gp));
+    EGX_RC(small_path_buffers(gp));
+    const int m_pad = kTile;
+    const int nblk = (n + 255) / 256;  // k_xgrad_point: one partial row of d sums per 256 training points
+    std::vector<double> xn, slab, y, z, wt(n_pad, 0.0), part((size_t)nblk * d), f(p), a_vec(p), u(p), dd(p), df(d);
+    auto reduce_out = [&](int k) {
+        double sacc = 0.0;
+        for (int sidx = 0; sidx < nblk; sidx++) sacc += part[(size_t)sidx * d + k];
+        return sacc;
+    };
+    auto contract = [&](const double *weights) -> int {
+        EGX_RC(launch_xgrad_point(w.stream, gp->corr, gp->sp_xq, m_pad, 1, gp->d_xT, n_pad, n, d, gp->d_fit_coef,
+                                  gp->fit_hcols, weights, gp->sp_out));
+        EGX_HIP_CHECK(hipMemcpyAsync(part.data(), gp->sp_out, sizeof(double) * (size_t)nblk * d, hipMemcpyDeviceToHost,
+                                     w.stream));
+        EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+        return EGX_SUCCESS;
+    };
+    for (int64_t a = 0; a < m; a++) {
+        EGX_RC(small_path_query(gp, xq, a, xn, slab));
+        if (gy) {
+            EGX_RC(contract(gp->d_gamma));
+            hm::regression_jac_dot(gp->mean, xn.data(), d, gp->beta.data(), df.data());
+            for (int k = 0; k < d; k++) gy[(size_t)a * d + k] = (df[k] + reduce_out(k)) * gp->y_std / gp->x_std[k];
+        }
+        if (gv) {
+            EGX_RC(small_path_solve(gp, y, z, true));
+            hm::regression_row(gp->mean, xn.data(), d, f.data());
+            for (int l = 0; l < p; l++) {  // A = f - ft^T rt
+                double sacc = 0.0;
+                for (int i = 0; i < n; i++) sacc += gp->ft[(size_t)i * p + l] * y[i];
+                a_vec[l] = f[l] - sacc;
+            }
+            for (int i = 0; i < p; i++) {
+                double sacc = a_vec[i];
+                for (int l = 0; l < i; l++) sacc -= gp->ft_qr_r[(size_t)l * p + i] * u[l];
+                u[i] = sacc / gp->ft_qr_r[(size_t)i * p + i];
+            }
+            for (int i = p - 1; i >= 0; i--) {
+                double sacc = u[i];
+                for (int l = i + 1; l < p; l++) sacc -= gp->ft_qr_r[(size_t)i * p + l] * dd[l];
+                dd[i] = sacc / gp->ft_qr_r[(size_t)i * p + i];
+            }
+            for (int i = 0; i < n; i++) {  // -(R^-1 r + R^-1 F D)_i
+                double e = 0.0;
+                for (int l = 0; l < p; l++) e += gp->h_neg_invkf[(size_t)i * p + l] * dd[l];
+                wt[i] = -z[i] + e;
+            }
+            EGX_HIP_CHECK(hipMemcpyAsync(gp->sp_wt, wt.data(), sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
+            EGX_RC(contract(gp->sp_wt));
+            hm::regression_jac_dot(gp->mean, xn.data(), d, dd.data(), df.data());
+            for (int k = 0; k < d; k++) gv[(size_t)a * d + k] = 2.0 * gp->sigma2 * (df[k] + reduce_out(k)) / gp->x_std[k];
+        }
+    }
+    return EGX_SUCCESS;
+}
+
+// predict_var of a few points through the cached W (built on the third such call after a fit, or by any gradient call)
+static int predict_var_small(egx_gp *gp, const double *xq, int64_t m, double *vout) {
+    const int n = gp->n, d = gp->d, p = gp->p;
+    EGX_RC(ensure_winv(gp));
+    EGX_RC(small_path_buffers(gp));
+    std::vector<double> xn, slab, y, z, f(p), u(p);
+    for (int64_t a = 0; a < m; a++) {
+        EGX_RC(small_path_query(gp, xq, a, xn, slab));
+        EGX_RC(small_path_solve(gp, y, z, false));
+        double s0 = 0.0;
+        for (int i = 0; i < n; i++) s0 += y[i] * y[i];
+        hm::regression_row(gp->mean, xn.data(), d, f.data());
+        double usq = 0.0;
+        for (int i = 0; i < p; i++) {  // u = (Rq^T)^-1 (ft^T rt - f)   algorithm.rs:352-367
+            double sacc = -f[i];
+            for (int t = 0; t < n; t++) sacc += gp->ft[(size_t)t * p + i] * y[t];
+            for (int l = 0; l < i; l++) sacc -= gp->ft_qr_r[(size_t)l * p + i] * u[l];
+            u[i] = sacc / gp->ft_qr_r[(size_t)i * p + i];
+            usq += u[i] * u[i];
+        }
+        const double mse = gp->sigma2 * (1.0 - s0 + usq);
+        vout[a] = (mse < 0.0) ? 0.0 : mse;
+    }
     return EGX_SUCCESS;
 }
 
@@ -590,6 +755,7 @@ static int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, doubl
         return EGX_ERR_INVALID_VALUE;
     }
     EGX_RC(set_device(gp));
+    if (m > 0 && m <= 8) return xgrad_small(gp, xq, m, gy, gv);
     Workspace &w = gp->ws[0];
     const int n = gp->n, n_pad = gp->n_pad, d = gp->d, p = gp->p, rp = gp->rhs_pad;
     if (gv) EGX_RC(ensure_winv(gp));
@@ -879,6 +1045,8 @@ void egx_gp_destroy(egx_gp *gp) {
     if (gp->d_fit_coef) hipFree(gp->d_fit_coef);
     if (gp->d_W) hipFree(gp->d_W);
     if (gp->d_neg_invkf) hipFree(gp->d_neg_invkf);
+    for (double *q : {gp->sp_R, gp->sp_P, gp->sp_y, gp->sp_z, gp->sp_wt, gp->sp_out, gp->sp_xq})
+        if (q) hipFree(q);
     if (gp->d_Rinv) hipFree(gp->d_Rinv);
     if (gp->d_gout) hipFree(gp->d_gout);
     if (gp->d_theta) hipFree(gp->d_theta);
@@ -1254,6 +1422,7 @@ int32_t egx_gp_set_inner(egx_gp *gp, const egx_gp_inner_view *v) {
     gp->fit_hcols = hcols;
     gp->fitted = true;
     gp->fit_epoch++;
+    gp->small_var_calls = 0;
     return EGX_SUCCESS;
 }
 

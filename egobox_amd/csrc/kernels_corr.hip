@@ -146,13 +146,17 @@ __global__ __launch_bounds__(256) void k_predict_mean(const double *__restrict__
                                                       const double *__restrict__ xT, int64_t ldx, int n_pad,
                                                       int d, const double *__restrict__ coef, int hcols,
                                                       const double *__restrict__ gamma,
-                                                      double *__restrict__ racc) {
+                                                      double *__restrict__ racc, int slabs_per_split, int m_pad) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *xi = sm, *xj = sm + d * 64, *gs = sm + 2 * d * 64;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     stage_slab(xi, xqT, ldq, blockIdx.x * 64, d, tid);
     double sum[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int j0 = 0; j0 < n_pad; j0 += 64) {
+    // grid.y splits the training range (a few queries must still fill the chip); partial sums per split
+    const int j_lo = blockIdx.y * slabs_per_split * 64;
+    int j_hi = j_lo + slabs_per_split * 64;
+    if (j_hi > n_pad) j_hi = n_pad;
+    for (int j0 = j_lo; j0 < j_hi; j0 += 64) {
         __syncthreads();
         stage_slab(xj, xT, ldx, j0, d, tid);
         if (tid < 64) gs[tid] = gamma[j0 + tid];
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void k_predict_mean(const double *__restrict__
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 4);
         v += __shfl_xor(v, 8);
-        if (tx == 0) racc[blockIdx.x * 64 + ty * 4 + a] = v;
+        if (tx == 0) racc[(int64_t)blockIdx.y * m_pad + blockIdx.x * 64 + ty * 4 + a] = v;
     }
 }
 
@@ -253,6 +257,93 @@ __global__ __launch_bounds__(kXgThreads) void k_xgrad(const double *__restrict__
         for (int kk = 0; kk < DK; kk++)
             if (k0 + kk < d) o[k0 + kk] = acc[kk];
     }
+}
+
+// Few-query form of the x-gradient contraction (single-point calls): the lanes run over TRAINING points instead of queries
+// (one pair per lane, no sequential pair loop), the d partial sums are reduced across the workgroup.
+//   out[(blockIdx.y * m + a) * d + k] = sum over the block's 256 training points of w_j d r(x_a, x_j) / d x_ak
+template <int CORR>
+__global__ __launch_bounds__(256) void k_xgrad_point(const double *__restrict__ xqT, int64_t ldq, const double *__restrict__ xT,
+                                                     int64_t ldx, int n, int d, const double *__restrict__ coef, int hcols,
+                                                     const double *__restrict__ wvec, double *__restrict__ out, int m) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *xa = sm;            // [d]
+    double *cs = sm + d;        // [d * hcols]
+    double *red = cs + d * hcols;  // [4][d]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int a = blockIdx.x, j = blockIdx.y * 256 + tid;
+    for (int k = tid; k < d; k += 256) xa[k] = xqT[(int64_t)k * ldq + a];
+    for (int e = tid; e < d * hcols; e += 256) cs[e] = coef[e];
+    __syncthreads();
+    const bool live = j < n;
+    double rw = 0.0;
+    if (live) {
+        PairAcc<CORR> pa;
+        for (int k = 0; k < d; k++) pa.add(xa[k] - xT[(int64_t)k * ldx + j], cs + k * hcols, hcols);
+        rw = pa.value() * wvec[j];
+    }
+    for (int k = 0; k < d; k++) {
+        double v = live ? rw * xgrad_factor<CORR>(xa[k] - xT[(int64_t)k * ldx + j], cs + k * hcols, hcols) : 0.0;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave * d + k] = v;
+    }
+    __syncthreads();
+    for (int k = tid; k < d; k += 256)
+        out[((int64_t)blockIdx.y * m + a) * d + k] = ((red[k] + red[d + k]) + red[2 * d + k]) + red[3 * d + k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Single-point path of the variance (and its x-gradient): with W = C^-T cached (upper triangular, row-major)
+//   y = C^-1 r = W^T r      k_uptri_gemv_t  (rows split over grid.y, partial sums to P, summed in a fixed order)
+//   z = C^-T y = W y        k_uptri_gemv    (one wave per row, coalesced)
+// Two memory-bound passes over half of W instead of 2 x 64 dependent block solves: EGO asks for ONE point at a time.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_uptri_gemv_t(const double *__restrict__ W, int64_t ld, int n,
+                                                      const double *__restrict__ r, int rows_per_split,
+                                                      double *__restrict__ P, int n_pad) {
+    __shared__ double red[4][64];
+    const int tid = threadIdx.x, g = tid >> 6, jl = tid & 63;
+    const int j = blockIdx.x * 64 + jl;
+    const int i_lo = blockIdx.y * rows_per_split;
+    int i_hi = i_lo + rows_per_split;
+    const int jmax = blockIdx.x * 64 + 63;  // rows beyond the last column of this block are zero (upper triangular)
+    if (i_hi > jmax + 1) i_hi = jmax + 1;
+    if (i_hi > n) i_hi = n;
+    double part = 0.0;
+    for (int i0 = i_lo + g; i0 < i_hi; i0 += 32) {  // 8 independent loads in flight per lane
+        double mv[8], rv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + 4 * u;
+            const bool ok = i < i_hi;
+            mv[u] = ok ? W[(int64_t)i * ld + j] : 0.0;
+            rv[u] = ok ? r[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) part = __builtin_fma(mv[u], rv[u], part);
+    }
+    red[g][jl] = part;
+    __syncthreads();
+    if (g == 0) P[(int64_t)blockIdx.y * n_pad + j] = ((red[0][jl] + red[1][jl]) + red[2][jl]) + red[3][jl];
+}
+
+__global__ void k_sum_partials(const double *__restrict__ P, int nsplit, int n_pad, double *__restrict__ y) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_pad) return;
+    double sacc = 0.0;
+    for (int sp = 0; sp < nsplit; sp++) sacc += P[(int64_t)sp * n_pad + j];
+    y[j] = sacc;
+}
+
+__global__ __launch_bounds__(256) void k_uptri_gemv(const double *__restrict__ W, int64_t ld, int n,
+                                                    const double *__restrict__ y, double *__restrict__ z) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const double *row = W + (int64_t)i * ld;
+    double acc = 0.0;
+    for (int k = (i & ~63) + lane; k < n; k += 64) acc = __builtin_fma((k >= i) ? row[k] : 0.0, y[k], acc);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) z[i] = acc;
 }
 
 __global__ void k_fill_rows(double *__restrict__ M, int64_t ld, int r0, int rows_pad, const double *__restrict__ src,
@@ -395,10 +486,15 @@ int launch_cross_corr(hipStream_t s, int corr, const double *xqT, int64_t ldq, i
 
 int launch_predict_mean(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad, const double *xT,
                         int64_t ldx, int n_pad, int d, const double *coef, int hcols, const double *gamma,
-                        double *racc) {
+                        double *racc, int nsplit) {
     const size_t lds = (size_t)(2 * d * 64 + 64) * sizeof(double);
-    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_predict_mean<C_>, dim3(m_pad / 64), dim3(256), lds, s, xqT, ldq, xT,
-                                               ldx, n_pad, d, coef, hcols, gamma, racc));
+    const int slabs = n_pad / 64;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > slabs) nsplit = slabs;
+    const int per = (slabs + nsplit - 1) / nsplit;
+    nsplit = (slabs + per - 1) / per;
+    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_predict_mean<C_>, dim3(m_pad / 64, nsplit), dim3(256), lds, s, xqT, ldq, xT,
+                                               ldx, n_pad, d, coef, hcols, gamma, racc, per, m_pad));
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }
@@ -435,6 +531,31 @@ int launch_xgrad(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_
         EGX_DISPATCH_CORR(corr, EGX_XG(C_, 32));
     }
 #undef EGX_XG
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+// few queries (m <= 8), weights = a vector over the training points: out is (ceil(n / 256) x m x d) partial sums
+int launch_xgrad_point(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m, const double *xT, int64_t ldx, int n,
+                       int d, const double *coef, int hcols, const double *wvec, double *out) {
+    dim3 grid(m, (n + 255) / 256);
+    const size_t lds = (size_t)(d + d * hcols + 4 * d) * sizeof(double);
+    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_xgrad_point<C_>, grid, dim3(256), lds, s, xqT, ldq, xT, ldx, n, d, coef, hcols,
+                                               wvec, out, m));
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+// y (n_pad) <- W^T r, z (n_pad) <- W y for the upper-triangular W (n_pad x n_pad, ld); P: scratch of 32 * n_pad doubles
+int launch_uptri_solve_pair(hipStream_t s, const double *W, int64_t ld, int n, int n_pad, const double *r, double *P,
+                            double *y, double *z) {
+    int nsplit = (n + 255) / 256;
+    if (nsplit > 32) nsplit = 32;
+    const int per = (int)round_up((n + nsplit - 1) / nsplit, 4);
+    nsplit = (n + per - 1) / per;
+    hipLaunchKernelGGL(k_uptri_gemv_t, dim3(n_pad / 64, nsplit), dim3(256), 0, s, W, ld, n, r, per, P, n_pad);
+    hipLaunchKernelGGL(k_sum_partials, dim3((n_pad + 255) / 256), dim3(256), 0, s, (const double *)P, nsplit, n_pad, y);
+    hipLaunchKernelGGL(k_uptri_gemv, dim3((n + 3) / 4), dim3(256), 0, s, W, ld, n, (const double *)y, z);
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }
