@@ -930,3 +930,35 @@ def test_randomised_parity_sweep(egx, O):
             np.testing.assert_allclose(gy, wy, rtol=1e-5, atol=1e-5 * np.abs(wy).max())
             np.testing.assert_allclose(gv, wv, rtol=1e-5, atol=1e-5 * max(np.abs(wv).max(), 1e-12))
     assert checked >= 25
+
+
+def test_few_query_paths_agree_with_batched_paths_and_oracle(egx, O):
+    """m <= 8 takes the few-query paths (split-range mean, GEMV passes over the cached C^-T -- from the third small
+    predict_var call after a fit, or after any gradient call --, lanes-over-training-points gradient kernel); m > 8 the
+    batched ones.  Both must match the oracle, for every kernel and a non-trivial trend."""
+    x, y = _data(700, 5, seed=61)
+    rng = np.random.default_rng(8)
+    xq = rng.random((20, 5))
+    for corr in range(4):
+        theta = np.full(5, 0.9) * (3.0 if corr == 0 else 1.0)
+        ref = O.fit_fixed(x, y, theta, mean="Linear", corr=KINDS[corr])
+        with egx.GpHandle(x, y, mean=1, corr=corr) as h:
+            h.finalize(theta)
+            ry, rv = ref.predict(xq), ref.predict_var(xq)
+            wy, wv = ref.predict_valvar_gradients(xq)
+            for rep in range(4):  # the third small predict_var call switches to the C^-T path
+                small = h.predict_var(xq[:3])
+                np.testing.assert_allclose(small, rv[:3], rtol=PRED_RTOL, atol=PRED_RTOL * ref.inner.sigma2)
+            np.testing.assert_allclose(h.predict(xq[:2]), ry[:2], rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(ry).max())
+            np.testing.assert_allclose(h.predict(xq), ry, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(ry).max())
+            np.testing.assert_allclose(h.predict_var(xq), rv, rtol=PRED_RTOL, atol=PRED_RTOL * ref.inner.sigma2)
+            gy_s, gv_s = h.predict_valvar_gradients(xq[:8])
+            gy_b, gv_b = h.predict_valvar_gradients(xq)
+            np.testing.assert_allclose(gy_s, wy[:8], rtol=1e-6, atol=1e-6 * np.abs(wy).max())
+            np.testing.assert_allclose(gv_s, wv[:8], rtol=1e-6, atol=1e-6 * np.abs(wv).max())
+            np.testing.assert_allclose(gy_b, wy, rtol=1e-6, atol=1e-6 * np.abs(wy).max())
+            np.testing.assert_allclose(gv_b, wv, rtol=1e-6, atol=1e-6 * np.abs(wv).max())
+            h.finalize(theta * 1.3)  # a refit invalidates the cached C^-T
+            ref2 = O.fit_fixed(x, y, theta * 1.3, mean="Linear", corr=KINDS[corr])
+            np.testing.assert_allclose(h.predict_var_gradients(xq[:2]), ref2.predict_var_gradients(xq[:2]), rtol=1e-6,
+                                       atol=1e-6 * np.abs(wv).max())
