@@ -230,7 +230,9 @@ class SgpParams:
         starts_log10, _ = prepare_multistart(self._n_start, params0, bounds, seed=42 if self._seed is None else self._seed)
         n_evals = h.fit(10.0 ** starts_log10, [b[0] for b in bounds], [b[1] for b in bounds], est,
                         self._noise.init, self._max_eval)
-        return SparseGaussianProcess(h, self, n_evals)
+        sgp = SparseGaussianProcess(h, self, n_evals)
+        sgp._xy = (x, y)
+        return sgp
 
 
 class SparseGaussianProcess:
@@ -238,6 +240,7 @@ class SparseGaussianProcess:
 
     def __init__(self, handle, params, n_evals=0):
         self._h, self.params_, self.n_evals = handle, params, n_evals
+        self._xy = None
 
     @staticmethod
     def params(inducings, corr=None):
@@ -365,3 +368,57 @@ class SparseGpx:
 
     def __str__(self):
         return f"Mixture[Smooth(1)]({self._sgp.params_._corr}{self._sgp})"
+
+    # ---- JSON dump in the field layout of the reference's serde structs (SparseGaussianProcess :145-168, WoodburyData
+    #      :32-36; typetag "type_sgp" crates/moe/src/surrogates.rs:101): theta, sigma2, noise, likelihood, w_star,
+    #      inducings, w_data{vec, inv}, training_data, corr, method
+    def to_dict(self):
+        g = self._sgp
+        h = g._h
+        st = h.state(with_inv=True)
+
+        def nd(a):
+            a = np.asarray(a, dtype=np.float64)
+            return {"v": 1, "dim": list(a.shape), "data": a.ravel().tolist()}
+
+        corr = str(g.params_._corr)
+        expert = {"type_sgp": f"Sgp{corr}Surrogate", "corr": corr, "method": "Fitc" if g.params_._method == FITC else "Vfe",
+                  "theta": nd(st["theta"]), "sigma2": st["sigma2"], "noise": st["noise"], "likelihood": st["likelihood"],
+                  "w_star": nd(np.eye(h.d)), "inducings": nd(h.z),
+                  "w_data": {"vec": nd(st["w_vec"].reshape(-1, 1)), "inv": nd(st["w_inv"])},
+                  "training_data": [nd(g._xy[0]), nd(g._xy[1])], "nugget": g.params_._nugget}
+        return {"recombination": {"Smooth": 1.0}, "experts": [expert], "gp_type": "SparseGp"}
+
+    def save(self, filename):
+        import json
+        if not str(filename).endswith(".json"):
+            raise NotImplementedError("only the JSON format is written (the reference's .bin is bincode)")
+        with open(filename, "w") as f:
+            json.dump(self.to_dict(), f)
+        return True
+
+    @staticmethod
+    def load(filename):
+        """Rebuild on the GPU from a JSON dump: the stored (theta, sigma2, noise, inducings) are re-evaluated (one
+        likelihood evaluation, milliseconds) and the stored likelihood is checked against the recomputed one."""
+        import json
+        with open(filename) as f:
+            e = json.load(f)["experts"][0]
+
+        def arr(o):
+            return np.asarray(o["data"], dtype=np.float64).reshape(o["dim"])
+
+        corr = G.CORRS[e["corr"]]()
+        x, y = arr(e["training_data"][0]), arr(e["training_data"][1])
+        z, theta = arr(e["inducings"]), arr(e["theta"])
+        method = FITC if e["method"] == "Fitc" else VFE
+        params = SgpParams(corr, Inducings.Located(z)).sparse_method(method).nugget(e.get("nugget", G.DEFAULT_NUGGET))
+        h = SgpHandle(x, y, z, corr=corr.code, method=method, nugget=params._nugget)
+        h.finalize(theta, e["sigma2"], e["noise"])
+        lk = h.state()["likelihood"]
+        if not np.isclose(lk, e["likelihood"], rtol=1e-6, atol=1e-9):
+            h.close()
+            raise L.EgxError(L.ERR_LIKELIHOOD, f"stored likelihood {e['likelihood']} != recomputed {lk}")
+        sgp = SparseGaussianProcess(h, params, n_evals=1)
+        sgp._xy = (x, y)
+        return SparseGpx(sgp)

@@ -129,3 +129,22 @@ def test_numerical_gradients_like_the_reference(egx, S):
             # step sqrt(eps) ~ 1.5e-8: rounding of the predictions (~1e-14 absolute) is amplified by 1 / (2 h) ~ 3e7
             np.testing.assert_allclose(g[:, k], fd, rtol=2e-5, atol=atol)
     sgp.close()
+
+
+def test_sparse_gpx_save_load_roundtrip(egx, tmp_path):
+    x, y, z = _problem(500, 20, 2, seed=4)
+    gx = egx.SparseGpx.builder(z=z, n_start=0, max_eval=30, method=egx.SparseMethod.VFE).fit(x, y)
+    xq = np.random.default_rng(5).random((40, 2)) * 2 - 1
+    y0, v0 = gx.predict(xq), gx.predict_var(xq)
+    path = tmp_path / "sgp.json"
+    assert gx.save(str(path))
+    import json
+    d = json.load(open(path))
+    e = d["experts"][0]
+    assert d["gp_type"] == "SparseGp" and e["method"] == "Vfe" and e["w_data"]["inv"]["dim"] == [20, 20]
+    back = egx.SparseGpx.load(str(path))
+    np.testing.assert_allclose(back.predict(xq), y0, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(back.predict_var(xq), v0, rtol=1e-9, atol=1e-12)
+    assert back.likelihoods()[0] == pytest.approx(gx.likelihoods()[0], rel=1e-10)
+    with pytest.raises(NotImplementedError):
+        gx.save(str(tmp_path / "sgp.bin"))
