@@ -1,0 +1,137 @@
+// Internal header shared by the dense-GP host translation units (gp_host.hip: handle, evaluation, state;
+// gp_predict.hip: predictions and their x-gradients; gp_fit.hip: optimiser drivers and the theta-gradient).
+#pragma once
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <condition_variable>
+#include <mutex>
+#include <shared_mutex>
+#include <thread>
+#include <algorithm>
+#include <vector>
+
+#include "egx_internal.h"
+#include "host_math.h"
+#include "nelder_mead.h"
+
+#define EGX_RC(call)              \
+    do {                          \
+        int _rc = (call);         \
+        if (_rc) return _rc;      \
+    } while (0)
+
+namespace egx {
+
+// Scoped device allocation for the temporaries of one call (freed on every exit path).
+struct DevBuf {
+    double *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t n_doubles) {
+        EGX_HIP_CHECK(hipMalloc(&p, sizeof(double) * (n_doubles ? n_doubles : 1)));
+        return EGX_SUCCESS;
+    }
+};
+
+struct Workspace {
+    hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // look-ahead (panel) stream
+    hipEvent_t ev_lu = nullptr, ev_panel = nullptr;
+    double *M = nullptr;       // (m_tot x ld): correlation matrix / factor + appended RHS rows
+    double *dinv = nullptr;    // (n_pad/64) x 64 x 64 inverses of the diagonal tiles
+    double *dW = nullptr;      // (n_pad/256) x 256 x 256 transposed inverses of the diagonal blocks (lazy)
+    double *d_coef = nullptr;  // d x hcols
+    double *d_diag = nullptr;  // n
+    double *d_vec = nullptr;   // n_pad (gamma)
+    double *d_rhs = nullptr;   // n_pad (rho, destroyed by the back-substitution)
+    int *d_info = nullptr;
+    double *h_coef = nullptr;  // pinned
+    double *h_rows = nullptr;  // pinned: q x n_pad solved RHS rows (ft^T, yt^T)
+    double *h_diag = nullptr;  // pinned: n
+    double *h_vec = nullptr;   // pinned: n_pad
+    int *h_info = nullptr;     // pinned
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    GemmTrace trace;
+};
+
+struct EvalResult {
+    double lkh = -std::numeric_limits<double>::infinity();
+    int status = EGX_STATUS_OK;
+    double sigma2n = 0.0;         // rho^2 / n in normalised units
+    std::vector<double> beta;     // p
+    std::vector<double> rho;      // n
+    std::vector<double> ft;       // n x p row-major
+    std::vector<double> ft_qr_r;  // p x p row-major
+};
+
+}  // namespace egx
+
+struct egx_gp {
+    int device = 0;
+    int n = 0, d = 0, p = 0, h = 0, corr = 0, mean = 0;
+    double nugget = 0.0;
+    int n_pad = 0, rhs_pad = 0, m_tot = 0, q = 0;
+    int64_t ld = 0;
+    bool has_w = false;
+    std::vector<double> w_star;  // d x h
+    std::vector<double> x_raw, y_raw, xnorm, x_mean, x_std, ynorm, F;
+    double y_mean = 0.0, y_std = 1.0;
+    double *d_xT = nullptr;    // d x n_pad (k-major normalised inputs, zero padded)
+    double *d_rhsT = nullptr;  // q x n_pad: columns of F then y (normalised), as rows
+    std::vector<egx::Workspace> ws;
+    // exclusive for everything that touches the fitted state or all workspaces; SHARED for egx_gp_likelihood, whose
+    // concurrent callers (the reference's rayon multistart closures, algorithm.rs:928-945) each take a workspace
+    // from the pool below
+    std::shared_mutex mu;
+    std::mutex pool_mu;
+    std::condition_variable pool_cv;
+    std::vector<char> ws_busy;
+    // fitted state (lives in ws[0])
+    bool fitted = false;
+    std::vector<double> theta;  // h
+    double likelihood = 0.0, sigma2 = 0.0;
+    std::vector<double> beta, gamma, ft, ft_qr_r;
+    std::vector<double> fit_coef;
+    int fit_hcols = 1;
+    double *d_gamma = nullptr;  // n_pad
+    double *d_fit_coef = nullptr;
+    // gradient scratch (allocated on first use)
+    double *d_W = nullptr, *d_Rinv = nullptr, *d_gout = nullptr, *d_theta = nullptr;
+    // x-gradient state (lazy, per fitted factor): d_W = C^-T (shared with the theta-gradient scratch) and
+    // -R^-1 F = -C^-T ft as an (n_pad x rhs_pad) matrix
+    double *d_neg_invkf = nullptr;
+    std::vector<double> h_neg_invkf;  // host copy (n x p) for the single-point path
+    // device scratch of the single-point path, allocated once (a hipMalloc per call would cost more than the kernels)
+    double *sp_R = nullptr, *sp_P = nullptr, *sp_y = nullptr, *sp_z = nullptr, *sp_wt = nullptr, *sp_out = nullptr,
+           *sp_xq = nullptr;
+    int sp_nsplit = 0;
+    int small_var_calls = 0;  // single-point predict_var calls since the fit: the third one builds W = C^-T
+    uint64_t fit_epoch = 0, winv_epoch = ~(uint64_t)0;
+    egx_timings timings{};
+};
+
+namespace egx {
+
+const std::string &last_error_string();  // this thread's message (egx_last_error)
+int set_device(const egx_gp *gp);
+int make_coef(const egx_gp *gp, const double *theta, int64_t theta_len, std::vector<double> &coef, int &hcols,
+              std::vector<double> *theta_full);
+int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coef, int hcols);
+int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, bool keep);
+void record_timings(egx_gp *gp, Workspace &w, double host_ms, double solve_ms);
+bool has_nan(const double *theta, int64_t len);
+int eval_one(egx_gp *gp, int widx, const double *theta, int64_t theta_len, EvalResult &res, bool keep);
+int backward_solve(egx_gp *gp, Workspace &w);
+int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len);
+// gp_predict.hip
+int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *vout);
+int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv);
+
+}  // namespace egx
