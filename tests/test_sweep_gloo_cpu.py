@@ -107,7 +107,9 @@ def _moe_worker(rank, world, port, q):
     xq = np.random.default_rng(2).random((25, 2)) * [3.0, 1.0]
     out = {}
     for recomb in ("smooth", "hard"):
-        out[recomb] = GpMixture(experts, gmx, recomb, rank=rank, world=world).predict_valvar(xq)
+        mix = GpMixture(experts, gmx, recomb, rank=rank, world=world)
+        out[recomb] = mix.predict_valvar(xq)
+        out[recomb + "_grad"] = mix.predict_valvar_gradients(xq[:9])  # (m, nx) matrices through the same all-reduce
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -140,6 +142,9 @@ def test_moe_experts_sharded_over_two_ranks_gloo():
     xq = np.random.default_rng(2).random((25, 2)) * [3.0, 1.0]
     for recomb in ("smooth", "hard"):
         want = GpMixture(experts, gmx, recomb).predict_valvar(xq)
+        want_g = GpMixture(experts, gmx, recomb).predict_valvar_gradients(xq[:9])
         for r in range(2):
             np.testing.assert_allclose(res[r][recomb][0], want[0], rtol=1e-12, atol=1e-13)
             np.testing.assert_allclose(res[r][recomb][1], want[1], rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(res[r][recomb + "_grad"][0], want_g[0], rtol=1e-11, atol=1e-12)
+            np.testing.assert_allclose(res[r][recomb + "_grad"][1], want_g[1], rtol=1e-11, atol=1e-12)
