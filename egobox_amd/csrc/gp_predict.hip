@@ -39,9 +39,12 @@ int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *
         return EGX_ERR_INVALID_VALUE;
     }
     EGX_RC(set_device(gp));
-    if (vout && !yout && m > 0 && m <= 8) {  // a few points at a time: EGO's inner loop
+    if (vout && m > 0 && m <= 8) {  // a few points at a time: EGO's inner loop (its criteria ask for value AND variance)
         const bool have_w = gp->winv_epoch == gp->fit_epoch && gp->d_W && gp->d_neg_invkf;
-        if (have_w || ++gp->small_var_calls >= 3) return predict_var_small(gp, xq, m, vout);
+        if (have_w || ++gp->small_var_calls >= 3) {
+            if (yout) EGX_RC(predict_impl(gp, xq, m, yout, nullptr));  // split-range mean kernel
+            return predict_var_small(gp, xq, m, vout);
+        }
     }
     Workspace &w = gp->ws[0];
     const int n = gp->n, n_pad = gp->n_pad, d = gp->d, p = gp->p;

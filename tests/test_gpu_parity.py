@@ -952,6 +952,9 @@ def test_few_query_paths_agree_with_batched_paths_and_oracle(egx, O):
             np.testing.assert_allclose(h.predict(xq[:2]), ry[:2], rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(ry).max())
             np.testing.assert_allclose(h.predict(xq), ry, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(ry).max())
             np.testing.assert_allclose(h.predict_var(xq), rv, rtol=PRED_RTOL, atol=PRED_RTOL * ref.inner.sigma2)
+            ys, vs = h.predict_valvar(xq[:4])  # value + variance of a few points: both few-query paths in one call
+            np.testing.assert_allclose(ys, ry[:4], rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(ry).max())
+            np.testing.assert_allclose(vs, rv[:4], rtol=PRED_RTOL, atol=PRED_RTOL * ref.inner.sigma2)
             gy_s, gv_s = h.predict_valvar_gradients(xq[:8])
             gy_b, gv_b = h.predict_valvar_gradients(xq)
             np.testing.assert_allclose(gy_s, wy[:8], rtol=1e-6, atol=1e-6 * np.abs(wy).max())

@@ -30,6 +30,7 @@ for n in (128, 256, 512, 1024, 2048, 4096):
     out = {"n": n, "d": d, "likelihood_ms": t(lambda: h.likelihood(th)), "fit_fixed_ms": t(lambda: h.finalize(th))}
     out["predict_1_ms"] = t(lambda: h.predict(xq))
     out["predict_var_1_ms"] = t(lambda: h.predict_var(xq))
+    out["predict_valvar_1_ms"] = t(lambda: h.predict_valvar(xq))
     out["predict_gradients_1_ms"] = t(lambda: h.predict_gradients(xq))
     out["predict_var_gradients_1_ms"] = t(lambda: h.predict_var_gradients(xq))
     tm = h.timings()
