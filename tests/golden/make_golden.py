@@ -124,6 +124,8 @@ def main():
                    63.17475741, 61.26331775, -7.46009727, 44.39159189, 2.17091422],
             "theta_sq_half": [0.0437386, 0.00697978],  # theta = sqrt(2 * .)
             "x": [-1.3, 2.5], "e": 5e-6, "epsilon": 1e-5},
+        "griewank": {  # crates/gp/src/algorithm.rs:1319-1323 (the synthetic workload's function, raw inputs)
+            "x": [[1.0, 1.0, 1.0, 1.0, 1.0], [2.0, 2.0, 2.0, 2.0, 2.0]], "expected": [0.72890641, 1.01387135], "tol": 1e-8},
         "python_kriging": {  # python/egobox/tests/test_gpmix.py:24-53 (default fit => theta* of golden A)
             "xt": [0.0, 1.0, 2.0, 3.0, 4.0], "yt": [0.0, 1.0, 1.5, 0.9, 1.0],
             "predict_1.0": 1.0, "var_1.0": 0.0, "places": 7,

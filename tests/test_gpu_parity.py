@@ -965,3 +965,38 @@ def test_few_query_paths_agree_with_batched_paths_and_oracle(egx, O):
             ref2 = O.fit_fixed(x, y, theta * 1.3, mean="Linear", corr=KINDS[corr])
             np.testing.assert_allclose(h.predict_var_gradients(xq[:2]), ref2.predict_var_gradients(xq[:2]), rtol=1e-6,
                                        atol=1e-6 * np.abs(wv).max())
+
+
+def test_reference_constant_function(egx):
+    """algorithm.rs:1216-1237: a constant response (zero sample std -> divisor 1, sigma2 = 0): predictions are the
+    constant to 1e-6, with the full-dimension kernel and with a supplied (d x 1) KPLS rotation like the reference's
+    kpls_dim(Some(1)), tuned and at a fixed theta."""
+    rng = np.random.default_rng(42)
+    xt = rng.random((5, 3))
+    yt = np.full(5, 3.1)
+    xtest = np.random.default_rng(43).random((5, 3))
+    for w in (None, np.array([[0.6], [0.5], [0.4]])):
+        for tuning in (egx.ThetaTuning.Fixed([0.1]), egx.ThetaTuning.Full([0.1], [(1e-2, 1e1)])):
+            p = egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr()).theta_tuning(tuning).n_start(2)
+            if w is not None:
+                p.kpls_dim(1).kpls_weights(w)
+            gp = p.fit(xt, yt)
+            yp, vp = gp.predict_valvar(xtest)
+            np.testing.assert_allclose(yp, 3.1, atol=1e-6)
+            assert np.all(np.isfinite(vp)) and np.all(vp >= 0.0) and np.all(vp <= 1e-12)
+            gp.close()
+
+
+def test_reference_fixed_theta(egx):
+    """algorithm.rs:1641-1657: the default (tuned) fit moves theta off its initial guess; refitting with
+    ThetaTuning::Fixed(theta*) returns exactly theta*."""
+    xt = np.array([[0.0], [1.0], [2.0], [3.0], [4.0]])
+    yt = np.array([0.0, 1.0, 1.5, 0.9, 1.0])
+    gp = egx.Kriging.params().fit(xt, yt)
+    expected = gp.theta().copy()
+    assert abs(expected[0] - egx.ThetaTuning.DEFAULT_INIT) > 1e-6
+    gp2 = egx.Kriging.params().theta_tuning(egx.ThetaTuning.Fixed(expected)).fit(xt, yt)
+    np.testing.assert_array_equal(gp2.theta(), expected)
+    assert gp2.likelihood() == pytest.approx(gp.likelihood(), rel=1e-12)
+    gp.close()
+    gp2.close()

@@ -111,3 +111,16 @@ def test_host_cpp_under_address_and_ub_sanitizers(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, (out.stdout, out.stderr)
     assert out.stdout.startswith("OK") and "runtime error" not in out.stderr
+
+
+def test_griewank_known_answer(golden_dir):
+    """The synthetic workload's target function against the reference's own pin (algorithm.rs:1319-1323): both the
+    oracle's and the product's griewank take unit-cube inputs and map them to [-600, 600]^d."""
+    import json
+    import os
+    import egobox_amd.workload as W
+    from oracle import gp_oracle as O
+    k = json.load(open(os.path.join(golden_dir, "kat.json")))["griewank"]
+    x01 = (np.array(k["x"]) + 600.0) / 1200.0
+    np.testing.assert_allclose(W.griewank(x01), k["expected"], atol=k["tol"])
+    np.testing.assert_allclose(O.griewank(x01), k["expected"], atol=k["tol"])
