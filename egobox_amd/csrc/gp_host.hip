@@ -575,13 +575,16 @@ int32_t egx_gp_likelihood(egx_gp *gp, const double *theta, int64_t theta_len, do
     }
     std::shared_lock<std::shared_mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
-    // take a free workspace; workspace 0 (where a fitted factor lives) is the last choice
+    // take a free workspace.  Workspace 0 holds the factor of a FITTED model: while the model is fitted and other
+    // workspaces exist, callers wait for one of those instead of overwriting the fit (a handle with a single workspace
+    // has no choice: the evaluation un-fits it, as documented in the header)
     int wi = -1;
     {
         std::unique_lock<std::mutex> pl(gp->pool_mu);
         if (gp->ws_busy.size() != gp->ws.size()) gp->ws_busy.assign(gp->ws.size(), 0);
         for (;;) {
-            for (int i = (int)gp->ws.size() - 1; i >= 0 && wi < 0; i--)
+            const int lowest = (gp->fitted && gp->ws.size() > 1) ? 1 : 0;
+            for (int i = (int)gp->ws.size() - 1; i >= lowest && wi < 0; i--)
                 if (!gp->ws_busy[i]) wi = i;
             if (wi >= 0) break;
             gp->pool_cv.wait(pl);

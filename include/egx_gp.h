@@ -115,7 +115,10 @@ int32_t egx_gp_dims(const egx_gp *gp, int64_t *n, int64_t *d, int64_t *p, int64_
  * One evaluation of `reduced_likelihood(fx, corr.value(d, theta, w), ...)`
  * (algorithm.rs:892-896, 988-1056).  theta_len is h or 1 (broadcast,
  * algorithm.rs:829-838).  *lkh is the reduced likelihood (NOT negated);
- * on status != 0 it is -inf (the reference's objective is then +inf). */
+ * on status != 0 it is -inf (the reference's objective is then +inf).
+ * Thread-safe: concurrent callers each take a workspace from the handle's pool (n_workspaces).  The fitted factor
+ * lives in workspace 0: with n_workspaces > 1 a fitted model is never disturbed (callers wait for another workspace);
+ * with a single workspace an evaluation overwrites it and the handle must be finalized again before predicting. */
 int32_t egx_gp_likelihood(egx_gp *gp, const double *theta, int64_t theta_len, double *lkh,
                           int32_t *status);
 /* k candidates, thetas is (k x theta_len); the multistart / theta-sweep unit of

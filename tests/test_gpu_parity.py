@@ -1000,3 +1000,44 @@ def test_reference_fixed_theta(egx):
     assert gp2.likelihood() == pytest.approx(gp.likelihood(), rel=1e-12)
     gp.close()
     gp2.close()
+
+
+def test_concurrent_mixed_calls_on_one_handle(egx):
+    """Threads hammering ONE fitted handle with predictions, gradients and (on the spare workspace) likelihood
+    evaluations: every result equals the serial one (exclusive lock for the fitted state, shared lock + workspace pool for
+    the likelihood; Python releases the GIL around every C call)."""
+    from concurrent.futures import ThreadPoolExecutor
+    x, y = _data(800, 4, seed=71)
+    theta = np.full(4, 0.9)
+    rng = np.random.default_rng(9)
+    xqs = [rng.random((m, 4)) for m in (1, 3, 50, 200)]
+    thetas = [theta * f for f in (0.8, 1.0, 1.2, 1.5)]
+    with egx.GpHandle(x, y, corr=3, n_workspaces=2) as h:
+        h.finalize(theta)
+        serial = {"p": [h.predict(q) for q in xqs], "v": [h.predict_var(q) for q in xqs],
+                  "g": [h.predict_valvar_gradients(q[:5]) for q in xqs], "l": [h.likelihood(t) for t in thetas]}
+
+        def job(i):
+            kind, k = "pvgl"[i % 4], (i // 4) % 4
+            if kind == "p":
+                return kind, k, h.predict(xqs[k])
+            if kind == "v":
+                return kind, k, h.predict_var(xqs[k])
+            if kind == "g":
+                return kind, k, h.predict_valvar_gradients(xqs[k][:5])
+            return kind, k, h.likelihood(thetas[k])
+
+        with ThreadPoolExecutor(6) as pool:
+            results = list(pool.map(job, range(64)))
+        for kind, k, val in results:
+            want = serial[kind][k]
+            if kind == "g":
+                np.testing.assert_array_equal(val[0], want[0])
+                np.testing.assert_array_equal(val[1], want[1])
+            elif kind == "l":
+                assert val == want
+            elif kind == "v":  # few-point variances switch to the cached C^-T path on the third call: same value to rounding
+                np.testing.assert_allclose(val, want, rtol=1e-9, atol=1e-12)
+            else:
+                np.testing.assert_array_equal(val, want)
+        np.testing.assert_array_equal(h.predict(xqs[2]), serial["p"][2])  # the fit survived (workspace 1 served the likelihoods)
