@@ -612,13 +612,15 @@ int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int
     }
     std::unique_lock<std::shared_mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
-    const int nws = (int)gp->ws.size();
+    // a fitted model keeps its factor (workspace 0) as long as another workspace exists
+    const int ws_lo = (gp->fitted && gp->ws.size() > 1) ? 1 : 0;
+    const int nws = (int)gp->ws.size() - ws_lo;
     // Software pipeline over the workspaces: every workspace has its own stream pair, so the serial panel
     // factorisations of one candidate overlap the trailing updates of the others; as soon as a candidate has
     // been read back its workspace is re-used for candidate c + nws.
-    std::vector<int> launched(nws, 0);
+    std::vector<int> launched(nws + ws_lo, 0);
     auto enqueue = [&](int64_t c) -> int {
-        const int wi = (int)(c % nws);
+        const int wi = ws_lo + (int)(c % nws);
         const double *th = thetas + c * theta_len;
         std::vector<double> coef;
         int hcols = 1;
@@ -636,7 +638,7 @@ int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int
     };
     for (int64_t c = 0; c < k && c < nws; c++) EGX_RC(enqueue(c));
     for (int64_t c = 0; c < k; c++) {
-        const int wi = (int)(c % nws);
+        const int wi = ws_lo + (int)(c % nws);
         if (launched[wi]) {
             EvalResult res;
             EGX_RC(finish_eval(gp, gp->ws[wi], res, false));

@@ -1041,3 +1041,22 @@ def test_concurrent_mixed_calls_on_one_handle(egx):
             else:
                 np.testing.assert_array_equal(val, want)
         np.testing.assert_array_equal(h.predict(xqs[2]), serial["p"][2])  # the fit survived (workspace 1 served the likelihoods)
+
+
+def test_batch_likelihood_keeps_a_fitted_model(egx):
+    """egx_gp_likelihood_batch on a fitted handle with spare workspaces pipelines over those and leaves the fit alone; with a
+    single workspace it has to take it."""
+    x, y = _data(500, 3, seed=73)
+    thetas = egx.theta_sweep_candidates(5, 3, seed=1)
+    with egx.GpHandle(x, y, corr=3, n_workspaces=3) as h:
+        h.finalize([0.9, 0.9, 0.9])
+        y0 = h.predict(x[:4])
+        lk, st = h.likelihood_batch(thetas)
+        np.testing.assert_array_equal(h.predict(x[:4]), y0)
+        lk1 = [h.likelihood(t)[0] for t in thetas]
+        np.testing.assert_array_equal(lk, lk1)
+    with egx.GpHandle(x, y, corr=3, n_workspaces=1) as h1:
+        h1.finalize([0.9, 0.9, 0.9])
+        h1.likelihood_batch(thetas)
+        with pytest.raises(egx.NotFittedError):
+            h1.predict(x[:4])
