@@ -122,11 +122,13 @@ int32_t egx_gp_dims(const egx_gp *gp, int64_t *n, int64_t *d, int64_t *p, int64_
 int32_t egx_gp_likelihood(egx_gp *gp, const double *theta, int64_t theta_len, double *lkh,
                           int32_t *status);
 /* k candidates, thetas is (k x theta_len); the multistart / theta-sweep unit of
- * algorithm.rs:928-945 (rayon par_iter over starts). */
+ * algorithm.rs:928-945 (rayon par_iter over starts).  Pipelines over the handle's workspaces; a fitted model keeps
+ * workspace 0 (and stays fitted) when n_workspaces > 1. */
 int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len,
                                 double *lkh /*k*/, int32_t *status /*k*/);
 /* NEW capability (the reference has no theta-gradient, algorithm.rs:880):
- * dL/dtheta (length h); validated by finite differences of the parity-checked likelihood. */
+ * dL/dtheta (length h); validated by finite differences of the parity-checked likelihood.
+ * Runs on workspace 0 (it needs the factor, C^-T and R^-1 at this theta): a fitted model is un-fitted by the call. */
 int32_t egx_gp_likelihood_grad(egx_gp *gp, const double *theta, int64_t theta_len, double *lkh,
                                double *dlkh_dtheta /*h*/, int32_t *status);
 
