@@ -16,6 +16,7 @@ void set_error(const std::string &msg);
         hipError_t _e = (expr);                                                          \
         if (_e != hipSuccess) {                                                          \
             ::egx::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));         \
+            (void)hipGetLastError(); /* the runtime's last error is sticky: reset it */ \
             return EGX_ERR_HIP;                                                          \
         }                                                                                \
     } while (0)

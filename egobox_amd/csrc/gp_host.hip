@@ -519,6 +519,7 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
         hipError_t _e = (expr);                                                   \
         if (_e != hipSuccess) {                                                   \
             set_error(std::string(#expr) + ": " + hipGetErrorString(_e));         \
+            (void)hipGetLastError();                                              \
             return fail(EGX_ERR_HIP);                                             \
         }                                                                         \
     } while (0)

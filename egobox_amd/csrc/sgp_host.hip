@@ -388,6 +388,7 @@ int32_t egx_sgp_create(const egx_sgp_config *cfg_in, const double *x, const doub
         hipError_t _e = (expr);                                                   \
         if (_e != hipSuccess) {                                                   \
             set_error(std::string(#expr) + ": " + hipGetErrorString(_e));         \
+            (void)hipGetLastError();                                              \
             return fail(EGX_ERR_HIP);                                             \
         }                                                                         \
     } while (0)

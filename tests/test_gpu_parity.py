@@ -1060,3 +1060,24 @@ def test_batch_likelihood_keeps_a_fitted_model(egx):
         h1.likelihood_batch(thetas)
         with pytest.raises(egx.NotFittedError):
             h1.predict(x[:4])
+
+
+def test_device_allocation_failure_is_an_error_not_a_crash(egx):
+    """n = 200 000 would need a 320 GB correlation matrix (> the 288 GB of the GPU): create fails with the HIP error
+    code and message, nothing leaks, and the library keeps working."""
+    import torch
+    n = 200_000
+    x = np.linspace(0.0, 1.0, n).reshape(-1, 1)
+    y = np.sin(x[:, 0])
+    with egx.GpHandle(x[:300], y[:300], corr=3) as h:  # first use loads code objects / runtime pools: not part of the check
+        h.likelihood([5.0])
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    with pytest.raises(egx.EgxError) as ei:
+        egx.GpHandle(x, y)
+    assert ei.value.rc == egx._lib.ERR_HIP and "hipMalloc" in str(ei.value)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) < 64 << 20
+    with egx.GpHandle(x[:300], y[:300], corr=3) as h:  # still alive
+        assert h.likelihood([5.0])[1] == 0
