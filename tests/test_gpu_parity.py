@@ -1081,3 +1081,19 @@ def test_device_allocation_failure_is_an_error_not_a_crash(egx):
     assert abs(free0 - free1) < 64 << 20
     with egx.GpHandle(x[:300], y[:300], corr=3) as h:  # still alive
         assert h.likelihood([5.0])[1] == 0
+
+
+def test_not_positive_definite_in_a_large_matrix(egx):
+    """A bad pivot deep inside a multi-group factorisation (look-ahead streams, chip-filling updates): the status channel
+    reports NOT_POSITIVE_DEFINITE, nothing hangs, and the handle evaluates a good theta right afterwards."""
+    x, y = _data(6000, 3, seed=77)
+    x = x.copy()
+    x[4321] = x[1234]  # duplicated point + negative nugget -> a negative pivot at column ~4321
+    with egx.GpHandle(x, y, corr=3, nugget=-1e-6) as h:
+        lk, st = h.likelihood([1.0, 1.0, 1.0])
+        assert st == egx._lib.STATUS_NOT_POSITIVE_DEFINITE and lk == -math.inf
+        with pytest.raises(egx.LinalgError):
+            h.finalize([1.0, 1.0, 1.0])
+    with egx.GpHandle(x, y, corr=3) as h2:  # default nugget: the duplicate is regularised
+        lk2, st2 = h2.likelihood([1.0, 1.0, 1.0])
+        assert st2 == 0 and np.isfinite(lk2)
