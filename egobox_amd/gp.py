@@ -484,11 +484,11 @@ class GpParams:
                 raise L.InvalidValueError(
                     L.ERR_INVALID_VALUE,
                     f"Dimension reduction {self._kpls_dim} should be smaller than actual training input dimensions {nx}")
-            if self._kpls_weights is None:
-                raise NotImplementedError(
-                    "KPLS rotations come from linfa-pls in the reference (out of the accelerated path); "
-                    "pass them with .kpls_weights(w_star)")
-            w = self._kpls_weights
+            if self._kpls_weights is None:  # algorithm.rs:843-855: rotations of a PLS regression of y on x
+                from .kpls import pls_rotations
+                w = pls_rotations(x, y, self._kpls_dim)
+            else:
+                w = self._kpls_weights
         nws = 1 if self._theta_tuning.kind == "Fixed" else min(self._n_workspaces, self._n_start + 1)
         h = GpHandle(x, y, mean=self._mean.code, corr=self._corr.code, nugget=self._nugget, device=self._device,
                      n_workspaces=max(1, nws), w_star=w)

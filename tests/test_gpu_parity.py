@@ -1097,3 +1097,18 @@ def test_not_positive_definite_in_a_large_matrix(egx):
     with egx.GpHandle(x, y, corr=3) as h2:  # default nugget: the duplicate is regularised
         lk2, st2 = h2.likelihood([1.0, 1.0, 1.0])
         assert st2 == 0 and np.isfinite(lk2)
+
+
+def test_reference_kpls_griewank(egx):
+    """algorithm.rs:1325-1375: KPLS (3 components of a PLS regression, now computed on the host by egobox_amd/kpls.py) on
+    Griewank in 5 dimensions, 100 training points, default tuned fit: normalised RMS error of 100 test predictions
+    below 1e-2, the reference's own bound."""
+    from egobox_amd import workload
+    xt = workload.lhs(100, 5, 42)
+    xtest = workload.lhs(100, 5, 0)
+    gp = egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr()).kpls_dim(3).fit(
+        -600.0 + 1200.0 * xt, workload.griewank(xt))
+    assert gp.theta().shape == (3,)
+    ytest, ytrue = gp.predict(-600.0 + 1200.0 * xtest), workload.griewank(xtest)
+    assert np.linalg.norm(ytrue - ytest) / np.linalg.norm(ytrue) < 1e-2
+    gp.close()

@@ -124,3 +124,19 @@ def test_griewank_known_answer(golden_dir):
     x01 = (np.array(k["x"]) + 600.0) / 1200.0
     np.testing.assert_allclose(W.griewank(x01), k["expected"], atol=k["tol"])
     np.testing.assert_allclose(O.griewank(x01), k["expected"], atol=k["tol"])
+
+
+def test_pls_rotations_match_scikit_learn_up_to_sign():
+    """egobox_amd/kpls.py restates the PLS1 regression the reference takes from linfa-pls (a port of scikit-learn's);
+    scikit-learn is only the checker here.  Column signs are a convention the kernels never see."""
+    sk = pytest.importorskip("sklearn.cross_decomposition")
+    from egobox_amd.kpls import pls_rotations
+    rng = np.random.default_rng(0)
+    x = rng.random((100, 5)) * 1200 - 600
+    i = np.arange(1, 6)
+    y = (x * x).sum(1) / 4000 - np.prod(np.cos(x / np.sqrt(i)), axis=1) + 1
+    for k in (1, 3, 5):
+        mine = pls_rotations(x, y, k)
+        ref = sk.PLSRegression(n_components=k).fit(x, y).x_rotations_
+        np.testing.assert_allclose(np.abs(mine), np.abs(ref), rtol=1e-8, atol=1e-10)
+    assert np.all(pls_rotations(x, np.full(100, 3.1), 2) == 0.0)  # constant response -> zero weights (algorithm.rs:846-850)
