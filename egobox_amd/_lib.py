@@ -80,6 +80,14 @@ SIGNATURES = [
     ("egx_cross_corr", C.c_int32, [C.c_int32, c_double_p, C.c_int64, c_double_p, C.c_int64, C.c_int64, c_double_p,
                                    c_double_p]),
     ("egx_potrf", C.c_int32, [c_double_p, C.c_int64, c_int32_p]),
+    ("egx_sweep_unique_id", C.c_int32, [C.c_void_p]),
+    ("egx_sweep_create", C.c_int32, [C.POINTER(GpConfig), c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_void_p,
+                                     C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ("egx_sweep_destroy", None, [C.c_void_p]),
+    ("egx_sweep_handle", C.c_void_p, [C.c_void_p]),
+    ("egx_sweep_info", C.c_int32, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int64_p]),
+    ("egx_sweep_likelihood", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_int32_p]),
+    ("egx_sweep_allgather", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
     ("egx_gp_last_timings", C.c_int32, [C.c_void_p, C.POINTER(Timings)]),
     ("egx_mfma_probe", C.c_int32, [c_double_p]),
     ("egx_sgp_config_default", None, [C.POINTER(SgpConfig)]),

@@ -1,6 +1,7 @@
 // Internal header shared by the dense-GP host translation units (gp_host.hip: handle, evaluation, state;
 // gp_predict.hip: predictions and their x-gradients; gp_fit.hip: optimiser drivers and the theta-gradient).
 #pragma once
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -94,7 +95,7 @@ struct egx_gp {
     std::condition_variable pool_cv;
     std::vector<char> ws_busy;
     // fitted state (lives in ws[0])
-    bool fitted = false;
+    std::atomic<bool> fitted{false};  // read by concurrent egx_gp_likelihood callers while another one clears it
     std::vector<double> theta;  // h
     double likelihood = 0.0, sigma2 = 0.0;
     std::vector<double> beta, gamma, ft, ft_qr_r;
@@ -114,6 +115,7 @@ struct egx_gp {
     int sp_nsplit = 0;
     int small_var_calls = 0;  // single-point predict_var calls since the fit: the third one builds W = C^-T
     uint64_t fit_epoch = 0, winv_epoch = ~(uint64_t)0;
+    uint64_t winv_fail_epoch = ~(uint64_t)0;  // fit for which the C^-T cache could not be built (batched path serves it)
     egx_timings timings{};
 };
 

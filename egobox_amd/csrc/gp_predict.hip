@@ -28,6 +28,8 @@ static int upload_queries(egx_gp *gp, const double *xq, int64_t m0, int m, int m
 }
 
 static int predict_var_small(egx_gp *gp, const double *xq, int64_t m, double *vout);
+static int ensure_winv(egx_gp *gp);
+static int small_path_buffers(egx_gp *gp);
 
 int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *vout) {
     if (!gp->fitted) {
@@ -39,11 +41,32 @@ int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *
         return EGX_ERR_INVALID_VALUE;
     }
     EGX_RC(set_device(gp));
-    if (vout && m > 0 && m <= 8) {  // a few points at a time: EGO's inner loop (its criteria ask for value AND variance)
+    if (vout && m > 0 && m <= 8 && gp->winv_fail_epoch != gp->fit_epoch) {
+        // a few points at a time: EGO's inner loop (its criteria ask for value AND variance).  The cached C^-T behind
+        // this path is an OPTIMISATION (a second n_pad^2 matrix): when it cannot be had -- allocation failure, or less
+        // than its size + 25 % free on the device -- the batched path below serves the call, for this fit and all later
+        // small calls on it.
         const bool have_w = gp->winv_epoch == gp->fit_epoch && gp->d_W && gp->d_neg_invkf;
         if (have_w || ++gp->small_var_calls >= 3) {
-            if (yout) EGX_RC(predict_impl(gp, xq, m, yout, nullptr));  // split-range mean kernel
-            return predict_var_small(gp, xq, m, vout);
+            int rc = EGX_SUCCESS;
+            if (!have_w && !gp->d_W) {
+                size_t fr = 0, tot = 0;
+                const size_t need = sizeof(double) * (size_t)gp->n_pad * gp->n_pad;
+                if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < need + need / 4) rc = EGX_ERR_HIP;
+            }
+            if (rc == EGX_SUCCESS) rc = ensure_winv(gp);
+            if (rc == EGX_SUCCESS) rc = small_path_buffers(gp);
+            if (rc == EGX_SUCCESS) {
+                if (yout) EGX_RC(predict_impl(gp, xq, m, yout, nullptr));  // split-range mean kernel
+                return predict_var_small(gp, xq, m, vout);
+            }
+            (void)hipGetLastError();
+            if (gp->winv_epoch != gp->fit_epoch) {  // give a half-built cache back
+                if (gp->d_W) (void)hipFree(gp->d_W);
+                if (gp->d_neg_invkf) (void)hipFree(gp->d_neg_invkf);
+                gp->d_W = gp->d_neg_invkf = nullptr;
+            }
+            gp->winv_fail_epoch = gp->fit_epoch;
         }
     }
     Workspace &w = gp->ws[0];

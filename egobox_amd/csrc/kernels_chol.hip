@@ -253,8 +253,11 @@ using SmallShape = GemmShape<64, 64, 32, 32, 256>;    // 4x lower per-tile laten
 template <bool LOWER, int BM, int BN, int WM, int WN, int NTHREADS, bool SWZ, bool PIPE = false>
 __global__ __launch_bounds__(NTHREADS, (WM * WN > 2048 ? 2 : (NTHREADS == 512 ? 4 : 2))) void k_gemm_nt_sub(
     double *__restrict__ C, int64_t ldc, const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
-    int64_t ldb, int K, int nbx, int nby, int ktri) {
+    int64_t ldb, int K, int nbx, int nby, int ktri, const int *__restrict__ info) {
     using S = GemmShape<BM, BN, WM, WN, NTHREADS>;
+    // a failed pivot anywhere earlier in this factorisation (algorithm.rs:893-896: the candidate is +inf): nothing
+    // left to compute, every later kernel of the factorisation returns at once
+    if (info != nullptr && *info != 0) return;
     // XCD-aware tile order (SWZ).  Workgroup w lands on XCD w % 8 (observed dispatch order, used for speed only,
     // never for correctness).  Tiles are grouped in 8x8 super-tiles; super-tile ST goes to XCD ST % 8 and its 64
     // tiles are the 64 workgroups resident on that XCD (2 per CU), which then share 8 A and 8 B panel blocks
@@ -363,8 +366,10 @@ using PanelShape = GemmShape<64, 64, 16, 64>;
 
 __global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, int64_t ldp,
                                                        const double *__restrict__ L, int64_t ldl,
-                                                       const double *__restrict__ dinv, int nbk) {
+                                                       const double *__restrict__ dinv, int nbk,
+                                                       const int *__restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (info != nullptr && *info != 0) return;  // failed pivot earlier: early exit (see k_gemm_nt_sub)
     __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double *Pw = P + (int64_t)blockIdx.x * 64 * ldp;  // this workgroup's 64 rows
@@ -615,6 +620,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_potf2_block(double *__restrict
                                                               int col0, int n_valid) {
     constexpr int NW = NT / 64;
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    if (*info != 0) return;  // a previous block of this factorisation already failed: early exit
     __builtin_amdgcn_s_setprio(3);   // on the look-ahead stream this workgroup shares its CU with trailing-update waves
     double *Ls = sm;                 // current diagonal tile / its factor, [64][65]
     double *cb = sm + TS * TLD;      // 2 x 64 broadcast lines
@@ -904,7 +910,8 @@ int chol_init() {
 // Tile shape: 128x128 (64x64 per wave) when the launch fills the chip, 64x64 (32x32 per wave) otherwise: a
 // 128x128xK tile is one wave-chain of K/4*16 MFMAs (~43 us at K = 256), so small grids are latency bound.
 int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
-                       const double *B, int64_t ldb, int M, int N, int K, int lower, int ktri, bool *used_big_tile) {
+                       const double *B, int64_t ldb, int M, int N, int K, int lower, int ktri, bool *used_big_tile,
+                       const int *info) {
     if (used_big_tile) *used_big_tile = false;
     if (M <= 0 || N <= 0 || K <= 0) return EGX_SUCCESS;
     if (M % 128 || N % 128 || K % KC) {
@@ -930,7 +937,7 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         const dim3 g1((unsigned)wide_tiles), g2(M / 128, N / 256);
 #define EGX_WIDE(LOW, PIPE, GRID, FLAG)                                                                             \
     hipLaunchKernelGGL((k_gemm_nt_sub<LOW, 128, 256, 64, 64, 512, false, PIPE>), GRID, dim3(512), WideShape::LDS_BYTES, s, \
-                       C, ldc, A, lda, B, ldb, K, nbx, nby, FLAG)
+                       C, ldc, A, lda, B, ldb, K, nbx, nby, FLAG, info)
         if (lower && g_gemm_pipe) EGX_WIDE(true, true, g1, 2);
         else if (lower) EGX_WIDE(true, false, g1, 2);
         else if (g_gemm_pipe) EGX_WIDE(false, true, g2, 0);
@@ -943,10 +950,10 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         dim3 grid(M / 64, N / 64);
         if (lower)
             hipLaunchKernelGGL((k_gemm_nt_sub<true, 64, 64, 32, 32, 256, false>), grid, dim3(256), SmallShape::LDS_BYTES, s,
-                               C, ldc, A, lda, B, ldb, K, M / 64, N / 64, ktri);
+                               C, ldc, A, lda, B, ldb, K, M / 64, N / 64, ktri, info);
         else
             hipLaunchKernelGGL((k_gemm_nt_sub<false, 64, 64, 32, 32, 256, false>), grid, dim3(256), SmallShape::LDS_BYTES,
-                               s, C, ldc, A, lda, B, ldb, K, M / 64, N / 64, ktri);
+                               s, C, ldc, A, lda, B, ldb, K, M / 64, N / 64, ktri, info);
     } else {
         const int nbx = M / 128, nby = N / 128;
         const int nsx = (nbx + 7) / 8, nsy = (nby + 7) / 8;
@@ -962,10 +969,10 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         dim3 grid(8 * per_xcd * 64);
         if (lower)
             hipLaunchKernelGGL((k_gemm_nt_sub<true, 128, 128, 32, 64, 512, true>), grid, dim3(512), TrailShape::LDS_BYTES, s,
-                               C, ldc, A, lda, B, ldb, K, nbx, nby, ktri);
+                               C, ldc, A, lda, B, ldb, K, nbx, nby, ktri, info);
         else
             hipLaunchKernelGGL((k_gemm_nt_sub<false, 128, 128, 32, 64, 512, true>), grid, dim3(512), TrailShape::LDS_BYTES,
-                               s, C, ldc, A, lda, B, ldb, K, nbx, nby, ktri);
+                               s, C, ldc, A, lda, B, ldb, K, nbx, nby, ktri, info);
     }
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
@@ -1028,7 +1035,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         if (below > 0)
             hipLaunchKernelGGL(k_panel_trsm, dim3(below / 64), dim3(256), PanelShape::LDS_BYTES, st,
                                M + (int64_t)(k0 + nbk) * ld + k0, ld, (const double *)diag, ld,
-                               (const double *)dtiles, nbk);
+                               (const double *)dtiles, nbk, (const int *)info);
     };
     // Two-level blocking: kNB-wide panels are factored inside a group of `g_potrf_group` panels (right-looking within
     // the group's columns), the trailing matrix is then updated once per GROUP with K = group width.  The C tile
@@ -1044,7 +1051,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             if (r1 < g0 + gw) {
                 const double *pan = M + (int64_t)r1 * ld + k0;
                 int rc2 = launch_gemm_nt_sub(st, M + (int64_t)r1 * ld + r1, ld, pan, ld, pan, ld, m_tot - r1, g0 + gw - r1,
-                                             nbk, 1, 0);
+                                             nbk, 1, 0, nullptr, info);
                 if (rc2) return rc2;
             }
         }
@@ -1061,7 +1068,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         const bool look = (s2 != nullptr) && (n_pad - r1 - gw1 >= 3072);
         const double *pan = M + (int64_t)r1 * ld + g0;
         // LU: the next group's columns only
-        rc = launch_gemm_nt_sub(s, M + (int64_t)r1 * ld + r1, ld, pan, ld, pan, ld, m_tot - r1, gw1, gw, 1, 0);
+        rc = launch_gemm_nt_sub(s, M + (int64_t)r1 * ld + r1, ld, pan, ld, pan, ld, m_tot - r1, gw1, gw, 1, 0, nullptr, info);
         if (rc) return rc;
         if (look) {
             EGX_HIP_CHECK(hipEventRecord(ev_lu, s));
@@ -1078,7 +1085,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             if (timed) EGX_HIP_CHECK(hipEventRecord(trace->e0[trace->used], s));
             bool big = false;
             rc = launch_gemm_nt_sub(s, M + (int64_t)r2 * ld + r2, ld, pan2, ld, pan2, ld, m_tot - r2, n_pad - r2, gw, 1,
-                                    0, &big);
+                                    0, &big, info);
             if (rc) return rc;
             if (timed && big) {
                 EGX_HIP_CHECK(hipEventRecord(trace->e1[trace->used], s));
@@ -1120,7 +1127,7 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
             // rows below the current block are still zero in these columns and are skipped
             const int m_eff = tri_rows ? ((k0 + nbk < m) ? (k0 + nbk) : m) : m;
             hipLaunchKernelGGL(k_panel_trsm, dim3(m_eff / 64), dim3(256), PanelShape::LDS_BYTES, s, RT + k0, ldr, diag,
-                               ldm, dtiles, nbk);
+                               ldm, dtiles, nbk, (const int *)nullptr);
             const int ncols = gend - (k0 + nbk);
             if (ncols > 0) {
                 rc = launch_gemm_nt_sub(s, RT + (k0 + nbk), ldr, RT + k0, ldr, M + (int64_t)(k0 + nbk) * ldm + k0, ldm,

@@ -75,7 +75,10 @@ inline NmResult nelder_mead(F &&fn, const std::vector<double> &x0, const std::ve
         } else if (fr < sf[sw]) {
             sx[wv] = xr; sf[wv] = fr;
         } else {
-            if (evals >= maxeval) break;
+            if (evals >= maxeval) {  // budget exhausted: keep the reflection if it improved on the worst vertex
+                if (fr < sf[wv]) { sx[wv] = xr; sf[wv] = fr; }
+                break;
+            }
             std::vector<double> xc = along(fr < sf[wv] ? -0.5 : 0.5);
             const double fc = fn(xc);
             evals++;

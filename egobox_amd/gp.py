@@ -589,7 +589,7 @@ class GaussianProcess:
         return (self._h.d, 1)
 
     def kpls_dim(self):
-        return self._h.h if self._h.h < self._h.d else None
+        return self._h.h if self._h._w is not None else None
 
     @property
     def training_data(self):

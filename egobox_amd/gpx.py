@@ -98,8 +98,8 @@ class GpMix:
         else:
             n_start = self.n_start
         params.theta_tuning(tuning).n_start(n_start).kpls_dim(self.kpls_dim)
-        if self.seed is not None:
-            params._seed = int(self.seed)
+        # `seed` feeds the mixture's clustering rng only (python/src/gp_mix.rs:177-181); the GP multistart LHS is always
+        # seeded with 42 (crates/gp/src/optimization.rs:62), so params._seed keeps its default
         return Gpx([params.fit(xt, yt)], self)
 
 
@@ -167,6 +167,8 @@ class Gpx:
         tuning = {t.kind: {"init": _nd(t.init)}} if t.kind != "Fixed" else {"Fixed": _nd(t.init)}
         if t.kind != "Fixed":
             tuning[t.kind]["bounds"] = {"v": 1, "dim": [len(t.bounds)], "data": [list(b) for b in t.bounds]}
+        if t.kind == "Partial":  # ThetaTuning::Partial { init, bounds, active } (crates/gp/src/parameters.rs:24-32)
+            tuning[t.kind]["active"] = [int(a) for a in t.active]
         m = _SURROGATE_NAME[str(e.params_._mean)]
         c = _SURROGATE_NAME[str(e.params_._corr)]
         return {
@@ -218,7 +220,9 @@ class Gpx:
             w = _from_nd(e["w_star"])
             theta = _from_nd(e["theta"])
             params = G.GpParams(mean, corr).nugget(p["nugget"]).theta_tuning(G.ThetaTuning.Fixed(theta))
-            if w.shape[0] != w.shape[1]:
+            # KPLS is decided from the DATA: kpls_dim == nx gives a square, non-identity rotation (the reference only
+            # rejects kpls_dim > nx, algorithm.rs:798-807), and r_chol / gamma were computed with the rotated kernel
+            if p.get("kpls_dim") is not None or not np.array_equal(w, np.eye(w.shape[0], w.shape[1])):
                 params.kpls_weights(w)
             if refit:
                 experts.append(params.fit(x, y))

@@ -58,6 +58,104 @@ def sweep_likelihood(evaluate, thetas, rank=None, world=None, device=None):
     return lkh, status
 
 
+class Sweep:
+    """`egx_sweep*` of include/egx_gp.h: this rank's replica of the training set + the RCCL communicator.
+
+    The collective lives INSIDE libegx_gp_hip.so (ncclAllGather on the library's own stream); this class only
+    moves the 128-byte unique id between the ranks.  `id_bytes`: None builds no communicator (world must be 1),
+    "new" asks the library for a fresh id (rank 0), bytes = the id received from rank 0.
+    """
+
+    def __init__(self, x, y, mean=0, corr=0, nugget=None, device=-1, rank=0, world=1, id_bytes=None, n_workspaces=2):
+        import ctypes as C
+        from . import _lib as L
+        lib = L.load()
+        self._lib, self._C, self._L = lib, C, L
+        x = L.as_f64(x, 2)
+        y = L.as_f64(np.asarray(y).reshape(-1), 1)
+        cfg = L.GpConfig()
+        lib.egx_gp_config_default(C.byref(cfg))
+        cfg.corr, cfg.mean, cfg.device, cfg.n_workspaces = int(corr), int(mean), int(device), int(n_workspaces)
+        if nugget is not None:
+            cfg.nugget = float(nugget)
+        if isinstance(id_bytes, str) and id_bytes == "new":
+            id_bytes = self.unique_id()
+        self.id_bytes = id_bytes
+        idbuf = None
+        if id_bytes is not None:
+            if len(id_bytes) != 128:
+                raise L.InvalidValueError(L.ERR_INVALID_VALUE, "the RCCL unique id has 128 bytes")
+            idbuf = C.create_string_buffer(bytes(id_bytes), 128)
+        self._h = C.c_void_p()
+        L.check(lib.egx_sweep_create(C.byref(cfg), L.dptr(x), L.dptr(y), x.shape[0], x.shape[1],
+                                     C.cast(idbuf, C.c_void_p) if idbuf is not None else None, int(rank), int(world),
+                                     C.byref(self._h)))
+        self.rank, self.world, self.d = int(rank), int(world), x.shape[1]
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _lib as L
+        buf = C.create_string_buffer(128)
+        L.check(L.load().egx_sweep_unique_id(C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def info(self):
+        C = self._C
+        r, w, rr, v, na = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        self._L.check(self._lib.egx_sweep_info(self._h, C.byref(r), C.byref(w), C.byref(rr), C.byref(v), C.byref(na)))
+        return {"rank": r.value, "world": w.value, "rccl_ranks": rr.value, "rccl_version": v.value,
+                "n_allgathers": na.value}
+
+    def likelihood(self, thetas):
+        """COLLECTIVE: (k x h) candidates -> (lkh (k,), status (k,)), complete on every rank."""
+        L = self._L
+        thetas = L.as_f64(thetas, 2)
+        k = thetas.shape[0]
+        lk = np.empty(k)
+        st = np.empty(k, dtype=np.int32)
+        L.check(self._lib.egx_sweep_likelihood(self._h, L.dptr(thetas), k, thetas.shape[1], L.dptr(lk),
+                                               st.ctypes.data_as(L.c_int32_p)))
+        return lk, st
+
+    def allgather(self, v):
+        """COLLECTIVE: (count,) doubles per rank -> (world, count)."""
+        L = self._L
+        v = L.as_f64(np.asarray(v).reshape(-1), 1)
+        out = np.empty((self.world, v.size))
+        L.check(self._lib.egx_sweep_allgather(self._h, L.dptr(v), v.size, L.dptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.egx_sweep_destroy(self._h)
+            self._h = self._C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def rendezvous_sweep(x, y, device, **kw):
+    """One `Sweep` per rank of the default torch.distributed group: rank 0 draws the RCCL unique id, the group's
+    store-backed object broadcast carries its 128 bytes to the other ranks (the only thing torch does here)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return Sweep(x, y, device=device, rank=0, world=1, id_bytes="new", **kw)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [Sweep.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return Sweep(x, y, device=device, rank=rank, world=world, id_bytes=box[0], **kw)
+
+
 def best_candidate(lkh, status):
     """arg-max of the likelihood over candidates that evaluated cleanly (the reduce of algorithm.rs:942-945)."""
     lkh = np.asarray(lkh)

@@ -220,6 +220,40 @@ int32_t egx_cross_corr(int32_t corr, const double *xq_norm, int64_t m, const dou
  * zeroed).  *info = 0, or 1-based index of the first non-positive pivot. */
 int32_t egx_potrf(double *a, int64_t n, int32_t *info);
 
+/* ==== multi-GPU theta sweep (BASELINE config 4) ================================
+ * Replaces the rayon multistart of crates/gp/src/algorithm.rs:928-945 (independent likelihood evaluations, one
+ * per start, arg-min reduce :942-945) and the serial expert loop of crates/moe/src/algorithm.rs:167-177 at node
+ * scale: ONE PROCESS PER GPU, the training set replicated on every rank (4 MiB at n = 16384, d = 32), candidate
+ * k evaluated by rank k mod world through egx_gp_likelihood_batch, and one RCCL all-gather (ncclAllGather over xGMI)
+ * of {likelihood f64, status} -- 16 B per candidate -- so that every rank returns the full (k) result.
+ * RCCL (librccl.so.1) is bound at run time on the first egx_sweep_* call; a single-GPU user never loads it.
+ *
+ * Rendezvous: rank 0 calls egx_sweep_unique_id and hands the EGX_SWEEP_ID_BYTES bytes to the other ranks by any
+ * out-of-band channel (MPI_Bcast, a file, torch.distributed's store ...); all ranks then call egx_sweep_create
+ * collectively.  world == 1 with nccl_id == NULL needs no RCCL at all; world == 1 WITH an id builds a one-rank
+ * communicator (the same code path as world > 1). */
+#define EGX_SWEEP_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+typedef struct egx_sweep egx_sweep;
+int32_t egx_sweep_unique_id(void *id_out /*EGX_SWEEP_ID_BYTES*/);
+/* cfg / x / y / n / d as egx_gp_create (cfg->device selects this rank's GPU; n_workspaces is raised to 2). */
+int32_t egx_sweep_create(const egx_gp_config *cfg, const double *x, const double *y, int64_t n, int64_t d,
+                         const void *nccl_id /*EGX_SWEEP_ID_BYTES or NULL*/, int32_t rank, int32_t world,
+                         egx_sweep **out);
+void egx_sweep_destroy(egx_sweep *sw);
+/* this rank's GP handle (owned by the sweep): finalize / predict with the winning theta on it */
+egx_gp *egx_sweep_handle(egx_sweep *sw);
+/* rccl_ranks = ranks of the RCCL communicator (0 when none was built), rccl_version = ncclGetVersion code */
+int32_t egx_sweep_info(const egx_sweep *sw, int32_t *rank, int32_t *world, int32_t *rccl_ranks, int32_t *rccl_version,
+                       int64_t *n_allgathers);
+/* COLLECTIVE: every rank passes the same thetas (k x theta_len); lkh / status (k) are complete on every rank.
+ * Semantics per candidate as egx_gp_likelihood_batch (status is the value channel, failures are not errors). */
+int32_t egx_sweep_likelihood(egx_sweep *sw, const double *thetas, int64_t k, int64_t theta_len, double *lkh /*k*/,
+                             int32_t *status /*k*/);
+/* COLLECTIVE helper for the mixture-of-experts path (expert e on rank e mod world): recv (world x count) <- the
+ * concatenation over ranks of send (count), e.g. per-expert mean / variance vectors before the recombination of
+ * crates/moe/src/algorithm.rs:670-685. */
+int32_t egx_sweep_allgather(egx_sweep *sw, const double *send, int64_t count, double *recv /*world*count*/);
+
 /* ---- measurement ------------------------------------------------------------
  * HIP-event durations (ms) of the stages of the most recent likelihood /
  * finalize call on workspace 0, measured on the stream the kernels ran on. */

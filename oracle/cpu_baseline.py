@@ -1,0 +1,124 @@
+"""TEST INFRASTRUCTURE ONLY: the "blas-feature-shaped" CPU baseline of SURVEY 8d (ii), MEASURED at full size.
+
+One fixed-theta fit of the BASELINE workload (classic LHS + Griewank, squared exponential, constant mean) on the
+host cores, in the shape the reference takes with its `blas` cargo feature (crates/gp/Cargo.toml:20):
+
+  correlation build   oracle/blas_shaped.c, OpenMP over rows, all cores (utils.rs:80-104 + correlation_models.rs
+                      value + the scatter of algorithm.rs:997-1001, fused -- the most favourable CPU form)
+  cholesky            LAPACK dpotrf through scipy (algorithm.rs:1077), OpenBLAS threads pinned and printed
+  solves + scalar     dtrtrs for F and y, GLS for the constant trend, likelihood (algorithm.rs:1080-1115, 1037-1043)
+
+Run as its own process (`python -m oracle.cpu_baseline --n 16384 --d 32`) so that no other threadpool (torch's
+OpenMP, a second OpenBLAS) competes with LAPACK: bench.py's cpu_baseline leg does exactly that and parses the one
+JSON line this prints.  Never imported by the product.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "lib", "libblas_shaped.so")
+
+
+def _corr_lib():
+    lib = C.CDLL(LIB)
+    dp = C.POINTER(C.c_double)
+    lib.blas_shaped_corr_matrix.restype = C.c_int
+    lib.blas_shaped_corr_matrix.argtypes = [C.c_int, dp, C.c_int64, C.c_int64, dp, C.c_double, dp]
+    lib.blas_shaped_threads.restype = C.c_int
+    return lib
+
+
+def corr_matrix(kind, xn, theta, nugget):
+    """(n x n) correlation matrix, both triangles, by the threaded C restatement (kind 0..3)."""
+    lib = _corr_lib()
+    xn = np.ascontiguousarray(xn, dtype=np.float64)
+    theta = np.ascontiguousarray(theta, dtype=np.float64)
+    n, d = xn.shape
+    r = np.empty((n, n))
+    dp = C.POINTER(C.c_double)
+    rc = lib.blas_shaped_corr_matrix(int(kind), xn.ctypes.data_as(dp), n, d, theta.ctypes.data_as(dp), float(nugget),
+                                     r.ctypes.data_as(dp))
+    if rc:
+        raise RuntimeError(f"blas_shaped_corr_matrix failed: {rc}")
+    return r
+
+
+def measure(n, d, seed=42, blas_threads=None):
+    from scipy.linalg import lapack
+    from threadpoolctl import threadpool_info, threadpool_limits
+    sys.path.insert(0, os.path.dirname(_HERE))
+    from oracle import gp_oracle as O
+    if blas_threads:
+        threadpool_limits(limits=int(blas_threads), user_api="blas")
+    x = O.lhs_classic(n, d, seed)
+    y = O.griewank(x)
+    theta = np.full(d, 0.5 / math.sqrt(d))
+    _, _, xn, _, _, yn, _, ys, fx = O.prepare_training(x, y)
+    t0 = time.perf_counter()
+    r = corr_matrix(0, xn, theta, O.DEFAULT_NUGGET)
+    t1 = time.perf_counter()
+    # r is symmetric: its C-order buffer read as Fortran order is the same matrix, so dpotrf works in place
+    c, info = lapack.dpotrf(r.T, lower=1, overwrite_a=1, clean=0)
+    t2 = time.perf_counter()
+    if info != 0:
+        raise RuntimeError(f"dpotrf info {info}")
+    rhs = np.asfortranarray(np.hstack([fx, yn]))
+    sol, info = lapack.dtrtrs(c, rhs, lower=1, trans=0, unitdiag=0, overwrite_b=1)
+    ft, yt = sol[:, :-1], sol[:, -1:]
+    beta = np.linalg.lstsq(ft, yt, rcond=None)[0]
+    rho = yt - ft @ beta
+    sigma2 = float((rho * rho).sum() / n)
+    logdet = float(np.log10(np.diag(c)).sum() * 2.0 / n)
+    lkh = -n * (math.log10(sigma2) + logdet)
+    gamma, info = lapack.dtrtrs(c, np.asfortranarray(rho), lower=1, trans=1, unitdiag=0)
+    t3 = time.perf_counter()
+    pools = threadpool_info()
+    blas = [p for p in pools if p.get("user_api") == "blas"]
+    lib = _corr_lib()
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count()
+    t_fit = t3 - t0
+    return {
+        "value": 1.0 / t_fit, "unit": "fits/s", "kind": "port",
+        "cores": int(max([p["num_threads"] for p in blas] + [lib.blas_shaped_threads()])),
+        "sample": (f"n={n} d={d} measured at full size: one fixed-theta fit, blas-feature shape: OpenMP correlation "
+                   f"build {t1 - t0:.3f}s ({lib.blas_shaped_threads()} threads) + LAPACK dpotrf {t2 - t1:.3f}s "
+                   f"({n ** 3 / 3 / (t2 - t1) / 1e9:.0f} GFLOP/s, OpenBLAS {blas[-1]['version'] if blas else '?'} "
+                   f"{max([p['num_threads'] for p in blas] + [0])} threads) + solves/likelihood {t3 - t2:.3f}s "
+                   f"= {t_fit:.3f}s per fit"),
+        "seconds": {"corr_build": t1 - t0, "dpotrf": t2 - t1, "solves_likelihood": t3 - t2, "fit": t_fit},
+        "dpotrf_gflops": n ** 3 / 3 / (t2 - t1) / 1e9,
+        "threads": {"openmp_corr_build": lib.blas_shaped_threads(),
+                    "blas": [{k: p.get(k) for k in ("internal_api", "version", "num_threads", "threading_layer")}
+                             for p in blas],
+                    "os_cpu_count": os.cpu_count(), "sched_affinity": affinity},
+        "likelihood": lkh, "n": n, "d": d,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--d", type=int, default=32)
+    ap.add_argument("--blas-threads", type=int, default=0)
+    ap.add_argument("--reps", type=int, default=1, help="best of this many repetitions")
+    args = ap.parse_args()
+    best = None
+    for _ in range(max(1, args.reps)):
+        m = measure(args.n, args.d, blas_threads=args.blas_threads)
+        if best is None or m["value"] > best["value"]:
+            best = m
+    print(json.dumps(best), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Oracle fixtures at the BASELINE.json configuration sizes (run in the BUILD container, CPU only).
+
+The numpy/scipy oracle (`oracle/gp_oracle.py`, pinned to the reference's golden vectors by
+tests/test_oracle_golden.py) needs ~100 s per likelihood at n = 16384 on 8 cores, too slow for the
+`-m gpu` test budget, so its outputs at the headline sizes are committed as DATA:
+
+  fit_n16384_d32_<corr>   config 3 / metric line: likelihood, sigma2, beta + 1000 predictions and variances
+                          (sq-exp and Matern-5/2, seed 42, theta = 0.5/sqrt(d))
+  grad_n4096_d32_<corr>   theta-gradient of the likelihood (oracle closed form), the largest n whose
+                          (pairs, d) table fits comfortably
+  sweep_n16384_d32        config 4: likelihood + status for 28 rows of theta_sweep_candidates(512, 32)
+                          (row 0, the first 13 LHS rows, the 14 rows with the smallest sum theta^2) and 3
+                          extra lower-bound rows that exercise the not-positive-definite status
+  expert_n8192_d16        config 5: one expert (seed 7) with 1000 predict / predict_var points
+
+Inputs are regenerated in the tests from the same seeds (oracle.lhs_classic / griewank ==
+egobox_amd.workload), so only thetas, scalars and the prediction vectors are stored.
+
+    python tests/golden/make_large_n.py [--only fit|grad|sweep|expert] [--out tests/golden/large_n.json]
+
+Parts are merged into an existing output file, so the script can be run piecewise.
+"""
+import argparse
+import importlib.util
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import gp_oracle as O  # noqa: E402
+
+
+def _multistart():
+    # the pure-numpy candidate generator of the product, loaded WITHOUT importing the package (no .so needed)
+    spec = importlib.util.spec_from_file_location("egx_multistart", os.path.join(ROOT, "egobox_amd", "multistart.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def queries(m, d, seed):
+    return np.random.default_rng(seed).random((m, d))
+
+
+def part_fit(out):
+    n, d = 16384, 32
+    x = O.lhs_classic(n, d, 42)
+    y = O.griewank(x)
+    theta = np.full(d, 0.5 / math.sqrt(d))
+    xq = queries(1000, d, 7)
+    # 200 of the queries sit on / next to training points (variance -> 0, the clamp region)
+    xq[:100] = x[:100]
+    xq[100:200] = x[100:200] + 1e-4
+    for corr in (O.SQEXP, O.MATERN52):
+        t0 = time.time()
+        gp = O.fit_fixed(x, y, theta, O.CONSTANT, corr)
+        diag = np.diag(gp.inner.r_chol)
+        rec = {
+            "n": n, "d": d, "seed": 42, "corr": corr, "mean": O.CONSTANT, "theta": theta.tolist(),
+            "likelihood": gp.likelihood, "sigma2": gp.inner.sigma2, "beta": gp.inner.beta[:, 0].tolist(),
+            "min_pivot": float(diag.min()), "gamma_head": gp.inner.gamma[:8, 0].tolist(),
+            "gamma_norm": float(np.linalg.norm(gp.inner.gamma)),
+            "query_seed": 7, "query_note": "rows 0..99 = x[0..99], rows 100..199 = x[100..199] + 1e-4, rest uniform",
+            "predict": gp.predict(xq).tolist(), "predict_var": gp.predict_var(xq).tolist(),
+        }
+        out[f"fit_n{n}_d{d}_{corr}"] = rec
+        print(f"fit {corr}: lkh {gp.likelihood!r} min pivot {diag.min():.3e} ({time.time() - t0:.0f}s)", flush=True)
+        del gp
+
+
+def part_grad(out):
+    n, d = 4096, 32
+    x = O.lhs_classic(n, d, 42)
+    y = O.griewank(x)
+    theta = np.full(d, 0.5 / math.sqrt(d)) * (1.0 + 0.3 * np.sin(np.arange(d)))
+    for corr in (O.SQEXP, O.MATERN52):
+        t0 = time.time()
+        lk, g = O.likelihood_grad(x, y, theta, O.CONSTANT, corr)
+        out[f"grad_n{n}_d{d}_{corr}"] = {"n": n, "d": d, "seed": 42, "corr": corr, "theta": theta.tolist(),
+                                          "likelihood": lk, "grad": g.tolist()}
+        print(f"grad {corr}: lkh {lk!r} |g| {np.linalg.norm(g):.6e} ({time.time() - t0:.0f}s)", flush=True)
+
+
+def part_sweep(out):
+    n, d = 16384, 32
+    x = O.lhs_classic(n, d, 42)
+    y = O.griewank(x)
+    cands = _multistart().theta_sweep_candidates(512, d)
+    order = np.argsort((cands ** 2).sum(axis=1))
+    rows = list(range(14))
+    rows += [int(r) for r in order if int(r) not in rows][:14]
+    extra = [np.full(d, v) for v in (0.01, 0.02, 0.03)]
+    key = f"sweep_n{n}_d{d}"
+    rec = out.get(key) or {"n": n, "d": d, "seed": 42, "corr": O.SQEXP, "candidates": "theta_sweep_candidates(512, 32)",
+                           "rows": rows, "thetas": [cands[r].tolist() for r in rows] + [e.tolist() for e in extra],
+                           "extra_rows_note": "last 3 thetas = all 0.01 / 0.02 / 0.03 (lower bound corner, NOT in the "
+                                              "512-row list): the status channel at size",
+                           "likelihood": [], "status": []}
+    thetas = np.array(rec["thetas"])
+    for i in range(len(rec["likelihood"]), len(thetas)):
+        t0 = time.time()
+        lk, st = O.likelihood_at(x, y, thetas[i], O.CONSTANT, O.SQEXP)
+        rec["likelihood"].append(lk if math.isfinite(lk) else None)
+        rec["status"].append(int(st))
+        out[key] = rec
+        print(f"sweep {i + 1}/{len(thetas)}: status {st} lkh {lk!r} ({time.time() - t0:.0f}s)", flush=True)
+        yield  # checkpoint after every candidate
+
+
+def part_expert(out):
+    n, d = 8192, 16
+    x = O.lhs_classic(n, d, 7)
+    y = O.griewank(x)
+    theta = np.full(d, 0.5 / math.sqrt(d))
+    xq = queries(100000, d, 7)[:1000]  # the first 1000 rows of config 5's 100 000 query points
+    t0 = time.time()
+    gp = O.fit_fixed(x, y, theta, O.CONSTANT, O.SQEXP)
+    out[f"expert_n{n}_d{d}"] = {
+        "n": n, "d": d, "seed": 7, "corr": O.SQEXP, "theta": theta.tolist(), "likelihood": gp.likelihood,
+        "sigma2": gp.inner.sigma2, "min_pivot": float(np.diag(gp.inner.r_chol).min()),
+        "query": "np.random.default_rng(7).random((100000, 16))[:1000]",
+        "predict": gp.predict(xq).tolist(), "predict_var": gp.predict_var(xq).tolist()}
+    print(f"expert: lkh {gp.likelihood!r} ({time.time() - t0:.0f}s)", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "large_n.json"))
+    args = ap.parse_args()
+    out = {}
+    if os.path.exists(args.out):
+        with open(args.out) as f:
+            out = json.load(f)
+
+    def save():
+        out["_generated_by"] = "tests/golden/make_large_n.py (oracle/gp_oracle.py, numpy %s)" % np.__version__
+        tmp = args.out + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(out, f)
+        os.replace(tmp, args.out)
+
+    want = lambda p: args.only in ("", p)  # noqa: E731
+    if want("expert"):
+        part_expert(out)
+        save()
+    if want("grad"):
+        part_grad(out)
+        save()
+    if want("fit"):
+        part_fit(out)
+        save()
+    if want("sweep"):
+        for _ in part_sweep(out):
+            save()
+        save()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,269 @@
+"""Every BASELINE.json configuration at its stated size, against the oracle.
+
+The numpy/scipy oracle needs ~100 s per likelihood at n = 16384, so its outputs at the headline sizes are committed
+as data (tests/golden/large_n.json, generated in the build container by tests/golden/make_large_n.py from
+oracle/gp_oracle.py, which tests/test_oracle_golden.py pins to the reference's golden vectors).  Inputs are
+regenerated here from the same seeds.  Bars: 1e-8 relative on the log-likelihood, 1e-6 relative on predictions
+(absolute floor where the reference clamps variances at 0, crates/gp/src/algorithm.rs:278).
+
+  config 2   n = 4096,  d = 8,  sq-exp: the well-posed straight-1e-8 case (oracle run in the test)
+  config 3   n = 16384, d = 32, sq-exp and Matern-5/2: likelihood, sigma2, beta, 1000 predictions/variances (fixture);
+             theta-gradient at n = 4096 (fixture) and at n = 16384 (two directional central differences)
+  config 4   theta sweep at n = 16384: likelihood_batch and the C-ABI sweep (RCCL communicator) on 31 candidates
+             incl. not-positive-definite ones; early exit of the failed candidates
+  config 5   8 experts x n = 8192, d = 16, predict_var on m = 100 000 points, smooth and hard recombination
+"""
+import json
+import math
+import os
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LK_RTOL = 1e-8
+PRED_RTOL = 1e-6
+KCODE = {"SquaredExponential": 0, "AbsoluteExponential": 1, "Matern32": 2, "Matern52": 3}
+
+
+@pytest.fixture(scope="module")
+def egx():
+    import egobox_amd
+    return egobox_amd
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import gp_oracle
+    return gp_oracle
+
+
+@pytest.fixture(scope="module")
+def large(golden_dir):
+    with open(os.path.join(golden_dir, "large_n.json")) as f:
+        return json.load(f)
+
+
+def _data(n, d, seed):
+    from egobox_amd import workload
+    return workload.make_training_set(n, d, seed=seed)
+
+
+def _fit_queries(x, d):
+    xq = np.random.default_rng(7).random((1000, d))
+    xq[:100] = x[:100]
+    xq[100:200] = x[100:200] + 1e-4
+    return xq
+
+
+# ------------------------------------------------------------------ config 2
+def test_config2_n4096_d8_sqexp_well_posed_straight_bar(egx, O):
+    """BASELINE configs[1] shape at a theta where the problem is well posed (oracle min pivot >> sqrt(nugget)): the
+    straight 1e-8 / 1e-6 bars, no self-disagreement allowance."""
+    n, d = 4096, 8
+    x, y = _data(n, d, 42)
+    theta = np.full(d, 2.0)
+    ref = O.fit_fixed(x, y, theta, corr=O.SQEXP)
+    assert np.diag(ref.inner.r_chol).min() > 1e-3
+    with egx.GpHandle(x, y, corr=0) as h:
+        h.finalize(theta)
+        lk, s2 = h.fitted_scalars()
+        assert lk == pytest.approx(ref.likelihood, rel=LK_RTOL)
+        assert s2 == pytest.approx(ref.inner.sigma2, rel=1e-8)
+        xq = np.random.default_rng(3).random((2000, d))
+        yp, vp = h.predict_valvar(xq)
+        np.testing.assert_allclose(yp, ref.predict(xq), rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(y).max())
+        vr = ref.predict_var(xq)
+        np.testing.assert_allclose(vp, vr, rtol=PRED_RTOL, atol=1e-9 * ref.inner.sigma2)
+
+
+# ------------------------------------------------------------------ config 3
+@pytest.mark.parametrize("corr", ["SquaredExponential", "Matern52"])
+def test_config3_n16384_d32_fit_matches_oracle_fixture(egx, large, corr):
+    rec = large[f"fit_n16384_d32_{corr}"]
+    n, d = rec["n"], rec["d"]
+    x, y = _data(n, d, rec["seed"])
+    theta = np.array(rec["theta"])
+    assert rec["min_pivot"] > 1e-4  # well posed: the straight bars apply
+    with egx.GpHandle(x, y, corr=KCODE[corr]) as h:
+        lk0, st0 = h.likelihood(theta)
+        assert st0 == 0 and lk0 == pytest.approx(rec["likelihood"], rel=LK_RTOL)
+        h.finalize(theta)
+        lk, s2 = h.fitted_scalars()
+        assert lk == lk0
+        assert s2 == pytest.approx(rec["sigma2"], rel=1e-8)
+        inner = h.inner(with_chol=False)
+        np.testing.assert_allclose(np.ravel(inner["beta"]), rec["beta"], rtol=1e-7, atol=1e-10)
+        gam = np.ravel(inner["gamma"])
+        assert np.linalg.norm(gam) == pytest.approx(rec["gamma_norm"], rel=1e-6)
+        np.testing.assert_allclose(gam[:8], rec["gamma_head"], rtol=1e-5, atol=1e-7 * np.abs(gam).max())
+        xq = _fit_queries(x, d)
+        yp, vp = h.predict_valvar(xq)
+        want_y, want_v = np.array(rec["predict"]), np.array(rec["predict_var"])
+        np.testing.assert_allclose(yp, want_y, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(y).max())
+        # variances: relative 1e-6 with an absolute floor of 1e-9 sigma2 (at / next to training points the value is a
+        # cancellation 1 - |rt|^2 + |u|^2 ~ 1e-13..1e-8 that the reference clamps at 0)
+        np.testing.assert_allclose(vp, want_v, rtol=PRED_RTOL, atol=1e-9 * rec["sigma2"])
+        assert np.all(vp >= 0.0)
+
+
+@pytest.mark.parametrize("corr", ["SquaredExponential", "Matern52"])
+def test_config3_theta_gradient_n4096_matches_oracle_fixture(egx, large, corr):
+    rec = large[f"grad_n4096_d32_{corr}"]
+    x, y = _data(rec["n"], rec["d"], rec["seed"])
+    theta = np.array(rec["theta"])
+    with egx.GpHandle(x, y, corr=KCODE[corr]) as h:
+        lk, g, st = h.likelihood_grad(theta)
+    assert st == 0 and lk == pytest.approx(rec["likelihood"], rel=LK_RTOL)
+    want = np.array(rec["grad"])
+    np.testing.assert_allclose(g, want, rtol=1e-6, atol=1e-6 * np.abs(want).max())
+
+
+def test_config3_theta_gradient_n16384_directional_differences(egx):
+    """config 3 proper (n = 16384, d = 32, Matern-5/2): the gradient against central differences of the
+    parity-checked likelihood along two directions."""
+    n, d = 16384, 32
+    x, y = _data(n, d, 42)
+    theta = egx.workload.default_theta(d)
+    rng = np.random.default_rng(11)
+    with egx.GpHandle(x, y, corr=3, n_workspaces=2) as h:
+        lk, g, st = h.likelihood_grad(theta)
+        assert st == 0 and np.all(np.isfinite(g))
+        for _ in range(2):
+            v = rng.standard_normal(d)
+            v /= np.linalg.norm(v)
+            eps = 1e-4 * theta[0]
+            lks, sts = h.likelihood_batch(np.stack([theta + eps * v, theta - eps * v]))
+            assert np.all(sts == 0)
+            fd = (lks[0] - lks[1]) / (2 * eps)
+            assert float(g @ v) == pytest.approx(fd, rel=2e-5, abs=1e-5 * np.linalg.norm(g))
+
+
+# ------------------------------------------------------------------ config 4
+def test_config4_sweep_candidates_n16384(egx, large):
+    """31 candidates of the theta sweep at size (28 rows of theta_sweep_candidates(512, 32) + 3 lower-bound rows):
+    likelihood_batch AND the C-ABI sweep (egx_sweep_*, one-rank RCCL communicator) against the oracle's
+    likelihoods and statuses; not-positive-definite candidates come back as status 1 / -inf."""
+    rec = large["sweep_n16384_d32"]
+    n, d = rec["n"], rec["d"]
+    x, y = _data(n, d, rec["seed"])
+    thetas = np.array(rec["thetas"])
+    rows = rec["rows"]
+    np.testing.assert_array_equal(thetas[:len(rows)], egx.theta_sweep_candidates(512, d)[rows])
+    want_st = np.array(rec["status"])
+    want_lk = np.array([np.nan if v is None else v for v in rec["likelihood"]])
+    assert len(want_st) == len(thetas), "fixture incomplete: rerun tests/golden/make_large_n.py --only sweep"
+
+    def check(lk, st):
+        np.testing.assert_array_equal(st, want_st)
+        ok = want_st == 0
+        np.testing.assert_allclose(lk[ok], want_lk[ok], rtol=LK_RTOL)
+        assert np.all(np.isneginf(lk[~ok]))
+
+    with egx.GpHandle(x, y, corr=0, n_workspaces=2) as h:
+        lk, st = h.likelihood_batch(thetas)
+        check(lk, st)
+    with egx.Sweep(x, y, corr=0, rank=0, world=1, id_bytes="new") as sw:
+        info = sw.info()
+        assert info["rccl_ranks"] == 1 and info["rccl_version"] > 0
+        lk2, st2 = sw.likelihood(thetas)
+        check(lk2, st2)
+        np.testing.assert_array_equal(lk2, lk)  # same kernels, same order of operations: bit identical
+        assert sw.info()["n_allgathers"] == 1
+        got = sw.allgather(np.arange(5.0))
+        np.testing.assert_array_equal(got, np.arange(5.0)[None, :])
+
+
+def test_config4_failed_candidate_exits_early(egx):
+    """algorithm.rs:893-896: a failed Cholesky is +inf at once.  Every kernel of the factorisation returns on entry
+    once the pivot flag is set, so a not-positive-definite candidate at n = 16384 costs a small fraction of a
+    regular evaluation (negative nugget: the first pivot block already fails)."""
+    n, d = 16384, 32
+    x, y = _data(n, d, 42)
+    theta = egx.workload.default_theta(d)
+    with egx.GpHandle(x, y, corr=0) as good, egx.GpHandle(x, y, corr=0, nugget=-0.9) as bad:
+        good.likelihood(theta)
+        bad.likelihood(theta)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            lk, st = good.likelihood(theta)
+        t_good = (time.perf_counter() - t0) / 3
+        assert st == 0
+        t0 = time.perf_counter()
+        for _ in range(3):
+            lk, st = bad.likelihood(theta)
+        t_bad = (time.perf_counter() - t0) / 3
+        assert st == 1 and lk == -math.inf
+        print(f"n=16384 evaluation: ok {t_good * 1e3:.2f} ms, not positive definite {t_bad * 1e3:.2f} ms")
+        assert t_bad < 0.25 * t_good
+        assert t_bad < 4e-3
+
+
+def test_sweep_c_host_drives_the_collective(tmp_path):
+    """tests/c_host/sweep_driver.c: a C99 host (no Python) creates the one-rank sweep with a fresh RCCL unique id
+    through the C ABI and checks egx_sweep_likelihood against egx_gp_likelihood_batch."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "sweep_driver"
+    libdir = os.path.join(root, "egobox_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{os.path.join(root, 'include')}",
+                    os.path.join(root, "tests", "c_host", "sweep_driver.c"), f"-L{libdir}", "-legx_gp_hip", "-lm",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert out.stdout.startswith("OK")
+
+
+# ------------------------------------------------------------------ config 5
+def test_config5_eight_experts_n8192_d16_m100000(egx, large):
+    """8 experts x n = 8192, d = 16 (disjoint LHS draws, seeds 7..14), m = 100 000 query points, smooth and hard
+    recombination (crates/moe/src/algorithm.rs:670-685, 894-910).  Expert 0 is pinned to the oracle fixture on the
+    first 1000 queries; the mixture is pinned to the recombination formulas applied to the experts' own outputs
+    with the ORACLE's mixture responsibilities (whose pdfs are pinned to gaussian_mixture.rs KATs)."""
+    from egobox_amd.moe import GaussianMixture, GpMixture
+    from oracle import moe_oracle as MO
+    rec = large["expert_n8192_d16"]
+    n, d, m, k = rec["n"], rec["d"], 100000, 8
+    theta = np.array(rec["theta"])
+    xq = np.random.default_rng(7).random((m, d))
+    experts = []
+    for e in range(k):
+        x, y = _data(n, d, 7 + e)
+        experts.append(egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr())
+                       .theta_tuning(egx.ThetaTuning.Fixed(theta)).fit(x, y))
+    try:
+        assert experts[0].likelihood() == pytest.approx(rec["likelihood"], rel=LK_RTOL)
+        assert experts[0].variance() == pytest.approx(rec["sigma2"], rel=1e-8)
+        t0 = time.perf_counter()
+        per_y, per_v = zip(*[e.predict_valvar(xq) for e in experts])
+        dt = time.perf_counter() - t0
+        print(f"8 experts x predict_valvar(m = {m}): {dt:.2f} s = {k * m / dt / 1e3:.0f} k expert-points/s")
+        per_y, per_v = np.array(per_y), np.array(per_v)
+        ymax = max(np.abs(per_y).max(), 1.0)
+        np.testing.assert_allclose(per_y[0][:1000], rec["predict"], rtol=PRED_RTOL, atol=PRED_RTOL * ymax)
+        np.testing.assert_allclose(per_v[0][:1000], rec["predict_var"], rtol=PRED_RTOL, atol=1e-9 * rec["sigma2"])
+        assert np.all(np.isfinite(per_v)) and np.all(per_v >= 0.0)
+        rng = np.random.default_rng(5)
+        w = rng.random(k) + 0.5
+        w /= w.sum()
+        means = rng.random((k, d))
+        covs = np.array([np.eye(d) * 0.3] * k)
+        gmo = MO.GaussianMixtureOracle(w, means, covs, 0.9)
+        p = gmo.predict_probas(xq)
+        c = gmo.predict(xq)
+        assert len(np.unique(c)) > 1
+        smooth = GpMixture(experts, GaussianMixture(w, means, covs, 0.9), "smooth")
+        val, var = smooth.predict_valvar(xq)
+        np.testing.assert_allclose(val, (per_y * p.T).sum(axis=0), rtol=1e-9, atol=1e-9 * ymax)
+        np.testing.assert_allclose(var, (per_v * p.T * p.T).sum(axis=0), rtol=1e-9, atol=1e-12 * per_v.max())
+        hard = GpMixture(experts, GaussianMixture(w, means, covs, 0.9), "hard")
+        val_h, var_h = hard.predict_valvar(xq)
+        rows = np.arange(m)
+        # routed subsets run through the same kernels in a different batch composition: values agree to rounding
+        np.testing.assert_allclose(val_h, per_y[c, rows], rtol=1e-9, atol=1e-9 * ymax)
+        np.testing.assert_allclose(var_h, per_v[c, rows], rtol=1e-7, atol=1e-10 * per_v.max())
+    finally:
+        for e in experts:
+            e.close()
