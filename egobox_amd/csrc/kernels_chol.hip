@@ -358,6 +358,161 @@ __global__ __launch_bounds__(NTHREADS, (WM * WN > 2048 ? 2 : (NTHREADS == 512 ? 
 }
 
 // ---------------------------------------------------------------------------------------------
+// C': the chip-filling trailing updates as a STREAM kernel (k_gemm_stream).  Same 128x256 workgroup tile / 64x64
+// wave tile as the wide k_gemm_nt_sub, but:
+//   * A/B panel chunks go global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave-instruction): no VGPR
+//     staging hop, no ds_write pass.  The LDS image of a chunk is UNPADDED, [384 rows][16 doubles] = 48 KB, and
+//     bank-conflict free through an XOR swizzle of the 16-byte slot (slot' = slot ^ ((row >> 1) & 7)) that is applied
+//     on the SOURCE address (the LDS-DMA destination is lane-linear) and again in the fragment reads.
+//   * three chunk stages (144 KB) form a ring with a prefetch distance of TWO chunks; the only wait in the K loop is
+//     a counted `s_waitcnt vmcnt(6)` (the newest chunk stays in flight) followed by ONE raw s_barrier per chunk.
+//   * a workgroup walks over several tiles (w, w + G, ...): the chunk stream runs across tile boundaries, so the next
+//     tile's first two chunks are already landing while the current tile is stored.
+//   * the accumulators start as -C (loaded while the first chunks land) and the epilogue is stores only
+//     (C_new = -(-C + A B^T)): no read-modify-write round trip at the end of a tile.
+// ---------------------------------------------------------------------------------------------
+constexpr int ST_ROWS = 384;                  // 128 A rows + 256 B rows per chunk
+constexpr int ST_STAGE = ST_ROWS * KC;        // doubles per stage (48 KB)
+constexpr int ST_NSTAGE = 3;
+constexpr int ST_LDS_BYTES = ST_NSTAGE * ST_STAGE * 8;
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
+
+// tile index -> (bx, by) of the 128x256 tiling; LOWER: column c holds the nbx - 2c tiles bx >= 2c
+template <bool LOWER>
+__device__ __forceinline__ void stream_tile_coords(int t, int nbx, int nby, int &bx, int &by) {
+    if (LOWER) {
+        const double bq = nbx + 1.0;
+        int c = (int)((bq - sqrt(bq * bq - 4.0 * t)) * 0.5);
+        if (c < 0) c = 0;
+        if (c >= nby) c = nby - 1;
+        while (c > 0 && c * nbx - c * (c - 1) > t) c--;
+        while (c + 1 < nby && (c + 1) * nbx - (c + 1) * c <= t) c++;
+        by = c;
+        bx = 2 * c + (t - (c * nbx - c * (c - 1)));
+    } else {
+        by = t / nbx;
+        bx = t - by * nbx;
+    }
+}
+
+template <bool LOWER>
+__global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, int64_t ldc, const double *__restrict__ A,
+                                                        int64_t lda, const double *__restrict__ B, int64_t ldb, int K,
+                                                        int nbx, int nby, int ntiles, const int *__restrict__ info) {
+    if (info != nullptr && *info != 0) return;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x, nch = K / KC;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int total = my_tiles * nch;  // chunks this workgroup streams
+
+    // ---- load side: wave w fills the 8-row groups w, w + 8 (A) and 16 + w + 8 i (B) of every stage
+    const int lrow = lane >> 3;
+    const int sw_ld = (4 * wave + (lane >> 4)) & 7;  // ((row >> 1) & 7) of this lane's row, the same for all 6 groups
+    const unsigned lpart = (unsigned)(((lane & 7) ^ sw_ld) * 2);
+    unsigned offA[2], offB[4];
+#pragma unroll
+    for (int i = 0; i < 2; i++) offA[i] = (unsigned)((8 * (wave + 8 * i) + lrow) * (int)lda) + lpart;
+#pragma unroll
+    for (int i = 0; i < 4; i++) offB[i] = (unsigned)((8 * (wave + 8 * i) + lrow) * (int)ldb) + lpart;
+    int t_l = blockIdx.x, ch_l = 0, issued = 0;
+    const double *pA_l, *pB_l;
+    {
+        int bx, by;
+        stream_tile_coords<LOWER>(t_l, nbx, nby, bx, by);
+        pA_l = A + (int64_t)bx * 128 * lda;
+        pB_l = B + (int64_t)by * 256 * ldb;
+    }
+    auto issue = [&](int stage) {
+        double *dst = smem + stage * ST_STAGE + wave * 128;  // group g starts at g * 8 rows * 16 doubles
+        const double *ga = pA_l + ch_l * KC, *gb = pB_l + ch_l * KC;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ga + offA[i]), (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gb + offB[i]), (lds_ptr_t)(dst + 2048 + i * 1024), 16, 0, 0);
+        issued++;
+        if (++ch_l == nch) {
+            ch_l = 0;
+            t_l += G;
+            if (t_l < ntiles) {
+                int bx, by;
+                stream_tile_coords<LOWER>(t_l, nbx, nby, bx, by);
+                pA_l = A + (int64_t)bx * 128 * lda;
+                pB_l = B + (int64_t)by * 256 * ldb;
+            }
+        }
+    };
+    if (total > 0) issue(0);
+    if (total > 1) issue(1);
+
+    // ---- compute side
+    const int wm0 = (wave >> 2) * 64, wn0 = (wave & 3) * 64;
+    const int frow = lane & 15, fk = lane >> 4;
+    // fragment reads are 16 bytes per lane (ds_read_b128: two consecutive k of one row), so a lane group fk feeds TWO
+    // MFMAs from one read: within an 8-deep k block the first MFMA contracts k = 0, 2, 4, 6 and the second k = 1, 3, 5, 7
+    // (the same permutation on A and B leaves the sum unchanged).  slot' = (4 kb + fk) ^ ((row >> 1) & 7) is
+    // conflict free for the b128 lane groups.
+    int foff[2];
+    foff[0] = frow * KC + ((fk ^ ((frow >> 1) & 7)) << 1);
+    foff[1] = foff[0] ^ 8;
+    const int aoff = wm0 * KC, boff = (128 + wn0) * KC;
+    unsigned coff[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) coff[r] = (unsigned)(((lane >> 4) + 4 * r) * (int)ldc + (lane & 15));
+
+    int g = 0, stage = 0;  // global chunk counter of this workgroup, stage = g % 3
+    for (int t = blockIdx.x; t < ntiles; t += G) {
+        int bx, by;
+        stream_tile_coords<LOWER>(t, nbx, nby, bx, by);
+        double *Ct = C + (int64_t)(bx * 128 + wm0) * ldc + by * 256 + wn0;
+        double4_t acc[4][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[mi][ni][r] = -Ct[(int64_t)mi * 16 * ldc + ni * 16 + coff[r]];
+        for (int ch = 0; ch < nch; ch++, g++) {
+            // chunk g has landed once this wave's own loads for it are done (the loads of chunk g + 1 may stay in
+            // flight) AND every other wave says the same (barrier).  The barrier also tells that every wave is done
+            // reading chunk g - 1, whose stage the loads of chunk g + 2 overwrite.
+            if (issued > g + 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (issued < total) issue(stage == 0 ? 2 : stage - 1);  // (g + 2) % 3
+            const double *As = smem + stage * ST_STAGE + aoff, *Bs = smem + stage * ST_STAGE + boff;
+            stage = (stage == ST_NSTAGE - 1) ? 0 : stage + 1;
+#pragma unroll
+            for (int kb = 0; kb < 2; kb++) {
+                d2_t a[4], b[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++) a[mi] = *reinterpret_cast<const d2_t *>(As + mi * 16 * KC + foff[kb]);
+#pragma unroll
+                for (int ni = 0; ni < 4; ni++) b[ni] = *reinterpret_cast<const d2_t *>(Bs + ni * 16 * KC + foff[kb]);
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ni++)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][h], b[ni][h], acc[mi][ni], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) Ct[(int64_t)mi * 16 * ldc + ni * 16 + coff[r]] = -acc[mi][ni][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // B: panel triangular solve  X = P * L^-T  for the 64-row slab of one workgroup.
 //    P: rows of the panel (ldp), columns [0, nbk) ; L: diagonal block (ldl) ; dinv: inverses of the
 //    64x64 diagonal tiles of L (row-major 64x64 each).  Block forward substitution over 64-col tiles.
@@ -871,6 +1026,9 @@ __global__ void k_gram_reduce(const double *__restrict__ P, int rows, int nsplit
 static int g_potf2_threads = 512;
 static int g_potrf_group = 2;    // panels per trailing update (EGX_POTRF_GROUP, 1..8)
 static int g_gemm_wide_min = 512;
+static int g_gemm_stream = 1;        // EGX_GEMM_STREAM=0: the register-staged wide kernel instead of k_gemm_stream
+static int g_stream_tpw = 0;         // EGX_STREAM_TPW: tiles per workgroup of k_gemm_stream (0 = one workgroup per CU walks all)
+static int g_stream_wgs = 256;       // EGX_STREAM_WGS: workgroups of the fully persistent form
 static int g_gemm_pipe = 0;          // EGX_GEMM_PIPE=1: hand software-pipelined K loop (measured 3 % SLOWER, run 20)
 static int g_gemm_small_max = 1024;  // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used  // EGX_GEMM_WIDE: minimum number of 128x256 tiles for the wide-tile kernel (0 = off)
 
@@ -886,6 +1044,9 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_GEMM_WIDE")) g_gemm_wide_min = std::atoi(e);
         if (const char *e = std::getenv("EGX_GEMM_SMALL")) g_gemm_small_max = std::atoi(e);
         if (const char *e = std::getenv("EGX_GEMM_PIPE")) g_gemm_pipe = std::atoi(e);
+        if (const char *e = std::getenv("EGX_GEMM_STREAM")) g_gemm_stream = std::atoi(e);
+        if (const char *e = std::getenv("EGX_STREAM_TPW")) g_stream_tpw = std::atoi(e);
+        if (const char *e = std::getenv("EGX_STREAM_WGS")) g_stream_wgs = std::atoi(e) > 0 ? std::atoi(e) : 256;
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -903,6 +1064,8 @@ int chol_init() {
         set(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 256, 64, 64, 512, false, true>), wide_lds);
         set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 256, 64, 64, 512, false, true>), wide_lds);
         set(reinterpret_cast<const void *>(&k_panel_trsm), PanelShape::LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<true>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<false>), ST_LDS_BYTES);
     });
     return rc_once;
 }
@@ -934,6 +1097,19 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         // experiment: 128x256 workgroup tile, 64x64 wave tiles (LDS operand reads per MFMA 0.5 instead of 0.75)
         using WideShape = GemmShape<128, 256, 64, 64, 512>;
         const int nbx = M / 128, nby = N / 256;  // LOWER: column c holds nbx - 2 c tiles (M >= N in the factorisation)
+        if (g_gemm_stream && K % KC == 0 && K >= 2 * KC) {
+            const int nt = (int)wide_tiles;
+            int grid = g_stream_tpw > 0 ? (nt + g_stream_tpw - 1) / g_stream_tpw : (nt < g_stream_wgs ? nt : g_stream_wgs);
+            if (grid < 1) grid = 1;
+            if (lower)
+                hipLaunchKernelGGL(k_gemm_stream<true>, dim3(grid), dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K,
+                                   nbx, nby, nt, info);
+            else
+                hipLaunchKernelGGL(k_gemm_stream<false>, dim3(grid), dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K,
+                                   nbx, nby, nt, info);
+            EGX_HIP_CHECK(hipGetLastError());
+            return EGX_SUCCESS;
+        }
         const dim3 g1((unsigned)wide_tiles), g2(M / 128, N / 256);
 #define EGX_WIDE(LOW, PIPE, GRID, FLAG)                                                                             \
     hipLaunchKernelGGL((k_gemm_nt_sub<LOW, 128, 256, 64, 64, 512, false, PIPE>), GRID, dim3(512), WideShape::LDS_BYTES, s, \

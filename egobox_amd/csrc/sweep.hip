@@ -12,6 +12,8 @@
 #include "gp_handle.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
+#include <cstdio>
 #include <rccl/rccl.h>
 
 namespace egx {
@@ -180,7 +182,22 @@ int32_t egx_sweep_create(const egx_gp_config *cfg_in, const double *x, const dou
         }
         ncclUniqueId id;
         std::memcpy(&id, nccl_id, sizeof id);
+        // RCCL >= 2.26 prints a version banner to STDOUT on the first communicator: keep the host's stdout clean (it
+        // may carry a protocol, e.g. bench.py's single JSON line) by pointing fd 1 at stderr for the duration of the
+        // init.  EGX_RCCL_BANNER=1 leaves it alone.
+        const char *keep = std::getenv("EGX_RCCL_BANNER");
+        int saved = -1;
+        if (!(keep && keep[0] == '1')) {
+            fflush(stdout);
+            saved = dup(1);
+            if (saved >= 0) dup2(2, 1);
+        }
         ncclResult_t r = api.CommInitRank(&sw->comm, world, id, rank);
+        if (saved >= 0) {
+            fflush(stdout);
+            dup2(saved, 1);
+            close(saved);
+        }
         if (r != ncclSuccess) {
             set_error(std::string("ncclCommInitRank: ") + api.GetErrorString(r));
             sw->comm = nullptr;

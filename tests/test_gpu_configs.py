@@ -213,7 +213,7 @@ def test_sweep_c_host_drives_the_collective(tmp_path):
                     f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, (out.stdout, out.stderr)
-    assert out.stdout.startswith("OK")
+    assert out.stdout.startswith("OK"), out.stdout  # RCCL's version banner goes to stderr (sweep.hip)
 
 
 # ------------------------------------------------------------------ config 5
