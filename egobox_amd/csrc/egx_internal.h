@@ -86,11 +86,16 @@ struct GemmTrace {
     int used = 0;
     bool ready = false;
 };
-// s2 / ev_lu / ev_panel: auxiliary (high priority) stream and two events for the one-block look-ahead;
-// s2 == nullptr runs everything in order on s.
+// Look-ahead resources: s2 = chain stream (diagonal blocks, panel solves), s3 = side stream (the off-critical-path rest
+// of the chain's updates), both high priority; events: ev_lu (next diagonal block updated), ev_lur (rest of the next
+// group's columns updated), ev_panel (chain of the next group done), ev_a / ev_b (hand-offs between s2 and s3).
+struct PotrfLookahead {
+    hipStream_t s2 = nullptr, s3 = nullptr;
+    hipEvent_t ev_lu = nullptr, ev_lur = nullptr, ev_panel = nullptr, ev_a = nullptr, ev_b = nullptr;
+};
+// lk == nullptr runs everything in order on s.
 int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
-                 hipStream_t s2 = nullptr, hipEvent_t ev_lu = nullptr, hipEvent_t ev_panel = nullptr,
-                 GemmTrace *trace = nullptr);
+                 const PotrfLookahead *lk = nullptr, GemmTrace *trace = nullptr);
 // rows [0, m) of RT (ld) are right-hand sides: RT <- RT * C^-T  (C = lower factor in M, n_pad cols)
 // tri_rows != 0: the rows are those of the identity (solution upper triangular): zero blocks are skipped
 int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, const double *dinv,

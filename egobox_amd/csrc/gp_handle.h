@@ -43,8 +43,7 @@ struct DevBuf {
 
 struct Workspace {
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;  // look-ahead (panel) stream
-    hipEvent_t ev_lu = nullptr, ev_panel = nullptr;
+    PotrfLookahead lk;  // look-ahead streams + events (lk.s2 == nullptr: look-ahead off)
     double *M = nullptr;       // (m_tot x ld): correlation matrix / factor + appended RHS rows
     double *dinv = nullptr;    // (n_pad/64) x 64 x 64 inverses of the diagonal tiles
     double *dW = nullptr;      // (n_pad/256) x 256 x 256 transposed inverses of the diagonal blocks (lazy)

@@ -43,9 +43,10 @@ static void free_workspace(Workspace &w) {
             hipEventDestroy(w.trace.e0[i]);
             hipEventDestroy(w.trace.e1[i]);
         }
-    if (w.ev_lu) hipEventDestroy(w.ev_lu);
-    if (w.ev_panel) hipEventDestroy(w.ev_panel);
-    if (w.stream2) hipStreamDestroy(w.stream2);
+    for (hipEvent_t e : {w.lk.ev_lu, w.lk.ev_lur, w.lk.ev_panel, w.lk.ev_a, w.lk.ev_b})
+        if (e) hipEventDestroy(e);
+    if (w.lk.s2) hipStreamDestroy(w.lk.s2);
+    if (w.lk.s3) hipStreamDestroy(w.lk.s3);
     if (w.stream) hipStreamDestroy(w.stream);
     w = Workspace();
 }
@@ -57,9 +58,10 @@ static int alloc_workspace(egx_gp *gp, Workspace &w) {
         if (!la || la[0] != '0') {
             int lo = 0, hi = 0;
             EGX_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            EGX_HIP_CHECK(hipStreamCreateWithPriority(&w.stream2, hipStreamNonBlocking, hi));
-            EGX_HIP_CHECK(hipEventCreateWithFlags(&w.ev_lu, hipEventDisableTiming));
-            EGX_HIP_CHECK(hipEventCreateWithFlags(&w.ev_panel, hipEventDisableTiming));
+            EGX_HIP_CHECK(hipStreamCreateWithPriority(&w.lk.s2, hipStreamNonBlocking, hi));
+            EGX_HIP_CHECK(hipStreamCreateWithPriority(&w.lk.s3, hipStreamNonBlocking, hi));
+            for (hipEvent_t *e : {&w.lk.ev_lu, &w.lk.ev_lur, &w.lk.ev_panel, &w.lk.ev_a, &w.lk.ev_b})
+                EGX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
     }
     EGX_HIP_CHECK(hipMalloc(&w.M, sizeof(double) * (size_t)gp->m_tot * gp->ld));
@@ -138,8 +140,8 @@ int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coef, int 
                            gp->ld, gp->n_pad));
     EGX_RC(launch_fill_rows(w.stream, w.M, gp->ld, gp->n_pad, gp->rhs_pad, gp->d_rhsT, gp->n_pad, gp->q, gp->n_pad));
     EGX_HIP_CHECK(hipEventRecord(w.ev[1], w.stream));
-    EGX_RC(launch_potrf(w.stream, w.M, gp->ld, gp->n_pad, gp->m_tot, w.dinv, w.d_info, w.stream2, w.ev_lu,
-                        w.ev_panel, &w.trace));
+    EGX_RC(launch_potrf(w.stream, w.M, gp->ld, gp->n_pad, gp->m_tot, w.dinv, w.d_info, w.lk.s2 ? &w.lk : nullptr,
+                        &w.trace));
     EGX_HIP_CHECK(hipEventRecord(w.ev[2], w.stream));
     EGX_RC(launch_gather_diag(w.stream, w.M, gp->ld, gp->n, w.d_diag));
     EGX_HIP_CHECK(hipMemcpyAsync(w.h_diag, w.d_diag, sizeof(double) * gp->n, hipMemcpyDeviceToHost, w.stream));

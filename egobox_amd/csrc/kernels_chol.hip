@@ -1026,6 +1026,7 @@ __global__ void k_gram_reduce(const double *__restrict__ P, int rows, int nsplit
 static int g_potf2_threads = 512;
 static int g_potrf_group = 2;    // panels per trailing update (EGX_POTRF_GROUP, 1..8)
 static int g_gemm_wide_min = 512;
+static int g_potrf_diag_first = 1;   // EGX_POTRF_DIAG_FIRST=0: updates on the critical path are not split (round-1 order)
 static int g_gemm_stream = 1;        // EGX_GEMM_STREAM=0: the register-staged wide kernel instead of k_gemm_stream
 static int g_stream_tpw = 0;         // EGX_STREAM_TPW: tiles per workgroup of k_gemm_stream (0 = one workgroup per CU walks all)
 static int g_stream_wgs = 256;       // EGX_STREAM_WGS: workgroups of the fully persistent form
@@ -1045,6 +1046,7 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_GEMM_SMALL")) g_gemm_small_max = std::atoi(e);
         if (const char *e = std::getenv("EGX_GEMM_PIPE")) g_gemm_pipe = std::atoi(e);
         if (const char *e = std::getenv("EGX_GEMM_STREAM")) g_gemm_stream = std::atoi(e);
+        if (const char *e = std::getenv("EGX_POTRF_DIAG_FIRST")) g_potrf_diag_first = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_TPW")) g_stream_tpw = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_WGS")) g_stream_wgs = std::atoi(e) > 0 ? std::atoi(e) : 256;
         auto set = [](const void *fn, int bytes) {
@@ -1181,13 +1183,18 @@ int launch_gram_lower(hipStream_t s, const double *W, int64_t ldw, int rows, int
     return EGX_SUCCESS;
 }
 
-// Flat right-looking factorisation with one-block look-ahead: as soon as the next block column has been
-// updated (LU_k) the next diagonal-block factorisation + panel solve run on the auxiliary stream `s2`,
-// concurrently with the rest of the trailing update (RU_k) on `s`.  The serial panel work (one workgroup,
-// then latency-bound solves) is thereby hidden behind the MFMA-bound update for all but the last blocks.
-// s2 == nullptr disables the look-ahead (everything in order on `s`).
+// Right-looking factorisation, two-level blocking (kNB-wide panels inside groups of `g_potrf_group` panels, ONE trailing
+// update per group with K = group width) with a look-ahead whose CRITICAL PATH is kept narrow:
+//   * the critical path of a right-looking Cholesky is  potf2(k) -> trsm(k) -> update of panel k+1 -> potf2(k+1) ...
+//     Only the DIAGONAL block of panel k+1 has to be up to date before potf2(k+1) may start, so every update on that
+//     path is split into the diagonal block (a 256x256 launch on the chain's stream) and the rest (on a side stream,
+//     overlapping the next diagonal-block factorisation); the panel solve that follows waits for the rest.
+//   * as soon as the next group's first diagonal block has been updated (LUd) that group's chain -- diagonal blocks,
+//     panel solves, in-group updates -- runs on the auxiliary high-priority streams (lk->s2 / lk->s3), concurrently with
+//     the rest of the look-ahead columns (LUr) and the trailing update (RU) on `s`.
+// lk == nullptr (or lk->s2 == nullptr) runs everything in order on `s`.
 int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
-                 hipStream_t s2, hipEvent_t ev_lu, hipEvent_t ev_panel, GemmTrace *trace) {
+                 const PotrfLookahead *lk, GemmTrace *trace) {
     if (trace) trace->used = 0;
     int rc = chol_init();
     if (rc) return rc;
@@ -1195,7 +1202,8 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         set_error("potrf: padded sizes must be multiples of 128");
         return EGX_ERR_INVALID_VALUE;
     }
-    auto panel = [&](hipStream_t st, int k0, int nbk) {
+    hipStream_t s2 = lk ? lk->s2 : nullptr, s3 = (lk && g_potrf_diag_first) ? lk->s3 : nullptr;
+    auto potf2 = [&](hipStream_t st, int k0, int nbk) {
         double *diag = M + (int64_t)k0 * ld + k0;
         double *dtiles = dinv + (int64_t)(k0 / 64) * 4096;
         // 512 threads (two MFMA waves per SIMD) is ~10 % faster alone; the 256-thread variant (1 wave per SIMD) fits
@@ -1207,33 +1215,58 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         else
             hipLaunchKernelGGL(k_potf2_block<256>, dim3(1), dim3(256), POTF2_LDS_BYTES, st, diag, ld, nbk, dtiles, info,
                                k0, n_pad);
+    };
+    auto trsm = [&](hipStream_t st, int k0, int nbk) {
         const int below = m_tot - (k0 + nbk);
         if (below > 0)
             hipLaunchKernelGGL(k_panel_trsm, dim3(below / 64), dim3(256), PanelShape::LDS_BYTES, st,
-                               M + (int64_t)(k0 + nbk) * ld + k0, ld, (const double *)diag, ld,
-                               (const double *)dtiles, nbk, (const int *)info);
+                               M + (int64_t)(k0 + nbk) * ld + k0, ld, (const double *)(M + (int64_t)k0 * ld + k0), ld,
+                               (const double *)(dinv + (int64_t)(k0 / 64) * 4096), nbk, (const int *)info);
     };
-    // Two-level blocking: kNB-wide panels are factored inside a group of `g_potrf_group` panels (right-looking within
-    // the group's columns), the trailing matrix is then updated once per GROUP with K = group width.  The C tile
-    // read-modify-write (and the tile prologue) is thereby paid once per K = 512 instead of once per K = 256:
-    // C traffic of the factorisation halves and the MFMA K loop is a larger share of every tile.
+    // C[r0.., c0..c0+N) -= P[r0.., k0..k0+K) P[c0..c0+N, k0..k0+K)^T for the M rows from r0
+    auto update = [&](hipStream_t st, int r0, int c0, int Mr, int N, int k0, int K, int lower, bool *big) -> int {
+        return launch_gemm_nt_sub(st, M + (int64_t)r0 * ld + c0, ld, M + (int64_t)r0 * ld + k0, ld,
+                                  M + (int64_t)c0 * ld + k0, ld, Mr, N, K, lower, 0, big, info);
+    };
     const int GW = g_potrf_group * kNB;
     auto gwidth = [&](int g0) { return (n_pad - g0 < GW) ? (n_pad - g0) : GW; };
-    auto inner_factor = [&](hipStream_t st, int g0, int gw) -> int {
+    // panels of one group on stream `st`; `side` != nullptr splits every in-group update into the next diagonal block
+    // (on st) and the rest (on side); `first_wait` is waited for before the FIRST panel solve (the rest of the update
+    // that brought this group's columns up to date)
+    auto inner_factor = [&](hipStream_t st, int g0, int gw, hipStream_t side, hipEvent_t first_wait) -> int {
+        hipEvent_t pending = first_wait;
         for (int k0 = g0; k0 < g0 + gw; k0 += kNB) {
             const int nbk = (g0 + gw - k0 < kNB) ? (g0 + gw - k0) : kNB;
-            panel(st, k0, nbk);
+            potf2(st, k0, nbk);
+            if (pending) {
+                EGX_HIP_CHECK(hipStreamWaitEvent(st, pending, 0));
+                pending = nullptr;
+            }
+            trsm(st, k0, nbk);
             const int r1 = k0 + nbk;
-            if (r1 < g0 + gw) {
-                const double *pan = M + (int64_t)r1 * ld + k0;
-                int rc2 = launch_gemm_nt_sub(st, M + (int64_t)r1 * ld + r1, ld, pan, ld, pan, ld, m_tot - r1, g0 + gw - r1,
-                                             nbk, 1, 0, nullptr, info);
+            if (r1 >= g0 + gw) break;
+            const int ncols = g0 + gw - r1;
+            const int nb1 = ncols < kNB ? ncols : kNB;  // width of the next panel
+            const int rest_rows = m_tot - r1 - nb1;
+            if (side && rest_rows >= 2048) {
+                int rc2 = update(st, r1, r1, nb1, nb1, k0, nbk, 1, nullptr);  // the next diagonal block only
+                if (rc2) return rc2;
+                EGX_HIP_CHECK(hipEventRecord(lk->ev_a, st));
+                EGX_HIP_CHECK(hipStreamWaitEvent(side, lk->ev_a, 0));
+                // everything below it (blocks above the diagonal inside this rectangle are written but never read)
+                rc2 = update(side, r1 + nb1, r1, rest_rows, ncols, k0, nbk, 0, nullptr);
+                if (rc2) return rc2;
+                EGX_HIP_CHECK(hipEventRecord(lk->ev_b, side));
+                pending = lk->ev_b;
+            } else {
+                int rc2 = update(st, r1, r1, m_tot - r1, ncols, k0, nbk, 1, nullptr);
                 if (rc2) return rc2;
             }
         }
+        if (pending) EGX_HIP_CHECK(hipStreamWaitEvent(st, pending, 0));
         return EGX_SUCCESS;
     };
-    rc = inner_factor(s, 0, gwidth(0));
+    rc = inner_factor(s, 0, gwidth(0), s3, nullptr);
     if (rc) return rc;
     for (int g0 = 0; g0 < n_pad; g0 += GW) {
         const int gw = gwidth(g0);
@@ -1242,26 +1275,38 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         const int gw1 = gwidth(r1);
         // the cross-stream hand-off costs ~2 x 10 us; below ~3k trailing columns RU is shorter than that
         const bool look = (s2 != nullptr) && (n_pad - r1 - gw1 >= 3072);
-        const double *pan = M + (int64_t)r1 * ld + g0;
-        // LU: the next group's columns only
-        rc = launch_gemm_nt_sub(s, M + (int64_t)r1 * ld + r1, ld, pan, ld, pan, ld, m_tot - r1, gw1, gw, 1, 0, nullptr, info);
-        if (rc) return rc;
-        if (look) {
-            EGX_HIP_CHECK(hipEventRecord(ev_lu, s));
-            EGX_HIP_CHECK(hipStreamWaitEvent(s2, ev_lu, 0));
-            rc = inner_factor(s2, r1, gw1);
+        const int nb1 = gw1 < kNB ? gw1 : kNB;
+        if (look && s3) {
+            // LUd: the next group's first diagonal block; its chain may start.  LUr: the rest of the next group's columns.
+            rc = update(s, r1, r1, nb1, nb1, g0, gw, 1, nullptr);
             if (rc) return rc;
-            EGX_HIP_CHECK(hipEventRecord(ev_panel, s2));
+            EGX_HIP_CHECK(hipEventRecord(lk->ev_lu, s));
+            EGX_HIP_CHECK(hipStreamWaitEvent(s2, lk->ev_lu, 0));
+            rc = update(s, r1 + nb1, r1, m_tot - r1 - nb1, gw1, g0, gw, 0, nullptr);
+            if (rc) return rc;
+            EGX_HIP_CHECK(hipEventRecord(lk->ev_lur, s));
+            rc = inner_factor(s2, r1, gw1, s3, lk->ev_lur);
+            if (rc) return rc;
+            EGX_HIP_CHECK(hipEventRecord(lk->ev_panel, s2));
+        } else {
+            // LU: the next group's columns only
+            rc = update(s, r1, r1, m_tot - r1, gw1, g0, gw, 1, nullptr);
+            if (rc) return rc;
+            if (look) {
+                EGX_HIP_CHECK(hipEventRecord(lk->ev_lu, s));
+                EGX_HIP_CHECK(hipStreamWaitEvent(s2, lk->ev_lu, 0));
+                rc = inner_factor(s2, r1, gw1, nullptr, nullptr);
+                if (rc) return rc;
+                EGX_HIP_CHECK(hipEventRecord(lk->ev_panel, s2));
+            }
         }
         // RU: the rest of the trailing matrix
         const int r2 = r1 + gw1;
         if (r2 < n_pad) {
-            const double *pan2 = M + (int64_t)r2 * ld + g0;
             const bool timed = trace && trace->ready && trace->used < GemmTrace::kMax;
             if (timed) EGX_HIP_CHECK(hipEventRecord(trace->e0[trace->used], s));
             bool big = false;
-            rc = launch_gemm_nt_sub(s, M + (int64_t)r2 * ld + r2, ld, pan2, ld, pan2, ld, m_tot - r2, n_pad - r2, gw, 1,
-                                    0, &big, info);
+            rc = update(s, r2, r2, m_tot - r2, n_pad - r2, g0, gw, 1, &big);
             if (rc) return rc;
             if (timed && big) {
                 EGX_HIP_CHECK(hipEventRecord(trace->e1[trace->used], s));
@@ -1271,9 +1316,9 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             }
         }
         if (look) {
-            EGX_HIP_CHECK(hipStreamWaitEvent(s, ev_panel, 0));
+            EGX_HIP_CHECK(hipStreamWaitEvent(s, lk->ev_panel, 0));
         } else {
-            rc = inner_factor(s, r1, gw1);
+            rc = inner_factor(s, r1, gw1, nullptr, nullptr);
             if (rc) return rc;
         }
     }
