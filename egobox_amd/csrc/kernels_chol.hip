@@ -1028,7 +1028,11 @@ static int g_potrf_group = 2;    // panels per trailing update (EGX_POTRF_GROUP,
 static int g_gemm_wide_min = 512;
 static int g_potrf_diag_first = 1;   // EGX_POTRF_DIAG_FIRST=0: updates on the critical path are not split (round-1 order)
 static int g_gemm_stream = 1;        // EGX_GEMM_STREAM=0: the register-staged wide kernel instead of k_gemm_stream
-static int g_stream_tpw = 0;         // EGX_STREAM_TPW: tiles per workgroup of k_gemm_stream (0 = one workgroup per CU walks all)
+static int g_stream_tpw = 1;         // EGX_STREAM_TPW: tiles per workgroup of k_gemm_stream (0 = one workgroup per CU walks all;
+                                     // measured: the fully persistent form is the fastest kernel alone, 54 vs 50 TFLOP/s, but
+                                     // holds every CU for the whole update and starves the look-ahead chain)
+static int g_stream_min_tiles = 128;  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles go to k_gemm_stream
+static int g_tail_lookahead = 1;      // EGX_TAIL_LOOKAHEAD=0: no look-ahead below 3072 trailing columns (round-1 behaviour)
 static int g_stream_wgs = 256;       // EGX_STREAM_WGS: workgroups of the fully persistent form
 static int g_gemm_pipe = 0;          // EGX_GEMM_PIPE=1: hand software-pipelined K loop (measured 3 % SLOWER, run 20)
 static int g_gemm_small_max = 1024;  // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used  // EGX_GEMM_WIDE: minimum number of 128x256 tiles for the wide-tile kernel (0 = off)
@@ -1048,6 +1052,8 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_GEMM_STREAM")) g_gemm_stream = std::atoi(e);
         if (const char *e = std::getenv("EGX_POTRF_DIAG_FIRST")) g_potrf_diag_first = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_TPW")) g_stream_tpw = std::atoi(e);
+        if (const char *e = std::getenv("EGX_STREAM_MIN")) g_stream_min_tiles = std::atoi(e);
+        if (const char *e = std::getenv("EGX_TAIL_LOOKAHEAD")) g_tail_lookahead = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_WGS")) g_stream_wgs = std::atoi(e) > 0 ? std::atoi(e) : 256;
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -1094,12 +1100,13 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         else
             wide_tiles = (int64_t)(M / 128) * (N / 256);
     }
-    if (g_gemm_wide_min > 0 && wide_tiles >= g_gemm_wide_min && !ktri && (!lower || M >= N)) {
-        if (used_big_tile) *used_big_tile = true;
-        // experiment: 128x256 workgroup tile, 64x64 wave tiles (LDS operand reads per MFMA 0.5 instead of 0.75)
+    const bool stream_ok = g_gemm_stream && K % KC == 0 && K >= 2 * KC && wide_tiles >= g_stream_min_tiles;
+    if (g_gemm_wide_min > 0 && (wide_tiles >= g_gemm_wide_min || stream_ok) && !ktri && (!lower || M >= N)) {
+        if (used_big_tile) *used_big_tile = wide_tiles >= g_gemm_wide_min;  // the chip-filling launches (roofline trace)
+        // 128x256 workgroup tile, 64x64 wave tiles (LDS operand reads per MFMA 0.5 instead of 0.75)
         using WideShape = GemmShape<128, 256, 64, 64, 512>;
         const int nbx = M / 128, nby = N / 256;  // LOWER: column c holds nbx - 2 c tiles (M >= N in the factorisation)
-        if (g_gemm_stream && K % KC == 0 && K >= 2 * KC) {
+        if (stream_ok) {
             const int nt = (int)wide_tiles;
             int grid = g_stream_tpw > 0 ? (nt + g_stream_tpw - 1) / g_stream_tpw : (nt < g_stream_wgs ? nt : g_stream_wgs);
             if (grid < 1) grid = 1;
@@ -1248,7 +1255,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             const int ncols = g0 + gw - r1;
             const int nb1 = ncols < kNB ? ncols : kNB;  // width of the next panel
             const int rest_rows = m_tot - r1 - nb1;
-            if (side && rest_rows >= 2048) {
+            if (side && rest_rows >= 128) {
                 int rc2 = update(st, r1, r1, nb1, nb1, k0, nbk, 1, nullptr);  // the next diagonal block only
                 if (rc2) return rc2;
                 EGX_HIP_CHECK(hipEventRecord(lk->ev_a, st));
@@ -1274,7 +1281,9 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         if (r1 >= n_pad) break;  // (right-hand-side rows below the last block were solved by its panel)
         const int gw1 = gwidth(r1);
         // the cross-stream hand-off costs ~2 x 10 us; below ~3k trailing columns RU is shorter than that
-        const bool look = (s2 != nullptr) && (n_pad - r1 - gw1 >= 3072);
+        // (with the diagonal-block-first split the hand-off pays down to the last group: the next diagonal block is
+        //  factored while the rest of this group's update runs)
+        const bool look = (s2 != nullptr) && (n_pad - r1 - gw1 >= 3072 || (s3 != nullptr && g_tail_lookahead));
         const int nb1 = gw1 < kNB ? gw1 : kNB;
         if (look && s3) {
             // LUd: the next group's first diagonal block; its chain may start.  LUr: the rest of the next group's columns.

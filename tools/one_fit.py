@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""A few fixed-theta fits at one size, nothing else: the command profiled for timelines
+(`rocprofv3 --kernel-trace -- python tools/one_fit.py [n] [d] [reps]`)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import egobox_amd as egx  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+x, y = egx.workload.make_training_set(n, d, 42)
+th = egx.workload.default_theta(d)
+h = egx.GpHandle(x, y)
+for i in range(reps):
+    t0 = time.perf_counter()
+    h.finalize(th * (1 + 0.01 * i))
+    print(f"fit {i}: {1e3 * (time.perf_counter() - t0):.3f} ms  {h.timings()}", flush=True)
+h.close()
