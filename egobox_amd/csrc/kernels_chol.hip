@@ -1031,8 +1031,9 @@ static int g_gemm_stream = 1;        // EGX_GEMM_STREAM=0: the register-staged w
 static int g_stream_tpw = 1;         // EGX_STREAM_TPW: tiles per workgroup of k_gemm_stream (0 = one workgroup per CU walks all;
                                      // measured: the fully persistent form is the fastest kernel alone, 54 vs 50 TFLOP/s, but
                                      // holds every CU for the whole update and starves the look-ahead chain)
-static int g_stream_min_tiles = 128;  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles go to k_gemm_stream
-static int g_tail_lookahead = 1;      // EGX_TAIL_LOOKAHEAD=0: no look-ahead below 3072 trailing columns (round-1 behaviour)
+static int g_stream_min_tiles = 512;  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles go to k_gemm_stream
+static int g_tail_lookahead = 0;      // EGX_TAIL_LOOKAHEAD=1: look-ahead also below 3072 trailing columns (measured: n = 4096 fit
+                                      // 3.37 -> 3.27 ms alone, but 460 -> 313 fits/s with two in flight: the extra hand-offs cost more)
 static int g_stream_wgs = 256;       // EGX_STREAM_WGS: workgroups of the fully persistent form
 static int g_gemm_pipe = 0;          // EGX_GEMM_PIPE=1: hand software-pipelined K loop (measured 3 % SLOWER, run 20)
 static int g_gemm_small_max = 1024;  // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used  // EGX_GEMM_WIDE: minimum number of 128x256 tiles for the wide-tile kernel (0 = off)
