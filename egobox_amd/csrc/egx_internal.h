@@ -63,6 +63,10 @@ int launch_gather_diag(hipStream_t s, const double *M, int64_t ld, int n, double
 // per-row reductions over the first n columns of rows [0, m): s0[q] = sum rt^2, sl[q*p + l] = sum rt*ft_l
 int launch_row_reduce(hipStream_t s, const double *RT, int64_t ld, int m, int n, const double *ftT,
                       int64_t ldf, int p, double *s0, double *sl);
+// device-side GLS helpers: G <- -Gneg (lower, leading q x q) + identity padding; rho <- yt - ft beta with block sums of rho^2
+int launch_gram_finish(hipStream_t s, const double *Gneg, double *G, int64_t ldg, int rows, int q);
+int launch_gls_residual(hipStream_t s, const double *ftT, int64_t ld, const double *yt, const double *beta, int p, int n,
+                        int n_pad, double *rho, double *part);
 // zero the strict upper triangle of the leading n x n block
 int launch_zero_upper(hipStream_t s, double *M, int64_t ld, int n);
 // likelihood-gradient accumulation (new capability): for all i>j

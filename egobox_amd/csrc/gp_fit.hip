@@ -1,5 +1,6 @@
 // Optimiser drivers above the likelihood (GpValidParams::fit with ThetaTuning::Full / Partial,
-// crates/gp/src/algorithm.rs:873-960, optimization.rs:26-169): multistart Nelder-Mead (stand-in for the un-vendored COBYLA),
+// crates/gp/src/algorithm.rs:873-960, optimization.rs:26-169): multistart COBYLA (cobyla.h: Powell's method restated, all
+// starts in lock-step through one likelihood batch per round; EGX_FIT_OPTIMIZER=nelder-mead keeps the round-1 stand-in),
 // the new theta-gradient of the likelihood and a projected L-BFGS on it.
 #include "gp_handle.h"
 
@@ -47,13 +48,54 @@ static int32_t fit_nm_core(egx_gp *gp, const double *theta_base /*h*/, const std
             set_error("theta start points must be > 0");
             return EGX_ERR_INVALID_VALUE;
         }
-    // The starts are independent optimisations (rayon par_iter over theta_inits rows, algorithm.rs:928-945):
-    // one host thread per workspace, start s runs on workspace s % n_threads.
-    const int nthreads = (int)std::min<int64_t>((int64_t)gp->ws.size(), n_starts);
     std::vector<NmResult> results((size_t)n_starts);
+    gp->fitted = false;
+    const char *opt_env = std::getenv("EGX_FIT_OPTIMIZER");
+    const bool use_nm = opt_env && std::string(opt_env) == "nelder-mead";
+    if (!use_nm) {
+        // COBYLA (cobyla.h), one machine per start, rhobeg 0.5 / ftol_rel 1e-4 (optimization.rs:16-24), all machines
+        // advanced in LOCK-STEP: their trial points form one likelihood batch per round, pipelined over the
+        // handle's workspaces (the reference runs the starts as rayon tasks, algorithm.rs:928-945)
+        std::vector<CobylaBox> mach;
+        mach.reserve((size_t)n_starts);
+        for (int64_t s = 0; s < n_starts; s++) {
+            std::vector<double> x0(h);
+            for (int i = 0; i < h; i++) x0[i] = std::log10(theta0s[s * h + i]);
+            mach.emplace_back(x0, blo, bhi, 0.5, 1e-4, per_start);
+        }
+        std::vector<double> thetas, lk, x;
+        std::vector<int32_t> st;
+        std::vector<int64_t> who;
+        for (;;) {
+            thetas.clear();
+            who.clear();
+            for (int64_t s = 0; s < n_starts; s++)
+                if (mach[(size_t)s].ask(x)) {
+                    who.push_back(s);
+                    const size_t off = thetas.size();
+                    thetas.insert(thetas.end(), theta_base, theta_base + hfull);
+                    for (int i = 0; i < h; i++) thetas[off + active[i]] = std::pow(10.0, x[i]);
+                }
+            if (who.empty()) break;
+            lk.assign(who.size(), 0.0);
+            st.assign(who.size(), 0);
+            EGX_RC(likelihood_batch_core(gp, thetas.data(), (int64_t)who.size(), hfull, lk.data(), st.data()));
+            for (size_t q = 0; q < who.size(); q++) {
+                const bool ok = st[q] == EGX_STATUS_OK && !std::isnan(lk[q]);
+                mach[(size_t)who[q]].tell(ok ? -lk[q] : std::numeric_limits<double>::infinity());  // algorithm.rs:893-896
+            }
+        }
+        for (int64_t s = 0; s < n_starts; s++) {
+            const CobylaBox &m = mach[(size_t)s];
+            double fb = m.best_f();
+            if (std::isnan(fb) || fb >= 1e30) fb = std::numeric_limits<double>::infinity();  // optimization.rs:153-157
+            results[(size_t)s] = NmResult{fb, m.best_x(), m.evals()};
+        }
+    } else {
+    // EGX_FIT_OPTIMIZER=nelder-mead: the round-1 stand-in, one host thread per workspace, start s on workspace s % n_threads
+    const int nthreads = (int)std::min<int64_t>((int64_t)gp->ws.size(), n_starts);
     std::vector<int> rcs((size_t)nthreads, EGX_SUCCESS);
     std::vector<std::string> errs((size_t)nthreads);
-    gp->fitted = false;
     auto worker = [&](int t) {
         if (hipSetDevice(gp->device) != hipSuccess) {
             rcs[t] = EGX_ERR_HIP;
@@ -93,6 +135,7 @@ static int32_t fit_nm_core(egx_gp *gp, const double *theta_base /*h*/, const std
             set_error(errs[t]);
             return rcs[t];
         }
+    }
     for (int64_t s = 0; s < n_starts; s++) {
         evals += results[(size_t)s].evals;
         if (results[(size_t)s].f < best_f) {  // algorithm.rs:942-945 reduce to min (first wins ties)
@@ -175,9 +218,11 @@ static int likelihood_grad_core(egx_gp *gp, const double *theta, int64_t theta_l
     if (!gp->d_gout) EGX_HIP_CHECK(hipMalloc(&gp->d_gout, sizeof(double) * 2 * kMaxDim));
     if (!gp->d_theta) EGX_HIP_CHECK(hipMalloc(&gp->d_theta, sizeof(double) * kMaxDim));
     // gamma = C^-T rho
-    std::memset(w.h_vec, 0, sizeof(double) * n_pad);
-    std::memcpy(w.h_vec, res.rho.data(), sizeof(double) * n);
-    EGX_HIP_CHECK(hipMemcpyAsync(w.d_rhs, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
+    if (!res.rho_on_device) {
+        std::memset(w.h_vec, 0, sizeof(double) * n_pad);
+        std::memcpy(w.h_vec, res.rho.data(), sizeof(double) * n);
+        EGX_HIP_CHECK(hipMemcpyAsync(w.d_rhs, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
+    }
     EGX_RC(backward_solve(gp, w));
     // W = I * C^-T  (rows of the identity as right-hand sides), then -R^-1 = 0 - W W^T (lower tiles)
     gp->winv_epoch = ~(uint64_t)0;

@@ -17,6 +17,7 @@
 #include "egx_internal.h"
 #include "host_math.h"
 #include "nelder_mead.h"
+#include "cobyla.h"
 
 #define EGX_RC(call)              \
     do {                          \
@@ -52,6 +53,13 @@ struct Workspace {
     double *d_vec = nullptr;   // n_pad (gamma)
     double *d_rhs = nullptr;   // n_pad (rho, destroyed by the back-substitution)
     int *d_info = nullptr;
+    // device-side GLS (p > 1 trend columns): Gram matrix of [ft | yt] and its factor, all (rhs_pad x rhs_pad)
+    double *d_gneg = nullptr, *d_gram = nullptr, *d_gdinv = nullptr, *d_gramP = nullptr, *d_beta = nullptr,
+           *d_part = nullptr;
+    int *d_ginfo = nullptr;
+    double *h_gram = nullptr, *h_part = nullptr, *h_beta = nullptr;  // pinned
+    int *h_ginfo = nullptr;                                          // pinned
+    bool gls_enqueued = false;  // this evaluation took the device GLS route (set by enqueue_eval)
     double *h_coef = nullptr;  // pinned
     double *h_rows = nullptr;  // pinned: q x n_pad solved RHS rows (ft^T, yt^T)
     double *h_diag = nullptr;  // pinned: n
@@ -66,7 +74,8 @@ struct EvalResult {
     int status = EGX_STATUS_OK;
     double sigma2n = 0.0;         // rho^2 / n in normalised units
     std::vector<double> beta;     // p
-    std::vector<double> rho;      // n
+    bool rho_on_device = false;   // device GLS: rho already sits (zero padded) in the workspace's d_rhs
+    std::vector<double> rho;      // n (host GLS)
     std::vector<double> ft;       // n x p row-major
     std::vector<double> ft_qr_r;  // p x p row-major
 };
@@ -80,6 +89,7 @@ struct egx_gp {
     int n_pad = 0, rhs_pad = 0, m_tot = 0, q = 0;
     int64_t ld = 0;
     bool has_w = false;
+    bool gls_device = false;  // p >= 2: GLS through the Gram matrix on the device (gp_host.hip finish_eval)
     std::vector<double> w_star;  // d x h
     std::vector<double> x_raw, y_raw, xnorm, x_mean, x_std, ynorm, F;
     double y_mean = 0.0, y_std = 1.0;
@@ -131,6 +141,7 @@ bool has_nan(const double *theta, int64_t len);
 int eval_one(egx_gp *gp, int widx, const double *theta, int64_t theta_len, EvalResult &res, bool keep);
 int backward_solve(egx_gp *gp, Workspace &w);
 int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len);
+int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len, double *lkh, int32_t *status);
 // gp_predict.hip
 int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *vout);
 int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv);

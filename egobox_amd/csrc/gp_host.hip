@@ -31,6 +31,12 @@ static void free_workspace(Workspace &w) {
     if (w.d_vec) hipFree(w.d_vec);
     if (w.d_rhs) hipFree(w.d_rhs);
     if (w.d_info) hipFree(w.d_info);
+    for (double *q : {w.d_gneg, w.d_gram, w.d_gdinv, w.d_gramP, w.d_beta, w.d_part})
+        if (q) hipFree(q);
+    if (w.d_ginfo) hipFree(w.d_ginfo);
+    for (double *q : {w.h_gram, w.h_part, w.h_beta})
+        if (q) hipHostFree(q);
+    if (w.h_ginfo) hipHostFree(w.h_ginfo);
     if (w.h_coef) hipHostFree(w.h_coef);
     if (w.h_rows) hipHostFree(w.h_rows);
     if (w.h_diag) hipHostFree(w.h_diag);
@@ -77,6 +83,20 @@ static int alloc_workspace(egx_gp *gp, Workspace &w) {
     EGX_HIP_CHECK(hipHostMalloc(&w.h_diag, sizeof(double) * (size_t)gp->n_pad, hipHostMallocDefault));
     EGX_HIP_CHECK(hipHostMalloc(&w.h_vec, sizeof(double) * (size_t)gp->n_pad, hipHostMallocDefault));
     EGX_HIP_CHECK(hipHostMalloc(&w.h_info, sizeof(int), hipHostMallocDefault));
+    if (gp->gls_device) {
+        const size_t g2 = (size_t)gp->rhs_pad * gp->rhs_pad;
+        EGX_HIP_CHECK(hipMalloc(&w.d_gneg, sizeof(double) * g2));
+        EGX_HIP_CHECK(hipMalloc(&w.d_gram, sizeof(double) * g2));
+        EGX_HIP_CHECK(hipMalloc(&w.d_gdinv, sizeof(double) * (size_t)(gp->rhs_pad / 64) * 4096));
+        EGX_HIP_CHECK(hipMalloc(&w.d_gramP, sizeof(double) * gram_scratch_doubles(gp->rhs_pad, gp->n_pad)));
+        EGX_HIP_CHECK(hipMalloc(&w.d_beta, sizeof(double) * (size_t)gp->rhs_pad));
+        EGX_HIP_CHECK(hipMalloc(&w.d_part, sizeof(double) * (size_t)((gp->n_pad + 255) / 256)));
+        EGX_HIP_CHECK(hipMalloc(&w.d_ginfo, sizeof(int)));
+        EGX_HIP_CHECK(hipHostMalloc(&w.h_gram, sizeof(double) * g2, hipHostMallocDefault));
+        EGX_HIP_CHECK(hipHostMalloc(&w.h_part, sizeof(double) * (size_t)((gp->n_pad + 255) / 256), hipHostMallocDefault));
+        EGX_HIP_CHECK(hipHostMalloc(&w.h_beta, sizeof(double) * (size_t)gp->rhs_pad, hipHostMallocDefault));
+        EGX_HIP_CHECK(hipHostMalloc(&w.h_ginfo, sizeof(int), hipHostMallocDefault));
+    }
     for (auto &e : w.ev) EGX_HIP_CHECK(hipEventCreate(&e));
     for (int i = 0; i < GemmTrace::kMax; i++) {
         EGX_HIP_CHECK(hipEventCreate(&w.trace.e0[i]));
@@ -145,11 +165,149 @@ int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coef, int 
     EGX_HIP_CHECK(hipEventRecord(w.ev[2], w.stream));
     EGX_RC(launch_gather_diag(w.stream, w.M, gp->ld, gp->n, w.d_diag));
     EGX_HIP_CHECK(hipMemcpyAsync(w.h_diag, w.d_diag, sizeof(double) * gp->n, hipMemcpyDeviceToHost, w.stream));
-    EGX_HIP_CHECK(hipMemcpyAsync(w.h_rows, w.M + (size_t)gp->n_pad * gp->ld, sizeof(double) * (size_t)gp->q * gp->n_pad,
-                                 hipMemcpyDeviceToHost, w.stream));
+    w.gls_enqueued = gp->gls_device;
+    if (gp->gls_device) {
+        // p > 1: ft never leaves the device.  Gram matrix of the solved rows [ft | yt] (split-K MFMA, fixed-order
+        // reduction), its Cholesky factor by the same blocked kernels (R = L^T is the reference's QR factor with a
+        // positive diagonal, row p of L is z = L^-1 ft^T yt), and only that (rhs_pad x rhs_pad) factor goes to the host
+        const int g = gp->rhs_pad;
+        EGX_RC(launch_gram_lower(w.stream, w.M + (size_t)gp->n_pad * gp->ld, gp->ld, g, gp->n_pad, w.d_gneg, g, w.d_gramP));
+        EGX_RC(launch_gram_finish(w.stream, w.d_gneg, w.d_gram, g, g, gp->q));
+        EGX_HIP_CHECK(hipMemsetAsync(w.d_ginfo, 0, sizeof(int), w.stream));
+        EGX_RC(launch_potrf(w.stream, w.d_gram, g, g, g, w.d_gdinv, w.d_ginfo));
+        EGX_HIP_CHECK(hipMemcpyAsync(w.h_gram, w.d_gram, sizeof(double) * (size_t)g * g, hipMemcpyDeviceToHost, w.stream));
+        EGX_HIP_CHECK(hipMemcpyAsync(w.h_ginfo, w.d_ginfo, sizeof(int), hipMemcpyDeviceToHost, w.stream));
+    } else {
+        EGX_HIP_CHECK(hipMemcpyAsync(w.h_rows, w.M + (size_t)gp->n_pad * gp->ld,
+                                     sizeof(double) * (size_t)gp->q * gp->n_pad, hipMemcpyDeviceToHost, w.stream));
+    }
     EGX_HIP_CHECK(hipMemcpyAsync(w.h_info, w.d_info, sizeof(int), hipMemcpyDeviceToHost, w.stream));
     EGX_HIP_CHECK(hipEventRecord(w.ev[3], w.stream));
     return EGX_SUCCESS;
+}
+
+// Device GLS route of finish_eval (p >= 2).  Returns 0 = evaluation finished (out filled), 1 = fall back to the host
+// Householder route, < 0 = -(egx_rc) on a HIP failure.
+//   A = ft^T ft = L L^T,  z = L^-1 ft^T yt  (device, enqueue_eval)  ->  R = L^T (algorithm.rs:1007 `qr`, positive
+//   diagonal), beta = R^-1 z (:1030), rho = yt - ft beta and sum rho^2 on the device (:1031-1032).
+// The conditioning test of :1010-1027 compares sigma_min / sigma_max of R with 1e-10.  Here the ratio is ESTIMATED in
+// O(p^2) (a few steps of power iteration on R^T R and of inverse iteration through two triangular solves); the Gram
+// route is taken only when the estimate is >= 1e-8 and the factor's diagonal ratio >= 1e-4 (normal equations keep
+// at least half the digits there).  Anything closer to the threshold goes to the host Householder + SVD route, which
+// decides exactly as for p = 1.
+static int finish_eval_device_gls(egx_gp *gp, Workspace &w, EvalResult &out, bool keep) {
+    const int n = gp->n, p = gp->p, n_pad = gp->n_pad, g = gp->rhs_pad;
+    if (*w.h_ginfo != 0) return 1;
+    const double *L = w.h_gram;  // (g x g) row-major lower factor
+    double dmin = std::numeric_limits<double>::infinity(), dmax = 0.0;
+    for (int i = 0; i < p; i++) {
+        const double v = L[(size_t)i * g + i];
+        if (!(v > 0.0) || !std::isfinite(v)) return 1;
+        dmin = std::fmin(dmin, v);
+        dmax = std::fmax(dmax, v);
+    }
+    if (dmin / dmax < 1e-4) return 1;
+    // row-oriented triangular kernels on the (g-strided) factor: contiguous inner loops
+    auto mul_lt = [&](const std::vector<double> &v, std::vector<double> &u) {  // u = L^T v
+        std::fill(u.begin(), u.end(), 0.0);
+        for (int l = 0; l < p; l++) {
+            const double *row = L + (size_t)l * g;
+            const double vl = v[l];
+            for (int i = 0; i <= l; i++) u[i] += row[i] * vl;
+        }
+    };
+    auto mul_l = [&](const std::vector<double> &u, std::vector<double> &v) {  // v = L u
+        for (int i = 0; i < p; i++) {
+            const double *row = L + (size_t)i * g;
+            double s = 0.0;
+            for (int l = 0; l <= i; l++) s += row[l] * u[l];
+            v[i] = s;
+        }
+    };
+    auto solve_l = [&](std::vector<double> &v) {  // v <- L^-1 v
+        for (int i = 0; i < p; i++) {
+            const double *row = L + (size_t)i * g;
+            double s = v[i];
+            for (int l = 0; l < i; l++) s -= row[l] * v[l];
+            v[i] = s / row[i];
+        }
+    };
+    auto solve_lt = [&](std::vector<double> &v) {  // v <- L^-T v
+        for (int i = p - 1; i >= 0; i--) {
+            const double *row = L + (size_t)i * g;
+            const double wi = v[i] / row[i];
+            v[i] = wi;
+            for (int l = 0; l < i; l++) v[l] -= row[l] * wi;
+        }
+    };
+    {   // sigma_max^2 by power iteration on R^T R = L L^T (R = L^T), 1 / sigma_min^2 by inverse iteration
+        std::vector<double> v(p), u(p);
+        auto normalize = [&](std::vector<double> &t) {
+            double s = 0.0;
+            for (double e : t) s += e * e;
+            s = std::sqrt(s);
+            for (double &e : t) e /= s;
+            return s;
+        };
+        for (int i = 0; i < p; i++) v[i] = 1.0 + 0.37 * ((i * 2654435761u) % 1000) / 1000.0;
+        normalize(v);
+        double smax2 = 0.0, sinv2 = 0.0;
+        for (int it = 0; it < 5; it++) {
+            mul_lt(v, u);
+            mul_l(u, v);
+            smax2 = normalize(v);
+        }
+        for (int i = 0; i < p; i++) v[i] = 1.0 - 0.29 * ((i * 40503u) % 1000) / 1000.0;
+        normalize(v);
+        for (int it = 0; it < 5; it++) {
+            solve_l(v);
+            solve_lt(v);
+            sinv2 = normalize(v);
+        }
+        const double ratio = 1.0 / std::sqrt(sinv2 * smax2);  // ~ sigma_min / sigma_max
+        if (!(ratio >= 1e-8)) return 1;
+    }
+    // beta = L^-T z   (z = row p of the factor)
+    std::vector<double> beta(L + (size_t)p * g, L + (size_t)p * g + p);
+    solve_lt(beta);
+    std::memcpy(w.h_beta, beta.data(), sizeof(double) * p);
+    if (hipMemcpyAsync(w.d_beta, w.h_beta, sizeof(double) * p, hipMemcpyHostToDevice, w.stream) != hipSuccess) return -EGX_ERR_HIP;
+    const double *rows = w.M + (size_t)n_pad * gp->ld;
+    int rc = launch_gls_residual(w.stream, rows, gp->ld, rows + (size_t)p * gp->ld, w.d_beta, p, n, n_pad, w.d_rhs, w.d_part);
+    if (rc) return -rc;
+    const int nblk = (n_pad + 255) / 256;
+    if (hipMemcpyAsync(w.h_part, w.d_part, sizeof(double) * nblk, hipMemcpyDeviceToHost, w.stream) != hipSuccess ||
+        hipStreamSynchronize(w.stream) != hipSuccess) {
+        set_error("device GLS: copy / synchronise failed");
+        (void)hipGetLastError();
+        return -EGX_ERR_HIP;
+    }
+    double rho_sqr = 0.0;
+    for (int b = 0; b < nblk; b++) rho_sqr += w.h_part[b];
+    double slog = 0.0;
+    for (int i = 0; i < n; i++) slog += std::log10(w.h_diag[i]);
+    const double sigma2n = rho_sqr / (double)n;
+    out.lkh = -(double)n * (std::log10(sigma2n) + slog * 2.0 / (double)n);  // algorithm.rs:1039-1043
+    out.sigma2n = sigma2n;
+    out.status = EGX_STATUS_OK;
+    out.rho_on_device = true;
+    if (keep) {
+        out.beta = beta;
+        out.ft_qr_r.assign((size_t)p * p, 0.0);
+        for (int i = 0; i < p; i++)
+            for (int l = i; l < p; l++) out.ft_qr_r[(size_t)i * p + l] = L[(size_t)l * g + i];
+        // the fitted state keeps a host copy of ft (serde schema, few-query prediction paths)
+        std::vector<double> tmp((size_t)p * n_pad);
+        if (hipMemcpy(tmp.data(), rows, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost) != hipSuccess) {
+            set_error("device GLS: download of ft failed");
+            (void)hipGetLastError();
+            return -EGX_ERR_HIP;
+        }
+        out.ft.assign((size_t)n * p, 0.0);
+        for (int l = 0; l < p; l++)
+            for (int i = 0; i < n; i++) out.ft[(size_t)i * p + l] = tmp[(size_t)l * n_pad + i];
+    }
+    return 0;
 }
 
 // Host half: algorithm.rs:1007-1043 on the downloaded ft, yt, diag(C).
@@ -166,6 +324,15 @@ int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, bool keep) {
             out.status = EGX_STATUS_NOT_POSITIVE_DEFINITE;
             return EGX_SUCCESS;
         }
+    if (w.gls_enqueued) {
+        int route = finish_eval_device_gls(gp, w, out, keep);
+        if (route <= 0) return route < 0 ? -route : EGX_SUCCESS;  // done (or a HIP error)
+        // route 1: the Gram route is not trustworthy here (ft too ill conditioned for normal equations): the solved
+        // rows come over after all and the Householder path below decides, exactly as for p = 1
+        EGX_HIP_CHECK(hipMemcpyAsync(w.h_rows, w.M + (size_t)n_pad * gp->ld, sizeof(double) * (size_t)gp->q * n_pad,
+                                     hipMemcpyDeviceToHost, w.stream));
+        EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+    }
     // ft (column-major copy for the QR), yt
     std::vector<double> a((size_t)n * p), qty(n);
     for (int l = 0; l < p; l++) std::memcpy(&a[(size_t)l * n], w.h_rows + (size_t)l * n_pad, sizeof(double) * n);
@@ -325,9 +492,11 @@ int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     }
     // gamma = C^-T rho   (algorithm.rs:1034)
     const int n = gp->n, n_pad = gp->n_pad;
-    std::memset(w.h_vec, 0, sizeof(double) * n_pad);
-    std::memcpy(w.h_vec, res.rho.data(), sizeof(double) * n);
-    EGX_HIP_CHECK(hipMemcpyAsync(w.d_rhs, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
+    if (!res.rho_on_device) {
+        std::memset(w.h_vec, 0, sizeof(double) * n_pad);
+        std::memcpy(w.h_vec, res.rho.data(), sizeof(double) * n);
+        EGX_HIP_CHECK(hipMemcpyAsync(w.d_rhs, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
+    }
     EGX_HIP_CHECK(hipEventRecord(w.ev[4], w.stream));
     EGX_RC(backward_solve(gp, w));
     EGX_HIP_CHECK(hipMemcpyAsync(gp->d_gamma, w.d_vec, sizeof(double) * n_pad, hipMemcpyDeviceToDevice, w.stream));
@@ -354,7 +523,48 @@ int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     if (host_ms < 0) host_ms = 0;
     record_timings(gp, w, host_ms, std::chrono::duration<double, std::milli>(t2 - t1).count());
     return EGX_SUCCESS;
-}}  // namespace egx
+}
+// k candidates pipelined over the handle's workspaces (caller holds gp->mu exclusively and has set the device)
+int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len, double *lkh, int32_t *status) {
+    // a fitted model keeps its factor (workspace 0) as long as another workspace exists
+    const int ws_lo = (gp->fitted && gp->ws.size() > 1) ? 1 : 0;
+    const int nws = (int)gp->ws.size() - ws_lo;
+    // Software pipeline over the workspaces: every workspace has its own stream pair, so the serial panel
+    // factorisations of one candidate overlap the trailing updates of the others; as soon as a candidate has
+    // been read back its workspace is re-used for candidate c + nws.
+    std::vector<int> launched(nws + ws_lo, 0);
+    auto enqueue = [&](int64_t c) -> int {
+        const int wi = ws_lo + (int)(c % nws);
+        const double *th = thetas + c * theta_len;
+        std::vector<double> coef;
+        int hcols = 1;
+        EGX_RC(make_coef(gp, th, theta_len, coef, hcols, nullptr));
+        launched[wi] = 0;
+        if (has_nan(th, theta_len)) {
+            lkh[c] = -std::numeric_limits<double>::infinity();
+            status[c] = EGX_STATUS_NAN_THETA;
+            return EGX_SUCCESS;
+        }
+        if (wi == 0) gp->fitted = false;
+        EGX_RC(enqueue_eval(gp, gp->ws[wi], coef, hcols));
+        launched[wi] = 1;
+        return EGX_SUCCESS;
+    };
+    for (int64_t c = 0; c < k && c < nws; c++) EGX_RC(enqueue(c));
+    for (int64_t c = 0; c < k; c++) {
+        const int wi = ws_lo + (int)(c % nws);
+        if (launched[wi]) {
+            EvalResult res;
+            EGX_RC(finish_eval(gp, gp->ws[wi], res, false));
+            lkh[c] = res.lkh;
+            status[c] = res.status;
+            if (wi == 0) record_timings(gp, gp->ws[0], 0.0, 0.0);
+        }
+        if (c + nws < k) EGX_RC(enqueue(c + nws));
+    }
+    return EGX_SUCCESS;
+}
+}  // namespace egx
 
 // =================================================================================================
 // C ABI
@@ -483,6 +693,10 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
     gp->h = gp->has_w ? (int)cfg.kpls_dim : (int)d;
     if (gp->has_w) gp->w_star.assign(cfg.w_star, cfg.w_star + d * cfg.kpls_dim);
     gp->q = gp->p + 1;
+    {
+        const char *e = std::getenv("EGX_GLS_DEVICE");  // 0 = always the host Householder route (A/B, debugging)
+        gp->gls_device = gp->p >= 2 && !(e && e[0] == '0');
+    }
     // 256-column granularity lets every trailing update of a large fit use the 128x256 tile (N % 256 == 0)
     gp->n_pad = (int)round_up(n, n >= 4096 ? kNB : kTile);
     gp->rhs_pad = (int)round_up(gp->q, kRhsPad);
@@ -615,43 +829,7 @@ int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int
     }
     std::unique_lock<std::shared_mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
-    // a fitted model keeps its factor (workspace 0) as long as another workspace exists
-    const int ws_lo = (gp->fitted && gp->ws.size() > 1) ? 1 : 0;
-    const int nws = (int)gp->ws.size() - ws_lo;
-    // Software pipeline over the workspaces: every workspace has its own stream pair, so the serial panel
-    // factorisations of one candidate overlap the trailing updates of the others; as soon as a candidate has
-    // been read back its workspace is re-used for candidate c + nws.
-    std::vector<int> launched(nws + ws_lo, 0);
-    auto enqueue = [&](int64_t c) -> int {
-        const int wi = ws_lo + (int)(c % nws);
-        const double *th = thetas + c * theta_len;
-        std::vector<double> coef;
-        int hcols = 1;
-        EGX_RC(make_coef(gp, th, theta_len, coef, hcols, nullptr));
-        launched[wi] = 0;
-        if (has_nan(th, theta_len)) {
-            lkh[c] = -std::numeric_limits<double>::infinity();
-            status[c] = EGX_STATUS_NAN_THETA;
-            return EGX_SUCCESS;
-        }
-        if (wi == 0) gp->fitted = false;
-        EGX_RC(enqueue_eval(gp, gp->ws[wi], coef, hcols));
-        launched[wi] = 1;
-        return EGX_SUCCESS;
-    };
-    for (int64_t c = 0; c < k && c < nws; c++) EGX_RC(enqueue(c));
-    for (int64_t c = 0; c < k; c++) {
-        const int wi = ws_lo + (int)(c % nws);
-        if (launched[wi]) {
-            EvalResult res;
-            EGX_RC(finish_eval(gp, gp->ws[wi], res, false));
-            lkh[c] = res.lkh;
-            status[c] = res.status;
-            if (wi == 0) record_timings(gp, gp->ws[0], 0.0, 0.0);
-        }
-        if (c + nws < k) EGX_RC(enqueue(c + nws));
-    }
-    return EGX_SUCCESS;
+    return likelihood_batch_core(gp, thetas, k, theta_len, lkh, status);
 }
 
 int32_t egx_gp_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {

@@ -361,6 +361,44 @@ __global__ void k_gather_diag(const double *__restrict__ M, int64_t ld, int n, d
     if (i < n) out[i] = M[(int64_t)i * ld + i];
 }
 
+// Device-side GLS (algorithm.rs:1007-1032 for p > 1 trend columns), helpers around the Gram matrix of [ft | yt]:
+// G (rows x rows, ldg) <- -Gneg on the lower triangle of the leading q x q block, identity on the padding diagonal
+__global__ void k_gram_finish(const double *__restrict__ Gneg, double *__restrict__ G, int64_t ldg, int rows, int q) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= rows) return;
+    double v = 0.0;
+    if (i < q && j <= i) v = -Gneg[(int64_t)i * ldg + j];
+    else if (i >= q && j == i) v = 1.0;
+    G[(int64_t)i * ldg + j] = v;
+}
+
+// rho (n_pad, zero beyond n) <- yt - sum_l beta_l ft_l  (ft_l = row l of ftT);  part[block] <- sum of rho^2 over the
+// block's 256 points, reduced in a fixed order (the host adds the n_pad / 256 partial sums in order: deterministic)
+__global__ __launch_bounds__(256) void k_gls_residual(const double *__restrict__ ftT, int64_t ld, const double *__restrict__ yt,
+                                                      const double *__restrict__ beta, int p, int n, int n_pad,
+                                                      double *__restrict__ rho, double *__restrict__ part) {
+    __shared__ double bs[256];
+    __shared__ double red[256];
+    const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+    double acc = (i < n) ? yt[i] : 0.0;
+    for (int l0 = 0; l0 < p; l0 += 256) {
+        const int cnt = (p - l0 < 256) ? (p - l0) : 256;
+        __syncthreads();
+        if (tid < cnt) bs[tid] = beta[l0 + tid];
+        __syncthreads();
+        if (i < n)
+            for (int l = 0; l < cnt; l++) acc = __builtin_fma(-bs[l], ftT[(int64_t)(l0 + l) * ld + i], acc);
+    }
+    if (i < n_pad) rho[i] = acc;
+    red[tid] = acc * acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) part[blockIdx.x] = red[0];
+}
+
 __global__ void k_zero_upper(double *__restrict__ M, int64_t ld, int n) {
     const int64_t total = (int64_t)n * n;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -569,6 +607,20 @@ int launch_fill_rows(hipStream_t s, double *M, int64_t ld, int r0, int rows_pad,
 
 int launch_gather_diag(hipStream_t s, const double *M, int64_t ld, int n, double *out) {
     hipLaunchKernelGGL(k_gather_diag, dim3((n + 255) / 256), dim3(256), 0, s, M, ld, n, out);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_gram_finish(hipStream_t s, const double *Gneg, double *G, int64_t ldg, int rows, int q) {
+    hipLaunchKernelGGL(k_gram_finish, dim3((rows + 255) / 256, rows), dim3(256), 0, s, Gneg, G, ldg, rows, q);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_gls_residual(hipStream_t s, const double *ftT, int64_t ld, const double *yt, const double *beta, int p, int n,
+                        int n_pad, double *rho, double *part) {
+    hipLaunchKernelGGL(k_gls_residual, dim3((n_pad + 255) / 256), dim3(256), 0, s, ftT, ld, yt, beta, p, n, n_pad, rho,
+                       part);
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }

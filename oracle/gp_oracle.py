@@ -130,6 +130,8 @@ def corr_value(kind, d, theta, weights):
             s = math.sqrt(3.0)
             for j in range(d.shape[1]):
                 for l in range(theta_w.shape[1]):
+                    if theta_w[j, l] == 0.0:
+                        continue  # factor is exactly 1.0 (w = identity: the reference multiplies by it d*(h-1) times)
                     a *= 1.0 + s * theta_w[j, l] * abs_d[:, j]
         else:
             s = math.sqrt(5.0)
@@ -137,6 +139,8 @@ def corr_value(kind, d, theta, weights):
             for j in range(d.shape[1]):
                 for l in range(theta_w.shape[1]):
                     v = theta_w[j, l]
+                    if v == 0.0:
+                        continue  # factor is exactly 1.0
                     a *= 1.0 + s * v * abs_d[:, j] + c53 * (v * v * d[:, j] * d[:, j])
         b = np.exp(-s * abs_d.dot(theta_w).sum(axis=1))
         return (a * b).reshape(-1, 1)

@@ -267,3 +267,58 @@ def test_config5_eight_experts_n8192_d16_m100000(egx, large):
     finally:
         for e in experts:
             e.close()
+
+
+# ------------------------------------------------------------------ device-side GLS for p > 1 trend columns
+@pytest.mark.parametrize("mean,d,n", [(1, 32, 3000), (2, 32, 4096), (2, 6, 1500)])
+def test_device_gls_matches_host_householder_route(egx, O, mean, d, n):
+    """algorithm.rs:1006-1043 with a Linear / Quadratic trend (p = 33 / 561 / 28 columns): the device route (Gram matrix of
+    [ft | yt] by split-K MFMA, its Cholesky factor = the QR factor R, beta = R^-1 z, rho and sum rho^2 on the device)
+    against the host Householder-QR route on the same factorisation, and against the oracle where it is quick."""
+    x, y = _data(n, d, 5)
+    y = y + 3.0 * x[:, 0] - 2.0 * x[:, 1] ** 2
+    theta = np.full(d, 2.0 / math.sqrt(d))
+    res = {}
+    for route in ("1", "0"):
+        os.environ["EGX_GLS_DEVICE"] = route
+        try:
+            with egx.GpHandle(x, y, mean=mean, corr=3) as h:
+                lk, st = h.likelihood(theta)
+                assert st == 0
+                h.finalize(theta)
+                inner = h.inner()
+                xq = np.random.default_rng(1).random((300, d))
+                res[route] = (lk, h.fitted_scalars(), np.ravel(inner["beta"]), inner["ft_qr_r"], h.predict(xq),
+                              h.predict_var(xq), np.ravel(inner["gamma"]))
+        finally:
+            os.environ.pop("EGX_GLS_DEVICE", None)
+    dev, host = res["1"], res["0"]
+    assert dev[0] == pytest.approx(host[0], rel=1e-9)
+    assert dev[1][0] == dev[0] and dev[1][1] == pytest.approx(host[1][1], rel=1e-8)
+    np.testing.assert_allclose(dev[2], host[2], rtol=1e-6, atol=1e-8 * np.abs(host[2]).max())
+    np.testing.assert_allclose(dev[3], host[3], rtol=1e-7, atol=1e-9 * np.abs(host[3]).max())  # R of the QR, positive diagonal
+    np.testing.assert_allclose(dev[4], host[4], rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(y).max())
+    np.testing.assert_allclose(dev[5], host[5], rtol=1e-5, atol=1e-8 * dev[1][1])
+    np.testing.assert_allclose(dev[6], host[6], rtol=1e-5, atol=1e-7 * np.abs(host[6]).max())
+    if n <= 3000:
+        ref = O.fit_fixed(x, y, theta, mean=("Constant", "Linear", "Quadratic")[mean], corr="Matern52")
+        assert dev[0] == pytest.approx(ref.likelihood, rel=LK_RTOL)
+
+
+def test_device_gls_quadratic_trend_costs_like_the_constant_one(egx):
+    """Quadratic mean at d = 32 (p = 561) and n = 16384 -- one likelihood evaluation within 1.2x of
+    the Constant-mean time (the host route needed a 16384 x 561 Householder QR per evaluation)."""
+    n, d = 16384, 32
+    x, y = _data(n, d, 42)
+    theta = egx.workload.default_theta(d)
+    times = {}
+    for mean in (0, 2):
+        with egx.GpHandle(x, y, mean=mean, corr=0) as h:
+            h.likelihood(theta)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                lk, st = h.likelihood(theta)
+            times[mean] = (time.perf_counter() - t0) / 3
+            assert st == 0 and np.isfinite(lk)
+    print(f"likelihood at n=16384, d=32: constant {times[0] * 1e3:.1f} ms, quadratic (p=561) {times[2] * 1e3:.1f} ms")
+    assert times[2] < 1.3 * times[0]

@@ -392,6 +392,23 @@ def test_full_fit_improves_likelihood(egx):
     gp.close()
 
 
+def test_default_tuned_fit_lands_on_the_reference_theta_golden_a(egx, golden_dir):
+    """The reference's notebook (doc/Gpx_Tutorial.ipynb cells 9-14): default Kriging fit (11 COBYLA runs) prints
+    theta* = 1.83209405, likelihood 0.57817407, variance 0.30494059.  egx_gp_fit (csrc/cobyla.h, all starts in
+    lock-step through one likelihood batch per round) lands on the same optimum: theta to 1e-3 relative -- ftol_rel =
+    1e-4 stops that early --, likelihood to 1e-6, variance to 1e-3."""
+    with open(os.path.join(golden_dir, "golden_a.json")) as f:
+        ga = json.load(f)
+    xt, yt = np.array(ga["xt"]).reshape(-1, 1), np.array(ga["yt"])
+    gp = egx.Gpx.builder().fit(xt, yt)
+    assert gp.thetas()[0][0] == pytest.approx(ga["theta_printed_8_digits"], rel=1e-3)
+    assert gp.likelihoods()[0] == pytest.approx(ga["likelihood"], abs=1e-6)
+    assert gp.variances()[0] == pytest.approx(ga["variance"], rel=1e-3)
+    e = gp._experts[0]
+    assert 11 <= e.n_evals <= 11 * 25   # clamp(10 h, 25, max_eval = 50) per start, algorithm.rs:933-936
+    e.close()
+
+
 def test_multistart_threads_are_deterministic(egx):
     """Starts are independent optimisations reduced by min: running them on 1 or 3 workspaces (host threads +
     streams) must give the same theta and likelihood."""
