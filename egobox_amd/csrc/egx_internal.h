@@ -69,11 +69,13 @@ int launch_gls_residual(hipStream_t s, const double *ftT, int64_t ld, const doub
                         int n_pad, double *rho, double *part);
 // zero the strict upper triangle of the leading n x n block
 int launch_zero_upper(hipStream_t s, double *M, int64_t ld, int n);
-// likelihood-gradient accumulation (new capability): for all i>j
-//   tr[k]  += 2*Rinv[i][j]*dR_k[i][j],  q[k] += 2*gamma_i*gamma_j*dR_k[i][j]
-int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d,
-                      const double *theta, const double *Rinv, int64_t ld, const double *gamma,
-                      double *out /*2*d, zeroed by the launcher*/);
+// likelihood-gradient accumulation (new capability): for all i > j and every output k < nout
+//   out[k] += 2 Rinv[i][j] dR_k[i][j],  out[nout + k] += 2 gamma_i gamma_j dR_k[i][j]
+// hcols == 1: output k = input dimension k, dR_k = R d(log r)/d(coef_k) (nout = d; w = I: coef = theta);
+// hcols  > 1 (KPLS + Matern): output k = theta_k, dR_k = R sum_j wabs[j][k] (d log m / dt)(coef[j][k] a_j) a_j (nout = h)
+int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d, const double *coef, int hcols,
+                      const double *wabs, int nout, const double *Rinv, int64_t ld, const double *gamma,
+                      double *out /*2*nout, zeroed by the launcher*/);
 
 // ---- kernels_chol.hip -------------------------------------------------------
 // In-place blocked right-looking Cholesky of the leading n_pad x n_pad block (lower), applied to

@@ -198,7 +198,7 @@ static int likelihood_grad_core(egx_gp *gp, const double *theta, int64_t theta_l
     if (has_nan(theta, theta_len)) {
         *lkh = -std::numeric_limits<double>::infinity();
         *status = EGX_STATUS_NAN_THETA;
-        for (int k = 0; k < d; k++) grad[k] = 0.0;
+        for (int k = 0; k < gp->h; k++) grad[k] = 0.0;
         return EGX_SUCCESS;
     }
     gp->fitted = false;
@@ -209,14 +209,15 @@ static int likelihood_grad_core(egx_gp *gp, const double *theta, int64_t theta_l
     *lkh = res.lkh;
     *status = res.status;
     if (res.status != EGX_STATUS_OK) {
-        for (int k = 0; k < d; k++) grad[k] = 0.0;
+        for (int k = 0; k < gp->h; k++) grad[k] = 0.0;
         return EGX_SUCCESS;
     }
     const size_t sq = (size_t)n_pad * n_pad;
     if (!gp->d_W) EGX_HIP_CHECK(hipMalloc(&gp->d_W, sizeof(double) * sq));
     if (!gp->d_Rinv) EGX_HIP_CHECK(hipMalloc(&gp->d_Rinv, sizeof(double) * sq));
     if (!gp->d_gout) EGX_HIP_CHECK(hipMalloc(&gp->d_gout, sizeof(double) * 2 * kMaxDim));
-    if (!gp->d_theta) EGX_HIP_CHECK(hipMalloc(&gp->d_theta, sizeof(double) * kMaxDim));
+    // d_theta: the coefficient table (d x hcols) followed by |w| (d x h)
+    if (!gp->d_theta) EGX_HIP_CHECK(hipMalloc(&gp->d_theta, sizeof(double) * 2 * kMaxDim * kMaxDim));
     // gamma = C^-T rho
     if (!res.rho_on_device) {
         std::memset(w.h_vec, 0, sizeof(double) * n_pad);
@@ -236,16 +237,49 @@ static int likelihood_grad_core(egx_gp *gp, const double *theta, int64_t theta_l
     EGX_RC(launch_trsm_rows(w.stream, w.M, gp->ld, n_pad, w.dinv, gp->d_W, n_pad, n_pad, 1));
     EGX_HIP_CHECK(hipMemsetAsync(gp->d_Rinv, 0, sizeof(double) * sq, w.stream));
     EGX_RC(launch_gemm_nt_sub(w.stream, gp->d_Rinv, n_pad, gp->d_W, n_pad, gp->d_W, n_pad, n_pad, n_pad, n_pad, 1, 1));
-    EGX_HIP_CHECK(hipMemcpyAsync(gp->d_theta, thfull.data(), sizeof(double) * d, hipMemcpyHostToDevice, w.stream));
-    EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
-    EGX_RC(launch_grad_accum(w.stream, gp->corr, gp->d_xT, n_pad, n, d, gp->d_theta, gp->d_Rinv, n_pad, w.d_vec,
+    const int h = gp->h;
+    const int nout = (hcols == 1) ? d : h;
+    std::vector<double> wabs;
+    {
+        std::vector<double> up(coef);  // (d x hcols), then |w| (d x h) for the KPLS + Matern form
+        if (hcols > 1) {
+            wabs.resize((size_t)d * h);
+            for (size_t e = 0; e < wabs.size(); e++) wabs[e] = std::fabs(gp->w_star[e]);
+            up.insert(up.end(), wabs.begin(), wabs.end());
+        }
+        EGX_HIP_CHECK(hipMemcpyAsync(gp->d_theta, up.data(), sizeof(double) * up.size(), hipMemcpyHostToDevice, w.stream));
+        EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+    }
+    EGX_RC(launch_grad_accum(w.stream, gp->corr, gp->d_xT, n_pad, n, d, gp->d_theta, hcols,
+                             hcols > 1 ? gp->d_theta + (size_t)d * hcols : nullptr, nout, gp->d_Rinv, n_pad, w.d_vec,
                              gp->d_gout));
-    std::vector<double> gout(2 * d);
-    EGX_HIP_CHECK(hipMemcpyAsync(gout.data(), gp->d_gout, sizeof(double) * 2 * d, hipMemcpyDeviceToHost, w.stream));
+    std::vector<double> gout(2 * nout);
+    EGX_HIP_CHECK(hipMemcpyAsync(gout.data(), gp->d_gout, sizeof(double) * 2 * nout, hipMemcpyDeviceToHost, w.stream));
     EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
-    // dL/dtheta_k = (1/ln10) [ gamma^T dR_k gamma / sigma2 - tr(R^-1 dR_k) ] ; d_Rinv holds -R^-1
+    // dL/dc_k = (1/ln10) [ gamma^T dR_k gamma / sigma2 - tr(R^-1 dR_k) ] ; d_Rinv holds -R^-1
     const double ln10 = std::log(10.0);
-    for (int k = 0; k < d; k++) grad[k] = (gout[d + k] / res.sigma2n + gout[k]) / ln10;
+    std::vector<double> pk(nout);
+    for (int k = 0; k < nout; k++) pk[k] = (gout[nout + k] / res.sigma2n + gout[k]) / ln10;
+    if (!gp->has_w || hcols > 1) {
+        for (int k = 0; k < h; k++) grad[k] = pk[k];  // w = I (c = theta), or KPLS + Matern (outputs are per theta)
+    } else {
+        // KPLS with a collapsed per-dimension coefficient c_j (make_coef): chain rule dc_j / dtheta_l
+        //   sq-exp : c_j = sqrt(sum_l (theta_l w_jl)^2)  ->  theta_l w_jl^2 / c_j     (correlation_models.rs:97-98)
+        //   abs-exp: c_j = sum_l theta_l |w_jl|           ->  |w_jl|                   (:191)
+        const double *wm = gp->w_star.data();
+        for (int l = 0; l < h; l++) {
+            double sacc = 0.0;
+            for (int j = 0; j < d; j++) {
+                const double wjl = wm[(size_t)j * h + l];
+                if (gp->corr == EGX_CORR_SQUARED_EXPONENTIAL) {
+                    if (coef[j] > 0.0) sacc += pk[j] * thfull[l] * wjl * wjl / coef[j];
+                } else {
+                    sacc += pk[j] * std::fabs(wjl);
+                }
+            }
+            grad[l] = sacc;
+        }
+    }
     return EGX_SUCCESS;
 }
 }  // namespace egx
@@ -257,10 +291,6 @@ int32_t egx_gp_likelihood_grad(egx_gp *gp, const double *theta, int64_t theta_le
     if (!gp || !theta || !lkh || !grad || !status) {
         set_error("NULL argument");
         return EGX_ERR_INVALID_VALUE;
-    }
-    if (gp->has_w) {
-        set_error("likelihood gradient with KPLS weights is not implemented");
-        return EGX_ERR_UNSUPPORTED;
     }
     std::unique_lock<std::shared_mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
@@ -275,10 +305,6 @@ int32_t egx_gp_fit_lbfgs(egx_gp *gp, const double *theta0s, int64_t n_starts, co
     if (!gp || !theta0s || !lo || !hi || n_starts < 1) {
         set_error("NULL argument / no start point");
         return EGX_ERR_INVALID_VALUE;
-    }
-    if (gp->has_w) {
-        set_error("likelihood gradient with KPLS weights is not implemented");
-        return EGX_ERR_UNSUPPORTED;
     }
     const int h = gp->h;
     if (bounds_len != 1 && bounds_len != h) {

@@ -435,20 +435,21 @@ __global__ __launch_bounds__(256) void k_row_reduce(const double *__restrict__ R
 // Matern52 (s5 a + 10/3 theta a^2)/(1 + s5 t + 5/3 t^2) - s5 a.
 template <int CORR>
 __global__ __launch_bounds__(256) void k_grad_accum(const double *__restrict__ xT, int64_t ldx, int n, int d,
-                                                    const double *__restrict__ theta,
+                                                    const double *__restrict__ coef, int hcols,
+                                                    const double *__restrict__ wabs, int nout,
                                                     const double *__restrict__ Rinv, int64_t ld,
                                                     const double *__restrict__ gamma, double *__restrict__ out) {
     const int bi = blockIdx.x, bj = blockIdx.y;
     if (bj > bi) return;
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *xi = sm, *xj = sm + d * 64, *red = sm + 2 * d * 64;  // red[2*d]
+    double *xi = sm, *xj = sm + d * 64, *red = sm + 2 * d * 64;  // red[2 * nout]
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     stage_slab(xi, xT, ldx, bi * 64, d, tid);
     stage_slab(xj, xT, ldx, bj * 64, d, tid);
-    for (int e = tid; e < 2 * d; e += 256) red[e] = 0.0;
+    for (int e = tid; e < 2 * nout; e += 256) red[e] = 0.0;
     __syncthreads();
     double r[4][4];
-    tile_pairs<CORR>(xi, xj, theta, 1, d, ty, tx, r);
+    tile_pairs<CORR>(xi, xj, coef, hcols, d, ty, tx, r);
     double wt[4][4], wq[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -460,36 +461,53 @@ __global__ __launch_bounds__(256) void k_grad_accum(const double *__restrict__ x
             wt[a][b] = on ? rv * Rinv[(int64_t)i * ld + j] : 0.0;
             wq[a][b] = on ? rv * gamma[i] * gamma[j] : 0.0;
         }
-    for (int k = 0; k < d; k++) {
-        const double th = theta[k];
+    // d log r / d c for one scaled distance: sq-exp -c a^2 ; abs-exp -a ; Matern a (m'(t) / m(t)), t = c a
+    auto dlog = [](double c, double ad) -> double {
+        if (CORR == EGX_CORR_SQUARED_EXPONENTIAL) return -c * ad * ad;
+        if (CORR == EGX_CORR_ABSOLUTE_EXPONENTIAL) return -ad;
+        const double t = c * ad;
+        if (CORR == EGX_CORR_MATERN32) return kSqrt3 * ad / (1.0 + kSqrt3 * t) - kSqrt3 * ad;
+        return (kSqrt5 * ad + (10.0 / 3.0) * c * ad * ad) / (1.0 + kSqrt5 * t + k5over3 * t * t) - kSqrt5 * ad;
+    };
+    for (int k = 0; k < nout; k++) {
         double st = 0.0, sq = 0.0;
+        if (hcols == 1) {
+            // output k = input dimension k, derivative with respect to the per-dimension coefficient c_k
+            const double th = coef[k];
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+            for (int a = 0; a < 4; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const double ad = fabs(xi[k * 64 + ty * 4 + a] - xj[k * 64 + tx * 4 + b]);
-                double g;
-                if (CORR == EGX_CORR_SQUARED_EXPONENTIAL) g = -th * ad * ad;
-                else if (CORR == EGX_CORR_ABSOLUTE_EXPONENTIAL) g = -ad;
-                else if (CORR == EGX_CORR_MATERN32) g = kSqrt3 * ad / (1.0 + kSqrt3 * th * ad) - kSqrt3 * ad;
-                else {
-                    const double t = th * ad;
-                    g = (kSqrt5 * ad + (10.0 / 3.0) * th * ad * ad) / (1.0 + kSqrt5 * t + k5over3 * t * t) - kSqrt5 * ad;
+                for (int b = 0; b < 4; b++) {
+                    const double g = dlog(th, fabs(xi[k * 64 + ty * 4 + a] - xj[k * 64 + tx * 4 + b]));
+                    st = __builtin_fma(wt[a][b], g, st);
+                    sq = __builtin_fma(wq[a][b], g, sq);
                 }
-                st = __builtin_fma(wt[a][b], g, st);
-                sq = __builtin_fma(wq[a][b], g, sq);
+        } else {
+            // KPLS + Matern: output k = theta_k, d log r / d theta_k = sum_j |w_jk| (d log m / d t)(theta_k |w_jk| a_j) a_j
+            for (int jd = 0; jd < d; jd++) {
+                const double c = coef[jd * hcols + k], wa = wabs[jd * hcols + k];
+                if (wa == 0.0) continue;
+#pragma unroll
+                for (int a = 0; a < 4; a++)
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const double g = wa * dlog(c, fabs(xi[jd * 64 + ty * 4 + a] - xj[jd * 64 + tx * 4 + b]));
+                        st = __builtin_fma(wt[a][b], g, st);
+                        sq = __builtin_fma(wq[a][b], g, sq);
+                    }
             }
+        }
         for (int o = 32; o > 0; o >>= 1) {
             st += __shfl_xor(st, o);
             sq += __shfl_xor(sq, o);
         }
         if ((tid & 63) == 0) {
             atomicAdd(&red[k], st);
-            atomicAdd(&red[d + k], sq);
+            atomicAdd(&red[nout + k], sq);
         }
     }
     __syncthreads();
-    for (int e = tid; e < 2 * d; e += 256) atomicAdd(&out[e], red[e]);
+    for (int e = tid; e < 2 * nout; e += 256) atomicAdd(&out[e], red[e]);
 }
 
 // =============================================================================================
@@ -638,14 +656,14 @@ int launch_row_reduce(hipStream_t s, const double *RT, int64_t ld, int m, int n,
     return EGX_SUCCESS;
 }
 
-int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d, const double *theta,
-                      const double *Rinv, int64_t ld, const double *gamma, double *out) {
-    EGX_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double) * 2 * d, s));
+int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d, const double *coef, int hcols,
+                      const double *wabs, int nout, const double *Rinv, int64_t ld, const double *gamma, double *out) {
+    EGX_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double) * 2 * nout, s));
     const int nt = (n + 63) / 64;
     dim3 grid(nt, nt);
-    const size_t lds = (size_t)(2 * d * 64 + 2 * d) * sizeof(double);
-    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_grad_accum<C_>, grid, dim3(256), lds, s, xT, ldx, n, d, theta, Rinv,
-                                               ld, gamma, out));
+    const size_t lds = (size_t)(2 * d * 64 + 2 * nout) * sizeof(double);
+    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_grad_accum<C_>, grid, dim3(256), lds, s, xT, ldx, n, d, coef, hcols, wabs,
+                                               nout, Rinv, ld, gamma, out));
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }

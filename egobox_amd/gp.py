@@ -206,7 +206,7 @@ class GpHandle:
     def likelihood_grad(self, theta):
         theta = L.as_f64(np.atleast_1d(theta), 1)
         lk, st = C.c_double(), C.c_int32()
-        g = np.zeros(self.d)
+        g = np.zeros(self.h)
         L.check(self._lib.egx_gp_likelihood_grad(self._h, L.dptr(theta), theta.size, C.byref(lk), L.dptr(g),
                                                  C.byref(st)))
         return lk.value, g, st.value

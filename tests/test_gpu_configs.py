@@ -322,3 +322,52 @@ def test_device_gls_quadratic_trend_costs_like_the_constant_one(egx):
             assert st == 0 and np.isfinite(lk)
     print(f"likelihood at n=16384, d=32: constant {times[0] * 1e3:.1f} ms, quadratic (p=561) {times[2] * 1e3:.1f} ms")
     assert times[2] < 1.3 * times[0]
+
+
+# ------------------------------------------------------------------ theta-gradient with KPLS weights
+@pytest.mark.parametrize("corr", range(4))
+def test_theta_gradient_with_kpls_weights_vs_finite_differences(egx, corr):
+    """dL/dtheta_l through the coefficient table make_coef builds from w_star (correlation_models.rs:97-101 sq-exp,
+    :191 abs-exp, :333 / :505 Matern): against central differences of the parity-checked likelihood, and for the
+    identity rotation against the plain gradient."""
+    rng = np.random.default_rng(40 + corr)
+    n, d, hk = 700, 6, 3
+    x, y = _data(n, d, 9)
+    w = rng.standard_normal((d, hk))
+    w /= np.linalg.norm(w, axis=0)
+    theta = np.array([0.9, 1.4, 0.6]) * (2.0 if corr in (1, 2, 3) else 1.0)
+    with egx.GpHandle(x, y, corr=corr, w_star=w, n_workspaces=2) as h:
+        assert h.h == hk
+        lk, g, st = h.likelihood_grad(theta)
+        assert st == 0 and g.shape == (hk,)
+        for l in range(hk):
+            e = np.zeros(hk)
+            e[l] = 1e-5 * theta[l]
+            lks, sts = h.likelihood_batch(np.stack([theta + e, theta - e]))
+            assert np.all(sts == 0)
+            fd = (lks[0] - lks[1]) / (2 * e[l])
+            assert g[l] == pytest.approx(fd, rel=2e-5, abs=1e-6 * np.abs(g).max())
+    th6 = np.array([0.5, 0.9, 1.3, 0.7, 1.1, 0.8]) * (2.0 if corr else 1.0)
+    with egx.GpHandle(x, y, corr=corr, w_star=np.eye(d)) as hw, egx.GpHandle(x, y, corr=corr) as h0:
+        lw, gw, _ = hw.likelihood_grad(th6)
+        l0, g0, _ = h0.likelihood_grad(th6)
+        assert lw == pytest.approx(l0, rel=1e-12)
+        np.testing.assert_allclose(gw, g0, rtol=1e-9, atol=1e-9 * np.abs(g0).max())
+
+
+def test_lbfgs_fit_with_kpls_weights(egx):
+    """egx_gp_fit_lbfgs on a KPLS-reduced model (kpls_dim = 2 of d = 8): ends at a likelihood no worse than the start's
+    and with a small projected gradient."""
+    x, y = _data(600, 8, 21)
+    base = lambda: egx.GaussianProcess.params(egx.ConstantMean(), egx.Matern52Corr()).kpls_dim(2).n_start(0)
+    gp = base().optimizer("lbfgs").max_eval(120).fit(x, y)
+    th = gp.theta()
+    assert th.shape == (2,) and np.all(th >= 1e-2 * (1 - 1e-9)) and np.all(th <= 1e1 * (1 + 1e-9))
+    with egx.GpHandle(x, y, corr=3, w_star=gp.handle._w) as h:
+        l0, _ = h.likelihood(np.full(2, 0.1))
+        l1, g1, st = h.likelihood_grad(th)
+        assert st == 0 and l1 == pytest.approx(gp.likelihood(), rel=1e-10) and l1 >= l0
+        gx = th * np.log(10.0) * g1
+        free = (th > 1e-2 * 1.001) & (th < 1e1 * 0.999)
+        assert np.all(np.abs(gx[free]) <= 1e-2 * max(1.0, abs(l1)))
+    gp.close()
