@@ -397,7 +397,18 @@ __device__ __forceinline__ void stream_tile_coords(int t, int nbx, int nby, int 
     }
 }
 
-template <bool LOWER>
+#ifdef EGX_STREAM_PROFILE
+__device__ long long g_stream_stamps[1 << 14][6];  // per tile: wall start, wall end, cycles start / after C load / after K loop / end
+#define EGX_SSTAMP(slot, i, v)                                     \
+    if (threadIdx.x == 0) g_stream_stamps[(slot) & 0x3fff][i] = (long long)(v)
+#else
+#define EGX_SSTAMP(slot, i, v)
+#endif
+// VARIANT: where a wave issues its six LDS-DMA pieces of chunk g + 2 inside chunk g
+//   0  all six right after the barrier
+//   1  two after the barrier, two after the first 16 MFMAs, two after the first 32
+//   2  waves 0-3 right after the barrier, waves 4-7 (their SIMD partners) after their first 32 MFMAs
+template <bool LOWER, int VARIANT>
 __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, int64_t ldc, const double *__restrict__ A,
                                                         int64_t lda, const double *__restrict__ B, int64_t ldb, int K,
                                                         int nbx, int nby, int ntiles, const int *__restrict__ info) {
@@ -426,15 +437,21 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
         pA_l = A + (int64_t)bx * 128 * lda;
         pB_l = B + (int64_t)by * 256 * ldb;
     }
-    auto issue = [&](int stage) {
+    // pieces [p0, p1) of the six (0, 1: A groups; 2..5: B groups) of the load cursor's chunk into `stage`
+    auto issue_pieces = [&](int stage, int p0, int p1) {
         double *dst = smem + stage * ST_STAGE + wave * 128;  // group g starts at g * 8 rows * 16 doubles
         const double *ga = pA_l + ch_l * KC, *gb = pB_l + ch_l * KC;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ga + offA[i]), (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; i++)
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gb + offB[i]), (lds_ptr_t)(dst + 2048 + i * 1024), 16, 0, 0);
+        for (int i = 0; i < 6; i++) {
+            if (i < p0 || i >= p1) continue;
+            if (i < 2)
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ga + offA[i]), (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gb + offB[i - 2]), (lds_ptr_t)(dst + 2048 + (i - 2) * 1024), 16,
+                                                 0, 0);
+        }
+    };
+    auto issue_done = [&]() {
         issued++;
         if (++ch_l == nch) {
             ch_l = 0;
@@ -446,6 +463,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
                 pB_l = B + (int64_t)by * 256 * ldb;
             }
         }
+    };
+    auto issue = [&](int stage) {
+        issue_pieces(stage, 0, 6);
+        issue_done();
     };
     if (total > 0) issue(0);
     if (total > 1) issue(1);
@@ -470,6 +491,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
         int bx, by;
         stream_tile_coords<LOWER>(t, nbx, nby, bx, by);
         double *Ct = C + (int64_t)(bx * 128 + wm0) * ldc + by * 256 + wn0;
+        EGX_SSTAMP(t, 0, wall_clock64());
+        EGX_SSTAMP(t, 2, clock64());
         double4_t acc[4][4];
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
@@ -477,6 +500,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
             for (int ni = 0; ni < 4; ni++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) acc[mi][ni][r] = -Ct[(int64_t)mi * 16 * ldc + ni * 16 + coff[r]];
+#ifdef EGX_STREAM_PROFILE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        EGX_SSTAMP(t, 3, clock64());
         for (int ch = 0; ch < nch; ch++, g++) {
             // chunk g has landed once this wave's own loads for it are done (the loads of chunk g + 1 may stay in
             // flight) AND every other wave says the same (barrier).  The barrier also tells that every wave is done
@@ -484,7 +511,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
             if (issued > g + 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (issued < total) issue(stage == 0 ? 2 : stage - 1);  // (g + 2) % 3
+            const bool more = issued < total;
+            const int nst = stage == 0 ? 2 : stage - 1;  // (g + 2) % 3
+            if (more) {
+                if (VARIANT == 0) issue_pieces(nst, 0, 6);
+                else if (VARIANT == 1) issue_pieces(nst, 0, 2);
+                else if (VARIANT == 2 && wave < 4) issue_pieces(nst, 0, 6);
+            }
             const double *As = smem + stage * ST_STAGE + aoff, *Bs = smem + stage * ST_STAGE + boff;
             stage = (stage == ST_NSTAGE - 1) ? 0 : stage + 1;
 #pragma unroll
@@ -495,20 +528,35 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
 #pragma unroll
                 for (int ni = 0; ni < 4; ni++) b[ni] = *reinterpret_cast<const d2_t *>(Bs + ni * 16 * KC + foff[kb]);
 #pragma unroll
-                for (int h = 0; h < 2; h++)
+                for (int h = 0; h < 2; h++) {
 #pragma unroll
                     for (int mi = 0; mi < 4; mi++)
 #pragma unroll
                         for (int ni = 0; ni < 4; ni++)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][h], b[ni][h], acc[mi][ni], 0, 0, 0);
+                    if (VARIANT == 1 && kb == 0 && more) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_pieces(nst, 2 + 2 * h, 4 + 2 * h);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (VARIANT == 2 && kb == 0 && more && wave >= 4) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue_pieces(nst, 0, 6);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            if (more) issue_done();
         }
+        EGX_SSTAMP(t, 4, clock64());
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
 #pragma unroll
             for (int ni = 0; ni < 4; ni++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) Ct[(int64_t)mi * 16 * ldc + ni * 16 + coff[r]] = -acc[mi][ni][r];
+        EGX_SSTAMP(t, 5, clock64());
+        EGX_SSTAMP(t, 1, wall_clock64());
     }
 }
 
@@ -1031,6 +1079,7 @@ static int g_gemm_stream = 1;        // EGX_GEMM_STREAM=0: the register-staged w
 static int g_stream_tpw = 1;         // EGX_STREAM_TPW: tiles per workgroup of k_gemm_stream (0 = one workgroup per CU walks all;
                                      // measured: the fully persistent form is the fastest kernel alone, 54 vs 50 TFLOP/s, but
                                      // holds every CU for the whole update and starves the look-ahead chain)
+static int g_stream_variant = 0;      // EGX_STREAM_VARIANT: placement of the LDS-DMA issue inside a chunk (see k_gemm_stream)
 static int g_stream_min_tiles = 512;  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles go to k_gemm_stream
 static int g_tail_lookahead = 0;      // EGX_TAIL_LOOKAHEAD=1: look-ahead also below 3072 trailing columns (measured: n = 4096 fit
                                       // 3.37 -> 3.27 ms alone, but 460 -> 313 fits/s with two in flight: the extra hand-offs cost more)
@@ -1054,6 +1103,7 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_POTRF_DIAG_FIRST")) g_potrf_diag_first = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_TPW")) g_stream_tpw = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_MIN")) g_stream_min_tiles = std::atoi(e);
+        if (const char *e = std::getenv("EGX_STREAM_VARIANT")) g_stream_variant = std::atoi(e);
         if (const char *e = std::getenv("EGX_TAIL_LOOKAHEAD")) g_tail_lookahead = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_WGS")) g_stream_wgs = std::atoi(e) > 0 ? std::atoi(e) : 256;
         auto set = [](const void *fn, int bytes) {
@@ -1073,8 +1123,12 @@ int chol_init() {
         set(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 256, 64, 64, 512, false, true>), wide_lds);
         set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 256, 64, 64, 512, false, true>), wide_lds);
         set(reinterpret_cast<const void *>(&k_panel_trsm), PanelShape::LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_stream<true>), ST_LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_stream<false>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<true, 0>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<false, 0>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<true, 1>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<false, 1>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<true, 2>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<false, 2>), ST_LDS_BYTES);
     });
     return rc_once;
 }
@@ -1111,12 +1165,18 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
             const int nt = (int)wide_tiles;
             int grid = g_stream_tpw > 0 ? (nt + g_stream_tpw - 1) / g_stream_tpw : (nt < g_stream_wgs ? nt : g_stream_wgs);
             if (grid < 1) grid = 1;
-            if (lower)
-                hipLaunchKernelGGL(k_gemm_stream<true>, dim3(grid), dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K,
-                                   nbx, nby, nt, info);
-            else
-                hipLaunchKernelGGL(k_gemm_stream<false>, dim3(grid), dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K,
-                                   nbx, nby, nt, info);
+#define EGX_STREAM(LOW, V) \
+    hipLaunchKernelGGL((k_gemm_stream<LOW, V>), dim3(grid), dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx, nby, nt, info)
+            if (lower) {
+                if (g_stream_variant == 1) EGX_STREAM(true, 1);
+                else if (g_stream_variant == 2) EGX_STREAM(true, 2);
+                else EGX_STREAM(true, 0);
+            } else {
+                if (g_stream_variant == 1) EGX_STREAM(false, 1);
+                else if (g_stream_variant == 2) EGX_STREAM(false, 2);
+                else EGX_STREAM(false, 0);
+            }
+#undef EGX_STREAM
             EGX_HIP_CHECK(hipGetLastError());
             return EGX_SUCCESS;
         }

@@ -3,9 +3,11 @@
 //   gemm_lab [n=15872] [K=512]
 // 1. correctness: both kernels on copies of the same matrix, LOWER and full rectangle, max |difference|
 // 2. speed: TFLOP/s of each variant (several tiles-per-workgroup settings), interleaved repetitions
+#define EGX_STREAM_PROFILE 1
 #include "../egobox_amd/csrc/kernels_chol.hip"
 #include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 namespace egx { void set_error(const std::string &m) { fprintf(stderr, "error: %s\n", m.c_str()); } }
 using namespace egx;
@@ -31,8 +33,8 @@ int main(int argc, char **argv) {
         hipMemcpy(M0, h.data(), sizeof(double) * elems, hipMemcpyHostToDevice);
     }
     chol_init();
-    auto run = [&](double *M, int lower, int stream, int tpw, int wgs) {
-        g_gemm_stream = stream; g_stream_tpw = tpw; g_stream_wgs = wgs;
+    auto run = [&](double *M, int lower, int stream, int tpw, int wgs, int variant = 0) {
+        g_gemm_stream = stream; g_stream_tpw = tpw; g_stream_wgs = wgs; g_stream_variant = variant;
         return launch_gemm_nt_sub(0, M + K, ld, M, ld, M, ld, n, n, K, lower);
     };
     // ---- correctness (on the leading n_check rows / columns so that the host comparison stays quick)
@@ -67,17 +69,17 @@ int main(int argc, char **argv) {
         }
     // ---- speed
     n = n_speed;
-    struct V { const char *name; int stream, tpw, wgs; };
-    std::vector<V> vs = {{"wide (register staged)", 0, 0, 256}, {"stream persistent 256", 1, 0, 256},
-                         {"stream persistent 248", 1, 0, 248}, {"stream tpw=1", 1, 1, 256}, {"stream tpw=2", 1, 2, 256},
-                         {"stream tpw=4", 1, 4, 256}};
+    struct V { const char *name; int stream, tpw, wgs, variant; };
+    std::vector<V> vs = {{"wide (register staged)", 0, 0, 256, 0}, {"stream persistent v0", 1, 0, 256, 0},
+                         {"stream persistent v1 (spread issue)", 1, 0, 256, 1}, {"stream persistent v2 (staggered halves)", 1, 0, 256, 2},
+                         {"stream tpw=1 v0", 1, 1, 256, 0}, {"stream tpw=1 v1", 1, 1, 256, 1}, {"stream tpw=1 v2", 1, 1, 256, 2}};
     const double flops = 2.0 * K * ((double)n * (n + 128) / 2.0);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<std::vector<double>> ms(vs.size());
     for (int rep = 0; rep < 5; rep++)
         for (size_t v = 0; v < vs.size(); v++) {
             hipEventRecord(e0);
-            run(M1, 1, vs[v].stream, vs[v].tpw, vs[v].wgs);
+            run(M1, 1, vs[v].stream, vs[v].tpw, vs[v].wgs, vs[v].variant);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float t; hipEventElapsedTime(&t, e0, e1);
             if (rep) ms[v].push_back(t);
@@ -87,6 +89,28 @@ int main(int argc, char **argv) {
         const double med = ms[v][ms[v].size() / 2];
         printf("n=%d K=%d LOWER  %-26s median %.3f ms  %.2f TFLOP/s  (min %.3f max %.3f)\n", n, K, vs[v].name, med,
                flops / med / 1e9, ms[v].front(), ms[v].back());
+    }
+    // ---- per-tile phase breakdown of the stream kernel (one tile per workgroup), shader-clock cycles
+    for (int variant = 0; variant < 3; variant++) {
+        static long long st[1 << 14][6];
+        memset(st, 0, sizeof st);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_stream_stamps), st, sizeof st);
+        run(M1, 1, 1, 1, 256, variant);
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stream_stamps), sizeof st);
+        std::vector<double> cl, kl, sto, tot, mhz;
+        for (int i = 0; i < (1 << 14); i++) {
+            if (st[i][5] == 0) continue;
+            cl.push_back((double)(st[i][3] - st[i][2]));
+            kl.push_back((double)(st[i][4] - st[i][3]));
+            sto.push_back((double)(st[i][5] - st[i][4]));
+            tot.push_back((double)(st[i][5] - st[i][2]));
+            if (st[i][1] > st[i][0]) mhz.push_back((double)(st[i][5] - st[i][2]) / ((st[i][1] - st[i][0]) / 100.0));
+        }
+        auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+        const double ideal = (double)K / 4.0 * 16.0 * 2.0 * 64.0;  // MFMAs per wave x 2 waves per SIMD x 64 cycles
+        printf("variant %d, %zu tiles: C load %.0f  K loop %.0f (MFMA-bound %.0f -> %.3f)  store %.0f  tile %.0f cycles; clock p50 %.0f MHz\n",
+               variant, tot.size(), med(cl), med(kl), ideal, ideal / med(kl), med(sto), med(tot), med(mhz));
     }
     return 0;
 }
