@@ -1079,7 +1079,8 @@ static int g_gemm_stream = 1;        // EGX_GEMM_STREAM=0: the register-staged w
 static int g_stream_tpw = 1;         // EGX_STREAM_TPW: tiles per workgroup of k_gemm_stream (0 = one workgroup per CU walks all;
                                      // measured: the fully persistent form is the fastest kernel alone, 54 vs 50 TFLOP/s, but
                                      // holds every CU for the whole update and starves the look-ahead chain)
-static int g_stream_variant = 0;      // EGX_STREAM_VARIANT: placement of the LDS-DMA issue inside a chunk (see k_gemm_stream)
+static int g_stream_variant = 2;      // EGX_STREAM_VARIANT: placement of the LDS-DMA issue inside a chunk (see k_gemm_stream;
+                                      // measured alone, n = 15872: v0 57.8, v1 58.5, v2 58.9 TFLOP/s persistent)
 static int g_stream_min_tiles = 512;  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles go to k_gemm_stream
 static int g_tail_lookahead = 0;      // EGX_TAIL_LOOKAHEAD=1: look-ahead also below 3072 trailing columns (measured: n = 4096 fit
                                       // 3.37 -> 3.27 ms alone, but 460 -> 313 fits/s with two in flight: the extra hand-offs cost more)
