@@ -90,8 +90,14 @@ template <int CORR>
 __global__ __launch_bounds__(256) void k_corr_sym(const double *__restrict__ xT, int64_t ldx, int n, int d,
                                                   const double *__restrict__ coef, int hcols, double diag,
                                                   double *__restrict__ M, int64_t ld) {
-    const int bi = blockIdx.x, bj = blockIdx.y;
-    if ((bj >> 1) > (bi >> 1)) return;  // strictly-upper 128x128 tiles are never read
+    // 1-D grid over the 128x128 tiles of the LOWER triangle only (4 workgroups per tile): a 2-D grid with an early exit
+    // for the strictly-upper tiles launches twice the workgroups and leaves the real ones unevenly spread over the CUs
+    const int t = blockIdx.x >> 2, sub = blockIdx.x & 3;
+    int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while (I * (I + 1) / 2 > t) I--;
+    while ((I + 1) * (I + 2) / 2 <= t) I++;
+    const int J = t - I * (I + 1) / 2;
+    const int bi = 2 * I + (sub >> 1), bj = 2 * J + (sub & 1);
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *xi = sm, *xj = sm + d * 64;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
@@ -522,7 +528,8 @@ __global__ __launch_bounds__(256) void k_grad_accum(const double *__restrict__ x
 
 int launch_corr_sym(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d, const double *coef,
                     int hcols, double nugget, double *M, int64_t ld, int n_pad) {
-    dim3 grid(n_pad / 64, n_pad / 64);
+    const int nt2 = n_pad / 128;  // n_pad is a multiple of 128
+    dim3 grid((unsigned)(4 * (nt2 * (nt2 + 1) / 2)));
     const size_t lds = (size_t)2 * d * 64 * sizeof(double);
     EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_corr_sym<C_>, grid, dim3(256), lds, s, xT, ldx, n, d, coef, hcols,
                                                1.0 + nugget, M, ld));
