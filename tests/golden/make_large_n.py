@@ -58,6 +58,8 @@ def part_fit(out):
     xq[:100] = x[:100]
     xq[100:200] = x[100:200] + 1e-4
     for corr in (O.SQEXP, O.MATERN52):
+        if f"fit_n{n}_d{d}_{corr}" in out:
+            continue
         t0 = time.time()
         gp = O.fit_fixed(x, y, theta, O.CONSTANT, corr)
         diag = np.diag(gp.inner.r_chol)
@@ -72,6 +74,7 @@ def part_fit(out):
         out[f"fit_n{n}_d{d}_{corr}"] = rec
         print(f"fit {corr}: lkh {gp.likelihood!r} min pivot {diag.min():.3e} ({time.time() - t0:.0f}s)", flush=True)
         del gp
+        yield  # checkpoint
 
 
 def part_grad(out):
@@ -154,7 +157,8 @@ def main():
         part_grad(out)
         save()
     if want("fit"):
-        part_fit(out)
+        for _ in part_fit(out):
+            save()
         save()
     if want("sweep"):
         for _ in part_sweep(out):
