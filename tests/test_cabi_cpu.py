@@ -170,3 +170,18 @@ int main(void) {
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, out
     assert "n >= 2" in out.stdout
+
+
+def test_sweep_argument_validation_needs_no_device(egx):
+    """egx_sweep_create rejects an inconsistent (rank, world) / a missing unique id before it touches a device."""
+    lib = egx._lib.load()
+    x = np.random.default_rng(0).random((10, 2))
+    y = x.sum(axis=1)
+    h = C.c_void_p()
+    dp = egx._lib.dptr
+    for rank, world, idp in ((2, 2, None), (-1, 1, None), (0, 0, None), (0, 2, None)):
+        rc = lib.egx_sweep_create(None, dp(x), dp(y), 10, 2, idp, rank, world, C.byref(h))
+        assert rc == egx._lib.ERR_INVALID_VALUE and not h.value, (rank, world)
+    assert b"rank" in lib.egx_last_error() or b"unique id" in lib.egx_last_error()
+    assert lib.egx_sweep_info(None, None, None, None, None, None) == egx._lib.ERR_INVALID_VALUE
+    lib.egx_sweep_destroy(None)  # no-op

@@ -120,3 +120,19 @@ def test_multistart_cobyla_lands_on_the_reference_theta_of_the_notebook(trace_ex
     assert total <= 11 * 25
     assert 10.0 ** best[1] == pytest.approx(ga["theta_printed_8_digits"], rel=1e-3)
     assert -best[0] == pytest.approx(ga["likelihood"], abs=1e-6)
+
+
+def test_cobyla_under_address_and_ub_sanitizers(tmp_path):
+    """csrc/cobyla.h built with -fsanitize=address,undefined: every test problem in both modes, 1 to 5 variables, tiny
+    budgets (the initial simplex is cut short) included."""
+    exe = tmp_path / "cobyla_trace_san"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Werror", "-fsanitize=address,undefined",
+                    "-fno-omit-frame-pointer", os.path.join(ROOT, "tests", "c_host", "cobyla_trace.cpp"), "-o", str(exe)],
+                   check=True)
+    for cs in range(5):
+        for mode in (0, 1):
+            for maxeval in (1, 2, 7, 300):
+                out = subprocess.run([str(exe), str(cs), "0.5", "1e-7", str(maxeval), str(mode)], capture_output=True,
+                                     text=True)
+                assert out.returncode == 0 and "runtime error" not in out.stderr, (cs, mode, maxeval, out.stderr[-400:])
+                assert int(out.stdout.strip().split("\n")[-1].split()[4]) <= maxeval
