@@ -10,6 +10,7 @@
 // RCCL is bound at run time (dlopen of librccl.so.1 on the first sweep call): libegx_gp_hip.so itself keeps
 // libamdhip64 as its only link-time dependency, and single-GPU users never load the collective library.
 #include "gp_handle.h"
+#include "sweep_shard.h"
 
 #include <dlfcn.h>
 #include <unistd.h>
@@ -251,27 +252,18 @@ int32_t egx_sweep_likelihood(egx_sweep *sw, const double *thetas, int64_t k, int
     if (k == 0) return EGX_SUCCESS;
     EGX_RC(set_device(sw->gp));
     const int world = sw->world, rank = sw->rank;
-    const int64_t per = (k + world - 1) / world;
-    const int64_t mine = (k > rank) ? (k - rank + world - 1) / world : 0;
+    const int64_t per = sweep_slots_per_rank(k, world), mine = sweep_count_of_rank(k, rank, world);
     // this rank's shard: candidates rank, rank + world, ...
     std::vector<double> th((size_t)mine * theta_len), lk(mine);
     std::vector<int32_t> st(mine);
     for (int64_t j = 0; j < mine; j++)
-        std::memcpy(&th[(size_t)j * theta_len], thetas + (size_t)(rank + j * world) * theta_len, sizeof(double) * theta_len);
+        std::memcpy(&th[(size_t)j * theta_len], thetas + (size_t)sweep_candidate(rank, j, world) * theta_len,
+                    sizeof(double) * theta_len);
     if (mine) EGX_RC(egx_gp_likelihood_batch(sw->gp, th.data(), mine, theta_len, lk.data(), st.data()));
     // fixed-size payload per rank: per x {likelihood, status}; unused slots NaN
-    std::vector<double> send((size_t)per * 2, std::numeric_limits<double>::quiet_NaN()), recv((size_t)per * 2 * world);
-    for (int64_t j = 0; j < mine; j++) {
-        send[2 * j] = lk[j];
-        send[2 * j + 1] = (double)st[j];
-    }
+    std::vector<double> send = sweep_pack(lk.data(), st.data(), mine, per), recv((size_t)per * 2 * world);
     EGX_RC(sweep_allgather_doubles(sw, send.data(), per * 2, recv.data()));
-    for (int r = 0; r < world; r++)
-        for (int64_t j = 0; r + j * world < k; j++) {
-            const int64_t c = r + j * world;
-            lkh[c] = recv[((size_t)r * per + j) * 2];
-            status[c] = (int32_t)recv[((size_t)r * per + j) * 2 + 1];
-        }
+    sweep_unpack(recv.data(), k, world, lkh, status);
     return EGX_SUCCESS;
 }
 

@@ -148,3 +148,15 @@ def test_moe_experts_sharded_over_two_ranks_gloo():
             np.testing.assert_allclose(res[r][recomb][1], want[1], rtol=1e-12, atol=1e-13)
             np.testing.assert_allclose(res[r][recomb + "_grad"][0], want_g[0], rtol=1e-11, atol=1e-12)
             np.testing.assert_allclose(res[r][recomb + "_grad"][1], want_g[1], rtol=1e-11, atol=1e-12)
+
+
+def test_library_sweep_partition_arithmetic(tmp_path):
+    """The C++ sharding / payload layout of egx_sweep_likelihood (csrc/sweep_shard.h) for simulated worlds of 1-8 ranks
+    and ragged candidate counts, under ASan + UBSan (tests/c_host/sweep_shard_test.cpp)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "sweep_shard_test"
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-fsanitize=address,undefined",
+                    os.path.join(root, "tests", "c_host", "sweep_shard_test.cpp"), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), (out.stdout, out.stderr)
