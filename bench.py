@@ -221,7 +221,12 @@ def main():
             "corr_build_gbps": tim1[0]["corr_bytes"] / (corr_ms * 1e-3) / 1e9,
             "corr_build_roofline": {"bound": "hbm", "achieved": tim1[0]["corr_bytes"] / (corr_ms * 1e-3) / 1e9,
                                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                    "frac": tim1[0]["corr_bytes"] / (corr_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                                    "frac": tim1[0]["corr_bytes"] / (corr_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                    "traffic": (None if pmc is None or "k_corr_sym" not in pmc else
+                                                pmc["k_corr_sym"].get("write_size_bytes_per_launch_raw", 0.0)
+                                                + pmc["k_corr_sym"].get("fetch_size_bytes_per_launch_raw", 0.0)),
+                                    "note": "K1 is bound by FP64 VALU issue at d = 32 (3 d + ~25 ops per pair), not by "
+                                            "its 1.08 GB of writes: DESIGN.md section 4"},
             "candidates_ok": int(ok.sum()), "candidates_failed": int((~ok).sum()),
             "likelihood_checksum": float(np.sum(lkhs[args.warmup * nb:][ok])),
         }

@@ -101,10 +101,11 @@ def main():
         x, y = workload.make_training_set(n, d, 42)
         k = 16 if args.quick else 64
         thetas = egx.theta_sweep_candidates(512, d)[:k]
-        h = egx.GpHandle(x, y, n_workspaces=2)
-        h.likelihood_batch(thetas[:2])
+        # through the boundary's multi-GPU entry point (egx_sweep_*, one-rank RCCL communicator on this box)
+        h = egx.Sweep(x, y, rank=0, world=1, id_bytes="new")
+        h.likelihood(thetas[:2])
         t0 = time.perf_counter()
-        lk, st = h.likelihood_batch(thetas)
+        lk, st = h.likelihood(thetas)
         t = time.perf_counter() - t0
         emit({"config": 4, "n": n, "d": d, "candidates_timed": k, "of_sweep": 512, "evals_per_s_this_gpu": k / t,
               "status_counts": {int(s): int((st == s).sum()) for s in np.unique(st)},

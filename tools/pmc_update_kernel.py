@@ -23,6 +23,24 @@ def rows(db):
         return list(cur.execute(q))
 
 
+def corr_sym_summary(dbs, n, d=32):
+    """K1 (k_corr_sym): bytes per launch from the same passes; algorithmic = 8 n d + 8 n (n + 1) / 2."""
+    acc, nd = {}, {}
+    for db in dbs:
+        for name, ctr, val, gx, wx, did in rows(db):
+            if "k_corr_sym" not in name:
+                continue
+            acc[ctr] = acc.get(ctr, 0.0) + val
+            nd.setdefault(ctr, set()).add((db, did))
+    res = {"algorithmic_bytes_per_launch": 8.0 * n * d + 8.0 * n * (n + 1) / 2}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        if c in acc:
+            res[c.lower() + "_bytes_per_launch_raw"] = acc[c] * 1000.0 / max(1, len(nd[c]))
+    if "SQ_BUSY_CYCLES" in acc and "GRBM_GUI_ACTIVE" in acc:
+        res["launches"] = len(nd["GRBM_GUI_ACTIVE"])
+    return res
+
+
 def main(out, n, dbs):
     agg = {}       # counter -> (sum, dispatches)
     per_xcd = {}   # counter -> values count
@@ -66,6 +84,7 @@ def main(out, n, dbs):
         res["grbm_gui_active_avg_per_dispatch"] = gui_avg
     if "SQ_INSTS_VALU_MFMA_MOPS_F64" in agg:
         res["mfma_flops_executed_per_launch"] = agg["SQ_INSTS_VALU_MFMA_MOPS_F64"][0] * 512.0 / max(1, len(ndisp["SQ_INSTS_VALU_MFMA_MOPS_F64"]))
+    res["k_corr_sym"] = corr_sym_summary(dbs, n)
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1))
