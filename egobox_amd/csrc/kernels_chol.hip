@@ -635,8 +635,7 @@ __device__ long long g_potf2_stamps[4][6];
 #endif
 constexpr int TS = 64;
 constexpr int TLD = 65;  // padded LDS row (doubles): per-lane row accesses are conflict free
-constexpr int POTF2_AUX = TS * TLD + 2 * TS + TS + 4 * 16 * 17;  // tile + two broadcast lines + reciprocal diagonal + the four
-                                                                // 16x16 diagonal-block inverses of wg_inv_64 (doubles)
+constexpr int POTF2_AUX = TS * TLD + 2 * TS + TS;  // tile + two broadcast lines + reciprocal diagonal (doubles)
 constexpr int POTF2_LDS_BYTES = POTF2_AUX * 8 + GemmShape<192, 64, 48, 32, 512>::LDS_BYTES;  // staging of the 192-row phases
 static_assert((POTF2_AUX * 8) % 16 == 0, "MFMA staging must stay 16-byte aligned");
 static_assert(GemmShape<192, 64, 48, 32, 512>::LDS_BYTES >= TS * TLD * 8, "inverse scratch aliases the MFMA staging");
@@ -721,41 +720,23 @@ __device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, i
     }
 }
 
-// Workgroup: X = L^-1 (lower) for the factored tile T, into X (LDS, stride TLD), all on 16x16 blocks:
-//   0. Z_b = L(b,b)^-1 for the four diagonal 16x16 blocks, in parallel (one wave per block, inverse column per lane,
-//      a 16-step forward substitution on broadcast LDS reads) -> Di (4 x 16 x 17 doubles);
-//   1. block column by block column from the right: X(rt,cb) = [delta - sum_{cb < kb <= rt} X(rt,kb) L(kb,cb)] Z_cb,
-//      the bracket (phase 1) and the product with Z_cb (phase 2) both on the matrix cores.
-// (Round 1 did phase 2 as a 16-step back substitution by one wave: 12.8k cycles per tile; this form: see
-//  profiles/r02_potf2_*.)
-constexpr int DI_LD = 17, DI_BLK = 16 * DI_LD;
+// Workgroup: X = L^-1 (lower) for the factored tile T; row `lane` of X per lane, into X (LDS, stride TLD).
+// Strips of 16 columns from the right; the contributions of the already finished strips are split over the
+// eight waves (2 columns each), the short in-strip back substitution is done by wave 0.
 template <int NW>
-__device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, double *X, double *Di, int tid) {
+__device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, double *X, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
     const int frow = lane & 15, fk = lane >> 4;
-    for (int b = wave; b < 4; b += NW)
-        if (lane < 16) {
-            const double *D = T + (b * 16) * TLD + b * 16;
-            double z[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                double sacc = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < i; k++) sacc = __builtin_fma(-D[i * TLD + k], z[k], sacc);
-                z[i] = sacc * rd[b * 16 + i];
-            }
-#pragma unroll
-            for (int i = 0; i < 16; i++) Di[b * DI_BLK + i * DI_LD + lane] = z[i];
-        }
-    __syncthreads();
 #pragma unroll 1
     for (int cbk = 3; cbk >= 0; cbk--) {
+        // bulk on the matrix cores: 16x16 tile (rt, cbk), rt > cbk:  - sum_{cbk < kb <= rt} X(rt, kb) L(kb, cbk);
+        // the diagonal tile starts as the identity, tiles above it are zero
         for (int rt = wave; rt < 4; rt += NW) {
             double *xt = X + (rt * 16 + fk) * TLD + cbk * 16 + frow;
             double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
             if (rt == cbk) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) acc[r] = Di[cbk * DI_BLK + (fk + 4 * r) * DI_LD + frow];
+                for (int r = 0; r < 4; r++) acc[r] = (fk + 4 * r == frow) ? 1.0 : 0.0;
             } else if (rt > cbk) {
                 for (int kb = cbk + 1; kb <= rt; kb++) {
                     const double *arow = X + (rt * 16 + frow) * TLD + kb * 16 + fk;   // A[i][k] = X(rt*16+i, kb*16+k)
@@ -769,21 +750,21 @@ __device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, dou
             for (int r = 0; r < 4; r++) xt[(4 * r) * TLD] = acc[r];
         }
         __syncthreads();
-        for (int rt = wave; rt < 4; rt += NW)
-            if (rt > cbk) {
-                const double *arow = X + (rt * 16 + frow) * TLD + cbk * 16 + fk;  // the bracket, A[i][k]
-                const double *bz = Di + cbk * DI_BLK + fk * DI_LD + frow;          // B[k][j] = Z_cb[k][j]
-                double av[4];
+        if (wave == 0) {
+            double x[16];
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++) av[kk] = arow[kk * 4];
-                double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < 16; c++) x[c] = X[lane * TLD + cbk * 16 + c];
 #pragma unroll
-                for (int kk = 0; kk < 4; kk++)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bz[(kk * 4) * DI_LD], acc, 0, 0, 0);
-                double *xt = X + (rt * 16 + fk) * TLD + cbk * 16 + frow;
+            for (int c = 15; c >= 0; c--) {
+                double sacc = x[c];
 #pragma unroll
-                for (int r = 0; r < 4; r++) xt[(4 * r) * TLD] = acc[r];
+                for (int k = c + 1; k < 16; k++)
+                    sacc = __builtin_fma(-x[k], T[(cbk * 16 + k) * TLD + cbk * 16 + c], sacc);
+                x[c] = sacc * rd[cbk * 16 + c];
             }
+#pragma unroll
+            for (int c = 0; c < 16; c++) X[lane * TLD + cbk * 16 + c] = x[c];
+        }
         __syncthreads();
     }
 }
@@ -847,7 +828,6 @@ __global__ __launch_bounds__(NT, NT / 256) void k_potf2_block(double *__restrict
     double *Ls = sm;                 // current diagonal tile / its factor, [64][65]
     double *cb = sm + TS * TLD;      // 2 x 64 broadcast lines
     double *rd = cb + 2 * TS;        // 64 reciprocal diagonal entries
-    double *Di = rd + TS;            // 4 x 16 x 17: inverses of the tile's 16x16 diagonal blocks
     double *stage = sm + POTF2_AUX;  // MFMA staging; aliased by the inverse scratch X [64][65]
     const int tid = threadIdx.x;
     const int nt = nbk / TS;
@@ -867,7 +847,7 @@ __global__ __launch_bounds__(NT, NT / 256) void k_potf2_block(double *__restrict
         // ---- steps 1+2: factor and invert the tile (all four waves, see wg_potf2_64 / wg_inv_64)
         wg_potf2_64<NW>(Ls, cb, rd, tid, info, col0 + s * TS, n_valid);
         EGX_STAMP(5);
-        wg_inv_64<NW>(Ls, rd, stage, Di, tid);
+        wg_inv_64<NW>(Ls, rd, stage, tid);
         EGX_STAMP(1);
         // ---- write the factor back (upper part zeroed) and the inverse to dinv
         {
@@ -914,7 +894,6 @@ __global__ __launch_bounds__(256, 1) void k_diag_tile_inverses(const double *__r
     __shared__ double Ls[TS * TLD];
     __shared__ double X[TS * TLD];
     __shared__ double rd[TS];
-    __shared__ double Di[4 * 16 * 17];
     const int tid = threadIdx.x, t = blockIdx.x;
     const double *src = M + (int64_t)(t * TS) * ld + t * TS;
     for (int e = tid; e < TS * TS; e += 256) {
@@ -924,7 +903,7 @@ __global__ __launch_bounds__(256, 1) void k_diag_tile_inverses(const double *__r
     __syncthreads();
     if (tid < TS) rd[tid] = 1.0 / Ls[tid * TLD + tid];
     __syncthreads();
-    wg_inv_64<4>(Ls, rd, X, Di, tid);
+    wg_inv_64<4>(Ls, rd, X, tid);
     double *dst = dinv + (int64_t)t * 4096;
     for (int e = tid; e < TS * TS; e += 256) dst[e] = X[(e >> 6) * TLD + (e & 63)];
 }
