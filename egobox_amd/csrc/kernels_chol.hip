@@ -408,6 +408,7 @@ __device__ long long g_stream_stamps[1 << 14][6];  // per tile: wall start, wall
 //   0  all six right after the barrier
 //   1  two after the barrier, two after the first 16 MFMAs, two after the first 32
 //   2  waves 0-3 right after the barrier, waves 4-7 (their SIMD partners) after their first 32 MFMAs
+//   3  mid-chunk barrier with fragments read one half chunk ahead (see the loop)
 template <bool LOWER, int VARIANT>
 __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, int64_t ldc, const double *__restrict__ A,
                                                         int64_t lda, const double *__restrict__ B, int64_t ldb, int K,
@@ -487,6 +488,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
     for (int r = 0; r < 4; r++) coff[r] = (unsigned)(((lane >> 4) + 4 * r) * (int)ldc + (lane & 15));
 
     int g = 0, stage = 0;  // global chunk counter of this workgroup, stage = g % 3
+    d2_t a0[4], b0[4];     // VARIANT 3: fragments of the coming half chunk, read one half ahead (live across tiles)
+#pragma unroll
+    for (int i = 0; i < 4; i++) a0[i] = b0[i] = d2_t{0.0, 0.0};
     for (int t = blockIdx.x; t < ntiles; t += G) {
         int bx, by;
         stream_tile_coords<LOWER>(t, nbx, nby, bx, by);
@@ -504,6 +508,63 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         EGX_SSTAMP(t, 3, clock64());
+        if constexpr (VARIANT == 3) {
+            // MID-CHUNK barrier: the synchronisation for chunk g + 1 sits between the two 8-deep halves of chunk g, the
+            // fragments of a half are read one half ahead, so the MFMA stream runs across the barrier and no LDS read
+            // latency is exposed behind it:
+            //   [read kb1(g)] [32 MFMA kb0(g)] [wait own loads of g + 1; barrier] [issue loads g + 2] [read kb0(g + 1)]
+            //   [32 MFMA kb1(g)]
+            // RAW: kb0/kb1(g + 1) are read after the barrier that follows every wave's wait for chunk g + 1.  WAR: the
+            // loads of g + 2 overwrite the stage of g - 1, whose last reads were issued before the previous barrier.
+            auto read_half = [&](int st, int kb, d2_t (&a)[4], d2_t (&b)[4]) {
+                const double *As = smem + st * ST_STAGE + aoff, *Bs = smem + st * ST_STAGE + boff;
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++) a[mi] = *reinterpret_cast<const d2_t *>(As + mi * 16 * KC + foff[kb]);
+#pragma unroll
+                for (int ni = 0; ni < 4; ni++) b[ni] = *reinterpret_cast<const d2_t *>(Bs + ni * 16 * KC + foff[kb]);
+            };
+            auto mma_quarter = [&](const d2_t (&a)[4], const d2_t (&b)[4], int h) {
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ni++)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][h], b[ni][h], acc[mi][ni], 0, 0, 0);
+            };
+            auto mma_half = [&](const d2_t (&a)[4], const d2_t (&b)[4]) {
+                mma_quarter(a, b, 0);
+                mma_quarter(a, b, 1);
+            };
+            if (g == 0) {  // the workgroup's very first chunk: the classic wait + barrier in front of its first read
+                if (issued > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                read_half(0, 0, a0, b0);
+            }
+            for (int ch = 0; ch < nch; ch++, g++) {
+                d2_t a1[4], b1[4];
+                read_half(stage, 1, a1, b1);
+                mma_half(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                const bool next = g + 1 < total;   // another chunk follows (possibly the next tile's first)
+                const bool more = issued < total;  // ... and one more to prefetch
+                const int st1 = (stage == ST_NSTAGE - 1) ? 0 : stage + 1;
+                if (next) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own pieces of chunk g + 1 (the only ones in flight)
+                    __builtin_amdgcn_s_barrier();
+                    if (more) {
+                        issue_pieces(stage == 0 ? 2 : stage - 1, 0, 6);  // chunk g + 2 -> stage of chunk g - 1
+                        issue_done();
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_quarter(a1, b1, 0);  // (fragments read before the first half: nothing to wait for behind the barrier)
+                __builtin_amdgcn_sched_barrier(0);
+                if (next) read_half(st1, 0, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_quarter(a1, b1, 1);
+                stage = st1;
+            }
+        } else
         for (int ch = 0; ch < nch; ch++, g++) {
             // chunk g has landed once this wave's own loads for it are done (the loads of chunk g + 1 may stay in
             // flight) AND every other wave says the same (barrier).  The barrier also tells that every wave is done
@@ -549,6 +610,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
             if (more) issue_done();
         }
         EGX_SSTAMP(t, 4, clock64());
+        // (the 16 row pointers of the C tile are rebuilt here instead of staying live through the K loop: the opaque
+        //  pass through an empty asm keeps the compiler from carrying 32 address VGPRs across 2048 MFMAs)
+#pragma unroll
+        for (int r = 0; r < 4; r++) asm volatile("" : "+v"(coff[r]));
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
 #pragma unroll
@@ -1130,6 +1195,8 @@ int chol_init() {
         set(reinterpret_cast<const void *>(&k_gemm_stream<false, 1>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<true, 2>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<false, 2>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<true, 3>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<false, 3>), ST_LDS_BYTES);
     });
     return rc_once;
 }
@@ -1170,10 +1237,12 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
     hipLaunchKernelGGL((k_gemm_stream<LOW, V>), dim3(grid), dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx, nby, nt, info)
             if (lower) {
                 if (g_stream_variant == 1) EGX_STREAM(true, 1);
+                else if (g_stream_variant == 3) EGX_STREAM(true, 3);
                 else if (g_stream_variant == 2) EGX_STREAM(true, 2);
                 else EGX_STREAM(true, 0);
             } else {
                 if (g_stream_variant == 1) EGX_STREAM(false, 1);
+                else if (g_stream_variant == 3) EGX_STREAM(false, 3);
                 else if (g_stream_variant == 2) EGX_STREAM(false, 2);
                 else EGX_STREAM(false, 0);
             }

@@ -39,12 +39,13 @@ int main(int argc, char **argv) {
     };
     // ---- correctness (on the leading n_check rows / columns so that the host comparison stays quick)
     n = n_check;
+    const int check_variant = argc > 3 ? atoi(argv[3]) : 3;
     for (int lower = 1; lower >= 0; lower--)
         for (int tpw : {0, 1, 3}) {
             hipMemcpy(M1, M0, sizeof(double) * elems, hipMemcpyDeviceToDevice);
             hipMemcpy(M2, M0, sizeof(double) * elems, hipMemcpyDeviceToDevice);
             run(M1, lower, 0, 0, 256);
-            run(M2, lower, 1, tpw, 256);
+            run(M2, lower, 1, tpw, 256, check_variant);
             hipDeviceSynchronize();
             std::vector<double> a(elems), b(elems);
             hipMemcpy(a.data(), M1, sizeof(double) * elems, hipMemcpyDeviceToHost);
@@ -64,15 +65,15 @@ int main(int argc, char **argv) {
             hipMemcpy(h0.data(), M0, sizeof(double) * elems, hipMemcpyDeviceToHost);
             for (int i = 0; i < n; i++)
                 for (int j = 0; j < K; j++) if (b[(size_t)i * ld + j] != h0[(size_t)i * ld + j]) pbad++;
-            printf("check lower=%d tpw=%d: %zu elements compared, max |stream - wide| = %.3e, %zu beyond 1e-12, panel touched %zu\n",
-                   lower, tpw, cmp, worst, bad, pbad);
+            printf("check variant %d lower=%d tpw=%d: %zu elements compared, max |stream - wide| = %.3e, %zu beyond 1e-12, panel touched %zu\n",
+                   check_variant, lower, tpw, cmp, worst, bad, pbad);
         }
     // ---- speed
     n = n_speed;
     struct V { const char *name; int stream, tpw, wgs, variant; };
     std::vector<V> vs = {{"wide (register staged)", 0, 0, 256, 0}, {"stream persistent v0", 1, 0, 256, 0},
                          {"stream persistent v1 (spread issue)", 1, 0, 256, 1}, {"stream persistent v2 (staggered halves)", 1, 0, 256, 2},
-                         {"stream tpw=1 v0", 1, 1, 256, 0}, {"stream tpw=1 v1", 1, 1, 256, 1}, {"stream tpw=1 v2", 1, 1, 256, 2}};
+                         {"stream persistent v3 (mid-chunk barrier)", 1, 0, 256, 3}, {"stream tpw=1 v0", 1, 1, 256, 0}, {"stream tpw=1 v2", 1, 1, 256, 2}, {"stream tpw=1 v3", 1, 1, 256, 3}};
     const double flops = 2.0 * K * ((double)n * (n + 128) / 2.0);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<std::vector<double>> ms(vs.size());
@@ -91,7 +92,7 @@ int main(int argc, char **argv) {
                flops / med / 1e9, ms[v].front(), ms[v].back());
     }
     // ---- per-tile phase breakdown of the stream kernel (one tile per workgroup), shader-clock cycles
-    for (int variant = 0; variant < 3; variant++) {
+    for (int variant = 0; variant < 4; variant++) {
         static long long st[1 << 14][6];
         memset(st, 0, sizeof st);
         hipMemcpyToSymbol(HIP_SYMBOL(g_stream_stamps), st, sizeof st);
