@@ -409,6 +409,7 @@ __device__ long long g_stream_stamps[1 << 14][6];  // per tile: wall start, wall
 //   1  two after the barrier, two after the first 16 MFMAs, two after the first 32
 //   2  waves 0-3 right after the barrier, waves 4-7 (their SIMD partners) after their first 32 MFMAs
 //   3  mid-chunk barrier with fragments read one half chunk ahead (see the loop)
+//   4  = 3 with the SIMD partners' LDS-DMA issue staggered by 16 MFMAs
 template <bool LOWER, int VARIANT>
 __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, int64_t ldc, const double *__restrict__ A,
                                                         int64_t lda, const double *__restrict__ B, int64_t ldb, int K,
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         EGX_SSTAMP(t, 3, clock64());
-        if constexpr (VARIANT == 3) {
+        if constexpr (VARIANT >= 3) {
             // MID-CHUNK barrier: the synchronisation for chunk g + 1 sits between the two 8-deep halves of chunk g, the
             // fragments of a half are read one half ahead, so the MFMA stream runs across the barrier and no LDS read
             // latency is exposed behind it:
@@ -551,14 +552,14 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
                 if (next) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own pieces of chunk g + 1 (the only ones in flight)
                     __builtin_amdgcn_s_barrier();
-                    if (more) {
-                        issue_pieces(stage == 0 ? 2 : stage - 1, 0, 6);  // chunk g + 2 -> stage of chunk g - 1
-                        issue_done();
-                    }
+                    // chunk g + 2 -> stage of chunk g - 1; VARIANT 4: the SIMD partners (waves 4-7) issue theirs 16 MFMAs later
+                    if (more && (VARIANT == 3 || wave < 4)) issue_pieces(stage == 0 ? 2 : stage - 1, 0, 6);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 mma_quarter(a1, b1, 0);  // (fragments read before the first half: nothing to wait for behind the barrier)
                 __builtin_amdgcn_sched_barrier(0);
+                if (VARIANT == 4 && next && more && wave >= 4) issue_pieces(stage == 0 ? 2 : stage - 1, 0, 6);
+                if (next && more) issue_done();
                 if (next) read_half(st1, 0, a0, b0);
                 __builtin_amdgcn_sched_barrier(0);
                 mma_quarter(a1, b1, 1);
@@ -1144,8 +1145,8 @@ static int g_gemm_stream = 1;        // EGX_GEMM_STREAM=0: the register-staged w
 static int g_stream_tpw = 1;         // EGX_STREAM_TPW: tiles per workgroup of k_gemm_stream (0 = one workgroup per CU walks all;
                                      // measured: the fully persistent form is the fastest kernel alone, 54 vs 50 TFLOP/s, but
                                      // holds every CU for the whole update and starves the look-ahead chain)
-static int g_stream_variant = 2;      // EGX_STREAM_VARIANT: placement of the LDS-DMA issue inside a chunk (see k_gemm_stream;
-                                      // measured alone, n = 15872: v0 57.8, v1 58.5, v2 58.9 TFLOP/s persistent)
+static int g_stream_variant = 3;      // EGX_STREAM_VARIANT: structure of a chunk (see k_gemm_stream; measured alone, n = 15872,
+                                      // persistent: v0 58.3, v1 58.9, v2 59.3, v3 60.3, v4 59.9 TFLOP/s; K loop 0.879 -> 0.909)
 static int g_stream_min_tiles = 512;  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles go to k_gemm_stream
 static int g_tail_lookahead = 0;      // EGX_TAIL_LOOKAHEAD=1: look-ahead also below 3072 trailing columns (measured: n = 4096 fit
                                       // 3.37 -> 3.27 ms alone, but 460 -> 313 fits/s with two in flight: the extra hand-offs cost more)
@@ -1197,6 +1198,8 @@ int chol_init() {
         set(reinterpret_cast<const void *>(&k_gemm_stream<false, 2>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<true, 3>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<false, 3>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<true, 4>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<false, 4>), ST_LDS_BYTES);
     });
     return rc_once;
 }
@@ -1238,11 +1241,13 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
             if (lower) {
                 if (g_stream_variant == 1) EGX_STREAM(true, 1);
                 else if (g_stream_variant == 3) EGX_STREAM(true, 3);
+                else if (g_stream_variant == 4) EGX_STREAM(true, 4);
                 else if (g_stream_variant == 2) EGX_STREAM(true, 2);
                 else EGX_STREAM(true, 0);
             } else {
                 if (g_stream_variant == 1) EGX_STREAM(false, 1);
                 else if (g_stream_variant == 3) EGX_STREAM(false, 3);
+                else if (g_stream_variant == 4) EGX_STREAM(false, 4);
                 else if (g_stream_variant == 2) EGX_STREAM(false, 2);
                 else EGX_STREAM(false, 0);
             }

@@ -73,7 +73,7 @@ int main(int argc, char **argv) {
     struct V { const char *name; int stream, tpw, wgs, variant; };
     std::vector<V> vs = {{"wide (register staged)", 0, 0, 256, 0}, {"stream persistent v0", 1, 0, 256, 0},
                          {"stream persistent v1 (spread issue)", 1, 0, 256, 1}, {"stream persistent v2 (staggered halves)", 1, 0, 256, 2},
-                         {"stream persistent v3 (mid-chunk barrier)", 1, 0, 256, 3}, {"stream tpw=1 v0", 1, 1, 256, 0}, {"stream tpw=1 v2", 1, 1, 256, 2}, {"stream tpw=1 v3", 1, 1, 256, 3}};
+                         {"stream persistent v3 (mid-chunk barrier)", 1, 0, 256, 3}, {"stream persistent v4 (v3 + staggered issue)", 1, 0, 256, 4}, {"stream tpw=1 v4", 1, 1, 256, 4}, {"stream tpw=1 v0", 1, 1, 256, 0}, {"stream tpw=1 v2", 1, 1, 256, 2}, {"stream tpw=1 v3", 1, 1, 256, 3}};
     const double flops = 2.0 * K * ((double)n * (n + 128) / 2.0);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     std::vector<std::vector<double>> ms(vs.size());
@@ -92,7 +92,7 @@ int main(int argc, char **argv) {
                flops / med / 1e9, ms[v].front(), ms[v].back());
     }
     // ---- per-tile phase breakdown of the stream kernel (one tile per workgroup), shader-clock cycles
-    for (int variant = 0; variant < 4; variant++) {
+    for (int variant = 0; variant < 5; variant++) {
         static long long st[1 << 14][6];
         memset(st, 0, sizeof st);
         hipMemcpyToSymbol(HIP_SYMBOL(g_stream_stamps), st, sizeof st);
