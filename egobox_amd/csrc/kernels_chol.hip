@@ -1139,6 +1139,7 @@ __global__ void k_gram_reduce(const double *__restrict__ P, int rows, int nsplit
 // =============================================================================================
 static int g_potf2_threads = 512;
 static int g_potrf_group = 2;    // panels per trailing update (EGX_POTRF_GROUP, 1..8)
+static bool g_potrf_group_set = false;  // EGX_POTRF_GROUP given: no size-dependent choice in launch_potrf
 static int g_gemm_wide_min = 512;
 static int g_potrf_diag_first = 1;   // EGX_POTRF_DIAG_FIRST=0: updates on the critical path are not split (round-1 order)
 static int g_gemm_stream = 1;        // EGX_GEMM_STREAM=0: the register-staged wide kernel instead of k_gemm_stream
@@ -1161,7 +1162,10 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_POTF2_THREADS")) g_potf2_threads = (std::atoi(e) == 256) ? 256 : 512;
         if (const char *e = std::getenv("EGX_POTRF_GROUP")) {
             const int g = std::atoi(e);
-            if (g >= 1 && g <= 8) g_potrf_group = g;
+            if (g >= 1 && g <= 8) {
+                g_potrf_group = g;
+                g_potrf_group_set = true;
+            }
         }
         if (const char *e = std::getenv("EGX_GEMM_WIDE")) g_gemm_wide_min = std::atoi(e);
         if (const char *e = std::getenv("EGX_GEMM_SMALL")) g_gemm_small_max = std::atoi(e);
@@ -1371,7 +1375,10 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         return launch_gemm_nt_sub(st, M + (int64_t)r0 * ld + c0, ld, M + (int64_t)r0 * ld + k0, ld,
                                   M + (int64_t)c0 * ld + k0, ld, Mr, N, K, lower, 0, big, info);
     };
-    const int GW = g_potrf_group * kNB;
+    // groups of four panels (K = 1024 per trailing update: half the C tile traffic and tile boundaries of K = 512) pay
+    // from n ~ 14000 on (measured, profiles/r02_run13_group_by_size.txt: n = 16384 -2 %, n = 12288 even, n = 8192 +5 %:
+    // the chain of a group gets longer while its trailing update shrinks)
+    const int GW = (g_potrf_group_set ? g_potrf_group : (n_pad >= 14336 ? 4 : 2)) * kNB;
     auto gwidth = [&](int g0) { return (n_pad - g0 < GW) ? (n_pad - g0) : GW; };
     // panels of one group on stream `st`; `side` != nullptr splits every in-group update into the next diagonal block
     // (on st) and the rest (on side); `first_wait` is waited for before the FIRST panel solve (the rest of the update
