@@ -203,12 +203,12 @@ def main():
             "roofline": {"bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic,
-                         "kernel": "k_gemm_nt_sub<LOWER,128,256,64,64,512> (Cholesky trailing update C -= P P^T once per "
-                                   "group of two 256-wide panels, K = 512; the launches that fill the chip, ~83% of the "
-                                   "factorisation's flops)",
+                         "kernel": "k_gemm_stream<LOWER> (Cholesky trailing update C -= P P^T, 128x256 tiles, once per group "
+                                   "of four 256-wide panels, K = 1024, at this size; the launches with >= 512 tiles, ~80% "
+                                   "of the factorisation's flops)",
                          "launches_per_fit": syrk_launches, "launch_ms_avg": syrk_ms / max(1, syrk_launches),
                          "flops_per_launch_avg": syrk_flops / max(1, syrk_launches),
-                         "how": "algorithmic flops (2*K*ncols*(ncols+1)/2 per launch) / HIP-event durations around every "
+                         "how": "algorithmic flops (2*K*ncols*(ncols+1)/2 per launch, K = group width) / HIP-event durations around every "
                                 "launch on the stream it is launched on, one fit in flight (separate leg after the timed "
                                 "region; in the timed region two candidates overlap and share the GPU)",
                          "traffic_source": (None if pmc is None else

@@ -68,8 +68,8 @@ def main(out, n, dbs):
         res["fetch_bytes_per_launch"] = per_launch("FETCH_SIZE") * 1000.0
     if per_launch("WRITE_SIZE") is not None:
         res["write_bytes_per_launch"] = per_launch("WRITE_SIZE") * 1000.0
-    # algorithmic C tile read of the 20 chip-filling launches of one fit (lower triangle, group width 512), averaged
-    gw = 512
+    # algorithmic C tile read of the chip-filling launches of one fit (lower triangle, one launch per group), averaged
+    gw = 1024 if n >= 14336 else 512  # launch_potrf: groups of four 256-wide panels from n_pad >= 14336
     ncs = [n - gw * (g + 2) for g in range(0, 64) if n - gw * (g + 2) > 0]
     # (the 128 appended right-hand-side rows ride along: nbx = (nc + 128) / 128 row tiles)
     ncs = [c for c in ncs if ((c + 128) // 128) * (c // 256) - (c // 256) * (c // 256 - 1) >= 512]
