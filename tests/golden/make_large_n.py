@@ -98,13 +98,21 @@ def part_sweep(out):
     order = np.argsort((cands ** 2).sum(axis=1))
     rows = list(range(14))
     rows += [int(r) for r in order if int(r) not in rows][:14]
-    extra = [np.full(d, v) for v in (0.01, 0.02, 0.03)]
+    extra = [np.full(d, v) for v in (0.01, 0.02, 0.03, 1e-3, 1e-4)]
     key = f"sweep_n{n}_d{d}"
     rec = out.get(key) or {"n": n, "d": d, "seed": 42, "corr": O.SQEXP, "candidates": "theta_sweep_candidates(512, 32)",
                            "rows": rows, "thetas": [cands[r].tolist() for r in rows] + [e.tolist() for e in extra],
-                           "extra_rows_note": "last 3 thetas = all 0.01 / 0.02 / 0.03 (lower bound corner, NOT in the "
-                                              "512-row list): the status channel at size",
+                           "extra_rows_note": "last 5 thetas = all 0.01 / 0.02 / 0.03 (lower bound corner: cond(R) ~ 1 / nugget, "
+                                              "ill posed) and all 1e-3 / 1e-4 (below the bounds: R ~ all ones, not positive "
+                                              "definite), NOT in the 512-row list: the status channel at size",
                            "likelihood": [], "status": []}
+    want = [cands[r].tolist() for r in rows] + [e.tolist() for e in extra]
+    if len(rec["thetas"]) < len(want):  # extend a fixture written with fewer extra rows
+        rec["thetas"] = rec["thetas"] + want[len(rec["thetas"]):]
+        rec["extra_rows_note"] = ("last 5 thetas = all 0.01 / 0.02 / 0.03 (lower bound corner: cond(R) ~ 1 / nugget, ill "
+                                  "posed) and all 1e-3 / 1e-4 (below the bounds: R ~ all ones, not positive definite), NOT "
+                                  "in the 512-row list: the status channel at size")
+    rec["n_extra"] = len(extra)
     thetas = np.array(rec["thetas"])
     for i in range(len(rec["likelihood"]), len(thetas)):
         t0 = time.time()
