@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--npoints", dest="n", type=int, default=16384)
     ap.add_argument("--dim", dest="d", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="candidates in flight per GPU (correlation-matrix workspaces of the sweep handle, 2 GiB each at "
+                         "n = 16384)")
     ap.add_argument("--sweep-batch", type=int, default=16,
                     help="candidate thetas per step, summed over ALL GPUs (fixed as N grows: strong scaling)")
     args = ap.parse_args()
@@ -128,7 +131,7 @@ def main():
     cands = base * 10.0 ** rng.uniform(-0.15, 0.15, size=(total, d))
 
     # uploads happen here: inputs resident.  Rank 0 draws the RCCL unique id; torch's store carries its 128 bytes
-    sw = egx.rendezvous_sweep(x, y, device=gpu)
+    sw = egx.rendezvous_sweep(x, y, device=gpu, n_workspaces=max(1, args.in_flight))
     lkhs = np.zeros(total)
     stats = np.zeros(total, dtype=np.int32)
 
@@ -191,7 +194,7 @@ def main():
                                    f"theta sweep around 0.5/sqrt(d), {nb} candidates per step over all GPUs",
                        "n": n, "d": d, "corr": "SquaredExponential", "mean": "Constant",
                        "parallelism": f"sweep-dp{world}", "sweep_batch_per_step": nb,
-                       "fits_in_flight_per_gpu": 2},
+                       "fits_in_flight_per_gpu": max(1, args.in_flight)},
             "fits_per_step": nb,
             "rccl_ranks": info["rccl_ranks"], "rccl_version": info["rccl_version"],
             "allgathers_in_timed_region": args.steps,
