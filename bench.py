@@ -4,8 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one pass of the hot path over one batch of `--sweep-batch` (default 16) candidate thetas of a theta
-sweep: every candidate is one fit in north_star's sense --
+One "step" = one pass of the hot path over one batch of `--sweep-batch` (default 24 = 3 in flight on each of 8 GPUs)
+candidate thetas of a theta sweep: every candidate is one fit in north_star's sense --
 correlation-matrix build (K1) + blocked FP64-MFMA Cholesky with fused forward solves (K3/K4) + GLS / reduced
 likelihood, i.e. one evaluation of the objective the reference's COBYLA multiplies
 (crates/gp/src/algorithm.rs:880-897, 988-1056).  The batch is FIXED as N grows (strong scaling): rank r evaluates
@@ -96,10 +96,10 @@ def main():
     ap.add_argument("--npoints", dest="n", type=int, default=16384)
     ap.add_argument("--dim", dest="d", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="candidates in flight per GPU (correlation-matrix workspaces of the sweep handle, 2 GiB each at "
                          "n = 16384)")
-    ap.add_argument("--sweep-batch", type=int, default=16,
+    ap.add_argument("--sweep-batch", type=int, default=24,
                     help="candidate thetas per step, summed over ALL GPUs (fixed as N grows: strong scaling)")
     args = ap.parse_args()
 
