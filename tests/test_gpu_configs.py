@@ -387,3 +387,23 @@ def test_lbfgs_fit_with_kpls_weights(egx):
         free = (th > 1e-2 * 1.001) & (th < 1e1 * 0.999)
         assert np.all(np.abs(gx[free]) <= 1e-2 * max(1.0, abs(l1)))
     gp.close()
+
+
+# ------------------------------------------------------------------ the stream kernel inside egx_potrf, against LAPACK
+@pytest.mark.parametrize("n", [5700, 6144, 7050, 14400])
+def test_potrf_with_stream_kernel_launches_vs_lapack(egx, n):
+    """egx_potrf at sizes whose trailing updates cross the 512-tile threshold of k_gemm_stream (LDS-DMA ring, mid-chunk
+    barrier, store-only epilogue; n >= 14336 also takes the groups of four panels): the factor against LAPACK's, and
+    L L^T against the matrix.  A kernel-shaped matrix (smooth, decaying off-diagonals) rather than a Wishart one: its
+    factor has the wide dynamic range of a correlation matrix."""
+    rng = np.random.default_rng(n)
+    t = np.sort(rng.random(n)) * 40.0
+    spd = np.exp(-np.abs(t[:, None] - t[None, :])) + 1e-3 * np.eye(n)  # Ornstein-Uhlenbeck kernel: well conditioned
+    spd = spd[np.ix_(p := rng.permutation(n), p)]
+    got, info = egx.potrf(spd)
+    assert info == 0
+    want = np.linalg.cholesky(spd)
+    np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-12)
+    assert np.all(np.triu(got, 1) == 0.0)
+    idx = rng.integers(0, n, 300)
+    np.testing.assert_allclose((got[idx] @ got.T)[:, idx], spd[np.ix_(idx, idx)], rtol=1e-12, atol=1e-12)
