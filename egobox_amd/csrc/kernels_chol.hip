@@ -971,8 +971,9 @@ __global__ __launch_bounds__(NT, NT / 256) void k_potf2_block(double *__restrict
 // wave issues one FP64 VALU instruction per ~8.5 cycles whether dependent or not (profiles/r02_run20_dp_latency.txt),
 // so the chain is written for INSTRUCTION COUNT: v_rsq_f64 (2^-24) + one Halley step instead of two Newton steps, the
 // diagonal entry from the same multiply as the column (p * rsqrt(p)), no selects on the factor (entries right of the
-// diagonal carry garbage that only ever meets other such entries), pivot check as one v_cmp_class whose lane mask is
-// examined by the scalar unit, 1/L_ii through an LDS side buffer: ~22 VALU instructions per column.
+// diagonal carry garbage that only ever meets other such entries),
+// the pivots checked once per strip (a failed one leaves NaNs), 1/L_ii through an LDS side buffer: ~21 VALU
+// instructions per column.
 // Accumulator convention: acc holds MINUS the tile, transposed and with the columns permuted, so that no operand ever
 // needs a transposition or a negation:
 //     lane (frow, fk), register q   <->   -T[row = frow][col = 4 fk + q]        (MFMA D[i][j], i = fk + 4 q, j = frow)
@@ -1068,7 +1069,6 @@ __device__ __forceinline__ void dpp_fnmac_late(double &acc, double src, double m
 struct RbChain {
     double a[16];    // matrix row `i` of the 16x16 tile, then of its factor (entries right of the diagonal: garbage)
     double z[4];     // row i of the inverse of the column-scaled factor, columns fk + 4 q
-    int first_bad;   // (wave-uniform) first column whose pivot was not a positive finite number, -1 if none
 };
 
 template <int J, int... Cs>
@@ -1095,10 +1095,8 @@ __device__ __forceinline__ double rb_chain_step(RbChain &ch, double p, int i, do
     // right of the diagonal, is masked out of the inverse below and zeroed when the factor is stored.
     const double l = ch.a[J] * y;
     ch.a[J] = l;
-    // a pivot that is not positive and finite makes L_JJ NaN (or leaves it non-positive): recorded here, acted upon at
-    // the end of the strip -- the NaNs stay inside this workgroup, and every later kernel returns on entry
-    const unsigned long long ok = __builtin_amdgcn_ballot_w64(__builtin_amdgcn_class(l, 0x180));  // +normal | +denormal
-    ch.first_bad = (ch.first_bad < 0 && !((ok >> J) & 1ull)) ? J : ch.first_bad;
+    // (a pivot that is not positive and finite makes L_JJ and everything after it NaN: looked for once per strip, in
+    // rb_chain_run -- the NaNs stay inside this workgroup, and every later kernel returns on entry)
     double pnext = 0.0;
     if constexpr (J < 15) {
         dpp_fnmac<J + 1>(ch.a[J + 1], l, l);
@@ -1119,10 +1117,9 @@ __device__ __forceinline__ void rb_chain_all(RbChain &ch, int i, double *rd_lane
 
 // wave 0: factor + invert the diagonal tile of a strip (rows in ch.a); publishes -Linv and the raw factor rows in LDS
 __device__ __forceinline__ void rb_chain_run(RbChain &ch, double *NL, double *LR, double *rd, int lane, int frow, int fk,
-                                             int *info, int gcol0, int n_valid, int *flag) {
+                                             int *info, int gcol0, int n_valid, int *fail_flag, int *refine_flag) {
 #pragma unroll
     for (int q = 0; q < 4; q++) ch.z[q] = (fk + 4 * q == frow) ? 1.0 : 0.0;
-    ch.first_bad = -1;
     double *rd_lane = (lane == 0) ? rd : rd + 16 + lane;
     rb_chain_all(ch, frow, rd_lane, std::make_integer_sequence<int, 16>{});
     const double r_own = rd[frow];
@@ -1151,15 +1148,19 @@ __device__ __forceinline__ void rb_chain_run(RbChain &ch, double *NL, double *LR
         hall = max(hall, __builtin_amdgcn_readlane(hmax, 16));
         hall = max(hall, __builtin_amdgcn_readlane(hmax, 32));
         hall = max(hall, __builtin_amdgcn_readlane(hmax, 48));
-        if (lane == 0) flag[1] = ((hall >> 20) - (ymin >> 20) >= RB_REFINE_LOG2) ? 1 : 0;
+        if (lane == 0) *refine_flag = ((hall >> 20) - (ymin >> 20) >= RB_REFINE_LOG2) ? 1 : 0;
     }
     if (fk == 0) {
 #pragma unroll
         for (int c = 0; c < 16; c += 2) *reinterpret_cast<d2_t *>(LR + frow * RB_LD + c) = d2_t{ch.a[c], ch.a[c + 1]};
     }
-    if (ch.first_bad >= 0 && lane == 0) {
-        if (gcol0 + ch.first_bad < n_valid) atomicCAS(info, 0, gcol0 + ch.first_bad + 1);
-        *flag = 1;
+    // the diagonal of the factor, lane i its own L_ii (read back from the rows just written): all positive and finite,
+    // or the first one that is not is the first pivot that failed
+    const unsigned int ok = (unsigned int)__builtin_amdgcn_ballot_w64(__builtin_amdgcn_class(LR[frow * RB_LD + frow], 0x180)) & 0xffffu;
+    if (ok != 0xffffu && lane == 0) {
+        const int first_bad = __builtin_ctz(~ok);
+        if (gcol0 + first_bad < n_valid) atomicCAS(info, 0, gcol0 + first_bad + 1);
+        *fail_flag = 1;
     }
 }
 
@@ -1207,7 +1208,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
             ch.a[c + 1] = v[1];
         }
         RB_STAMP(0, 0, 0);
-        rb_chain_run(ch, NL, LR, rd, lane, frow, fk, info, col0, n_valid, flag);
+        rb_chain_run(ch, NL, LR, rd, lane, frow, fk, info, col0, n_valid, flag, flag + 1);
         RB_STAMP(0, 0, 1);
         __syncthreads();
         if (*flag) return;
@@ -1220,7 +1221,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
                 ch.a[c] = v[0];
                 ch.a[c + 1] = v[1];
             }
-            rb_chain_run(ch, NL, LR, rd, lane, frow, fk, info, col0 + (k + 1) * 16, n_valid, flag);
+            rb_chain_run(ch, NL, LR, rd, lane, frow, fk, info, col0 + (k + 1) * 16, n_valid, flag, flag + 1);
             RB_STAMP(0, k + 1, 1);
             __syncthreads();
             RB_STAMP(0, k + 1, 2);
@@ -1566,7 +1567,7 @@ int chol_init() {
     static int rc_once = EGX_SUCCESS;
     std::call_once(once, [] {
         if (const char *e = std::getenv("EGX_POTF2_THREADS")) g_potf2_threads = (std::atoi(e) == 256) ? 256 : 512;
-        if (const char *e = std::getenv("EGX_POTF2_REG")) g_potf2_reg = std::atoi(e);
+        if (const char *e = std::getenv("EGX_POTF2_REG")) g_potf2_reg = (std::atoi(e) == 1) ? 16 : std::atoi(e);
         if (const char *e = std::getenv("EGX_POTRF_GROUP")) {
             const int g = std::atoi(e);
             if (g >= 1 && g <= 8) {

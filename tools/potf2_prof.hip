@@ -48,7 +48,7 @@ int main() {
     hipMalloc(&dinvA, sizeof(double) * 4 * 4096); hipMalloc(&dinvB, sizeof(double) * 4 * 4096); hipMalloc(&info, 4);
     std::mt19937_64 rng(7);
     std::normal_distribution<double> nd;
-    for (int nw = 8; nw <= 16; nw += 4)
+    for (int nw : {8, 12, 16})
     for (const Case &c : cases) {
         const int n = c.n, ld = c.ld;
         std::vector<double> a((size_t)LDMAX * LDMAX, 0.0);
@@ -125,7 +125,7 @@ int main() {
         for (int i = 0; i < n; i++)
             for (int j = 0; j < n; j++) a[i * n + j] = std::exp(-0.5 * (i - j) * (i - j) / 900.0) + (i == j ? 1e-3 : 0.0);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-        for (int nw = 8; nw <= 16; nw += 4)
+        for (int nw : {8, 12, 16})
         for (int which = (nw == 8 ? 0 : 1); which < 3; which++)
             for (int rep = 0; rep < 4; rep++) {
                 hipMemcpy(dA, a.data(), sizeof(double) * n * n, hipMemcpyHostToDevice);
