@@ -974,14 +974,14 @@ __global__ __launch_bounds__(NT, NT / 256) void k_potf2_block(double *__restrict
 // diagonal carry garbage that only ever meets other such entries),
 // the pivots checked once per strip (a failed one leaves NaNs), 1/L_ii through an LDS side buffer: ~21 VALU
 // instructions per column.
-// Accumulator convention: acc holds MINUS the tile, transposed and with the columns permuted, so that no operand ever
-// needs a transposition or a negation:
-//     lane (frow, fk), register q   <->   -T[row = frow][col = 4 fk + q]        (MFMA D[i][j], i = fk + 4 q, j = frow)
+// Accumulator convention: acc holds the tile transposed and with the columns permuted, so that no operand ever needs a
+// transposition (and the one subtraction is the MFMA's own neg:[1,0,0]):
+//     lane (frow, fk), register q   <->   T[row = frow][col = 4 fk + q]         (MFMA D[i][j], i = fk + 4 q, j = frow)
 // which is at once the D layout of v_mfma_f64_16x16x4 and its A/B operand layout (k slot fk of MFMA step q <-> k =
 // 4 fk + q; the same k permutation is used for the other operand, read as two ds_read_b128 of 4 consecutive doubles).
 // With pi(i) = 4 (i % 4) + i / 4 (the column of D row i):   D[i][j] += sum_k A'[i][k] B'[k][j]  gives
-//     update:  A' = X_C[pi(i)][k], B' = X_R[j][k]                      -> -T(R,C) += X_R X_C^T
-//     TRSM:    A' = -Linv[pi(i)][k], B' = acc (= -T(R,k)[j][k])        -> D = X_R in the same lane layout.
+//     update:  A' = -X_C[pi(i)][k], B' = X_R[j][k]                     -> T(R,C) -= X_R X_C^T
+//     TRSM:    A' = Linv[pi(i)][k], B' = acc (= T(R,k)[j][k])          -> D = X_R in the same lane layout.
 // The 64x64 tile inverses (`dinv`, used by the panel solve and the triangular solves) are built from the stored factor
 // by k_diag_tile_inverses, launched right behind this kernel.
 // ---------------------------------------------------------------------------------------------
@@ -995,35 +995,77 @@ constexpr int RB_LDS_BYTES = (RB_P_DOUBLES + 3 * 16 * RB_LD + RB_RD_DOUBLES) * 8
 // Tile -> (update wave, slot) for NU update waves, and per strip k the slots each phase touches (bit masks examined
 // by the scalar unit: two instructions per slot instead of ten).  The pairs {(r, r-1), (r, r)} are dealt first (same
 // wave, consecutive slots), then the other tiles in column-major order, each to the least loaded wave: every trailing
-// set {C > k} is balanced to +-1 tile (offsets / strides of the pair dealing found by exhaustive search).
+// set {C > k} is balanced to +-1 tile (offsets / strides of the pair dealing found by exhaustive search; the 16-wave
+// kernel has its own table, below).
 constexpr int rb_slots(int nu) { return nu == 7 ? 20 : (nu == 11 ? 13 : 9); }
 template <int NU>
 struct RbTab {
-    unsigned short rc[NU][rb_slots(NU)];  // R * 16 + C, 0x100 = none
+    int rc[NU][rb_slots(NU)];             // R * 16 + C, 0x100 = none (32-bit: fetched by scalar loads, not through vmcnt)
     unsigned int trsm[NU][16];            // phase A of strip k: slots with C == k, R > k
     unsigned int pair[NU][16];            // ... of those, the slot of (k+1, k) (slot + 1 is tile (k+1, k+1))
     unsigned int upd[NU][16];             // phase B of strip k: slots with C > k except (k+1, k+1)
 };
+// The 16-wave kernel's dealing (tools/rb_deal.py): update waves 3, 7, 11 (= waves 4, 8, 12, the ones that share the chain
+// wave's SIMD: wave -> SIMD was measured as [0 2 1 3][w % 4] or [1 3 0 2][w % 4]) own tiles of columns 0..4 only, so that
+// from strip 4 on -- where the strip time is the chain's -- no FP64 MFMA holds the DP pipe the chain's VALU instructions
+// need (an MFMA blocks it for 64 cycles: the chain ran 2 - 2.8x slower beside the trailing update, profiles/r02_run19_*).
+constexpr unsigned char rb_rc15[15][9] = {
+    {0x32, 0x33, 0xfe, 0xff, 0x53, 0x94, 0xe5, 0xd7, 0xe9}, {0x21, 0x22, 0xed, 0xee, 0x72, 0xa4, 0xf5, 0xe7, 0xf9},
+    {0x10, 0x11, 0xdc, 0xdd, 0x82, 0xb4, 0xa6, 0xf7, 0xca}, {0xf0, 0xc0, 0xf1, 0xc1, 0xf2, 0xc2, 0xf3, 0xc3, 0xf4},
+    {0xcb, 0xcc, 0x20, 0x41, 0x92, 0xc4, 0xb6, 0xa8, 0xda}, {0xba, 0xbb, 0x30, 0x51, 0x63, 0x85, 0xc6, 0xb8, 0xdb},
+    {0xa9, 0xaa, 0x40, 0x61, 0x73, 0x95, 0xd6, 0xc8, 0xea}, {0xe0, 0xb0, 0xe1, 0xb1, 0xe2, 0xb2, 0xe3, 0xb3, 0xe4},
+    {0x98, 0x99, 0x50, 0x71, 0x83, 0xa5, 0xe6, 0xb9, 0xfa}, {0x87, 0x88, 0x60, 0x81, 0x93, 0xb5, 0xf6, 0xd8, 0xeb},
+    {0x76, 0x77, 0x70, 0x91, 0x64, 0xc5, 0x97, 0xe8, 0xfb}, {0xd0, 0xa0, 0xd1, 0xa1, 0xd2, 0xa2, 0xd3, 0xa3, 0xd4},
+    {0x65, 0x66, 0x80, 0x42, 0x74, 0x86, 0xa7, 0xf8, 0xec}, {0x54, 0x55, 0x90, 0x52, 0x75, 0x96, 0xb7, 0xc9, 0xfc},
+    {0x43, 0x44, 0x31, 0x62, 0x84, 0xd5, 0xc7, 0xd9, 0xfd}};
 template <int NU>
 constexpr RbTab<NU> rb_make_tab() {
     constexpr int NS = rb_slots(NU);
-    constexpr int off = NU == 7 ? 2 : (NU == 11 ? 1 : 14), step = NU == 7 ? 6 : (NU == 11 ? 3 : 14);
+    constexpr int off = NU == 7 ? 2 : 1, step = NU == 7 ? 6 : 3;
     RbTab<NU> t{};
     int cnt[NU] = {};
     for (int w = 0; w < NU; w++)
         for (int s = 0; s < NS; s++) t.rc[w][s] = 0x100;
-    for (int r = 1; r < 16; r++) {
-        const int w = (off + step * (r - 1)) % NU;
-        t.rc[w][cnt[w]++] = (unsigned short)(r * 16 + r - 1);
-        t.rc[w][cnt[w]++] = (unsigned short)(r * 16 + r);
-    }
-    for (int c = 0; c < 16; c++)
-        for (int r = c + 2; r < 16; r++) {
-            int w = 0;
-            for (int v = 1; v < NU; v++)
-                if (cnt[v] < cnt[w]) w = v;
-            t.rc[w][cnt[w]++] = (unsigned short)(r * 16 + c);
+    if (NU == 15) {
+        for (int w = 0; w < NU; w++)
+            for (int s = 0; s < NS; s++) t.rc[w][s] = rb_rc15[w % 15][s % 9];
+    } else {
+        for (int r = 1; r < 16; r++) {
+            const int w = (off + step * (r - 1)) % NU;
+            t.rc[w][cnt[w]++] = r * 16 + r - 1;
+            t.rc[w][cnt[w]++] = r * 16 + r;
         }
+        for (int c = 0; c < 16; c++)
+            for (int r = c + 2; r < 16; r++) {
+                int w = 0;
+                for (int v = 1; v < NU; v++)
+                    if (cnt[v] < cnt[w]) w = v;
+                t.rc[w][cnt[w]++] = r * 16 + c;
+            }
+    }
+    // Slots in the order of their first use (column of the tile; a pair counts as its tile (r, r-1) and stays together):
+    // the block is loaded slot by slot, and what strip 0 needs should not queue behind what strip 9 needs.
+    for (int w = 0; w < NU; w++) {
+        int first[NS] = {}, len[NS] = {}, units = 0;
+        for (int s0 = 0; s0 < NS && t.rc[w][s0] < 0x100;) {
+            const int R = t.rc[w][s0] >> 4, C = t.rc[w][s0] & 15;
+            const bool pair = C + 1 == R && s0 + 1 < NS && t.rc[w][s0 + 1] == R * 16 + R;
+            first[units] = s0;
+            len[units++] = pair ? 2 : 1;
+            s0 += pair ? 2 : 1;
+        }
+        int sorted[NS] = {};
+        bool used[NS] = {};
+        int out = 0;
+        for (int n = 0; n < units; n++) {  // selection sort, stable
+            int best = -1;
+            for (int v = 0; v < units; v++)
+                if (!used[v] && (best < 0 || (t.rc[w][first[v]] & 15) < (t.rc[w][first[best]] & 15))) best = v;
+            used[best] = true;
+            for (int e = 0; e < len[best]; e++) sorted[out++] = t.rc[w][first[best] + e];
+        }
+        for (int s0 = 0; s0 < out; s0++) t.rc[w][s0] = sorted[s0];
+    }
     for (int w = 0; w < NU; w++)
         for (int k = 0; k < 16; k++) {
             t.trsm[w][k] = t.pair[w][k] = t.upd[w][k] = 0;
@@ -1037,6 +1079,40 @@ constexpr RbTab<NU> rb_make_tab() {
         }
     return t;
 }
+// every tile of the lower triangle except (0,0) exactly once; (r, r) right behind (r, r-1); masks consistent
+template <int NU>
+constexpr bool rb_tab_ok() {
+    constexpr int NS = rb_slots(NU);
+    const RbTab<NU> t = rb_make_tab<NU>();
+    int seen[16][16] = {};
+    for (int w = 0; w < NU; w++)
+        for (int s = 0; s < NS; s++) {
+            if (t.rc[w][s] >= 0x100) continue;
+            const int R = t.rc[w][s] >> 4, C = t.rc[w][s] & 15;
+            if (C > R || (R == 0 && C == 0)) return false;
+            seen[R][C]++;
+            if (R == C && (s == 0 || t.rc[w][s - 1] != R * 16 + R - 1)) return false;
+            if (s > 0 && R != C) {  // sorted by column (a pair counts as its first tile)
+                const int pr = t.rc[w][s - 1] >> 4, pc = t.rc[w][s - 1] & 15;
+                if ((pr == pc ? pc - 1 : pc) > C) return false;
+            }
+        }
+    for (int r = 0; r < 16; r++)
+        for (int c = 0; c <= r; c++)
+            if (seen[r][c] != ((r == 0 && c == 0) ? 0 : 1)) return false;
+    for (int k = 0; k < 15; k++) {
+        int trsm = 0, pair = 0, upd = 0;
+        for (int w = 0; w < NU; w++)
+            for (int s = 0; s < NS; s++) {
+                trsm += (t.trsm[w][k] >> s) & 1;
+                pair += (t.pair[w][k] >> s) & 1;
+                upd += (t.upd[w][k] >> s) & 1;
+            }
+        if (trsm != 15 - k || pair != 1 || upd != (15 - k) * (16 - k) / 2 - 1) return false;
+    }
+    return true;
+}
+static_assert(rb_tab_ok<7>() && rb_tab_ok<11>() && rb_tab_ok<15>(), "tile tables of the register-resident diagonal-block kernel");
 template <int NU>
 __constant__ const RbTab<NU> c_rb_tab = rb_make_tab<NU>();
 
@@ -1115,7 +1191,7 @@ __device__ __forceinline__ void rb_chain_all(RbChain &ch, int i, double *rd_lane
     ((p = rb_chain_step<Js>(ch, p, i, rd_lane)), ...);
 }
 
-// wave 0: factor + invert the diagonal tile of a strip (rows in ch.a); publishes -Linv and the raw factor rows in LDS
+// wave 0: factor + invert the diagonal tile of a strip (rows in ch.a); publishes Linv and the raw factor rows in LDS
 __device__ __forceinline__ void rb_chain_run(RbChain &ch, double *NL, double *LR, double *rd, int lane, int frow, int fk,
                                              int *info, int gcol0, int n_valid, int *fail_flag, int *refine_flag) {
 #pragma unroll
@@ -1131,7 +1207,7 @@ __device__ __forceinline__ void rb_chain_run(RbChain &ch, double *NL, double *LR
     int hmax = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const double nl = -r_own * ch.z[q];
+        const double nl = r_own * ch.z[q];
         NL[frow * RB_LD + fk + 4 * q] = nl;
         hmax = max(hmax, __double2hiint(nl) & 0x7fffffff);
     }
@@ -1164,12 +1240,13 @@ __device__ __forceinline__ void rb_chain_run(RbChain &ch, double *NL, double *LR
     }
 }
 
-// one 16x16x16 product on the matrix cores: c += A' B' with both operands as 4 consecutive doubles per lane
-#define RB_MFMA4(c, a01, a23, b0, b1, b2, b3)                                  \
-    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], b0, c, 0, 0, 0);           \
-    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], b1, c, 0, 0, 0);           \
-    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b2, c, 0, 0, 0);           \
-    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b3, c, 0, 0, 0)
+// one 16x16x16 product on the matrix cores: c +-= A' B' with both operands as 4 consecutive doubles per lane.  NEG = 1
+// negates A' in the instruction (the FP64 MFMAs of gfx940+ read their BLGP field as neg:[a,b,c]).
+#define RB_MFMA4(c, NEG, a01, a23, b0, b1, b2, b3)                               \
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[0], b0, c, 0, 0, NEG);           \
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a01[1], b1, c, 0, 0, NEG);           \
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b2, c, 0, 0, NEG);           \
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b3, c, 0, 0, NEG)
 
 #ifdef EGX_POTF2_PROFILE
 __device__ long long g_rb_stamps[2][16][8];  // [chain wave / update wave 1][strip][event]
@@ -1183,11 +1260,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
                                                           int col0, int n_valid) {
     constexpr int NU = NW - 1, RB_NS = rb_slots(NU);
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    if (*info != 0) return;  // a previous block of this factorisation already failed: early exit
+    const int failed_before = *info;  // examined once the loads of the block are on their way (below)
     __builtin_amdgcn_s_setprio(2);    // above the trailing-update workgroups this kernel may share its CU with
     double *P = sm;                   // X panel of the current strip, row = row of the block
     double *Dg = sm + RB_P_DOUBLES;   // hand-off of the next diagonal tile (update wave -> chain wave)
-    double *NL = Dg + 16 * RB_LD;     // -Linv of the current strip (chain wave -> update waves)
+    double *NL = Dg + 16 * RB_LD;     // Linv of the current strip (chain wave -> update waves)
     double *LR = NL + 16 * RB_LD;     // raw rows of the strip's 16x16 factor (chain wave -> the update wave that stores it)
     double *rd = LR + 16 * RB_LD;     // 1 / L_jj of the strip being factored
     int *flag = reinterpret_cast<int *>(rd + RB_RD_DOUBLES);
@@ -1207,6 +1284,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
             ch.a[c] = v[0];
             ch.a[c + 1] = v[1];
         }
+        if (failed_before != 0) return;  // a previous block of this factorisation already failed: early exit
         RB_STAMP(0, 0, 0);
         rb_chain_run(ch, NL, LR, rd, lane, frow, fk, info, col0, n_valid, flag, flag + 1);
         RB_STAMP(0, 0, 1);
@@ -1239,17 +1317,21 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
         int t = __builtin_amdgcn_readfirstlane(tab.rc[wave - 1][s]);
         asm volatile("" : "+s"(t));  // keep it in its SGPR: re-loading it from the table costs a memory round trip per use
         rc[s] = t;
-        acc[4 * s] = acc[4 * s + 1] = acc[4 * s + 2] = acc[4 * s + 3] = 0.0;
-        if (t < 0x100 && (t >> 4) < nb16) {
-            valid |= 1u << s;
-            const double *src = D + (int64_t)((t >> 4) * 16 + frow) * ld + (t & 15) * 16 + 4 * fk;
-            const d2_t v0 = *reinterpret_cast<const d2_t *>(src), v1 = *reinterpret_cast<const d2_t *>(src + 2);
-            acc[4 * s] = -v0[0];
-            acc[4 * s + 1] = -v0[1];
-            acc[4 * s + 2] = -v1[0];
-            acc[4 * s + 3] = -v1[1];
-        }
+        // The loads are unconditional (a slot without a tile re-reads tile (0,0) and never uses it) and the loaded
+        // registers are not touched before the tile's first MFMA: straight-line loads let the compiler wait for exactly
+        // the ones a phase needs (s_waitcnt vmcnt(n) counts in issue order = order of first use), and nothing is waited
+        // for before the first barrier -- 31k cycles, a fifth of the kernel, when the tiles were negated on arrival.
+        const bool have = t < 0x100 && (t >> 4) < nb16;
+        if (have) valid |= 1u << s;
+        const int tt = have ? t : 0;
+        const double *src = D + (int64_t)((tt >> 4) * 16 + frow) * ld + (tt & 15) * 16 + 4 * fk;
+        const d2_t v0 = *reinterpret_cast<const d2_t *>(src), v1 = *reinterpret_cast<const d2_t *>(src + 2);
+        acc[4 * s] = v0[0];
+        acc[4 * s + 1] = v0[1];
+        acc[4 * s + 2] = v1[0];
+        acc[4 * s + 3] = v1[1];
     }
+    if (failed_before != 0) return;  // a previous block of this factorisation already failed: early exit
     // the strictly upper 16x16 tiles of the 64x64 diagonal tiles are part of the factor's contract: zeros
     for (int zt = wave - 1; zt < 24; zt += NU) {
         const int t = zt / 6, e = zt % 6;
@@ -1271,7 +1353,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
     unsigned int m_trsm = tab.trsm[wave - 1][0] & valid, m_pair = tab.pair[wave - 1][0] & valid, m_upd = tab.upd[wave - 1][0] & valid;
     __syncthreads();
     if (*flag) return;
-    for (int k = 0; k + 1 < nb16; k++) {
+    // One strip.  It is a lambda so that strip 0 can be run OUTSIDE the loop: the compiler drains every outstanding load
+    // before it enters a loop that uses them (s_waitcnt vmcnt(0) at the preheader), which made the TRSM of strip 0 --
+    // it needs one or two of a wave's nine tiles -- wait for the whole block.
+    auto strip = [&](int k) -> bool {
         // the slot masks of the next strip: scalar loads, a strip ahead of their use
         const unsigned int n_trsm = tab.trsm[wave - 1][k + 1] & valid, n_pair = tab.pair[wave - 1][k + 1] & valid,
                            n_upd = tab.upd[wave - 1][k + 1] & valid;
@@ -1303,11 +1388,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
                 if (m_trsm & (1u << s)) {
                     const int R = rc[s] >> 4;
                     double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
-                    RB_MFMA4(x, n01, n23, acc[4 * s], acc[4 * s + 1], acc[4 * s + 2], acc[4 * s + 3]);
+                    RB_MFMA4(x, 0, n01, n23, acc[4 * s], acc[4 * s + 1], acc[4 * s + 2], acc[4 * s + 3]);
                     if (refine) {
-                        double4_t r = double4_t{acc[4 * s], acc[4 * s + 1], acc[4 * s + 2], acc[4 * s + 3]};  // -A
-                        RB_MFMA4(r, l01, l23, x[0], x[1], x[2], x[3]);                                         // -A + X L^T
-                        RB_MFMA4(x, n01, n23, r[0], r[1], r[2], r[3]);                                         // X + (A - X L^T) Linv^T
+                        double4_t r = double4_t{acc[4 * s], acc[4 * s + 1], acc[4 * s + 2], acc[4 * s + 3]};  // A
+                        RB_MFMA4(r, 1, l01, l23, x[0], x[1], x[2], x[3]);                                      // A - X L^T
+                        RB_MFMA4(x, 0, n01, n23, r[0], r[1], r[2], r[3]);                                      // X + (A - X L^T) Linv^T
                     }
                     double *px = P + (R * 16 + fr) * RB_LD + f4;
                     *reinterpret_cast<d2_t *>(px) = d2_t{x[0], x[1]};
@@ -1315,14 +1400,14 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
                     double *dst = D + (int64_t)(R * 16 + fr) * ld + k * 16 + f4;
                     *reinterpret_cast<d2_t *>(dst) = d2_t{x[0], x[1]};
                     *reinterpret_cast<d2_t *>(dst + 2) = d2_t{x[2], x[3]};
-                    if (s + 1 < RB_NS && (m_pair & (1u << s))) {  // slot s + 1 is tile (k+1, k+1): -T += X X^T, A' = own LDS rows
+                    if (s + 1 < RB_NS && (m_pair & (1u << s))) {  // slot s + 1 is tile (k+1, k+1): T -= X X^T, A' = own LDS rows
                         const double *pa = P + (R * 16 + pr) * RB_LD + f4;
                         const d2_t a01 = *reinterpret_cast<const d2_t *>(pa), a23 = *reinterpret_cast<const d2_t *>(pa + 2);
                         double4_t c4 = double4_t{acc[4 * s + 4], acc[4 * s + 5], acc[4 * s + 6], acc[4 * s + 7]};
-                        RB_MFMA4(c4, a01, a23, x[0], x[1], x[2], x[3]);
+                        RB_MFMA4(c4, 1, a01, a23, x[0], x[1], x[2], x[3]);
                         double *dg = Dg + fr * RB_LD + f4;
-                        *reinterpret_cast<d2_t *>(dg) = d2_t{-c4[0], -c4[1]};
-                        *reinterpret_cast<d2_t *>(dg + 2) = d2_t{-c4[2], -c4[3]};
+                        *reinterpret_cast<d2_t *>(dg) = d2_t{c4[0], c4[1]};
+                        *reinterpret_cast<d2_t *>(dg + 2) = d2_t{c4[2], c4[3]};
                     }
                 }
             }
@@ -1340,7 +1425,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
                 const d2_t a01 = *reinterpret_cast<const d2_t *>(pa), a23 = *reinterpret_cast<const d2_t *>(pa + 2);
                 const d2_t b01 = *reinterpret_cast<const d2_t *>(pb), b23 = *reinterpret_cast<const d2_t *>(pb + 2);
                 double4_t c4 = double4_t{acc[4 * s], acc[4 * s + 1], acc[4 * s + 2], acc[4 * s + 3]};
-                RB_MFMA4(c4, a01, a23, b01[0], b01[1], b23[0], b23[1]);
+                RB_MFMA4(c4, 1, a01, a23, b01[0], b01[1], b23[0], b23[1]);
                 acc[4 * s] = c4[0];
                 acc[4 * s + 1] = c4[1];
                 acc[4 * s + 2] = c4[2];
@@ -1350,11 +1435,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
         if (wave == 1) RB_STAMP(1, k, 3);
         __syncthreads();
         if (wave == 1) RB_STAMP(1, k, 4);
-        if (*flag) return;
+        if (*flag) return false;
         m_trsm = n_trsm;
         m_pair = n_pair;
         m_upd = n_upd;
-    }
+            return true;
+    };
+    if (nb16 > 1 && !strip(0)) return;
+    for (int k = 1; k + 1 < nb16; k++)
+        if (!strip(k)) return;
     if (wave == 1 + (nb16 - 1) % NU) store_diag(nb16 - 1);
 }
 
