@@ -983,7 +983,8 @@ __global__ __launch_bounds__(NT, NT / 256) void k_potf2_block(double *__restrict
 //     update:  A' = -X_C[pi(i)][k], B' = X_R[j][k]                     -> T(R,C) -= X_R X_C^T
 //     TRSM:    A' = Linv[pi(i)][k], B' = acc (= T(R,k)[j][k])          -> D = X_R in the same lane layout.
 // The 64x64 tile inverses (`dinv`, used by the panel solve and the triangular solves) are built from the stored factor
-// by k_diag_tile_inverses, launched right behind this kernel.
+// by k_diag_tile_inverses at the end of the factorisation; what the panel solve below the block needs instead -- the 16x16
+// inverses and refinement flags -- is left in those tile-inverse slots, see store_diag.
 // ---------------------------------------------------------------------------------------------
 #ifndef RB_REFINE_LOG2
 #define RB_REFINE_LOG2 5  // refine the strip's TRSM when log2(max |Linv| max L_ii) reaches this (-100: always, 100: never)
@@ -1256,8 +1257,8 @@ __device__ long long g_rb_stamps[2][16][8];  // [chain wave / update wave 1][str
 #define RB_STAMP(w, k, i)
 #endif
 template <int NW>  // waves: 1 chain wave + NW - 1 update waves (8, 12 or 16)
-__global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D, int64_t ld, int nbk, int *__restrict__ info,
-                                                          int col0, int n_valid) {
+__global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D, int64_t ld, int nbk, double *__restrict__ lin,
+                                                          int *__restrict__ info, int col0, int n_valid) {
     constexpr int NU = NW - 1, RB_NS = rb_slots(NU);
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int failed_before = *info;  // examined once the loads of the block are on their way (below)
@@ -1349,6 +1350,14 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
         double *dst = D + (int64_t)(k * 16 + frow) * ld + k * 16 + 4 * fk;
         *reinterpret_cast<d2_t *>(dst) = d2_t{(4 * fk <= frow) ? v0[0] : 0.0, (4 * fk + 1 <= frow) ? v0[1] : 0.0};
         *reinterpret_cast<d2_t *>(dst + 2) = d2_t{(4 * fk + 2 <= frow) ? v1[0] : 0.0, (4 * fk + 3 <= frow) ? v1[1] : 0.0};
+        // ... and its inverse + refinement flag, for the solve of the rows below the block (k_panel_trsm16): they travel in
+        // the slot of the 64x64 tile inverse this strip belongs to (tile j = k % 4 at doubles [256 j, 256 j + 256), flags at
+        // 1024 + j), which k_diag_tile_inverses overwrites with the 64x64 inverses once the factorisation is complete
+        const double *nl = NL + frow * RB_LD + 4 * fk;
+        double *dl = lin + (int64_t)(k >> 2) * 4096 + (k & 3) * 256 + frow * 16 + 4 * fk;
+        *reinterpret_cast<d2_t *>(dl) = *reinterpret_cast<const d2_t *>(nl);
+        *reinterpret_cast<d2_t *>(dl + 2) = *reinterpret_cast<const d2_t *>(nl + 2);
+        if (lane == 0) lin[(int64_t)(k >> 2) * 4096 + 1024 + (k & 3)] = flag[1] ? 1.0 : 0.0;
     };
     unsigned int m_trsm = tab.trsm[wave - 1][0] & valid, m_pair = tab.pair[wave - 1][0] & valid, m_upd = tab.upd[wave - 1][0] & valid;
     __syncthreads();
@@ -1445,6 +1454,94 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
     for (int k = 1; k + 1 < nb16; k++)
         if (!strip(k)) return;
     if (wave == 1 + (nb16 - 1) % NU) store_diag(nb16 - 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// B' (round 2): panel solve  X = P L^-T  below a diagonal block factored by k_potf2_reg, with the same 16x16 machinery:
+// one workgroup = ONE 16-row tile of the panel x all (<= 16) column strips, as FP64-MFMA accumulators of its four waves
+// (wave w owns the strips C = w mod 4: four tiles, 32 registers).  Per strip k: the wave that owns it turns its tile
+// into X_k = T_k Linv_k^T (Linv_k and the refinement flag were left by k_potf2_reg in the tile-inverse slots; the
+// refinement step is the diagonal-block kernel's), puts it into LDS (two buffers, one barrier per strip) and global;
+// every wave then applies  T_C -= X_k L(C,k)^T  to its strips right of k, the L(C,k) fragments (rows pi(frow), 32
+// contiguous bytes per lane) straight from the factored block in L2 and already in flight when the barrier opens.
+// No global round trip between the strips (the round-1 kernel, k_panel_trsm, re-reads its 64-row slab from global four
+// times per block: 38 us whatever the panel's height); 16-row workgroups keep n / 16 of them in flight, which is what a
+// 256-column panel of a small matrix needs to be spread over the chip at all.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, int64_t ldp, const double *__restrict__ L, int64_t ldl,
+                                                      const double *__restrict__ lin, int nbk, const int *__restrict__ info) {
+    __shared__ __attribute__((aligned(16))) double X[2][16 * RB_LD];
+    if (info != nullptr && *info != 0) return;  // failed pivot earlier: early exit (see k_gemm_nt_sub)
+    __builtin_amdgcn_s_setprio(2);
+    const int tid = threadIdx.x, lane = tid & 63, frow = lane & 15, fk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb16 = nbk >> 4;
+    const int prow = ((frow & 3) << 2) | (frow >> 2);  // pi(frow), see k_potf2_reg
+    double *Pw = P + (int64_t)(blockIdx.x * 16 + frow) * ldp + 4 * fk;  // + 16 C: this lane's four columns of strip C
+    const double *Lp = L + (int64_t)prow * ldl + 4 * fk;                // + (16 C) ldl + 16 k: row pi(frow) of tile (C, k)
+    double acc[16];  // slot t <-> strip C = 4 t + wave
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int C = 4 * t + wave;
+        const double *src = Pw + 16 * (C < nb16 ? C : 0);
+        const d2_t v0 = *reinterpret_cast<const d2_t *>(src), v1 = *reinterpret_cast<const d2_t *>(src + 2);
+        acc[4 * t] = v0[0];
+        acc[4 * t + 1] = v0[1];
+        acc[4 * t + 2] = v1[0];
+        acc[4 * t + 3] = v1[1];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < nb16) {
+            // A' fragments of this strip's updates: independent of X_k, so on their way before the barrier
+            d2_t a01[4], a23[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int C = 4 * t + wave;
+                const double *src = Lp + (int64_t)(16 * ((C > k && C < nb16) ? C : k)) * ldl + 16 * k;
+                a01[t] = *reinterpret_cast<const d2_t *>(src);
+                a23[t] = *reinterpret_cast<const d2_t *>(src + 2);
+            }
+            if (wave == (k & 3)) {
+                const double *lk = lin + (int64_t)(k >> 2) * 4096 + (k & 3) * 256;
+                const d2_t n01 = *reinterpret_cast<const d2_t *>(lk + prow * 16 + 4 * fk);
+                const d2_t n23 = *reinterpret_cast<const d2_t *>(lk + prow * 16 + 4 * fk + 2);
+                const bool refine = lin[(int64_t)(k >> 2) * 4096 + 1024 + (k & 3)] != 0.0;
+                const int sl = k >> 2;  // a constant once the strip loop is unrolled
+                double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
+                RB_MFMA4(x, 0, n01, n23, acc[4 * sl], acc[4 * sl + 1], acc[4 * sl + 2], acc[4 * sl + 3]);
+                if (refine) {  // X += (T - X L_kk^T) Linv^T, see the TRSM phase of k_potf2_reg
+                    const double *ld16 = Lp + (int64_t)(16 * k) * ldl + 16 * k;
+                    const d2_t r01 = *reinterpret_cast<const d2_t *>(ld16), r23 = *reinterpret_cast<const d2_t *>(ld16 + 2);
+                    const d2_t l01 = d2_t{(4 * fk <= prow) ? r01[0] : 0.0, (4 * fk + 1 <= prow) ? r01[1] : 0.0};
+                    const d2_t l23 = d2_t{(4 * fk + 2 <= prow) ? r23[0] : 0.0, (4 * fk + 3 <= prow) ? r23[1] : 0.0};
+                    double4_t r = double4_t{acc[4 * sl], acc[4 * sl + 1], acc[4 * sl + 2], acc[4 * sl + 3]};
+                    RB_MFMA4(r, 1, l01, l23, x[0], x[1], x[2], x[3]);
+                    RB_MFMA4(x, 0, n01, n23, r[0], r[1], r[2], r[3]);
+                }
+                double *xs = X[k & 1] + frow * RB_LD + 4 * fk;
+                *reinterpret_cast<d2_t *>(xs) = d2_t{x[0], x[1]};
+                *reinterpret_cast<d2_t *>(xs + 2) = d2_t{x[2], x[3]};
+                *reinterpret_cast<d2_t *>(Pw + 16 * k) = d2_t{x[0], x[1]};
+                *reinterpret_cast<d2_t *>(Pw + 16 * k + 2) = d2_t{x[2], x[3]};
+            }
+            __syncthreads();
+            const double *xs = X[k & 1] + frow * RB_LD + 4 * fk;
+            const d2_t b01 = *reinterpret_cast<const d2_t *>(xs), b23 = *reinterpret_cast<const d2_t *>(xs + 2);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int C = 4 * t + wave;
+                if (C > k && C < nb16) {
+                    double4_t c4 = double4_t{acc[4 * t], acc[4 * t + 1], acc[4 * t + 2], acc[4 * t + 3]};
+                    RB_MFMA4(c4, 1, a01[t], a23[t], b01[0], b01[1], b23[0], b23[1]);
+                    acc[4 * t] = c4[0];
+                    acc[4 * t + 1] = c4[1];
+                    acc[4 * t + 2] = c4[2];
+                    acc[4 * t + 3] = c4[3];
+                }
+            }
+        }
+    }
 }
 
 // Inverses of all 64x64 diagonal tiles of a GIVEN lower factor (used when a fitted model is loaded instead of
@@ -1855,12 +1952,12 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         // EGX_POTF2_THREADS=256 selects the latter for experiments.
         if (g_potf2_reg) {
             if (g_potf2_reg == 16)
-                hipLaunchKernelGGL(k_potf2_reg<16>, dim3(1), dim3(1024), RB_LDS_BYTES, st, diag, ld, nbk, info, k0, n_pad);
+                hipLaunchKernelGGL(k_potf2_reg<16>, dim3(1), dim3(1024), RB_LDS_BYTES, st, diag, ld, nbk, dtiles, info, k0, n_pad);
             else if (g_potf2_reg == 12)
-                hipLaunchKernelGGL(k_potf2_reg<12>, dim3(1), dim3(768), RB_LDS_BYTES, st, diag, ld, nbk, info, k0, n_pad);
+                hipLaunchKernelGGL(k_potf2_reg<12>, dim3(1), dim3(768), RB_LDS_BYTES, st, diag, ld, nbk, dtiles, info, k0, n_pad);
             else
-                hipLaunchKernelGGL(k_potf2_reg<8>, dim3(1), dim3(512), RB_LDS_BYTES, st, diag, ld, nbk, info, k0, n_pad);
-            hipLaunchKernelGGL(k_diag_tile_inverses, dim3(nbk / 64), dim3(256), 0, st, (const double *)diag, ld, dtiles);
+                hipLaunchKernelGGL(k_potf2_reg<8>, dim3(1), dim3(512), RB_LDS_BYTES, st, diag, ld, nbk, dtiles, info, k0, n_pad);
+            // (the 64x64 tile inverses `dinv` -- for the solves AFTER the factorisation -- are built at the end, all at once)
         } else if (g_potf2_threads == 512)
             hipLaunchKernelGGL(k_potf2_block<512>, dim3(1), dim3(512), POTF2_LDS_BYTES, st, diag, ld, nbk, dtiles, info,
                                k0, n_pad);
@@ -1870,7 +1967,11 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     };
     auto trsm = [&](hipStream_t st, int k0, int nbk) {
         const int below = m_tot - (k0 + nbk);
-        if (below > 0)
+        if (below > 0 && g_potf2_reg)
+            hipLaunchKernelGGL(k_panel_trsm16, dim3(below / 16), dim3(256), 0, st, M + (int64_t)(k0 + nbk) * ld + k0, ld,
+                               (const double *)(M + (int64_t)k0 * ld + k0), ld,
+                               (const double *)(dinv + (int64_t)(k0 / 64) * 4096), nbk, (const int *)info);
+        else if (below > 0)
             hipLaunchKernelGGL(k_panel_trsm, dim3(below / 64), dim3(256), PanelShape::LDS_BYTES, st,
                                M + (int64_t)(k0 + nbk) * ld + k0, ld, (const double *)(M + (int64_t)k0 * ld + k0), ld,
                                (const double *)(dinv + (int64_t)(k0 / 64) * 4096), nbk, (const int *)info);
@@ -1979,6 +2080,8 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             if (rc) return rc;
         }
     }
+    if (g_potf2_reg)  // every stream has been joined into `s`: the 64x64 tile inverses of the complete factor, one launch
+        hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64), dim3(256), 0, s, (const double *)M, ld, dinv);
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }

@@ -31,10 +31,10 @@ static std::vector<double> host_chol(const std::vector<double> &a, int n, int ld
 }
 
 struct Case { const char *name; int n, ld, off; int kind; };
-static void launch_reg(int nw, double *d, int64_t ld, int n, int *info, int k0, int nv) {
-    if (nw == 16) hipLaunchKernelGGL(k_potf2_reg<16>, dim3(1), dim3(1024), RB_LDS_BYTES, 0, d, ld, n, info, k0, nv);
-    else if (nw == 12) hipLaunchKernelGGL(k_potf2_reg<12>, dim3(1), dim3(768), RB_LDS_BYTES, 0, d, ld, n, info, k0, nv);
-    else hipLaunchKernelGGL(k_potf2_reg<8>, dim3(1), dim3(512), RB_LDS_BYTES, 0, d, ld, n, info, k0, nv);
+static void launch_reg(int nw, double *d, int64_t ld, int n, double *lin, int *info, int k0, int nv) {
+    if (nw == 16) hipLaunchKernelGGL(k_potf2_reg<16>, dim3(1), dim3(1024), RB_LDS_BYTES, 0, d, ld, n, lin, info, k0, nv);
+    else if (nw == 12) hipLaunchKernelGGL(k_potf2_reg<12>, dim3(1), dim3(768), RB_LDS_BYTES, 0, d, ld, n, lin, info, k0, nv);
+    else hipLaunchKernelGGL(k_potf2_reg<8>, dim3(1), dim3(512), RB_LDS_BYTES, 0, d, ld, n, lin, info, k0, nv);
 }
 
 int main() {
@@ -88,7 +88,7 @@ int main() {
         hipMemcpy(dB, ap.data(), sizeof(double) * a.size(), hipMemcpyHostToDevice);
         hipMemset(info, 0, 4);
         hipMemset(dinvB, 0, sizeof(double) * 4 * 4096);
-        launch_reg(nw, dB + (size_t)c.off * ld + c.off, (int64_t)ld, n, info, 0, n);
+        launch_reg(nw, dB + (size_t)c.off * ld + c.off, (int64_t)ld, n, dinvB, info, 0, n);
         hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n / 64), dim3(256), 0, 0, (const double *)(dB + (size_t)c.off * ld + c.off), (int64_t)ld, dinvB);
         hipError_t err = hipDeviceSynchronize();
         hipMemcpy(outB.data(), dB, sizeof(double) * a.size(), hipMemcpyDeviceToHost);
@@ -135,7 +135,7 @@ int main() {
                 if (which == 0)
                     hipLaunchKernelGGL(k_potf2_block<512>, dim3(1), dim3(512), POTF2_LDS_BYTES, 0, dA, (int64_t)ld, n, dinvA, info, 0, n);
                 else {
-                    launch_reg(nw, dA, (int64_t)ld, n, info, 0, n);
+                    launch_reg(nw, dA, (int64_t)ld, n, dinvB, info, 0, n);
                     if (which == 2) hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n / 64), dim3(256), 0, 0, (const double *)dA, (int64_t)ld, dinvB);
                 }
                 hipEventRecord(e1); hipEventSynchronize(e1);
