@@ -1479,66 +1479,88 @@ __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, in
     const int prow = ((frow & 3) << 2) | (frow >> 2);  // pi(frow), see k_potf2_reg
     double *Pw = P + (int64_t)(blockIdx.x * 16 + frow) * ldp + 4 * fk;  // + 16 C: this lane's four columns of strip C
     const double *Lp = L + (int64_t)prow * ldl + 4 * fk;                // + (16 C) ldl + 16 k: row pi(frow) of tile (C, k)
-    double acc[16];  // slot t <-> strip C = 4 t + wave
+    double acc[16];                  // slot t <-> strip C = 4 t + wave
+    d2_t n01[4], n23[4], l01[4], l23[4];  // for the strips this wave solves: Linv fragments, masked fragments of L(C, C)
+    bool refine[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
-        const int C = 4 * t + wave;
-        const double *src = Pw + 16 * (C < nb16 ? C : 0);
+        const int C = 4 * t + wave, Cc = C < nb16 ? C : 0;
+        const double *src = Pw + 16 * Cc;
         const d2_t v0 = *reinterpret_cast<const d2_t *>(src), v1 = *reinterpret_cast<const d2_t *>(src + 2);
         acc[4 * t] = v0[0];
         acc[4 * t + 1] = v0[1];
         acc[4 * t + 2] = v1[0];
         acc[4 * t + 3] = v1[1];
+        // everything a solve needs besides its tile comes from L2 (~1 us): fetched here, not when the strip comes up
+        const double *lk = lin + (int64_t)(Cc >> 2) * 4096 + (Cc & 3) * 256;
+        n01[t] = *reinterpret_cast<const d2_t *>(lk + prow * 16 + 4 * fk);
+        n23[t] = *reinterpret_cast<const d2_t *>(lk + prow * 16 + 4 * fk + 2);
+        refine[t] = lin[(int64_t)(Cc >> 2) * 4096 + 1024 + (Cc & 3)] != 0.0;
+        const double *ld16 = Lp + (int64_t)(16 * Cc) * ldl + 16 * Cc;
+        const d2_t r01 = *reinterpret_cast<const d2_t *>(ld16), r23 = *reinterpret_cast<const d2_t *>(ld16 + 2);
+        l01[t] = d2_t{(4 * fk <= prow) ? r01[0] : 0.0, (4 * fk + 1 <= prow) ? r01[1] : 0.0};
+        l23[t] = d2_t{(4 * fk + 2 <= prow) ? r23[0] : 0.0, (4 * fk + 3 <= prow) ? r23[1] : 0.0};
     }
+    // solve strip k = 4 t + wave: X_k = T_k Linv_k^T (+ one refinement step, see k_potf2_reg) -> LDS buffer k & 1, global
+    auto solve = [&](int t, int k) {
+        double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
+        RB_MFMA4(x, 0, n01[t], n23[t], acc[4 * t], acc[4 * t + 1], acc[4 * t + 2], acc[4 * t + 3]);
+        if (refine[t]) {
+            double4_t r = double4_t{acc[4 * t], acc[4 * t + 1], acc[4 * t + 2], acc[4 * t + 3]};
+            RB_MFMA4(r, 1, l01[t], l23[t], x[0], x[1], x[2], x[3]);
+            RB_MFMA4(x, 0, n01[t], n23[t], r[0], r[1], r[2], r[3]);
+        }
+        double *xs = X[k & 1] + frow * RB_LD + 4 * fk;
+        *reinterpret_cast<d2_t *>(xs) = d2_t{x[0], x[1]};
+        *reinterpret_cast<d2_t *>(xs + 2) = d2_t{x[2], x[3]};
+        *reinterpret_cast<d2_t *>(Pw + 16 * k) = d2_t{x[0], x[1]};
+        *reinterpret_cast<d2_t *>(Pw + 16 * k + 2) = d2_t{x[2], x[3]};
+    };
+    // the L(C, k) fragments (A' operands) of strip k for the four slots: fetched one strip ahead of their use
+    d2_t a01[4], a23[4];
+    auto fetch_l = [&](int k) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int C = 4 * t + wave;
+            const double *src = Lp + (int64_t)(16 * ((C > k && C < nb16) ? C : k)) * ldl + 16 * k;
+            a01[t] = *reinterpret_cast<const d2_t *>(src);
+            a23[t] = *reinterpret_cast<const d2_t *>(src + 2);
+        }
+    };
+    // T_C -= X_k L(C, k)^T for slot t (strip C = 4 t + wave)
+    auto update = [&](int t, const d2_t &b01, const d2_t &b23) {
+        double4_t c4 = double4_t{acc[4 * t], acc[4 * t + 1], acc[4 * t + 2], acc[4 * t + 3]};
+        RB_MFMA4(c4, 1, a01[t], a23[t], b01[0], b01[1], b23[0], b23[1]);
+        acc[4 * t] = c4[0];
+        acc[4 * t + 1] = c4[1];
+        acc[4 * t + 2] = c4[2];
+        acc[4 * t + 3] = c4[3];
+    };
+    fetch_l(0);
+    if (wave == 0) solve(0, 0);
+    __syncthreads();
+    // Strip k: everybody applies X_k; the wave that owns strip k + 1 updates THAT tile first and solves it at once, so the
+    // next X is on its way while the other updates of strip k still run (one barrier per strip, two X buffers).
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         if (k < nb16) {
-            // A' fragments of this strip's updates: independent of X_k, so on their way before the barrier
-            d2_t a01[4], a23[4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int C = 4 * t + wave;
-                const double *src = Lp + (int64_t)(16 * ((C > k && C < nb16) ? C : k)) * ldl + 16 * k;
-                a01[t] = *reinterpret_cast<const d2_t *>(src);
-                a23[t] = *reinterpret_cast<const d2_t *>(src + 2);
-            }
-            if (wave == (k & 3)) {
-                const double *lk = lin + (int64_t)(k >> 2) * 4096 + (k & 3) * 256;
-                const d2_t n01 = *reinterpret_cast<const d2_t *>(lk + prow * 16 + 4 * fk);
-                const d2_t n23 = *reinterpret_cast<const d2_t *>(lk + prow * 16 + 4 * fk + 2);
-                const bool refine = lin[(int64_t)(k >> 2) * 4096 + 1024 + (k & 3)] != 0.0;
-                const int sl = k >> 2;  // a constant once the strip loop is unrolled
-                double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
-                RB_MFMA4(x, 0, n01, n23, acc[4 * sl], acc[4 * sl + 1], acc[4 * sl + 2], acc[4 * sl + 3]);
-                if (refine) {  // X += (T - X L_kk^T) Linv^T, see the TRSM phase of k_potf2_reg
-                    const double *ld16 = Lp + (int64_t)(16 * k) * ldl + 16 * k;
-                    const d2_t r01 = *reinterpret_cast<const d2_t *>(ld16), r23 = *reinterpret_cast<const d2_t *>(ld16 + 2);
-                    const d2_t l01 = d2_t{(4 * fk <= prow) ? r01[0] : 0.0, (4 * fk + 1 <= prow) ? r01[1] : 0.0};
-                    const d2_t l23 = d2_t{(4 * fk + 2 <= prow) ? r23[0] : 0.0, (4 * fk + 3 <= prow) ? r23[1] : 0.0};
-                    double4_t r = double4_t{acc[4 * sl], acc[4 * sl + 1], acc[4 * sl + 2], acc[4 * sl + 3]};
-                    RB_MFMA4(r, 1, l01, l23, x[0], x[1], x[2], x[3]);
-                    RB_MFMA4(x, 0, n01, n23, r[0], r[1], r[2], r[3]);
-                }
-                double *xs = X[k & 1] + frow * RB_LD + 4 * fk;
-                *reinterpret_cast<d2_t *>(xs) = d2_t{x[0], x[1]};
-                *reinterpret_cast<d2_t *>(xs + 2) = d2_t{x[2], x[3]};
-                *reinterpret_cast<d2_t *>(Pw + 16 * k) = d2_t{x[0], x[1]};
-                *reinterpret_cast<d2_t *>(Pw + 16 * k + 2) = d2_t{x[2], x[3]};
-            }
-            __syncthreads();
             const double *xs = X[k & 1] + frow * RB_LD + 4 * fk;
             const d2_t b01 = *reinterpret_cast<const d2_t *>(xs), b23 = *reinterpret_cast<const d2_t *>(xs + 2);
+            const int tn = (k + 1) >> 2;  // slot of strip k + 1 in the wave that owns it
+            const bool next_owner = wave == ((k + 1) & 3) && k + 1 < nb16;
+            if (next_owner) {
+                update(tn, b01, b23);
+                solve(tn, k + 1);
+            }
+            // (the updates first: the fetch for the next strip overwrites the fragments)
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int C = 4 * t + wave;
-                if (C > k && C < nb16) {
-                    double4_t c4 = double4_t{acc[4 * t], acc[4 * t + 1], acc[4 * t + 2], acc[4 * t + 3]};
-                    RB_MFMA4(c4, 1, a01[t], a23[t], b01[0], b01[1], b23[0], b23[1]);
-                    acc[4 * t] = c4[0];
-                    acc[4 * t + 1] = c4[1];
-                    acc[4 * t + 2] = c4[2];
-                    acc[4 * t + 3] = c4[3];
-                }
+                if (C > k && C < nb16 && !(next_owner && t == tn)) update(t, b01, b23);
+            }
+            if (k + 1 < nb16) {
+                fetch_l(k + 1);
+                __syncthreads();
             }
         }
     }
