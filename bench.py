@@ -213,7 +213,7 @@ def main():
                          "flops_per_launch_avg": syrk_flops / max(1, syrk_launches),
                          "how": "algorithmic flops (2*K*ncols*(ncols+1)/2 per launch, K = group width) / HIP-event durations around every "
                                 "launch on the stream it is launched on, one fit in flight (separate leg after the timed "
-                                "region; in the timed region two candidates overlap and share the GPU)",
+                                "region; in the timed region the candidates in flight overlap and share the GPU)",
                          "traffic_source": (None if pmc is None else
                                             {"file": os.path.relpath(PMC_SUMMARY, ROOT),
                                              "fetch_bytes_per_launch_raw": pmc["fetch_bytes_per_launch"],

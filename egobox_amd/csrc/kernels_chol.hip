@@ -4,18 +4,19 @@
 // `cholesky()` / `solve_triangular()` (crates/gp/src/algorithm.rs:1004-1034, :337-367) or LAPACK
 // dpotrf/dtrtrs with the `blas` feature (:1077-1115).
 //
-// Structure per 256-column block k (flat right-looking, lower, row-major, in place):
-//   A  k_potf2_block : ONE workgroup factors the 256x256 diagonal block.  64x64 tiles are factored
-//                      by a single wave with one matrix row per lane held in registers (no
-//                      barriers: pivots and multipliers travel by v_readlane); tiles below are solved
-//                      by true forward substitution (row per lane, L broadcast from LDS).  Also emits
-//                      the inverse of every 64x64 diagonal tile (used by B and by the solves).
-//   B  k_panel_trsm  : rows below the block:  X = P * L_kk^-T, block substitution over 64-column
-//                      tiles: off-diagonal part as FP64-MFMA GEMM, diagonal tile via its inverse.
-//   C  k_gemm_nt_sub : trailing update  C -= P P^T  (lower tiles only) -- the n^3/3 flops --
-//                      128x128 workgroup tiles, 4 waves of 64x64, v_mfma_f64_16x16x4_f64,
-//                      A/B staged through LDS in 16-deep K chunks (double buffered, register
-//                      prefetch), padded LDS rows (18 doubles) so ds_read_b64 is conflict free.
+// Structure per 256-column block k (right-looking, lower, row-major, in place; blocks are grouped 2 or 4 to a trailing
+// update, with look-ahead on side streams: launch_potrf):
+//   A  k_potf2_reg    : ONE workgroup of 16 waves factors the 256x256 diagonal block with its 16x16 tiles resident in
+//                       FP64-MFMA accumulator registers; 16-column strips; the 16x16 diagonal tile by a DPP-broadcast
+//                       pivot chain on one wave, fused with its inverse.  (k_potf2_block, the LDS-tile kernel of round 1,
+//                       is kept behind EGX_POTF2_REG=0.)
+//   B  k_panel_trsm16 : rows below the block:  X = P * L_kk^-T, one 16-row tile per workgroup, strip by strip with the
+//                       16x16 inverses A left behind (+ one refinement step for ill-conditioned tiles).  k_panel_trsm
+//                       (64-row slabs, explicit 64x64 tile inverses) serves the solves after the factorisation.
+//   C  k_gemm_stream  : chip-filling trailing updates  C -= P P^T  (lower tiles only) -- the n^3/3 flops -- 128x256
+//      k_gemm_nt_sub    tiles, LDS-DMA ring; smaller launches by the register-staged 128x128 / 64x64 kernel:
+//                       v_mfma_f64_16x16x4_f64, A/B staged through LDS in 16-deep K chunks.
+//   k_diag_tile_inverses, once at the end: inverses of all 64x64 diagonal tiles (for launch_trsm_rows / k_block_inv256).
 // Right-hand-side rows appended below the square matrix ride along in B and C, so after the
 // factorisation they hold (C^-1 [F | y])^T: the forward solves of algorithm.rs:1006,1028 are fused
 // into the factorisation (classic augmented-matrix trick) and cost no extra pass over C.
