@@ -415,13 +415,17 @@ __device__ long long g_stream_stamps[1 << 14][6];  // per tile: wall start, wall
 template <bool LOWER, int VARIANT>
 __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, int64_t ldc, const double *__restrict__ A,
                                                         int64_t lda, const double *__restrict__ B, int64_t ldb, int K,
-                                                        int nbx, int nby, int ntiles, const int *__restrict__ info) {
+                                                        int nbx, int nby, int ntiles, int xcd, const int *__restrict__ info) {
     if (info != nullptr && *info != 0) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x, nch = K / KC;
-    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+    // Workgroup b runs on XCD b % 8.  xcd != 0 (one tile per workgroup): XCD x takes the x-th EIGHTH of the column-major
+    // tile list instead of every eighth tile, so that the workgroups that share an L2 share their panel columns.
+    const int bid = (xcd && G == ntiles) ? (int)(blockIdx.x & 7) * (ntiles >> 3) + min((int)(blockIdx.x & 7), ntiles & 7) + (int)(blockIdx.x >> 3)
+                                         : (int)blockIdx.x;
+    const int my_tiles = (ntiles - bid + G - 1) / G;
     const int total = my_tiles * nch;  // chunks this workgroup streams
 
     // ---- load side: wave w fills the 8-row groups w, w + 8 (A) and 16 + w + 8 i (B) of every stage
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
     for (int i = 0; i < 2; i++) offA[i] = (unsigned)((8 * (wave + 8 * i) + lrow) * (int)lda) + lpart;
 #pragma unroll
     for (int i = 0; i < 4; i++) offB[i] = (unsigned)((8 * (wave + 8 * i) + lrow) * (int)ldb) + lpart;
-    int t_l = blockIdx.x, ch_l = 0, issued = 0;
+    int t_l = bid, ch_l = 0, issued = 0;
     const double *pA_l, *pB_l;
     {
         int bx, by;
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
     d2_t a0[4], b0[4];     // VARIANT 3: fragments of the coming half chunk, read one half ahead (live across tiles)
 #pragma unroll
     for (int i = 0; i < 4; i++) a0[i] = b0[i] = d2_t{0.0, 0.0};
-    for (int t = blockIdx.x; t < ntiles; t += G) {
+    for (int t = bid; t < ntiles; t += G) {
         int bx, by;
         stream_tile_coords<LOWER>(t, nbx, nby, bx, by);
         double *Ct = C + (int64_t)(bx * 128 + wm0) * ldc + by * 256 + wn0;
@@ -1767,6 +1771,7 @@ static int g_stream_variant = 3;      // EGX_STREAM_VARIANT: structure of a chun
 static int g_stream_min_tiles = 512;  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles go to k_gemm_stream
 static int g_tail_lookahead = 0;      // EGX_TAIL_LOOKAHEAD=1: look-ahead also below 3072 trailing columns (measured: n = 4096 fit
                                       // 3.37 -> 3.27 ms alone, but 460 -> 313 fits/s with two in flight: the extra hand-offs cost more)
+static int g_stream_xcd = 0;         // EGX_STREAM_XCD=1: XCD-contiguous tile assignment in k_gemm_stream (one tile per workgroup)
 static int g_stream_wgs = 256;       // EGX_STREAM_WGS: workgroups of the fully persistent form
 static int g_gemm_pipe = 0;          // EGX_GEMM_PIPE=1: hand software-pipelined K loop (measured 3 % SLOWER, run 20)
 static int g_gemm_small_max = 1024;  // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used  // EGX_GEMM_WIDE: minimum number of 128x256 tiles for the wide-tile kernel (0 = off)
@@ -1790,6 +1795,7 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_GEMM_STREAM")) g_gemm_stream = std::atoi(e);
         if (const char *e = std::getenv("EGX_POTRF_DIAG_FIRST")) g_potrf_diag_first = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_TPW")) g_stream_tpw = std::atoi(e);
+        if (const char *e = std::getenv("EGX_STREAM_XCD")) g_stream_xcd = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_MIN")) g_stream_min_tiles = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_VARIANT")) g_stream_variant = std::atoi(e);
         if (const char *e = std::getenv("EGX_TAIL_LOOKAHEAD")) g_tail_lookahead = std::atoi(e);
@@ -1858,7 +1864,7 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
             int grid = g_stream_tpw > 0 ? (nt + g_stream_tpw - 1) / g_stream_tpw : (nt < g_stream_wgs ? nt : g_stream_wgs);
             if (grid < 1) grid = 1;
 #define EGX_STREAM(LOW, V) \
-    hipLaunchKernelGGL((k_gemm_stream<LOW, V>), dim3(grid), dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx, nby, nt, info)
+    hipLaunchKernelGGL((k_gemm_stream<LOW, V>), dim3(grid), dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx, nby, nt, g_stream_xcd, info)
             if (lower) {
                 if (g_stream_variant == 1) EGX_STREAM(true, 1);
                 else if (g_stream_variant == 3) EGX_STREAM(true, 3);
