@@ -1473,29 +1473,34 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
 // times per block: 38 us whatever the panel's height); 16-row workgroups keep n / 16 of them in flight, which is what a
 // 256-column panel of a small matrix needs to be spread over the chip at all.
 // ---------------------------------------------------------------------------------------------
+template <int RT>  // 16-row tiles per workgroup: 1 (panels of small matrices: n / 16 workgroups) or 2 (tall panels: the L
+                    // fragments and the barrier serve two tiles, half the workgroups, less CU time per row)
 __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, int64_t ldp, const double *__restrict__ L, int64_t ldl,
                                                       const double *__restrict__ lin, int nbk, const int *__restrict__ info) {
-    __shared__ __attribute__((aligned(16))) double X[2][16 * RB_LD];
+    __shared__ __attribute__((aligned(16))) double X[2][RT][16 * RB_LD];
     if (info != nullptr && *info != 0) return;  // failed pivot earlier: early exit (see k_gemm_nt_sub)
     __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x, lane = tid & 63, frow = lane & 15, fk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nb16 = nbk >> 4;
     const int prow = ((frow & 3) << 2) | (frow >> 2);  // pi(frow), see k_potf2_reg
-    double *Pw = P + (int64_t)(blockIdx.x * 16 + frow) * ldp + 4 * fk;  // + 16 C: this lane's four columns of strip C
-    const double *Lp = L + (int64_t)prow * ldl + 4 * fk;                // + (16 C) ldl + 16 k: row pi(frow) of tile (C, k)
-    double acc[16];                  // slot t <-> strip C = 4 t + wave
+    double *Pw = P + (int64_t)(blockIdx.x * 16 * RT + frow) * ldp + 4 * fk;  // + 16 r ldp + 16 C: row tile r, strip C
+    const double *Lp = L + (int64_t)prow * ldl + 4 * fk;                     // + (16 C) ldl + 16 k: row pi(frow) of tile (C, k)
+    double acc[RT][16];                   // row tile r, slot t <-> strip C = 4 t + wave
     d2_t n01[4], n23[4], l01[4], l23[4];  // for the strips this wave solves: Linv fragments, masked fragments of L(C, C)
     bool refine[4];
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         const int C = 4 * t + wave, Cc = C < nb16 ? C : 0;
-        const double *src = Pw + 16 * Cc;
-        const d2_t v0 = *reinterpret_cast<const d2_t *>(src), v1 = *reinterpret_cast<const d2_t *>(src + 2);
-        acc[4 * t] = v0[0];
-        acc[4 * t + 1] = v0[1];
-        acc[4 * t + 2] = v1[0];
-        acc[4 * t + 3] = v1[1];
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const double *src = Pw + (int64_t)(16 * r) * ldp + 16 * Cc;
+            const d2_t v0 = *reinterpret_cast<const d2_t *>(src), v1 = *reinterpret_cast<const d2_t *>(src + 2);
+            acc[r][4 * t] = v0[0];
+            acc[r][4 * t + 1] = v0[1];
+            acc[r][4 * t + 2] = v1[0];
+            acc[r][4 * t + 3] = v1[1];
+        }
         // everything a solve needs besides its tile comes from L2 (~1 us): fetched here, not when the strip comes up
         const double *lk = lin + (int64_t)(Cc >> 2) * 4096 + (Cc & 3) * 256;
         n01[t] = *reinterpret_cast<const d2_t *>(lk + prow * 16 + 4 * fk);
@@ -1508,18 +1513,22 @@ __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, in
     }
     // solve strip k = 4 t + wave: X_k = T_k Linv_k^T (+ one refinement step, see k_potf2_reg) -> LDS buffer k & 1, global
     auto solve = [&](int t, int k) {
-        double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
-        RB_MFMA4(x, 0, n01[t], n23[t], acc[4 * t], acc[4 * t + 1], acc[4 * t + 2], acc[4 * t + 3]);
-        if (refine[t]) {
-            double4_t r = double4_t{acc[4 * t], acc[4 * t + 1], acc[4 * t + 2], acc[4 * t + 3]};
-            RB_MFMA4(r, 1, l01[t], l23[t], x[0], x[1], x[2], x[3]);
-            RB_MFMA4(x, 0, n01[t], n23[t], r[0], r[1], r[2], r[3]);
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
+            RB_MFMA4(x, 0, n01[t], n23[t], acc[r][4 * t], acc[r][4 * t + 1], acc[r][4 * t + 2], acc[r][4 * t + 3]);
+            if (refine[t]) {
+                double4_t rs = double4_t{acc[r][4 * t], acc[r][4 * t + 1], acc[r][4 * t + 2], acc[r][4 * t + 3]};
+                RB_MFMA4(rs, 1, l01[t], l23[t], x[0], x[1], x[2], x[3]);
+                RB_MFMA4(x, 0, n01[t], n23[t], rs[0], rs[1], rs[2], rs[3]);
+            }
+            double *xs = X[k & 1][r] + frow * RB_LD + 4 * fk;
+            *reinterpret_cast<d2_t *>(xs) = d2_t{x[0], x[1]};
+            *reinterpret_cast<d2_t *>(xs + 2) = d2_t{x[2], x[3]};
+            double *dst = Pw + (int64_t)(16 * r) * ldp + 16 * k;
+            *reinterpret_cast<d2_t *>(dst) = d2_t{x[0], x[1]};
+            *reinterpret_cast<d2_t *>(dst + 2) = d2_t{x[2], x[3]};
         }
-        double *xs = X[k & 1] + frow * RB_LD + 4 * fk;
-        *reinterpret_cast<d2_t *>(xs) = d2_t{x[0], x[1]};
-        *reinterpret_cast<d2_t *>(xs + 2) = d2_t{x[2], x[3]};
-        *reinterpret_cast<d2_t *>(Pw + 16 * k) = d2_t{x[0], x[1]};
-        *reinterpret_cast<d2_t *>(Pw + 16 * k + 2) = d2_t{x[2], x[3]};
     };
     // the L(C, k) fragments (A' operands) of strip k for the four slots: fetched one strip ahead of their use
     d2_t a01[4], a23[4];
@@ -1532,14 +1541,17 @@ __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, in
             a23[t] = *reinterpret_cast<const d2_t *>(src + 2);
         }
     };
-    // T_C -= X_k L(C, k)^T for slot t (strip C = 4 t + wave)
-    auto update = [&](int t, const d2_t &b01, const d2_t &b23) {
-        double4_t c4 = double4_t{acc[4 * t], acc[4 * t + 1], acc[4 * t + 2], acc[4 * t + 3]};
-        RB_MFMA4(c4, 1, a01[t], a23[t], b01[0], b01[1], b23[0], b23[1]);
-        acc[4 * t] = c4[0];
-        acc[4 * t + 1] = c4[1];
-        acc[4 * t + 2] = c4[2];
-        acc[4 * t + 3] = c4[3];
+    // T_C -= X_k L(C, k)^T for slot t (strip C = 4 t + wave), all row tiles
+    auto update = [&](int t, const d2_t (&b01)[RT], const d2_t (&b23)[RT]) {
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            double4_t c4 = double4_t{acc[r][4 * t], acc[r][4 * t + 1], acc[r][4 * t + 2], acc[r][4 * t + 3]};
+            RB_MFMA4(c4, 1, a01[t], a23[t], b01[r][0], b01[r][1], b23[r][0], b23[r][1]);
+            acc[r][4 * t] = c4[0];
+            acc[r][4 * t + 1] = c4[1];
+            acc[r][4 * t + 2] = c4[2];
+            acc[r][4 * t + 3] = c4[3];
+        }
     };
     fetch_l(0);
     if (wave == 0) solve(0, 0);
@@ -1549,8 +1561,13 @@ __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, in
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         if (k < nb16) {
-            const double *xs = X[k & 1] + frow * RB_LD + 4 * fk;
-            const d2_t b01 = *reinterpret_cast<const d2_t *>(xs), b23 = *reinterpret_cast<const d2_t *>(xs + 2);
+            d2_t b01[RT], b23[RT];
+#pragma unroll
+            for (int r = 0; r < RT; r++) {
+                const double *xs = X[k & 1][r] + frow * RB_LD + 4 * fk;
+                b01[r] = *reinterpret_cast<const d2_t *>(xs);
+                b23[r] = *reinterpret_cast<const d2_t *>(xs + 2);
+            }
             const int tn = (k + 1) >> 2;  // slot of strip k + 1 in the wave that owns it
             const bool next_owner = wave == ((k + 1) & 3) && k + 1 < nb16;
             if (next_owner) {
@@ -1771,6 +1788,7 @@ static int g_stream_variant = 3;      // EGX_STREAM_VARIANT: structure of a chun
 static int g_stream_min_tiles = 512;  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles go to k_gemm_stream
 static int g_tail_lookahead = 0;      // EGX_TAIL_LOOKAHEAD=1: look-ahead also below 3072 trailing columns (measured: n = 4096 fit
                                       // 3.37 -> 3.27 ms alone, but 460 -> 313 fits/s with two in flight: the extra hand-offs cost more)
+static int g_panel_rt2_rows = 4096;  // EGX_PANEL_RT2: panels with at least this many rows use two 16-row tiles per workgroup
 static int g_stream_xcd = 0;         // EGX_STREAM_XCD=1: XCD-contiguous tile assignment in k_gemm_stream (one tile per workgroup)
 static int g_stream_wgs = 256;       // EGX_STREAM_WGS: workgroups of the fully persistent form
 static int g_gemm_pipe = 0;          // EGX_GEMM_PIPE=1: hand software-pipelined K loop (measured 3 % SLOWER, run 20)
@@ -1796,6 +1814,7 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_POTRF_DIAG_FIRST")) g_potrf_diag_first = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_TPW")) g_stream_tpw = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_XCD")) g_stream_xcd = std::atoi(e);
+        if (const char *e = std::getenv("EGX_PANEL_RT2")) g_panel_rt2_rows = std::atoi(e) > 0 ? std::atoi(e) : (1 << 30);
         if (const char *e = std::getenv("EGX_STREAM_MIN")) g_stream_min_tiles = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_VARIANT")) g_stream_variant = std::atoi(e);
         if (const char *e = std::getenv("EGX_TAIL_LOOKAHEAD")) g_tail_lookahead = std::atoi(e);
@@ -1996,8 +2015,12 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     };
     auto trsm = [&](hipStream_t st, int k0, int nbk) {
         const int below = m_tot - (k0 + nbk);
-        if (below > 0 && g_potf2_reg)
-            hipLaunchKernelGGL(k_panel_trsm16, dim3(below / 16), dim3(256), 0, st, M + (int64_t)(k0 + nbk) * ld + k0, ld,
+        if (below > 0 && g_potf2_reg && below >= g_panel_rt2_rows)  // (below is a multiple of 64)
+            hipLaunchKernelGGL(k_panel_trsm16<2>, dim3(below / 32), dim3(256), 0, st, M + (int64_t)(k0 + nbk) * ld + k0, ld,
+                               (const double *)(M + (int64_t)k0 * ld + k0), ld,
+                               (const double *)(dinv + (int64_t)(k0 / 64) * 4096), nbk, (const int *)info);
+        else if (below > 0 && g_potf2_reg)
+            hipLaunchKernelGGL(k_panel_trsm16<1>, dim3(below / 16), dim3(256), 0, st, M + (int64_t)(k0 + nbk) * ld + k0, ld,
                                (const double *)(M + (int64_t)k0 * ld + k0), ld,
                                (const double *)(dinv + (int64_t)(k0 / 64) * 4096), nbk, (const int *)info);
         else if (below > 0)
