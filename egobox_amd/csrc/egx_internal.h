@@ -80,11 +80,13 @@ int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, in
 // ---- kernels_chol.hip -------------------------------------------------------
 // In-place blocked right-looking Cholesky of the leading n_pad x n_pad block (lower), applied to
 // all m_tot >= n_pad rows (rows >= n_pad are right-hand sides: on return they hold (C^-1 B)^T).
-// dinv receives the inverses of the 64x64 diagonal tiles ((n_pad/64) * 4096 doubles).
+// dinv receives the inverses of the 64x64 diagonal tiles ((n_pad/64) * 4096 doubles) followed by one flag per tile
+// (1.0: ill-conditioned tile, the solves refine once; see k_panel_trsm): dinv_doubles(n_pad) doubles in all.
 // info (device int): 0 or 1-based index of the first non-positive pivot.
 // ev_syrk: optional accumulation of per-launch timings is done by the caller via events.
 // Optional per-launch timing of the big-tile trailing-update kernel (the dominant kernel): event pairs recorded on
 // the stream the kernel is launched on.  Filled by launch_potrf, read back by the caller after a stream sync.
+inline size_t dinv_doubles(int n_pad) { return (size_t)(n_pad / 64) * 4096 + (size_t)(n_pad / 64); }
 struct GemmTrace {
     static constexpr int kMax = 192;
     hipEvent_t e0[kMax], e1[kMax];

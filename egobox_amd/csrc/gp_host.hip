@@ -71,7 +71,7 @@ static int alloc_workspace(egx_gp *gp, Workspace &w) {
         }
     }
     EGX_HIP_CHECK(hipMalloc(&w.M, sizeof(double) * (size_t)gp->m_tot * gp->ld));
-    EGX_HIP_CHECK(hipMalloc(&w.dinv, sizeof(double) * (size_t)(gp->n_pad / 64) * 4096));
+    EGX_HIP_CHECK(hipMalloc(&w.dinv, sizeof(double) * dinv_doubles(gp->n_pad)));
     const int hmax = gp->has_w ? gp->h : 1;
     EGX_HIP_CHECK(hipMalloc(&w.d_coef, sizeof(double) * (size_t)gp->d * hmax));
     EGX_HIP_CHECK(hipMalloc(&w.d_diag, sizeof(double) * (size_t)gp->n_pad));
@@ -87,7 +87,7 @@ static int alloc_workspace(egx_gp *gp, Workspace &w) {
         const size_t g2 = (size_t)gp->rhs_pad * gp->rhs_pad;
         EGX_HIP_CHECK(hipMalloc(&w.d_gneg, sizeof(double) * g2));
         EGX_HIP_CHECK(hipMalloc(&w.d_gram, sizeof(double) * g2));
-        EGX_HIP_CHECK(hipMalloc(&w.d_gdinv, sizeof(double) * (size_t)(gp->rhs_pad / 64) * 4096));
+        EGX_HIP_CHECK(hipMalloc(&w.d_gdinv, sizeof(double) * dinv_doubles(gp->rhs_pad)));
         EGX_HIP_CHECK(hipMalloc(&w.d_gramP, sizeof(double) * gram_scratch_doubles(gp->rhs_pad, gp->n_pad)));
         EGX_HIP_CHECK(hipMalloc(&w.d_beta, sizeof(double) * (size_t)gp->rhs_pad));
         EGX_HIP_CHECK(hipMalloc(&w.d_part, sizeof(double) * (size_t)((gp->n_pad + 255) / 256)));
@@ -1002,7 +1002,7 @@ int32_t egx_potrf(double *a, int64_t n, int32_t *info) {
     for (int64_t i = n; i < n_pad; i++) hp[(size_t)i * n_pad + i] = 1.0;
     DevBuf d_M, d_dinv, d_info;  // d_info: one int stored in a double-sized slot
     EGX_RC(d_M.alloc(hp.size()));
-    EGX_RC(d_dinv.alloc((size_t)(n_pad / 64) * 4096));
+    EGX_RC(d_dinv.alloc(dinv_doubles(n_pad)));
     EGX_RC(d_info.alloc(1));
     EGX_HIP_CHECK(hipMemset(d_info.p, 0, sizeof(double)));
     EGX_HIP_CHECK(hipMemcpy(d_M.p, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));

@@ -642,7 +642,7 @@ using PanelShape = GemmShape<64, 64, 16, 64>;
 __global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, int64_t ldp,
                                                        const double *__restrict__ L, int64_t ldl,
                                                        const double *__restrict__ dinv, int nbk,
-                                                       const int *__restrict__ info) {
+                                                       const int *__restrict__ info, const double *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (info != nullptr && *info != 0) return;  // failed pivot earlier: early exit (see k_gemm_nt_sub)
     __builtin_amdgcn_s_setprio(2);
@@ -658,6 +658,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, i
         // sum_{t<c} X_t L[c,t]^T  (K = 64 c): X_t were written to global by this workgroup
         gemm_core<64, 64, 16, 64>(Pw, ldp, L + (int64_t)c * 64 * ldl, ldl, 64 * c, acc, smem, tid);
         // rhs = P_c - acc, in place
+        double rhs[4][4];
         {
             double cv[4][4];
 #pragma unroll
@@ -667,8 +668,10 @@ __global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, i
 #pragma unroll
             for (int ni = 0; ni < 4; ni++)
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    Pw[(int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf] = cv[ni][r] - acc[0][ni][r];
+                for (int r = 0; r < 4; r++) {
+                    rhs[ni][r] = cv[ni][r] - acc[0][ni][r];
+                    Pw[(int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf] = rhs[ni][r];
+                }
         }
         __syncthreads();  // workgroup-scope visibility of rhs before it is re-read as an operand
 #pragma unroll
@@ -681,6 +684,30 @@ __global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, i
             for (int r = 0; r < 4; r++)
                 Pw[(int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf] = acc[0][ni][r];
         __syncthreads();
+        if (flags != nullptr && flags[c] != 0.0) {
+            // Ill-conditioned diagonal tile (k_diag_tile_inverses: max |Linv| max L_ii >= 32): the explicit inverse leaves a
+            // residual rhs - X L_cc^T of order eps cond(L_cc) |rhs|; one refinement step, X += (rhs - X L_cc^T) Linv_cc^T,
+            // brings it back to eps |rhs| (as long as eps cond^2 < 1) -- see the TRSM phase of k_potf2_reg.
+            double4_t racc[1][4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) racc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+            gemm_core<64, 64, 16, 64>(Pw + c * 64, ldp, L + (int64_t)c * 64 * ldl + c * 64, ldl, 64, racc, smem, tid);  // X L_cc^T
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    Pw[(int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf] = rhs[ni][r] - racc[0][ni][r];
+            __syncthreads();
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) racc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+            gemm_core<64, 64, 16, 64>(Pw + c * 64, ldp, dinv + (int64_t)c * 4096, 64, 64, racc, smem, tid);
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    Pw[(int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf] = acc[0][ni][r] + racc[0][ni][r];
+            __syncthreads();
+        }
     }
 }
 
@@ -1591,10 +1618,11 @@ __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, in
 // Inverses of all 64x64 diagonal tiles of a GIVEN lower factor (used when a fitted model is loaded instead of
 // factored here): one workgroup per tile, same row-per-lane strip algorithm as in k_potf2_block.
 __global__ __launch_bounds__(256, 1) void k_diag_tile_inverses(const double *__restrict__ M, int64_t ld,
-                                                               double *__restrict__ dinv) {
+                                                               double *__restrict__ dinv, double *__restrict__ flags) {
     __shared__ double Ls[TS * TLD];
     __shared__ double X[TS * TLD];
     __shared__ double rd[TS];
+    __shared__ double red[2][256];
     const int tid = threadIdx.x, t = blockIdx.x;
     const double *src = M + (int64_t)(t * TS) * ld + t * TS;
     for (int e = tid; e < TS * TS; e += 256) {
@@ -1606,7 +1634,24 @@ __global__ __launch_bounds__(256, 1) void k_diag_tile_inverses(const double *__r
     __syncthreads();
     wg_inv_64<4>(Ls, rd, X, tid);
     double *dst = dinv + (int64_t)t * 4096;
-    for (int e = tid; e < TS * TS; e += 256) dst[e] = X[(e >> 6) * TLD + (e & 63)];
+    double xmax = 0.0;
+    for (int e = tid; e < TS * TS; e += 256) {
+        const double v = X[(e >> 6) * TLD + (e & 63)];
+        dst[e] = v;
+        xmax = fmax(xmax, fabs(v));
+    }
+    // flag of the tile for the solves that use its explicit inverse: max |Linv_ij| max L_ii (a stand-in for cond(L)) >= 32
+    red[0][tid] = xmax;
+    red[1][tid] = (tid < TS) ? Ls[tid * TLD + tid] : 0.0;
+    __syncthreads();
+    if (tid == 0 && flags != nullptr) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < 256; i++) {
+            a = fmax(a, red[0][i]);
+            b = fmax(b, red[1][i]);
+        }
+        flags[t] = (a * b >= 32.0 || !(a * b == a * b)) ? 1.0 : 0.0;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1788,6 +1833,7 @@ static int g_stream_variant = 3;      // EGX_STREAM_VARIANT: structure of a chun
 static int g_stream_min_tiles = 512;  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles go to k_gemm_stream
 static int g_tail_lookahead = 0;      // EGX_TAIL_LOOKAHEAD=1: look-ahead also below 3072 trailing columns (measured: n = 4096 fit
                                       // 3.37 -> 3.27 ms alone, but 460 -> 313 fits/s with two in flight: the extra hand-offs cost more)
+static int g_trsm_refine = 1;        // EGX_TRSM_REFINE=0: no refinement step in the solves after the factorisation
 static int g_panel_rt2_rows = 4096;  // EGX_PANEL_RT2: panels with at least this many rows use two 16-row tiles per workgroup
 static int g_stream_xcd = 0;         // EGX_STREAM_XCD=1: XCD-contiguous tile assignment in k_gemm_stream (one tile per workgroup)
 static int g_stream_wgs = 256;       // EGX_STREAM_WGS: workgroups of the fully persistent form
@@ -1814,6 +1860,7 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_POTRF_DIAG_FIRST")) g_potrf_diag_first = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_TPW")) g_stream_tpw = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_XCD")) g_stream_xcd = std::atoi(e);
+        if (const char *e = std::getenv("EGX_TRSM_REFINE")) g_trsm_refine = std::atoi(e);
         if (const char *e = std::getenv("EGX_PANEL_RT2")) g_panel_rt2_rows = std::atoi(e) > 0 ? std::atoi(e) : (1 << 30);
         if (const char *e = std::getenv("EGX_STREAM_MIN")) g_stream_min_tiles = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_VARIANT")) g_stream_variant = std::atoi(e);
@@ -2026,7 +2073,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         else if (below > 0)
             hipLaunchKernelGGL(k_panel_trsm, dim3(below / 64), dim3(256), PanelShape::LDS_BYTES, st,
                                M + (int64_t)(k0 + nbk) * ld + k0, ld, (const double *)(M + (int64_t)k0 * ld + k0), ld,
-                               (const double *)(dinv + (int64_t)(k0 / 64) * 4096), nbk, (const int *)info);
+                               (const double *)(dinv + (int64_t)(k0 / 64) * 4096), nbk, (const int *)info, (const double *)nullptr);
     };
     // C[r0.., c0..c0+N) -= P[r0.., k0..k0+K) P[c0..c0+N, k0..k0+K)^T for the M rows from r0
     auto update = [&](hipStream_t st, int r0, int c0, int Mr, int N, int k0, int K, int lower, bool *big) -> int {
@@ -2133,7 +2180,10 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         }
     }
     if (g_potf2_reg)  // every stream has been joined into `s`: the 64x64 tile inverses of the complete factor, one launch
-        hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64), dim3(256), 0, s, (const double *)M, ld, dinv);
+        hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64), dim3(256), 0, s, (const double *)M, ld, dinv,
+                           dinv + (int64_t)(n_pad / 64) * 4096);
+    else  // round 1's kernels leave no flags: no refinement in the solves that follow
+        EGX_HIP_CHECK(hipMemsetAsync(dinv + (int64_t)(n_pad / 64) * 4096, 0, sizeof(double) * (size_t)(n_pad / 64), s));
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }
@@ -2160,7 +2210,8 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
             // rows below the current block are still zero in these columns and are skipped
             const int m_eff = tri_rows ? ((k0 + nbk < m) ? (k0 + nbk) : m) : m;
             hipLaunchKernelGGL(k_panel_trsm, dim3(m_eff / 64), dim3(256), PanelShape::LDS_BYTES, s, RT + k0, ldr, diag,
-                               ldm, dtiles, nbk, (const int *)nullptr);
+                               ldm, dtiles, nbk, (const int *)nullptr,
+                               (const double *)(g_trsm_refine ? dinv + (int64_t)(n_pad / 64) * 4096 + k0 / 64 : nullptr));
             const int ncols = gend - (k0 + nbk);
             if (ncols > 0) {
                 rc = launch_gemm_nt_sub(s, RT + (k0 + nbk), ldr, RT + k0, ldr, M + (int64_t)(k0 + nbk) * ldm + k0, ldm,
@@ -2181,7 +2232,7 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
 }
 
 int launch_diag_tile_inverses(hipStream_t s, const double *M, int64_t ld, int n_pad, double *dinv) {
-    hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64), dim3(256), 0, s, M, ld, dinv);
+    hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64), dim3(256), 0, s, M, ld, dinv, dinv + (int64_t)(n_pad / 64) * 4096);
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }

@@ -413,8 +413,8 @@ int32_t egx_sgp_create(const egx_sgp_config *cfg_in, const double *x, const doub
     SGP_TRY(g->P.alloc(gram_scratch_doubles((int)ze, (int)np)));
     SGP_TRY(g->Kz.alloc(zp * zp));
     SGP_TRY(g->A.alloc(ze * zp));
-    SGP_TRY(g->dinv_z.alloc((zp / 64) * 4096));
-    SGP_TRY(g->dinv_a.alloc((zp / 64) * 4096));
+    SGP_TRY(g->dinv_z.alloc(dinv_doubles(zp)));
+    SGP_TRY(g->dinv_a.alloc(dinv_doubles(zp)));
     SGP_TRY(g->s0.alloc(np));
     SGP_TRY(g->sb.alloc(np));
     SGP_TRY(g->diag.alloc(zp));

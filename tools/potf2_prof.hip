@@ -89,7 +89,7 @@ int main() {
         hipMemset(info, 0, 4);
         hipMemset(dinvB, 0, sizeof(double) * 4 * 4096);
         launch_reg(nw, dB + (size_t)c.off * ld + c.off, (int64_t)ld, n, dinvB, info, 0, n);
-        hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n / 64), dim3(256), 0, 0, (const double *)(dB + (size_t)c.off * ld + c.off), (int64_t)ld, dinvB);
+        hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n / 64), dim3(256), 0, 0, (const double *)(dB + (size_t)c.off * ld + c.off), (int64_t)ld, dinvB, (double *)nullptr);
         hipError_t err = hipDeviceSynchronize();
         hipMemcpy(outB.data(), dB, sizeof(double) * a.size(), hipMemcpyDeviceToHost);
         hipMemcpy(iB.data(), dinvB, sizeof(double) * 4 * 4096, hipMemcpyDeviceToHost);
@@ -136,7 +136,7 @@ int main() {
                     hipLaunchKernelGGL(k_potf2_block<512>, dim3(1), dim3(512), POTF2_LDS_BYTES, 0, dA, (int64_t)ld, n, dinvA, info, 0, n);
                 else {
                     launch_reg(nw, dA, (int64_t)ld, n, dinvB, info, 0, n);
-                    if (which == 2) hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n / 64), dim3(256), 0, 0, (const double *)dA, (int64_t)ld, dinvB);
+                    if (which == 2) hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n / 64), dim3(256), 0, 0, (const double *)dA, (int64_t)ld, dinvB, (double *)nullptr);
                 }
                 hipEventRecord(e1); hipEventSynchronize(e1);
                 float ms; hipEventElapsedTime(&ms, e0, e1);
