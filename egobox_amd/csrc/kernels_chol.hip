@@ -1557,23 +1557,25 @@ __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, in
             *reinterpret_cast<d2_t *>(dst + 2) = d2_t{x[2], x[3]};
         }
     };
-    // the L(C, k) fragments (A' operands) of strip k for the four slots: fetched one strip ahead of their use
-    d2_t a01[4], a23[4];
+    // The L(C, k) fragments (A' operands) of strip k for the four slots, in two sets (k & 1): fetched TWO strips ahead of
+    // their use -- an L2 round trip (~1 us) is longer than a strip, and the set fetched during strip k - 1 would be
+    // waited for at the top of strip k.
+    d2_t a01[2][4], a23[2][4];
     auto fetch_l = [&](int k) {
 #pragma unroll
         for (int t = 0; t < 4; t++) {
             const int C = 4 * t + wave;
             const double *src = Lp + (int64_t)(16 * ((C > k && C < nb16) ? C : k)) * ldl + 16 * k;
-            a01[t] = *reinterpret_cast<const d2_t *>(src);
-            a23[t] = *reinterpret_cast<const d2_t *>(src + 2);
+            a01[k & 1][t] = *reinterpret_cast<const d2_t *>(src);
+            a23[k & 1][t] = *reinterpret_cast<const d2_t *>(src + 2);
         }
     };
     // T_C -= X_k L(C, k)^T for slot t (strip C = 4 t + wave), all row tiles
-    auto update = [&](int t, const d2_t (&b01)[RT], const d2_t (&b23)[RT]) {
+    auto update = [&](int t, int k, const d2_t (&b01)[RT], const d2_t (&b23)[RT]) {
 #pragma unroll
         for (int r = 0; r < RT; r++) {
             double4_t c4 = double4_t{acc[r][4 * t], acc[r][4 * t + 1], acc[r][4 * t + 2], acc[r][4 * t + 3]};
-            RB_MFMA4(c4, 1, a01[t], a23[t], b01[r][0], b01[r][1], b23[r][0], b23[r][1]);
+            RB_MFMA4(c4, 1, a01[k & 1][t], a23[k & 1][t], b01[r][0], b01[r][1], b23[r][0], b23[r][1]);
             acc[r][4 * t] = c4[0];
             acc[r][4 * t + 1] = c4[1];
             acc[r][4 * t + 2] = c4[2];
@@ -1581,6 +1583,7 @@ __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, in
         }
     };
     fetch_l(0);
+    if (nb16 > 1) fetch_l(1);
     if (wave == 0) solve(0, 0);
     __syncthreads();
     // Strip k: everybody applies X_k; the wave that owns strip k + 1 updates THAT tile first and solves it at once, so the
@@ -1598,17 +1601,16 @@ __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, in
             const int tn = (k + 1) >> 2;  // slot of strip k + 1 in the wave that owns it
             const bool next_owner = wave == ((k + 1) & 3) && k + 1 < nb16;
             if (next_owner) {
-                update(tn, b01, b23);
+                update(tn, k, b01, b23);
                 solve(tn, k + 1);
             }
-            // (the updates first: the fetch for the next strip overwrites the fragments)
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int C = 4 * t + wave;
-                if (C > k && C < nb16 && !(next_owner && t == tn)) update(t, b01, b23);
+                if (C > k && C < nb16 && !(next_owner && t == tn)) update(t, k, b01, b23);
             }
             if (k + 1 < nb16) {
-                fetch_l(k + 1);
+                if (k + 2 < nb16) fetch_l(k + 2);  // into the set strip k just finished with
                 __syncthreads();
             }
         }
