@@ -2,7 +2,10 @@
 """Headline benchmark: fixed-theta GP fits per second, n = 16384, d = 32, squared exponential.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either the driver's `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+     or plain `python bench.py --gpus N`, which re-launches itself under torch.distributed.run with N ranks on
+     127.0.0.1; either way the line is only printed when the world size IS N and the RCCL communicator inside the
+     library has N ranks)
 
 One "step" = one pass of the hot path over one batch of `--sweep-batch` (default 24 = 3 in flight on each of 8 GPUs)
 candidate thetas of a theta sweep: every candidate is one fit in north_star's sense --
@@ -88,6 +91,64 @@ def measured_traffic(n, d):
     return write + c_read + 2.0 * max(0.0, fetch - c_read), p
 
 
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run on
+    127.0.0.1 (one process per GPU, algorithm.rs:928-945's rayon workers at node scale) and pass its exit code on."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_launch(args, rank, world):
+    """CPU rehearsal of the launch path (tests/test_bench_launch_cpu.py): the same spawn / rendezvous / sharding /
+    max-over-ranks timing as the real run, gloo instead of RCCL and a STUB evaluator instead of the GPU library.
+    The line it prints is marked `dry_launch` and carries no performance number."""
+    import torch
+    import torch.distributed as dist
+    from egobox_amd import sweep as sweep_mod
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    nb = max(1, args.sweep_batch)
+    rng = np.random.default_rng(1234)
+    cands = rng.uniform(0.05, 0.2, size=((args.steps + args.warmup) * nb, args.d))
+
+    def stub(th):  # stands in for GpHandle.likelihood_batch
+        return -np.sum(th * th, axis=1), np.zeros(th.shape[0], dtype=np.int32)
+    out_lk = np.zeros(cands.shape[0])
+    for i in range(args.warmup):
+        sweep_mod.sweep_likelihood(stub, cands[i * nb:(i + 1) * nb])
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        out_lk[i * nb:(i + 1) * nb], _ = sweep_mod.sweep_likelihood(stub, cands[i * nb:(i + 1) * nb])
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    times = [elapsed]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        times = [float(p.item()) for p in parts]
+    ok = bool(np.allclose(out_lk[args.warmup * nb:], -np.sum(cands[args.warmup * nb:] ** 2, axis=1)))
+    if rank == 0:
+        print(json.dumps({"metric": "dry_launch", "value": None, "unit": None, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "dry_launch": True, "backend": "gloo" if world > 1 else "none",
+                          "rank_seconds": times, "results_complete_on_rank0": ok, "fits_per_step": nb}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,15 +162,31 @@ def main():
                          "n = 16384)")
     ap.add_argument("--sweep-batch", type=int, default=24,
                     help="candidate thetas per step, summed over ALL GPUs (fixed as N grows: strong scaling)")
+    ap.add_argument("--assignment", choices=("static", "dynamic"), default="static",
+                    help="candidates -> ranks: c mod N, or pulled from the node-wide counter (egx_sweep_set_assignment)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="CPU rehearsal of the launch path: gloo + a stub evaluator, no GPU, no performance number")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); refusing to print a "
+                         f"line that would be mislabelled\n")
+        sys.exit(2)
+    if args.dry_launch:
+        sys.exit(dry_launch(args, rank, world))
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    gpu = local_rank % max(1, torch.cuda.device_count())
+    if torch.cuda.device_count() < 1:
+        sys.stderr.write("bench.py: no GPU visible (the product has no CPU path; --dry-launch rehearses the launch only)\n")
+        sys.exit(3)
+    gpu = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(gpu)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -132,6 +209,8 @@ def main():
 
     # uploads happen here: inputs resident.  Rank 0 draws the RCCL unique id; torch's store carries its 128 bytes
     sw = egx.rendezvous_sweep(x, y, device=gpu, n_workspaces=max(1, args.in_flight))
+    if args.assignment == "dynamic":
+        sw.set_assignment(True)
     lkhs = np.zeros(total)
     stats = np.zeros(total, dtype=np.int32)
 
@@ -152,12 +231,25 @@ def main():
         step(i)
     barrier()
     elapsed = time.perf_counter() - t0
+    rank_seconds = [elapsed]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{gpu}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        rank_seconds = [float(p.item()) for p in parts]
+        elapsed = max(rank_seconds)  # MAX over ranks
+    per_rank_last, eval_s_last = sw.last_balance()
+    eval_seconds = [eval_s_last]
+    if world > 1:
+        t = torch.tensor([eval_s_last], dtype=torch.float64, device=f"cuda:{gpu}")
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+        eval_seconds = [float(p.item()) for p in parts]
     info = sw.info()
     sw.close()
+    if info["rccl_ranks"] != world:
+        sys.stderr.write(f"bench.py: the library's RCCL communicator has {info['rccl_ranks']} ranks, world is {world}\n")
+        sys.exit(4)
 
     if rank == 0:
         # ---- roofline leg (not part of `value`): ONE fit in flight on its own handle, so the HIP-event duration of
@@ -197,7 +289,12 @@ def main():
                        "fits_in_flight_per_gpu": max(1, args.in_flight)},
             "fits_per_step": nb,
             "rccl_ranks": info["rccl_ranks"], "rccl_version": info["rccl_version"],
-            "allgathers_in_timed_region": args.steps,
+            "allgathers_in_timed_region": args.steps, "assignment": args.assignment,
+            "rank_seconds": rank_seconds,
+            "last_step_balance": {"candidates_per_rank": [int(v) for v in per_rank_last],
+                                  "evaluation_seconds_per_rank": eval_seconds,
+                                  "imbalance_max_over_mean": (max(eval_seconds) / (sum(eval_seconds) / len(eval_seconds))
+                                                              if sum(eval_seconds) > 0 else None)},
             "cholesky_tflops_per_gpu_in_timed_region": fits * flops / elapsed / 1e12 / world,
             "stage_ms_single_fit": {"corr_build": corr_ms, "potrf_fused_fwd_solve": potrf_ms, "gamma_solve": solve_ms,
                                     "host_gls": host_ms},

@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libegx_gp_hip.so")
 
 # return codes / status values (egx_rc, egx_status)
-SUCCESS, ERR_INVALID_VALUE, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_FITTED, ERR_LINALG, ERR_LIKELIHOOD, ERR_UNSUPPORTED = range(8)
-STATUS_OK, STATUS_NOT_POSITIVE_DEFINITE, STATUS_ILL_CONDITIONED_FT, STATUS_ILL_CONDITIONED_F, STATUS_NAN_THETA = range(5)
+SUCCESS, ERR_INVALID_VALUE, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_FITTED, ERR_LINALG, ERR_LIKELIHOOD, ERR_UNSUPPORTED, ERR_PEER = range(9)
+STATUS_OK, STATUS_NOT_POSITIVE_DEFINITE, STATUS_ILL_CONDITIONED_FT, STATUS_ILL_CONDITIONED_F, STATUS_NAN_THETA, STATUS_RANK_FAILED = range(6)
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -87,6 +87,8 @@ SIGNATURES = [
     ("egx_sweep_handle", C.c_void_p, [C.c_void_p]),
     ("egx_sweep_info", C.c_int32, [C.c_void_p, c_int32_p, c_int32_p, c_int32_p, c_int32_p, c_int64_p]),
     ("egx_sweep_likelihood", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_int32_p]),
+    ("egx_sweep_set_assignment", C.c_int32, [C.c_void_p, C.c_int32]),
+    ("egx_sweep_last_balance", C.c_int32, [C.c_void_p, c_int64_p, c_double_p]),
     ("egx_sweep_allgather", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
     ("egx_gp_last_timings", C.c_int32, [C.c_void_p, C.POINTER(Timings)]),
     ("egx_mfma_probe", C.c_int32, [c_double_p]),
@@ -133,8 +135,12 @@ class LikelihoodComputationError(EgxError):
     pass
 
 
+class PeerError(EgxError):
+    """A collective call in which another rank failed or did not answer (EGX_ERR_PEER)."""
+
+
 _ERR = {ERR_INVALID_VALUE: InvalidValueError, ERR_NO_DEVICE: NoDeviceError, ERR_NOT_FITTED: NotFittedError,
-        ERR_LINALG: LinalgError, ERR_LIKELIHOOD: LikelihoodComputationError}
+        ERR_LINALG: LinalgError, ERR_LIKELIHOOD: LikelihoodComputationError, ERR_PEER: PeerError}
 
 _lib = None
 

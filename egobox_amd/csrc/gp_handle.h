@@ -141,7 +141,16 @@ bool has_nan(const double *theta, int64_t len);
 int eval_one(egx_gp *gp, int widx, const double *theta, int64_t theta_len, EvalResult &res, bool keep);
 int backward_solve(egx_gp *gp, Workspace &w);
 int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len);
-int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len, double *lkh, int32_t *status);
+// Where a batch takes its candidates from: the sequence 0 .. k-1 (nullptr), a rank's static shard or the node-wide
+// counter of a dynamic sweep (sweep.hip).  pull() hands out up to `want` candidate indices, 0 = exhausted.
+struct CandidateSource {
+    virtual int pull(int want, int64_t *out) = 0;
+    virtual ~CandidateSource() = default;
+};
+// Evaluates the candidates `src` hands out (rows of thetas, k x theta_len) pipelined over the handle's workspaces;
+// results go to lkh[c] / status[c] of the candidate's own index, evaluated[c] (optional, k chars) is set for them.
+int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len, double *lkh, int32_t *status,
+                          CandidateSource *src = nullptr, char *evaluated = nullptr);
 // gp_predict.hip
 int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *vout);
 int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv);

@@ -524,45 +524,84 @@ int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     record_timings(gp, w, host_ms, std::chrono::duration<double, std::milli>(t2 - t1).count());
     return EGX_SUCCESS;
 }
-// k candidates pipelined over the handle's workspaces (caller holds gp->mu exclusively and has set the device)
-int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len, double *lkh, int32_t *status) {
+// Candidates pipelined over the handle's workspaces (caller holds gp->mu exclusively and has set the device).
+// Every workspace has its own stream set, so the serial panel factorisations of one candidate overlap the trailing
+// updates of the others; a workspace whose candidate has been read back takes the next one the source hands out.
+int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len, double *lkh, int32_t *status,
+                          CandidateSource *src, char *evaluated) {
+    struct Sequential final : CandidateSource {
+        int64_t k, next = 0;
+        explicit Sequential(int64_t k_) : k(k_) {}
+        int pull(int want, int64_t *out) override {
+            int got = 0;
+            while (got < want && next < k) out[got++] = next++;
+            return got;
+        }
+    } seq(k);
+    if (!src) src = &seq;
     // a fitted model keeps its factor (workspace 0) as long as another workspace exists
     const int ws_lo = (gp->fitted && gp->ws.size() > 1) ? 1 : 0;
     const int nws = (int)gp->ws.size() - ws_lo;
-    // Software pipeline over the workspaces: every workspace has its own stream pair, so the serial panel
-    // factorisations of one candidate overlap the trailing updates of the others; as soon as a candidate has
-    // been read back its workspace is re-used for candidate c + nws.
-    std::vector<int> launched(nws + ws_lo, 0);
-    auto enqueue = [&](int64_t c) -> int {
-        const int wi = ws_lo + (int)(c % nws);
-        const double *th = thetas + c * theta_len;
-        std::vector<double> coef;
-        int hcols = 1;
-        EGX_RC(make_coef(gp, th, theta_len, coef, hcols, nullptr));
-        launched[wi] = 0;
-        if (has_nan(th, theta_len)) {
+    std::vector<int64_t> cand(nws, -1);  // candidate in flight on workspace ws_lo + i
+    bool exhausted = false;
+    int busy = 0;
+    // next candidate with a usable theta (NaN thetas are answered at once, algorithm.rs:885-891)
+    auto next_valid = [&](int64_t &c, std::vector<double> &coef, int &hcols) -> int {
+        while (!exhausted) {
+            if (src->pull(1, &c) == 0) {
+                exhausted = true;
+                break;
+            }
+            if (c < 0 || c >= k) {
+                set_error("likelihood batch: the candidate source returned an index out of range");
+                return EGX_ERR_INVALID_VALUE;
+            }
+            const double *th = thetas + c * theta_len;
+            EGX_RC(make_coef(gp, th, theta_len, coef, hcols, nullptr));
+            if (evaluated) evaluated[c] = 1;
+            if (!has_nan(th, theta_len)) return EGX_SUCCESS;
             lkh[c] = -std::numeric_limits<double>::infinity();
             status[c] = EGX_STATUS_NAN_THETA;
-            return EGX_SUCCESS;
         }
-        if (wi == 0) gp->fitted = false;
-        EGX_RC(enqueue_eval(gp, gp->ws[wi], coef, hcols));
-        launched[wi] = 1;
+        c = -1;
         return EGX_SUCCESS;
     };
-    for (int64_t c = 0; c < k && c < nws; c++) EGX_RC(enqueue(c));
-    for (int64_t c = 0; c < k; c++) {
-        const int wi = ws_lo + (int)(c % nws);
-        if (launched[wi]) {
-            EvalResult res;
-            EGX_RC(finish_eval(gp, gp->ws[wi], res, false));
-            lkh[c] = res.lkh;
-            status[c] = res.status;
-            if (wi == 0) record_timings(gp, gp->ws[0], 0.0, 0.0);
+    auto run = [&]() -> int {
+        for (int i = 0;; i = (i + 1) % nws) {
+            const int wi = ws_lo + i;
+            if (cand[i] >= 0) {
+                EvalResult res;
+                EGX_RC(finish_eval(gp, gp->ws[wi], res, false));
+                lkh[cand[i]] = res.lkh;
+                status[cand[i]] = res.status;
+                if (wi == 0) record_timings(gp, gp->ws[0], 0.0, 0.0);
+                cand[i] = -1;
+                busy--;
+            }
+            if (!exhausted) {
+                int64_t c;
+                std::vector<double> coef;
+                int hcols = 1;
+                EGX_RC(next_valid(c, coef, hcols));
+                if (c >= 0) {
+                    if (wi == 0) gp->fitted = false;
+                    EGX_RC(enqueue_eval(gp, gp->ws[wi], coef, hcols));
+                    cand[i] = c;
+                    busy++;
+                }
+            }
+            if (exhausted && busy == 0) return EGX_SUCCESS;
         }
-        if (c + nws < k) EGX_RC(enqueue(c + nws));
+    };
+    const int rc = run();
+    if (rc) {  // leave no work behind that still writes into the workspaces
+        const std::string msg = last_error_string();
+        for (int i = 0; i < nws; i++)
+            if (cand[i] >= 0) (void)hipStreamSynchronize(gp->ws[ws_lo + i].stream);
+        (void)hipGetLastError();
+        set_error(msg);
     }
-    return EGX_SUCCESS;
+    return rc;
 }
 }  // namespace egx
 

@@ -1,6 +1,14 @@
-// Multi-GPU theta sweep behind the C ABI (include/egx_gp.h, egx_sweep_*): one process per GPU, candidate k -> rank
-// k mod world, every rank evaluates its shard on its own device through egx_gp_likelihood_batch, ONE RCCL all-gather
-// of {likelihood, status} (16 B per candidate) over xGMI assembles the result on every rank.
+// Multi-GPU theta sweep behind the C ABI (include/egx_gp.h, egx_sweep_*): one process per GPU; candidate c goes to
+// rank c mod world (static) or to whichever rank pulls it first from a node-wide counter in POSIX shared memory
+// (dynamic: candidates that are not positive definite return ~10x sooner than the others); every rank evaluates its
+// share on its own device through the handle's batched likelihood path, ONE RCCL all-gather of {likelihood, status}
+// (16 B per candidate and rank) over xGMI assembles the result on every rank.
+//
+// Failure safety: the all-gather is ALWAYS reached.  A rank whose local work failed contributes a poisoned payload
+// (sweep_shard.h) and returns its error afterwards; the other ranks return EGX_ERR_PEER with the failed rank in the
+// message.  The staging buffers are allocated once in egx_sweep_create (payloads larger than them go in chunks), and
+// the wait for the collective has a deadline (EGX_SWEEP_TIMEOUT_S, default 1800 s) after which the communicator is
+// aborted instead of blocking for ever on a peer that died.
 //
 // Reference seam: the rayon multistart of crates/gp/src/algorithm.rs:928-945 (independent likelihood evaluations,
 // arg-min reduce :942-945) and the serial expert loop of crates/moe/src/algorithm.rs:167-177.  Evaluations at
@@ -13,6 +21,8 @@
 #include "sweep_shard.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <unistd.h>
 #include <cstdio>
 #include <rccl/rccl.h>
@@ -24,6 +34,7 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;  // optional
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
@@ -53,6 +64,7 @@ static RcclApi &rccl() {
         EGX_SYM(GetErrorString, "ncclGetErrorString");
         EGX_SYM(GetVersion, "ncclGetVersion");
 #undef EGX_SYM
+        a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(a.lib, "ncclCommAbort"));
         return a;
     }();
     return api;
@@ -71,51 +83,119 @@ static RcclApi &rccl() {
 
 using namespace egx;
 
+// node-wide candidate counters of the dynamic assignment: call number s of a sweep uses slot s % kSlots; rank 0 zeroes
+// slot (s + kSlots / 2) % kSlots at the start of call s (nobody touches that slot for the next kSlots / 2 - 1 calls, and
+// every call ends with an all-gather, which no rank leaves before every rank has stopped pulling)
+struct SweepCounters {
+    static constexpr int kSlots = 64;
+    std::atomic<int64_t> next[kSlots];
+};
+static_assert(std::atomic<int64_t>::is_always_lock_free, "the shared counters must be plain lock-free words");
+
 struct egx_sweep {
     egx_gp *gp = nullptr;
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
-    double *d_send = nullptr, *d_recv = nullptr;  // per x 2 and world x per x 2 doubles
+    // staging of the all-gather, allocated once: kChunk doubles per rank
+    static constexpr int64_t kChunk = 8192;
+    double *d_send = nullptr, *d_recv = nullptr;
     double *h_send = nullptr, *h_recv = nullptr;  // pinned
-    int64_t cap = 0;                              // entries per rank the buffers hold
     std::mutex mu;
     int64_t n_allgathers = 0;
+    // dynamic assignment
+    int dynamic = 0;
+    SweepCounters *counters = nullptr;  // shared memory (world > 1) or heap (world == 1)
+    bool counters_shared = false;
+    std::string shm_name;
+    int64_t call_seq = 0;
+    // balance of the last call
+    std::vector<int64_t> last_per_rank;
+    double last_eval_s = 0.0;
+    double timeout_s = 1800.0;
 };
 
-static int sweep_reserve(egx_sweep *sw, int64_t per) {
-    if (per <= sw->cap) return EGX_SUCCESS;
-    if (sw->d_send) (void)hipFree(sw->d_send);
-    if (sw->d_recv) (void)hipFree(sw->d_recv);
-    if (sw->h_send) (void)hipHostFree(sw->h_send);
-    if (sw->h_recv) (void)hipHostFree(sw->h_recv);
-    sw->d_send = sw->d_recv = sw->h_send = sw->h_recv = nullptr;
-    sw->cap = 0;
-    const size_t one = sizeof(double) * 2 * (size_t)per;
-    EGX_HIP_CHECK(hipMalloc(&sw->d_send, one));
-    EGX_HIP_CHECK(hipMalloc(&sw->d_recv, one * sw->world));
-    EGX_HIP_CHECK(hipHostMalloc(&sw->h_send, one, hipHostMallocDefault));
-    EGX_HIP_CHECK(hipHostMalloc(&sw->h_recv, one * sw->world, hipHostMallocDefault));
-    sw->cap = per;
-    return EGX_SUCCESS;
+namespace {
+
+// candidates of one rank in the order it evaluates them
+struct StaticSource final : egx::CandidateSource {
+    int64_t k, next;
+    int world;
+    StaticSource(int64_t k_, int rank, int world_) : k(k_), next(rank), world(world_) {}
+    int pull(int want, int64_t *out) override {
+        int got = 0;
+        while (got < want && next < k) {
+            out[got++] = next;
+            next += world;
+        }
+        return got;
+    }
+};
+struct DynamicSource final : egx::CandidateSource {
+    std::atomic<int64_t> *ctr;
+    int64_t k;
+    DynamicSource(std::atomic<int64_t> *c, int64_t k_) : ctr(c), k(k_) {}
+    int pull(int want, int64_t *out) override {
+        if (ctr->load(std::memory_order_relaxed) >= k) return 0;
+        const int64_t c0 = ctr->fetch_add(want, std::memory_order_relaxed);
+        int got = 0;
+        for (int64_t c = c0; c < c0 + want && c < k; c++) out[got++] = c;
+        return got;
+    }
+};
+
+// wait for the sweep's stream with a deadline; on expiry the communicator is aborted (a peer died or never arrived)
+int sweep_wait(egx_sweep *sw) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0;; spins++) {
+        const hipError_t q = hipStreamQuery(sw->stream);
+        if (q == hipSuccess) return EGX_SUCCESS;
+        if (q != hipErrorNotReady) {
+            set_error(std::string("sweep collective: ") + hipGetErrorString(q));
+            (void)hipGetLastError();
+            return EGX_ERR_HIP;
+        }
+        if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if ((spins & 1023) == 1023) {
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (el > sw->timeout_s) {
+                if (sw->comm && rccl().CommAbort) {
+                    rccl().CommAbort(sw->comm);
+                    sw->comm = nullptr;
+                }
+                set_error("sweep collective: no answer from the other ranks within " + std::to_string((int)sw->timeout_s) +
+                          " s (EGX_SWEEP_TIMEOUT_S); communicator aborted");
+                return EGX_ERR_PEER;
+            }
+        }
+    }
 }
 
+}  // namespace
+
 // all ranks: recv (world x count doubles) <- concatenation over ranks of send (count doubles); host buffers, pinned
-// staging, one ncclAllGather on the sweep's stream
+// staging allocated in egx_sweep_create, one ncclAllGather per kChunk doubles on the sweep's stream
 static int sweep_allgather_doubles(egx_sweep *sw, const double *send, int64_t count, double *recv) {
     if (sw->world == 1 && !sw->comm) {
         std::memcpy(recv, send, sizeof(double) * count);
         return EGX_SUCCESS;
     }
-    EGX_RC(sweep_reserve(sw, (count + 1) / 2));
-    std::memcpy(sw->h_send, send, sizeof(double) * count);
-    EGX_HIP_CHECK(hipMemcpyAsync(sw->d_send, sw->h_send, sizeof(double) * count, hipMemcpyHostToDevice, sw->stream));
-    EGX_NCCL_CHECK(rccl().AllGather(sw->d_send, sw->d_recv, (size_t)count, ncclDouble, sw->comm, sw->stream));
-    EGX_HIP_CHECK(hipMemcpyAsync(sw->h_recv, sw->d_recv, sizeof(double) * count * sw->world, hipMemcpyDeviceToHost,
-                                 sw->stream));
-    EGX_HIP_CHECK(hipStreamSynchronize(sw->stream));
-    std::memcpy(recv, sw->h_recv, sizeof(double) * count * sw->world);
-    sw->n_allgathers++;
+    if (!sw->comm) {
+        set_error("sweep collective: the communicator was aborted by an earlier failure");
+        return EGX_ERR_PEER;
+    }
+    for (int64_t off = 0; off < count; off += egx_sweep::kChunk) {
+        const int64_t len = std::min<int64_t>(egx_sweep::kChunk, count - off);
+        std::memcpy(sw->h_send, send + off, sizeof(double) * len);
+        EGX_HIP_CHECK(hipMemcpyAsync(sw->d_send, sw->h_send, sizeof(double) * len, hipMemcpyHostToDevice, sw->stream));
+        EGX_NCCL_CHECK(rccl().AllGather(sw->d_send, sw->d_recv, (size_t)len, ncclDouble, sw->comm, sw->stream));
+        EGX_HIP_CHECK(hipMemcpyAsync(sw->h_recv, sw->d_recv, sizeof(double) * len * sw->world, hipMemcpyDeviceToHost,
+                                     sw->stream));
+        EGX_RC(sweep_wait(sw));
+        for (int r = 0; r < sw->world; r++)
+            std::memcpy(recv + (size_t)r * count + off, sw->h_recv + (size_t)r * len, sizeof(double) * len);
+        sw->n_allgathers++;
+    }
     return EGX_SUCCESS;
 }
 
@@ -160,6 +240,10 @@ int32_t egx_sweep_create(const egx_gp_config *cfg_in, const double *x, const dou
     egx_sweep *sw = new egx_sweep();
     sw->rank = rank;
     sw->world = world;
+    if (const char *e = std::getenv("EGX_SWEEP_TIMEOUT_S")) {
+        const double t = std::atof(e);
+        if (t > 0.0) sw->timeout_s = t;
+    }
     int rc = egx_gp_create(&cfg, x, y, n, d, &sw->gp);
     if (rc) {
         delete sw;
@@ -174,6 +258,36 @@ int32_t egx_sweep_create(const egx_gp_config *cfg_in, const double *x, const dou
         set_error("egx_sweep_create: stream creation failed");
         (void)hipGetLastError();
         return fail(EGX_ERR_HIP);
+    }
+    {   // staging of the collective: allocated here, never inside a collective call
+        const size_t one = sizeof(double) * (size_t)egx_sweep::kChunk;
+        if (hipMalloc(&sw->d_send, one) != hipSuccess || hipMalloc(&sw->d_recv, one * world) != hipSuccess ||
+            hipHostMalloc(&sw->h_send, one, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&sw->h_recv, one * world, hipHostMallocDefault) != hipSuccess) {
+            set_error("egx_sweep_create: staging buffers");
+            (void)hipGetLastError();
+            return fail(EGX_ERR_HIP);
+        }
+    }
+    // candidate counters of the dynamic assignment: shared by the ranks of this node (named after the unique id)
+    if (world > 1) {
+        uint64_t hsh = 1469598103934665603ull;  // FNV-1a of the id
+        for (int i = 0; i < EGX_SWEEP_ID_BYTES; i++) hsh = (hsh ^ ((const unsigned char *)nccl_id)[i]) * 1099511628211ull;
+        char nm[64];
+        std::snprintf(nm, sizeof nm, "/egx_sweep_%016llx", (unsigned long long)hsh);
+        sw->shm_name = nm;
+        const int fd = shm_open(nm, O_CREAT | O_RDWR, 0600);
+        void *mem = MAP_FAILED;
+        if (fd >= 0 && ftruncate(fd, sizeof(SweepCounters)) == 0)  // a new object is zero filled
+            mem = mmap(nullptr, sizeof(SweepCounters), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (fd >= 0) close(fd);
+        if (mem != MAP_FAILED) {
+            sw->counters = static_cast<SweepCounters *>(mem);
+            sw->counters_shared = true;
+        }  // else: only the static assignment is available (egx_sweep_set_assignment reports it)
+    } else {
+        sw->counters = new SweepCounters();
+        for (auto &c : sw->counters->next) c.store(0);
     }
     if (nccl_id) {
         RcclApi &api = rccl();
@@ -218,6 +332,14 @@ void egx_sweep_destroy(egx_sweep *sw) {
     if (sw->h_send) hipHostFree(sw->h_send);
     if (sw->h_recv) hipHostFree(sw->h_recv);
     if (sw->stream) hipStreamDestroy(sw->stream);
+    if (sw->counters) {
+        if (sw->counters_shared) {
+            munmap(sw->counters, sizeof(SweepCounters));
+            if (sw->rank == 0) shm_unlink(sw->shm_name.c_str());
+        } else {
+            delete sw->counters;
+        }
+    }
     if (sw->gp) egx_gp_destroy(sw->gp);
     delete sw;
 }
@@ -242,6 +364,31 @@ int32_t egx_sweep_info(const egx_sweep *sw, int32_t *rank, int32_t *world, int32
     return EGX_SUCCESS;
 }
 
+int32_t egx_sweep_set_assignment(egx_sweep *sw, int32_t dynamic) {
+    if (!sw) {
+        set_error("NULL sweep handle");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::lock_guard<std::mutex> lock(sw->mu);
+    if (dynamic && !sw->counters) {
+        set_error("egx_sweep_set_assignment: no shared-memory counters on this node (shm_open failed): static only");
+        return EGX_ERR_UNSUPPORTED;
+    }
+    sw->dynamic = dynamic ? 1 : 0;
+    return EGX_SUCCESS;
+}
+
+int32_t egx_sweep_last_balance(const egx_sweep *sw, int64_t *per_rank, double *local_eval_s) {
+    if (!sw) {
+        set_error("NULL sweep handle");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (per_rank)
+        for (int r = 0; r < sw->world; r++) per_rank[r] = r < (int)sw->last_per_rank.size() ? sw->last_per_rank[r] : 0;
+    if (local_eval_s) *local_eval_s = sw->last_eval_s;
+    return EGX_SUCCESS;
+}
+
 int32_t egx_sweep_likelihood(egx_sweep *sw, const double *thetas, int64_t k, int64_t theta_len, double *lkh,
                              int32_t *status) {
     if (!sw || k < 0 || (k > 0 && (!thetas || !lkh || !status)) || theta_len < 1) {
@@ -250,20 +397,64 @@ int32_t egx_sweep_likelihood(egx_sweep *sw, const double *thetas, int64_t k, int
     }
     std::lock_guard<std::mutex> lock(sw->mu);
     if (k == 0) return EGX_SUCCESS;
-    EGX_RC(set_device(sw->gp));
     const int world = sw->world, rank = sw->rank;
-    const int64_t per = sweep_slots_per_rank(k, world), mine = sweep_count_of_rank(k, rank, world);
-    // this rank's shard: candidates rank, rank + world, ...
-    std::vector<double> th((size_t)mine * theta_len), lk(mine);
-    std::vector<int32_t> st(mine);
-    for (int64_t j = 0; j < mine; j++)
-        std::memcpy(&th[(size_t)j * theta_len], thetas + (size_t)sweep_candidate(rank, j, world) * theta_len,
-                    sizeof(double) * theta_len);
-    if (mine) EGX_RC(egx_gp_likelihood_batch(sw->gp, th.data(), mine, theta_len, lk.data(), st.data()));
-    // fixed-size payload per rank: per x {likelihood, status}; unused slots NaN
-    std::vector<double> send = sweep_pack(lk.data(), st.data(), mine, per), recv((size_t)per * 2 * world);
-    EGX_RC(sweep_allgather_doubles(sw, send.data(), per * 2, recv.data()));
-    sweep_unpack(recv.data(), k, world, lkh, status);
+    // ---- local part: every failure from here on is CARRIED to the collective, never returned before it
+    int local_rc = EGX_SUCCESS;
+    std::string local_msg;
+    std::vector<double> lk(k);
+    std::vector<int32_t> st(k);
+    std::vector<char> mine(k, 0);
+    const int64_t seq = sw->call_seq++;
+    const auto t0 = std::chrono::steady_clock::now();
+    {
+        std::atomic<int64_t> *ctr = nullptr;
+        if (sw->dynamic && sw->counters) {
+            ctr = &sw->counters->next[seq % SweepCounters::kSlots];
+            if (rank == 0) sw->counters->next[(seq + SweepCounters::kSlots / 2) % SweepCounters::kSlots].store(0);
+        }
+        StaticSource ssrc(k, rank, world);
+        DynamicSource dsrc(ctr, k);
+        egx::CandidateSource *src = ctr ? static_cast<egx::CandidateSource *>(&dsrc) : &ssrc;
+        local_rc = set_device(sw->gp);
+        if (!local_rc) {
+            std::unique_lock<std::shared_mutex> glock(sw->gp->mu);
+            local_rc = likelihood_batch_core(sw->gp, thetas, k, theta_len, lk.data(), st.data(), src, mine.data());
+        }
+        if (local_rc) local_msg = last_error_string();
+    }
+    sw->last_eval_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::vector<double> send;
+    if (local_rc) {
+        send = sweep_poison(k, local_rc);
+    } else {
+        send = sweep_payload(k);
+        for (int64_t c = 0; c < k; c++)
+            if (mine[c]) sweep_put(send, c, lk[c], st[c]);
+    }
+    // ---- the collective
+    std::vector<double> recv((size_t)k * 2 * world);
+    const int coll_rc = sweep_allgather_doubles(sw, send.data(), k * 2, recv.data());
+    if (coll_rc) {
+        if (local_rc) set_error(local_msg + " (and the collective failed: " + last_error_string() + ")");
+        return local_rc ? local_rc : coll_rc;
+    }
+    const SweepVerdict v = sweep_unpack(recv.data(), k, world, lkh, status, EGX_STATUS_RANK_FAILED);
+    sw->last_per_rank = v.per_rank;
+    if (local_rc) {
+        set_error(local_msg);
+        return local_rc;
+    }
+    if (v.failed_rank >= 0) {
+        set_error("egx_sweep_likelihood: rank " + std::to_string(v.failed_rank) + " failed with egx_rc " +
+                  std::to_string(v.failed_rc) + "; " + std::to_string(v.missing) + " of " + std::to_string(k) +
+                  " candidates have no result (status EGX_STATUS_RANK_FAILED)");
+        return EGX_ERR_PEER;
+    }
+    if (v.missing || v.duplicate) {
+        set_error("egx_sweep_likelihood: assignment inconsistent across ranks (" + std::to_string(v.missing) + " missing, " +
+                  std::to_string(v.duplicate) + " duplicated): did every rank select the same assignment mode?");
+        return EGX_ERR_PEER;
+    }
     return EGX_SUCCESS;
 }
 
@@ -274,8 +465,17 @@ int32_t egx_sweep_allgather(egx_sweep *sw, const double *send, int64_t count, do
     }
     std::lock_guard<std::mutex> lock(sw->mu);
     if (count == 0) return EGX_SUCCESS;
-    EGX_RC(set_device(sw->gp));
-    return sweep_allgather_doubles(sw, send, count, recv);
+    // (a failing set_device is carried into the collective as NaNs: every rank still arrives)
+    const int dev_rc = set_device(sw->gp);
+    const std::string dev_msg = dev_rc ? last_error_string() : std::string();
+    std::vector<double> poisoned;
+    if (dev_rc) poisoned.assign((size_t)count, std::numeric_limits<double>::quiet_NaN());
+    const int rc = sweep_allgather_doubles(sw, dev_rc ? poisoned.data() : send, count, recv);
+    if (dev_rc) {
+        set_error(dev_msg);
+        return dev_rc;
+    }
+    return rc;
 }
 
 }  // extern "C"

@@ -118,6 +118,19 @@ class Sweep:
                                                st.ctypes.data_as(L.c_int32_p)))
         return lk, st
 
+    def set_assignment(self, dynamic):
+        """0 / False: candidate c -> rank c mod world (default); 1 / True: ranks pull candidates from a node-wide counter
+        as their workspaces free up.  Every rank must select the same mode."""
+        self._L.check(self._lib.egx_sweep_set_assignment(self._h, 1 if dynamic else 0))
+
+    def last_balance(self):
+        """(candidates evaluated by every rank in the last likelihood() call, this rank's evaluation seconds)."""
+        C = self._C
+        per = np.zeros(self.world, dtype=np.int64)
+        sec = C.c_double()
+        self._L.check(self._lib.egx_sweep_last_balance(self._h, per.ctypes.data_as(self._L.c_int64_p), C.byref(sec)))
+        return per, sec.value
+
     def allgather(self, v):
         """COLLECTIVE: (count,) doubles per rank -> (world, count)."""
         L = self._L

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EGX_GP_ABI_VERSION 1
+#define EGX_GP_ABI_VERSION 2
 
 typedef struct egx_gp egx_gp; /* opaque: one training set resident on one GPU */
 
@@ -48,7 +48,8 @@ typedef enum {
     EGX_ERR_NOT_FITTED = 4,    /* predict* / get_inner before finalize/fit */
     EGX_ERR_LINALG = 5,        /* GpError::LinalgError (not positive definite), errors.rs:19 */
     EGX_ERR_LIKELIHOOD = 6,    /* GpError::LikelihoodComputationError, errors.rs:12 */
-    EGX_ERR_UNSUPPORTED = 7
+    EGX_ERR_UNSUPPORTED = 7,
+    EGX_ERR_PEER = 8           /* collective calls: another rank failed, or did not answer in time */
 } egx_rc;
 
 /* per-evaluation status (the value channel) */
@@ -57,7 +58,9 @@ typedef enum {
     EGX_STATUS_NOT_POSITIVE_DEFINITE = 1, /* cholesky()? failed, algorithm.rs:1004 */
     EGX_STATUS_ILL_CONDITIONED_FT = 2,    /* algorithm.rs:1022-1026 */
     EGX_STATUS_ILL_CONDITIONED_F = 3,     /* algorithm.rs:1015-1020 */
-    EGX_STATUS_NAN_THETA = 4              /* algorithm.rs:885-891 */
+    EGX_STATUS_NAN_THETA = 4,             /* algorithm.rs:885-891 */
+    EGX_STATUS_RANK_FAILED = 5            /* sweep only: the rank that held this candidate failed (the call returns
+                                             EGX_ERR_PEER on every other rank, the failing rank returns its own error) */
 } egx_status;
 
 /* crates/gp/src/correlation_models.rs: the four CorrelationModel impls */
@@ -249,6 +252,20 @@ int32_t egx_sweep_info(const egx_sweep *sw, int32_t *rank, int32_t *world, int32
  * Semantics per candidate as egx_gp_likelihood_batch (status is the value channel, failures are not errors). */
 int32_t egx_sweep_likelihood(egx_sweep *sw, const double *thetas, int64_t k, int64_t theta_len, double *lkh /*k*/,
                              int32_t *status /*k*/);
+/* Assignment of candidates to ranks for the following egx_sweep_likelihood calls: 0 = static (candidate c -> rank
+ * c mod world; the default), 1 = dynamic (ranks pull the next candidate from a node-wide counter in POSIX shared
+ * memory as their workspaces free up: candidates that are not positive definite return ~10x sooner than the others,
+ * SURVEY 8e).  The results are identical either way (every evaluation is deterministic and independent of the rank
+ * that runs it).  Every rank must select the same mode.  EGX_ERR_UNSUPPORTED when the shared memory is unavailable. */
+int32_t egx_sweep_set_assignment(egx_sweep *sw, int32_t dynamic);
+/* Balance of the last egx_sweep_likelihood: candidates evaluated by every rank (world entries, NULL = skip) and the
+ * wall time this rank spent in its own evaluations (seconds, NULL = skip). */
+int32_t egx_sweep_last_balance(const egx_sweep *sw, int64_t *per_rank /*world*/, double *local_eval_s);
+/* FAILURE SAFETY of the collectives: a rank whose local work fails (HIP error, out of memory, ...) still takes part
+ * in the all-gather with a poisoned payload and returns its own error afterwards; every other rank returns
+ * EGX_ERR_PEER (the candidates of the failed rank come back with status EGX_STATUS_RANK_FAILED, all others are
+ * valid).  A peer that never arrives is given EGX_SWEEP_TIMEOUT_S seconds (environment, default 1800), then the
+ * communicator is aborted and the call returns EGX_ERR_PEER instead of blocking for ever. */
 /* COLLECTIVE helper for the mixture-of-experts path (expert e on rank e mod world): recv (world x count) <- the
  * concatenation over ranks of send (count), e.g. per-expert mean / variance vectors before the recombination of
  * crates/moe/src/algorithm.rs:670-685. */

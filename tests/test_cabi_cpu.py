@@ -46,7 +46,7 @@ def test_header_symbols_are_exported_and_bound(egx):
 
 def test_abi_version_and_default_config(egx):
     lib = egx._lib.load()
-    assert lib.egx_abi_version() == 1
+    assert lib.egx_abi_version() == 2
     cfg = egx._lib.GpConfig()
     lib.egx_gp_config_default(C.byref(cfg))
     assert cfg.corr == 0 and cfg.mean == 0 and cfg.n_workspaces == 1 and cfg.device == -1
@@ -131,7 +131,7 @@ def test_header_is_valid_c_and_cpp(tmp_path):
     """include/egx_gp.h must compile as plain C (the Rust/cgo-style FFI consumers see it as C) and as C++."""
     c = tmp_path / "t.c"
     c.write_text('#include "egx_gp.h"\nint main(void) { egx_gp_config c; egx_timings t; (void)c; (void)t; '
-                 'return EGX_GP_ABI_VERSION == 1 ? 0 : 1; }\n')
+                 'return EGX_GP_ABI_VERSION == 2 ? 0 : 1; }\n')
     inc = os.path.join(ROOT, "include")
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", f"-I{inc}", str(c)], check=True)
     cpp = tmp_path / "t.cpp"
