@@ -51,6 +51,8 @@ SIGNATURES = [
     ("egx_last_error", C.c_char_p, []),
     ("egx_device_count", C.c_int32, []),
     ("egx_gp_config_default", None, [C.POINTER(GpConfig)]),
+    ("egx_trim", C.c_int64, []),
+    ("egx_pool_stats", None, [c_int64_p, c_int64_p, c_int64_p]),
     ("egx_normalize", C.c_int32, [c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
     ("egx_regression_ncols", C.c_int64, [C.c_int32, C.c_int64]),
     ("egx_regression_basis", C.c_int32, [C.c_int32, c_double_p, C.c_int64, C.c_int64, c_double_p]),
@@ -60,6 +62,8 @@ SIGNATURES = [
     ("egx_gp_dims", C.c_int32, [C.c_void_p, c_int64_p, c_int64_p, c_int64_p, c_int64_p]),
     ("egx_gp_likelihood", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_int32_p]),
     ("egx_gp_likelihood_batch", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_int32_p]),
+    ("egx_gp_set_lockstep", C.c_int32, [C.c_void_p, C.c_int32]),
+    ("egx_gp_get_lockstep", C.c_int32, [C.c_void_p]),
     ("egx_gp_likelihood_grad", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p, c_int32_p]),
     ("egx_gp_finalize", C.c_int32, [C.c_void_p, c_double_p, C.c_int64]),
     ("egx_gp_fit", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_int64, C.c_int64,
@@ -90,6 +94,8 @@ SIGNATURES = [
     ("egx_sweep_set_assignment", C.c_int32, [C.c_void_p, C.c_int32]),
     ("egx_sweep_last_balance", C.c_int32, [C.c_void_p, c_int64_p, c_double_p]),
     ("egx_sweep_allgather", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
+    ("egx_moe_predict_valvar", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), c_int32_p, C.c_int64, C.c_int64, c_double_p,
+                                           c_double_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_double_p]),
     ("egx_gp_last_timings", C.c_int32, [C.c_void_p, C.POINTER(Timings)]),
     ("egx_mfma_probe", C.c_int32, [c_double_p]),
     ("egx_sgp_config_default", None, [C.POINTER(SgpConfig)]),

@@ -101,9 +101,21 @@ struct PotrfLookahead {
     hipStream_t s2 = nullptr, s3 = nullptr;
     hipEvent_t ev_lu = nullptr, ev_lur = nullptr, ev_panel = nullptr, ev_a = nullptr, ev_b = nullptr;
 };
+// Lock-step batches: `count` matrices of one shape, matrix z at (pointer of matrix 0) + z * stride (elements).  Every
+// kernel of the factorisation takes the batch as grid.z; a matrix gets the same arithmetic alone and in a batch.
+struct GemmBatch {
+    int count = 1;
+    int64_t sC = 0, sA = 0, sB = 0;  // doubles between consecutive matrices' C / A / B
+    int sInfo = 0;                   // ints between their failure flags
+};
+struct PotrfBatch {
+    int count = 1;
+    int64_t sM = 0, sD = 0;  // doubles between consecutive matrices / their dinv blocks
+    int sI = 0;              // ints between their info words
+};
 // lk == nullptr runs everything in order on s.
 int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
-                 const PotrfLookahead *lk = nullptr, GemmTrace *trace = nullptr);
+                 const PotrfLookahead *lk = nullptr, GemmTrace *trace = nullptr, const PotrfBatch *batch = nullptr);
 // rows [0, m) of RT (ld) are right-hand sides: RT <- RT * C^-T  (C = lower factor in M, n_pad cols)
 // tri_rows != 0: the rows are those of the identity (solution upper triangular): zero blocks are skipped
 int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, const double *dinv,
@@ -120,7 +132,7 @@ int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const d
 // info != nullptr: device flag of the enclosing factorisation; the kernel returns at once when it is non-zero
 int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
                        const double *B, int64_t ldb, int M, int N, int K, int lower, int ktri = 0,
-                       bool *used_big_tile = nullptr, const int *info = nullptr);
+                       bool *used_big_tile = nullptr, const int *info = nullptr, const GemmBatch *batch = nullptr);
 // Gneg (rows x rows, ldg; lower 64x64 tiles) <- -(W W^T) for a small output and a long contraction (split-K, partial
 // tiles in the scratch P of gram_scratch_doubles(rows, K) doubles, summed in a fixed order)
 size_t gram_scratch_doubles(int rows, int K);

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <list>
 #include <condition_variable>
 #include <mutex>
 #include <shared_mutex>
@@ -44,7 +45,11 @@ struct DevBuf {
 
 struct Workspace {
     hipStream_t stream = nullptr;
+    hipStream_t eval_stream = nullptr;  // the stream the evaluation in flight was enqueued on: the workspace's own, or
+                                        // the leader's when it rides in a lock-step group (finish_eval waits on it)
     PotrfLookahead lk;  // look-ahead streams + events (lk.s2 == nullptr: look-ahead off)
+    // M, dinv and d_info are VIEWS into the handle's slabs (egx_gp::slab_*): consecutive workspaces sit at fixed
+    // strides, which is what lets a group of them be factored in lock-step by one launch sequence
     double *M = nullptr;       // (m_tot x ld): correlation matrix / factor + appended RHS rows
     double *dinv = nullptr;    // (n_pad/64) x 64 x 64 inverses of the diagonal tiles
     double *dW = nullptr;      // (n_pad/256) x 256 x 256 transposed inverses of the diagonal blocks (lazy)
@@ -96,6 +101,11 @@ struct egx_gp {
     double *d_xT = nullptr;    // d x n_pad (k-major normalised inputs, zero padded)
     double *d_rhsT = nullptr;  // q x n_pad: columns of F then y (normalised), as rows
     std::vector<egx::Workspace> ws;
+    // one allocation each for all workspaces' matrices, tile inverses and failure flags (strides in elements)
+    double *slab_M = nullptr, *slab_D = nullptr;
+    int *slab_I = nullptr;
+    int64_t stride_M = 0, stride_D = 0;
+    int lockstep = 1;  // candidates of a likelihood batch factored in lock-step (consecutive workspaces), <= ws.size()
     // exclusive for everything that touches the fitted state or all workspaces; SHARED for egx_gp_likelihood, whose
     // concurrent callers (the reference's rayon multistart closures, algorithm.rs:928-945) each take a workspace
     // from the pool below
@@ -135,6 +145,8 @@ int set_device(const egx_gp *gp);
 int make_coef(const egx_gp *gp, const double *theta, int64_t theta_len, std::vector<double> &coef, int &hcols,
               std::vector<double> *theta_full);
 int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coef, int hcols);
+// `count` evaluations on the consecutive workspaces w0 .. w0 + count - 1, factored in lock-step on the streams of w0
+int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> *coefs, int hcols);
 int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, bool keep);
 void record_timings(egx_gp *gp, Workspace &w, double host_ms, double solve_ms);
 bool has_nan(const double *theta, int64_t len);

@@ -23,14 +23,12 @@ int set_device(const egx_gp *gp) {
 }
 
 static void free_workspace(Workspace &w) {
-    if (w.M) hipFree(w.M);
-    if (w.dinv) hipFree(w.dinv);
+    // (M, dinv, d_info are views into the handle's slabs)
     if (w.dW) hipFree(w.dW);
     if (w.d_coef) hipFree(w.d_coef);
     if (w.d_diag) hipFree(w.d_diag);
     if (w.d_vec) hipFree(w.d_vec);
     if (w.d_rhs) hipFree(w.d_rhs);
-    if (w.d_info) hipFree(w.d_info);
     for (double *q : {w.d_gneg, w.d_gram, w.d_gdinv, w.d_gramP, w.d_beta, w.d_part})
         if (q) hipFree(q);
     if (w.d_ginfo) hipFree(w.d_ginfo);
@@ -57,8 +55,12 @@ static void free_workspace(Workspace &w) {
     w = Workspace();
 }
 
-static int alloc_workspace(egx_gp *gp, Workspace &w) {
+static int alloc_workspace(egx_gp *gp, Workspace &w, int index) {
+    w.M = gp->slab_M + (int64_t)index * gp->stride_M;
+    w.dinv = gp->slab_D + (int64_t)index * gp->stride_D;
+    w.d_info = gp->slab_I + index;
     EGX_HIP_CHECK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+    w.eval_stream = w.stream;
     {
         const char *la = std::getenv("EGX_LOOKAHEAD");
         if (!la || la[0] != '0') {
@@ -70,14 +72,11 @@ static int alloc_workspace(egx_gp *gp, Workspace &w) {
                 EGX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
         }
     }
-    EGX_HIP_CHECK(hipMalloc(&w.M, sizeof(double) * (size_t)gp->m_tot * gp->ld));
-    EGX_HIP_CHECK(hipMalloc(&w.dinv, sizeof(double) * dinv_doubles(gp->n_pad)));
     const int hmax = gp->has_w ? gp->h : 1;
     EGX_HIP_CHECK(hipMalloc(&w.d_coef, sizeof(double) * (size_t)gp->d * hmax));
     EGX_HIP_CHECK(hipMalloc(&w.d_diag, sizeof(double) * (size_t)gp->n_pad));
     EGX_HIP_CHECK(hipMalloc(&w.d_vec, sizeof(double) * (size_t)gp->n_pad));
     EGX_HIP_CHECK(hipMalloc(&w.d_rhs, sizeof(double) * (size_t)gp->n_pad));
-    EGX_HIP_CHECK(hipMalloc(&w.d_info, sizeof(int)));
     EGX_HIP_CHECK(hipHostMalloc(&w.h_coef, sizeof(double) * (size_t)gp->d * hmax, hipHostMallocDefault));
     EGX_HIP_CHECK(hipHostMalloc(&w.h_rows, sizeof(double) * (size_t)gp->q * gp->n_pad, hipHostMallocDefault));
     EGX_HIP_CHECK(hipHostMalloc(&w.h_diag, sizeof(double) * (size_t)gp->n_pad, hipHostMallocDefault));
@@ -104,6 +103,127 @@ static int alloc_workspace(egx_gp *gp, Workspace &w) {
     }
     w.trace.ready = true;
     return EGX_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Resource pool.  The reference's `fit` is one-shot per data set (GpValidParams::fit, algorithm.rs:785-794) and its
+// callers -- the expert loop of egobox-moe (crates/moe/src/algorithm.rs:167-177), EGO's surrogate refits -- create a new
+// model per call.  A new handle used to cost a 2 GiB hipMalloc (n = 16384), ~400 event / 3 stream creations per
+// workspace and a first factorisation at half speed on the never-touched allocation (round 2: 68 ms against 27 ms
+// resident).  Destroyed handles therefore leave everything device-side they own -- slabs, workspaces with their
+// streams / events / pinned buffers, the training-set buffers -- in a per-process pool keyed by the SHAPE of the handle;
+// the next egx_gp_create of that shape adopts it and only uploads x and y.  Bounded (EGX_POOL_MAX_GB, default 48; least
+// recently returned entries are freed first), emptied by egx_trim().  Nothing pooled is ever read before it is
+// rewritten: every evaluation rebuilds R including its identity padding, the right-hand-side rows and the flags.
+// ---------------------------------------------------------------------------------------------
+struct PoolKey {
+    int device = 0, n_pad = 0, d = 0, q = 0, hmax = 1, nws = 0;
+    bool gls = false;
+    bool operator==(const PoolKey &o) const {
+        return device == o.device && n_pad == o.n_pad && d == o.d && q == o.q && hmax == o.hmax && nws == o.nws && gls == o.gls;
+    }
+};
+struct PoolEntry {
+    PoolKey key;
+    double *d_xT = nullptr, *d_rhsT = nullptr, *d_gamma = nullptr, *d_fit_coef = nullptr;
+    double *slab_M = nullptr, *slab_D = nullptr;
+    int *slab_I = nullptr;
+    std::vector<Workspace> ws;
+    size_t bytes = 0;
+};
+static std::mutex g_pool_mu;
+static std::list<PoolEntry> g_pool;  // front = most recently returned
+static size_t g_pool_bytes = 0;
+static int64_t g_pool_hits = 0, g_pool_misses = 0;
+
+static size_t pool_cap_bytes() {
+    static const size_t cap = [] {
+        double gb = 48.0;
+        if (const char *e = std::getenv("EGX_POOL_MAX_GB")) gb = std::atof(e);
+        return gb <= 0.0 ? (size_t)0 : (size_t)(gb * 1073741824.0);
+    }();
+    return cap;
+}
+static void free_entry(PoolEntry &e) {
+    (void)hipSetDevice(e.key.device);
+    for (auto &w : e.ws) free_workspace(w);
+    for (double *q : {e.d_xT, e.d_rhsT, e.d_gamma, e.d_fit_coef, e.slab_M, e.slab_D})
+        if (q) (void)hipFree(q);
+    if (e.slab_I) (void)hipFree(e.slab_I);
+    e = PoolEntry();
+}
+static PoolKey pool_key(const egx_gp *gp, int nws) {
+    PoolKey k;
+    k.device = gp->device;
+    k.n_pad = gp->n_pad;
+    k.d = gp->d;
+    k.q = gp->q;
+    k.hmax = gp->has_w ? gp->h : 1;
+    k.nws = nws;
+    k.gls = gp->gls_device;
+    return k;
+}
+// adopt a pooled set of resources of this shape, if there is one
+static bool pool_take(egx_gp *gp, int nws) {
+    const PoolKey key = pool_key(gp, nws);
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    for (auto it = g_pool.begin(); it != g_pool.end(); ++it)
+        if (it->key == key) {
+            gp->d_xT = it->d_xT;
+            gp->d_rhsT = it->d_rhsT;
+            gp->d_gamma = it->d_gamma;
+            gp->d_fit_coef = it->d_fit_coef;
+            gp->slab_M = it->slab_M;
+            gp->slab_D = it->slab_D;
+            gp->slab_I = it->slab_I;
+            gp->ws = std::move(it->ws);
+            g_pool_bytes -= it->bytes;
+            g_pool.erase(it);
+            g_pool_hits++;
+            return true;
+        }
+    g_pool_misses++;
+    return false;
+}
+// hand a dying handle's resources to the pool (or free them when the pool is disabled / they alone exceed its bound)
+static void pool_give(egx_gp *gp) {
+    PoolEntry e;
+    e.key = pool_key(gp, (int)gp->ws.size());
+    e.d_xT = gp->d_xT;
+    e.d_rhsT = gp->d_rhsT;
+    e.d_gamma = gp->d_gamma;
+    e.d_fit_coef = gp->d_fit_coef;
+    e.slab_M = gp->slab_M;
+    e.slab_D = gp->slab_D;
+    e.slab_I = gp->slab_I;
+    e.ws = std::move(gp->ws);
+    e.bytes = sizeof(double) * ((size_t)gp->stride_M + (size_t)gp->stride_D) * e.ws.size();
+    gp->d_xT = gp->d_rhsT = gp->d_gamma = gp->d_fit_coef = gp->slab_M = gp->slab_D = nullptr;
+    gp->slab_I = nullptr;
+    gp->ws.clear();
+    bool complete = e.slab_M && e.slab_D && e.slab_I && e.d_xT && e.d_rhsT && e.d_gamma && e.d_fit_coef && !e.ws.empty();
+    for (auto &w : e.ws) {
+        complete = complete && w.stream && w.trace.ready;
+        w.eval_stream = w.stream;
+        w.trace.used = 0;
+        w.gls_enqueued = false;
+    }
+    const size_t cap = pool_cap_bytes();
+    if (!complete || e.bytes > cap) {  // a handle whose creation failed half way, or a pool too small for it
+        free_entry(e);
+        return;
+    }
+    std::list<PoolEntry> evicted;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        g_pool_bytes += e.bytes;
+        g_pool.push_front(std::move(e));
+        while (g_pool_bytes > cap && g_pool.size() > 1) {
+            g_pool_bytes -= g_pool.back().bytes;
+            evicted.splice(evicted.begin(), g_pool, std::prev(g_pool.end()));
+        }
+    }
+    for (auto &v : evicted) free_entry(v);
 }
 
 // theta (len 1 or h) -> per-dimension coefficient table (d x hcols), see kernels_corr.hip.
@@ -149,41 +269,65 @@ int make_coef(const egx_gp *gp, const double *theta, int64_t theta_len, std::vec
     return EGX_SUCCESS;
 }
 
-// GPU half of one likelihood evaluation: R assembly + RHS rows, factorisation with fused forward
-// solves, diagonal gather, async download of (diag C, ft^T, yt^T, info).  All asynchronous on w.stream.
-int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coef, int hcols) {
-    std::memcpy(w.h_coef, coef.data(), sizeof(double) * coef.size());
-    EGX_HIP_CHECK(hipMemcpyAsync(w.d_coef, w.h_coef, sizeof(double) * coef.size(), hipMemcpyHostToDevice, w.stream));
-    EGX_HIP_CHECK(hipMemsetAsync(w.d_info, 0, sizeof(int), w.stream));
-    EGX_HIP_CHECK(hipEventRecord(w.ev[0], w.stream));
-    EGX_RC(launch_corr_sym(w.stream, gp->corr, gp->d_xT, gp->n_pad, gp->n, gp->d, w.d_coef, hcols, gp->nugget, w.M,
-                           gp->ld, gp->n_pad));
-    EGX_RC(launch_fill_rows(w.stream, w.M, gp->ld, gp->n_pad, gp->rhs_pad, gp->d_rhsT, gp->n_pad, gp->q, gp->n_pad));
-    EGX_HIP_CHECK(hipEventRecord(w.ev[1], w.stream));
-    EGX_RC(launch_potrf(w.stream, w.M, gp->ld, gp->n_pad, gp->m_tot, w.dinv, w.d_info, w.lk.s2 ? &w.lk : nullptr,
-                        &w.trace));
-    EGX_HIP_CHECK(hipEventRecord(w.ev[2], w.stream));
-    EGX_RC(launch_gather_diag(w.stream, w.M, gp->ld, gp->n, w.d_diag));
-    EGX_HIP_CHECK(hipMemcpyAsync(w.h_diag, w.d_diag, sizeof(double) * gp->n, hipMemcpyDeviceToHost, w.stream));
-    w.gls_enqueued = gp->gls_device;
-    if (gp->gls_device) {
-        // p > 1: ft never leaves the device.  Gram matrix of the solved rows [ft | yt] (split-K MFMA, fixed-order
-        // reduction), its Cholesky factor by the same blocked kernels (R = L^T is the reference's QR factor with a
-        // positive diagonal, row p of L is z = L^-1 ft^T yt), and only that (rhs_pad x rhs_pad) factor goes to the host
-        const int g = gp->rhs_pad;
-        EGX_RC(launch_gram_lower(w.stream, w.M + (size_t)gp->n_pad * gp->ld, gp->ld, g, gp->n_pad, w.d_gneg, g, w.d_gramP));
-        EGX_RC(launch_gram_finish(w.stream, w.d_gneg, w.d_gram, g, g, gp->q));
-        EGX_HIP_CHECK(hipMemsetAsync(w.d_ginfo, 0, sizeof(int), w.stream));
-        EGX_RC(launch_potrf(w.stream, w.d_gram, g, g, g, w.d_gdinv, w.d_ginfo));
-        EGX_HIP_CHECK(hipMemcpyAsync(w.h_gram, w.d_gram, sizeof(double) * (size_t)g * g, hipMemcpyDeviceToHost, w.stream));
-        EGX_HIP_CHECK(hipMemcpyAsync(w.h_ginfo, w.d_ginfo, sizeof(int), hipMemcpyDeviceToHost, w.stream));
-    } else {
-        EGX_HIP_CHECK(hipMemcpyAsync(w.h_rows, w.M + (size_t)gp->n_pad * gp->ld,
-                                     sizeof(double) * (size_t)gp->q * gp->n_pad, hipMemcpyDeviceToHost, w.stream));
+// GPU half of `count` likelihood evaluations on the consecutive workspaces w0 ..: R assembly + RHS rows per candidate,
+// ONE factorisation launch sequence for all of them (lock-step batch, kernels_chol.hip) with fused forward solves,
+// diagonal gather, async download of (diag C, ft^T, yt^T, info) per candidate.  All asynchronous on the streams of
+// workspace w0; every member's eval_stream is set to it.
+int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> *coefs, int hcols) {
+    Workspace &lead = gp->ws[w0];
+    hipStream_t st = lead.stream;
+    for (int j = 0; j < count; j++) {
+        Workspace &w = gp->ws[w0 + j];
+        w.eval_stream = st;
+        std::memcpy(w.h_coef, coefs[j].data(), sizeof(double) * coefs[j].size());
+        EGX_HIP_CHECK(hipMemcpyAsync(w.d_coef, w.h_coef, sizeof(double) * coefs[j].size(), hipMemcpyHostToDevice, st));
     }
-    EGX_HIP_CHECK(hipMemcpyAsync(w.h_info, w.d_info, sizeof(int), hipMemcpyDeviceToHost, w.stream));
-    EGX_HIP_CHECK(hipEventRecord(w.ev[3], w.stream));
+    EGX_HIP_CHECK(hipMemsetAsync(lead.d_info, 0, sizeof(int) * (size_t)count, st));
+    EGX_HIP_CHECK(hipEventRecord(lead.ev[0], st));
+    for (int j = 0; j < count; j++) {
+        Workspace &w = gp->ws[w0 + j];
+        EGX_RC(launch_corr_sym(st, gp->corr, gp->d_xT, gp->n_pad, gp->n, gp->d, w.d_coef, hcols, gp->nugget, w.M, gp->ld,
+                               gp->n_pad));
+        EGX_RC(launch_fill_rows(st, w.M, gp->ld, gp->n_pad, gp->rhs_pad, gp->d_rhsT, gp->n_pad, gp->q, gp->n_pad));
+    }
+    EGX_HIP_CHECK(hipEventRecord(lead.ev[1], st));
+    PotrfBatch pb;
+    pb.count = count;
+    pb.sM = gp->stride_M;
+    pb.sD = gp->stride_D;
+    pb.sI = 1;
+    EGX_RC(launch_potrf(st, lead.M, gp->ld, gp->n_pad, gp->m_tot, lead.dinv, lead.d_info, lead.lk.s2 ? &lead.lk : nullptr,
+                        &lead.trace, &pb));
+    EGX_HIP_CHECK(hipEventRecord(lead.ev[2], st));
+    for (int j = 0; j < count; j++) {
+        Workspace &w = gp->ws[w0 + j];
+        EGX_RC(launch_gather_diag(st, w.M, gp->ld, gp->n, w.d_diag));
+        EGX_HIP_CHECK(hipMemcpyAsync(w.h_diag, w.d_diag, sizeof(double) * gp->n, hipMemcpyDeviceToHost, st));
+        w.gls_enqueued = gp->gls_device;
+        if (gp->gls_device) {
+            // p > 1: ft never leaves the device.  Gram matrix of the solved rows [ft | yt] (split-K MFMA, fixed-order
+            // reduction), its Cholesky factor by the same blocked kernels (R = L^T is the reference's QR factor with a
+            // positive diagonal, row p of L is z = L^-1 ft^T yt), and only that (rhs_pad x rhs_pad) factor goes to the host
+            const int g = gp->rhs_pad;
+            EGX_RC(launch_gram_lower(st, w.M + (size_t)gp->n_pad * gp->ld, gp->ld, g, gp->n_pad, w.d_gneg, g, w.d_gramP));
+            EGX_RC(launch_gram_finish(st, w.d_gneg, w.d_gram, g, g, gp->q));
+            EGX_HIP_CHECK(hipMemsetAsync(w.d_ginfo, 0, sizeof(int), st));
+            EGX_RC(launch_potrf(st, w.d_gram, g, g, g, w.d_gdinv, w.d_ginfo));
+            EGX_HIP_CHECK(hipMemcpyAsync(w.h_gram, w.d_gram, sizeof(double) * (size_t)g * g, hipMemcpyDeviceToHost, st));
+            EGX_HIP_CHECK(hipMemcpyAsync(w.h_ginfo, w.d_ginfo, sizeof(int), hipMemcpyDeviceToHost, st));
+        } else {
+            EGX_HIP_CHECK(hipMemcpyAsync(w.h_rows, w.M + (size_t)gp->n_pad * gp->ld,
+                                         sizeof(double) * (size_t)gp->q * gp->n_pad, hipMemcpyDeviceToHost, st));
+        }
+        EGX_HIP_CHECK(hipMemcpyAsync(w.h_info, w.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+    }
+    EGX_HIP_CHECK(hipEventRecord(lead.ev[3], st));
     return EGX_SUCCESS;
+}
+
+// one evaluation on one workspace (its own streams)
+int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coef, int hcols) {
+    return enqueue_eval_group(gp, (int)(&w - gp->ws.data()), 1, &coef, hcols);
 }
 
 // Device GLS route of finish_eval (p >= 2).  Returns 0 = evaluation finished (out filled), 1 = fall back to the host
@@ -312,7 +456,7 @@ static int finish_eval_device_gls(egx_gp *gp, Workspace &w, EvalResult &out, boo
 
 // Host half: algorithm.rs:1007-1043 on the downloaded ft, yt, diag(C).
 int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, bool keep) {
-    EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+    EGX_HIP_CHECK(hipStreamSynchronize(w.eval_stream));
     const int n = gp->n, p = gp->p, n_pad = gp->n_pad;
     out = EvalResult();
     if (*w.h_info != 0) {
@@ -525,8 +669,10 @@ int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     return EGX_SUCCESS;
 }
 // Candidates pipelined over the handle's workspaces (caller holds gp->mu exclusively and has set the device).
-// Every workspace has its own stream set, so the serial panel factorisations of one candidate overlap the trailing
-// updates of the others; a workspace whose candidate has been read back takes the next one the source hands out.
+// The workspaces form SLOTS of gp->lockstep consecutive ones; the candidates of a slot are factored in lock-step by one
+// launch sequence (enqueue_eval_group), different slots run on their own stream sets, so that the exposed serial parts
+// of one slot (first group's chain, the last ~3000 columns) overlap the trailing updates of the other.  A slot whose
+// candidates have been read back takes the next ones the source hands out.
 int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len, double *lkh, int32_t *status,
                           CandidateSource *src, char *evaluated) {
     struct Sequential final : CandidateSource {
@@ -542,7 +688,9 @@ int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t t
     // a fitted model keeps its factor (workspace 0) as long as another workspace exists
     const int ws_lo = (gp->fitted && gp->ws.size() > 1) ? 1 : 0;
     const int nws = (int)gp->ws.size() - ws_lo;
-    std::vector<int64_t> cand(nws, -1);  // candidate in flight on workspace ws_lo + i
+    const int B = gp->lockstep < nws ? (gp->lockstep < 1 ? 1 : gp->lockstep) : nws;
+    const int nslots = nws / B;
+    std::vector<std::vector<int64_t>> cand(nslots);  // candidates in flight on slot i (workspaces ws_lo + i B ...)
     bool exhausted = false;
     int busy = 0;
     // next candidate with a usable theta (NaN thetas are answered at once, algorithm.rs:885-891)
@@ -567,28 +715,30 @@ int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t t
         return EGX_SUCCESS;
     };
     auto run = [&]() -> int {
-        for (int i = 0;; i = (i + 1) % nws) {
-            const int wi = ws_lo + i;
-            if (cand[i] >= 0) {
-                EvalResult res;
-                EGX_RC(finish_eval(gp, gp->ws[wi], res, false));
-                lkh[cand[i]] = res.lkh;
-                status[cand[i]] = res.status;
-                if (wi == 0) record_timings(gp, gp->ws[0], 0.0, 0.0);
-                cand[i] = -1;
+        std::vector<std::vector<double>> coefs(B);
+        for (int i = 0;; i = (i + 1) % nslots) {
+            const int w0 = ws_lo + i * B;
+            if (!cand[i].empty()) {
+                for (size_t j = 0; j < cand[i].size(); j++) {
+                    EvalResult res;
+                    EGX_RC(finish_eval(gp, gp->ws[w0 + (int)j], res, false));
+                    lkh[cand[i][j]] = res.lkh;
+                    status[cand[i][j]] = res.status;
+                }
+                if (w0 == 0) record_timings(gp, gp->ws[0], 0.0, 0.0);
+                cand[i].clear();
                 busy--;
             }
-            if (!exhausted) {
+            int hcols = 1;
+            while (!exhausted && (int)cand[i].size() < B) {
                 int64_t c;
-                std::vector<double> coef;
-                int hcols = 1;
-                EGX_RC(next_valid(c, coef, hcols));
-                if (c >= 0) {
-                    if (wi == 0) gp->fitted = false;
-                    EGX_RC(enqueue_eval(gp, gp->ws[wi], coef, hcols));
-                    cand[i] = c;
-                    busy++;
-                }
+                EGX_RC(next_valid(c, coefs[cand[i].size()], hcols));
+                if (c >= 0) cand[i].push_back(c);
+            }
+            if (!cand[i].empty()) {
+                if (w0 == 0) gp->fitted = false;
+                EGX_RC(enqueue_eval_group(gp, w0, (int)cand[i].size(), coefs.data(), hcols));
+                busy++;
             }
             if (exhausted && busy == 0) return EGX_SUCCESS;
         }
@@ -596,8 +746,8 @@ int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t t
     const int rc = run();
     if (rc) {  // leave no work behind that still writes into the workspaces
         const std::string msg = last_error_string();
-        for (int i = 0; i < nws; i++)
-            if (cand[i] >= 0) (void)hipStreamSynchronize(gp->ws[ws_lo + i].stream);
+        for (int i = 0; i < nslots; i++)
+            if (!cand[i].empty()) (void)hipStreamSynchronize(gp->ws[ws_lo + i * B].stream);
         (void)hipGetLastError();
         set_error(msg);
     }
@@ -617,6 +767,26 @@ int32_t egx_device_count(void) {
     int c = 0;
     if (hipGetDeviceCount(&c) != hipSuccess) return 0;
     return c;
+}
+
+int64_t egx_trim(void) {
+    std::list<PoolEntry> all;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        all.swap(g_pool);
+        bytes = g_pool_bytes;
+        g_pool_bytes = 0;
+    }
+    for (auto &e : all) free_entry(e);
+    return (int64_t)bytes;
+}
+
+void egx_pool_stats(int64_t *cached_bytes, int64_t *hits, int64_t *misses) {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    if (cached_bytes) *cached_bytes = (int64_t)g_pool_bytes;
+    if (hits) *hits = g_pool_hits;
+    if (misses) *misses = g_pool_misses;
 }
 
 void egx_gp_config_default(egx_gp_config *cfg) {
@@ -778,17 +948,30 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
             return fail(EGX_ERR_HIP);                                             \
         }                                                                         \
     } while (0)
-    EGX_HIPF(hipMalloc(&gp->d_xT, sizeof(double) * xT.size()));
-    EGX_HIPF(hipMalloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
-    EGX_HIPF(hipMalloc(&gp->d_gamma, sizeof(double) * gp->n_pad));
-    EGX_HIPF(hipMalloc(&gp->d_fit_coef, sizeof(double) * (size_t)d * (gp->has_w ? gp->h : 1)));
+    int nws = cfg.n_workspaces < 1 ? 1 : cfg.n_workspaces;
+    // all workspaces' matrices / tile inverses / failure flags at fixed strides in one allocation each (lock-step batches)
+    gp->stride_M = (int64_t)gp->m_tot * gp->ld;
+    gp->stride_D = round_up((int64_t)dinv_doubles(gp->n_pad), 64);
+    if (!pool_take(gp, nws)) {  // no destroyed handle of this shape left its resources behind: allocate
+        EGX_HIPF(hipMalloc(&gp->d_xT, sizeof(double) * xT.size()));
+        EGX_HIPF(hipMalloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
+        EGX_HIPF(hipMalloc(&gp->d_gamma, sizeof(double) * gp->n_pad));
+        EGX_HIPF(hipMalloc(&gp->d_fit_coef, sizeof(double) * (size_t)d * (gp->has_w ? gp->h : 1)));
+        EGX_HIPF(hipMalloc(&gp->slab_M, sizeof(double) * (size_t)gp->stride_M * nws));
+        EGX_HIPF(hipMalloc(&gp->slab_D, sizeof(double) * (size_t)gp->stride_D * nws));
+        EGX_HIPF(hipMalloc(&gp->slab_I, sizeof(int) * (size_t)nws));
+        gp->ws.resize(nws);
+        for (int i = 0; i < nws; i++) {
+            rc = alloc_workspace(gp, gp->ws[i], i);
+            if (rc) return fail(rc);
+        }
+    }
     EGX_HIPF(hipMemcpy(gp->d_xT, xT.data(), sizeof(double) * xT.size(), hipMemcpyHostToDevice));
     EGX_HIPF(hipMemcpy(gp->d_rhsT, rhsT.data(), sizeof(double) * rhsT.size(), hipMemcpyHostToDevice));
-    int nws = cfg.n_workspaces < 1 ? 1 : cfg.n_workspaces;
-    gp->ws.resize(nws);
-    for (int i = 0; i < nws; i++) {
-        rc = alloc_workspace(gp, gp->ws[i]);
-        if (rc) return fail(rc);
+    {   // candidates of a likelihood batch factored in lock-step: see egx_gp_set_lockstep
+        int ls = nws < 4 ? nws : 4;
+        if (const char *e = std::getenv("EGX_LOCKSTEP")) ls = std::atoi(e);
+        gp->lockstep = ls < 1 ? 1 : (ls > nws ? nws : ls);
     }
     *out = gp;
     return EGX_SUCCESS;
@@ -797,11 +980,14 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
 void egx_gp_destroy(egx_gp *gp) {
     if (!gp) return;
     hipSetDevice(gp->device);
-    for (auto &w : gp->ws) free_workspace(w);
-    if (gp->d_xT) hipFree(gp->d_xT);
-    if (gp->d_rhsT) hipFree(gp->d_rhsT);
-    if (gp->d_gamma) hipFree(gp->d_gamma);
-    if (gp->d_fit_coef) hipFree(gp->d_fit_coef);
+    // nothing of this handle may still run when its resources change hands
+    for (auto &w : gp->ws) {
+        if (w.stream) (void)hipStreamSynchronize(w.stream);
+        if (w.lk.s2) (void)hipStreamSynchronize(w.lk.s2);
+        if (w.lk.s3) (void)hipStreamSynchronize(w.lk.s3);
+    }
+    (void)hipGetLastError();
+    pool_give(gp);
     if (gp->d_W) hipFree(gp->d_W);
     if (gp->d_neg_invkf) hipFree(gp->d_neg_invkf);
     for (double *q : {gp->sp_R, gp->sp_P, gp->sp_y, gp->sp_z, gp->sp_wt, gp->sp_out, gp->sp_xq})
@@ -870,6 +1056,25 @@ int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int
     EGX_RC(set_device(gp));
     return likelihood_batch_core(gp, thetas, k, theta_len, lkh, status);
 }
+
+static int default_lockstep(int nws) {
+    int ls = nws < 4 ? nws : 4;
+    if (const char *e = std::getenv("EGX_LOCKSTEP")) ls = std::atoi(e);
+    return ls < 1 ? 1 : (ls > nws ? nws : ls);
+}
+
+int32_t egx_gp_set_lockstep(egx_gp *gp, int32_t width) {
+    if (!gp || width < 0) {
+        set_error("egx_gp_set_lockstep: NULL handle or negative width");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
+    const int nws = (int)gp->ws.size();
+    gp->lockstep = width == 0 ? default_lockstep(nws) : (width > nws ? nws : width);
+    return EGX_SUCCESS;
+}
+
+int32_t egx_gp_get_lockstep(const egx_gp *gp) { return gp ? gp->lockstep : 0; }
 
 int32_t egx_gp_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     if (!gp || !theta) {

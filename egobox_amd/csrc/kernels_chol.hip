@@ -8,8 +8,7 @@
 // update, with look-ahead on side streams: launch_potrf):
 //   A  k_potf2_reg    : ONE workgroup of 16 waves factors the 256x256 diagonal block with its 16x16 tiles resident in
 //                       FP64-MFMA accumulator registers; 16-column strips; the 16x16 diagonal tile by a DPP-broadcast
-//                       pivot chain on one wave, fused with its inverse.  (k_potf2_block, the LDS-tile kernel of round 1,
-//                       is kept behind EGX_POTF2_REG=0.)
+//                       pivot chain on one wave, fused with its inverse.
 //   B  k_panel_trsm16 : rows below the block:  X = P * L_kk^-T, one 16-row tile per workgroup, strip by strip with the
 //                       16x16 inverses A left behind (+ one refinement step for ill-conditioned tiles).  k_panel_trsm
 //                       (64-row slabs, explicit 64x64 tile inverses) serves the solves after the factorisation.
@@ -20,6 +19,14 @@
 // Right-hand-side rows appended below the square matrix ride along in B and C, so after the
 // factorisation they hold (C^-1 [F | y])^T: the forward solves of algorithm.rs:1006,1028 are fused
 // into the factorisation (classic augmented-matrix trick) and cost no extra pass over C.
+//
+// LOCK-STEP BATCHES (round 3).  Every kernel of the factorisation takes a batch dimension: workgroup (x, y, z) works on
+// matrix z, whose every pointer is the pointer of matrix 0 plus a fixed element stride (the workspaces of a handle are
+// carved out of one slab).  The candidates of a theta sweep all have the same n and therefore the same launch
+// schedule, so `launch_potrf` factors nb of them through ONE launch sequence: the serial chain (diagonal block ->
+// panel solve -> in-group update) costs its latency once for nb matrices, every launch has nb x the tiles (the
+// look-ahead updates that used to be too small for the LDS-DMA stream kernel now fill the chip), and the per-matrix
+// arithmetic is unchanged -- a matrix gets bit for bit the factor it gets alone.
 //
 // FP64 MFMA on gfx950 runs at the FP64 vector rate (78.6 TFLOP/s chip peak, 64 cycles per
 // 16x16x4 instruction per SIMD): the matrix core is used because one instruction carries 2048
@@ -152,88 +159,6 @@ __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t 
     }
 }
 
-// EXPERIMENT, off by default (EGX_GEMM_PIPE=1): measured 140.6 vs 136.1 us per 128x256x512 tile against the
-// compiler's own schedule of gemm_core (profiles/r01_run20_pipe_ab.txt).
-// Software-pipelined variant for the 64x64 wave tile (2 waves per SIMD, so nothing else hides LDS latency): the
-// K chunk is consumed as two fragment sets of two k-steps each; the reads of a set are always issued one set ahead
-// of the MFMAs that use it, and the chunk barrier sits in the middle of the second set's MFMAs:
-//   [read set1(c)] [32 MFMA set0(c)] [LDS store chunk c+1] [16 MFMA set1(c)] [barrier] [read set0(c+1)] [16 MFMA set1(c)]
-// sched_barrier(0) pins this order (the scheduler otherwise sinks the reads right in front of their first use).
-template <int BM, int BN, int WM, int WN, int NTHREADS>
-__device__ __forceinline__ void gemm_core_pipe(const double *__restrict__ A, int64_t lda,
-                                               const double *__restrict__ B, int64_t ldb, int K,
-                                               double4_t (&acc)[WM / 16][WN / 16], double *smem, int tid) {
-    using S = GemmShape<BM, BN, WM, WN, NTHREADS>;
-    static_assert(KC == 16, "two fragment sets of two k-steps");
-    const int nchunks = K / KC;
-    if (nchunks <= 0) return;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int wm0 = (wave / S::WAVES_N) * WM, wn0 = (wave % S::WAVES_N) * WN;
-    const int frow = lane & 15, fk = lane >> 4;
-
-    d2_t ra[BM * 8 / NTHREADS], rb[BN * 8 / NTHREADS];
-    unsigned oa[BM * 8 / NTHREADS], ob[BN * 8 / NTHREADS];
-    tile_offsets<BM, NTHREADS>(lda, oa, tid);
-    tile_offsets<BN, NTHREADS>(ldb, ob, tid);
-    tile_load_regs<BM, NTHREADS>(A, oa, ra);
-    tile_load_regs<BN, NTHREADS>(B, ob, rb);
-    tile_store_lds<BM, NTHREADS>(smem, ra, tid);
-    tile_store_lds<BN, NTHREADS>(smem + S::A_TILE, rb, tid);
-    __syncthreads();
-
-    double a0[S::MT][2], b0[S::NT][2], a1[S::MT][2], b1[S::NT][2];
-    const int aoff = (wm0 + frow) * LDS_LD + fk, boff = S::A_TILE + (wn0 + frow) * LDS_LD + fk;
-#define EGX_READ_SET(stage, kk0, a, b)                                                           \
-    {                                                                                            \
-        _Pragma("unroll") for (int mi = 0; mi < S::MT; mi++) {                                   \
-            a[mi][0] = (stage)[aoff + mi * 16 * LDS_LD + (kk0) * 4];                             \
-            a[mi][1] = (stage)[aoff + mi * 16 * LDS_LD + (kk0) * 4 + 4];                         \
-        }                                                                                        \
-        _Pragma("unroll") for (int ni = 0; ni < S::NT; ni++) {                                   \
-            b[ni][0] = (stage)[boff + ni * 16 * LDS_LD + (kk0) * 4];                             \
-            b[ni][1] = (stage)[boff + ni * 16 * LDS_LD + (kk0) * 4 + 4];                         \
-        }                                                                                        \
-    }
-#define EGX_MMA(a, b, j)                                                                         \
-    {                                                                                            \
-        _Pragma("unroll") for (int mi = 0; mi < S::MT; mi++)                                     \
-            _Pragma("unroll") for (int ni = 0; ni < S::NT; ni++)                                 \
-                acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0); \
-    }
-    EGX_READ_SET(smem, 0, a0, b0);
-    for (int c = 0; c < nchunks; c++) {
-        const double *cur = smem + (c & 1) * S::STAGE;
-        double *nxt = smem + ((c + 1) & 1) * S::STAGE;
-        const bool more = (c + 1 < nchunks);
-        if (more) {
-            tile_load_regs<BM, NTHREADS>(A + (c + 1) * KC, oa, ra);
-            tile_load_regs<BN, NTHREADS>(B + (c + 1) * KC, ob, rb);
-        }
-        EGX_READ_SET(cur, 2, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        EGX_MMA(a0, b0, 0);
-        EGX_MMA(a0, b0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            tile_store_lds<BM, NTHREADS>(nxt, ra, tid);
-            tile_store_lds<BN, NTHREADS>(nxt + S::A_TILE, rb, tid);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        EGX_MMA(a1, b1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            __syncthreads();
-            EGX_READ_SET(nxt, 0, a0, b0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        EGX_MMA(a1, b1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#undef EGX_READ_SET
-#undef EGX_MMA
-    __syncthreads();
-}
-
 // ---------------------------------------------------------------------------------------------
 // C: trailing update / general  C -= A B^T.  grid = (M/128, N/128).
 // ---------------------------------------------------------------------------------------------
@@ -252,14 +177,30 @@ __device__ long long g_gemm_cycles[1 << 16][2];  // shader-clock ticks (s_memtim
 using TrailShape = GemmShape<128, 128, 32, 64, 512>;  // 8 waves, 2 workgroups per CU -> 4 MFMA waves per SIMD
 using SmallShape = GemmShape<64, 64, 32, 32, 256>;    // 4x lower per-tile latency: look-ahead column + small trailing matrices
 
-template <bool LOWER, int BM, int BN, int WM, int WN, int NTHREADS, bool SWZ, bool PIPE = false>
-__global__ __launch_bounds__(NTHREADS, (WM * WN > 2048 ? 2 : (NTHREADS == 512 ? 4 : 2))) void k_gemm_nt_sub(
+// A failed pivot anywhere earlier in this factorisation (algorithm.rs:893-896: the candidate is +inf): nothing left to
+// compute, every later kernel of the factorisation returns at once.  The flag may be SET while this kernel starts (the
+// look-ahead chain of the next group runs beside the trailing update), so ONE lane reads it and the workgroup decides
+// together: waves of a workgroup never part ways in front of a barrier.
+__device__ __forceinline__ bool wg_failed_before(const int *info) {
+    __shared__ int s_failed;
+    if (threadIdx.x == 0) s_failed = (info != nullptr) ? __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    __syncthreads();
+    return s_failed != 0;
+}
+
+template <bool LOWER, int BM, int BN, int WM, int WN, int NTHREADS, bool SWZ>
+__global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt_sub(
     double *__restrict__ C, int64_t ldc, const double *__restrict__ A, int64_t lda, const double *__restrict__ B,
-    int64_t ldb, int K, int nbx, int nby, int ktri, const int *__restrict__ info) {
+    int64_t ldb, int K, int nbx, int nby, int ktri, const int *__restrict__ info, GemmBatch bt) {
     using S = GemmShape<BM, BN, WM, WN, NTHREADS>;
-    // a failed pivot anywhere earlier in this factorisation (algorithm.rs:893-896: the candidate is +inf): nothing
-    // left to compute, every later kernel of the factorisation returns at once
-    if (info != nullptr && *info != 0) return;
+    {   // lock-step batch: matrix blockIdx.z
+        const int64_t z = blockIdx.z;
+        C += z * bt.sC;
+        A += z * bt.sA;
+        B += z * bt.sB;
+        if (info != nullptr) info += z * bt.sInfo;
+    }
+    if (wg_failed_before(info)) return;
     // XCD-aware tile order (SWZ).  Workgroup w lands on XCD w % 8 (observed dispatch order, used for speed only,
     // never for correctness).  Tiles are grouped in 8x8 super-tiles; super-tile ST goes to XCD ST % 8 and its 64
     // tiles are the 64 workgroups resident on that XCD (2 per CU), which then share 8 A and 8 B panel blocks
@@ -323,12 +264,8 @@ __global__ __launch_bounds__(NTHREADS, (WM * WN > 2048 ? 2 : (NTHREADS == 512 ? 
     // ktri: both operands are upper triangular (row i is zero left of column i), C lower: the K range of tile
     // (bx, by), bx >= by, starts at the first row of the tile (used for R^-1 = C^-T C^-1 in the theta-gradient)
     const int koff = (ktri & 1) ? bx * BM : 0;
-    if constexpr (PIPE)
-        gemm_core_pipe<BM, BN, WM, WN, NTHREADS>(A + (int64_t)bx * BM * lda + koff, lda, B + (int64_t)by * BN * ldb + koff,
-                                                 ldb, K - koff, acc, smem, tid);
-    else
-        gemm_core<BM, BN, WM, WN, NTHREADS>(A + (int64_t)bx * BM * lda + koff, lda, B + (int64_t)by * BN * ldb + koff, ldb,
-                                            K - koff, acc, smem, tid);
+    gemm_core<BM, BN, WM, WN, NTHREADS>(A + (int64_t)bx * BM * lda + koff, lda, B + (int64_t)by * BN * ldb + koff, ldb,
+                                        K - koff, acc, smem, tid);
     EGX_GSTAMP(1);
     const int wave = tid >> 6, lane = tid & 63;
     const int r0 = bx * BM + (wave / S::WAVES_N) * WM + (lane >> 4);
@@ -406,25 +343,24 @@ __device__ long long g_stream_stamps[1 << 14][6];  // per tile: wall start, wall
 #else
 #define EGX_SSTAMP(slot, i, v)
 #endif
-// VARIANT: where a wave issues its six LDS-DMA pieces of chunk g + 2 inside chunk g
-//   0  all six right after the barrier
-//   1  two after the barrier, two after the first 16 MFMAs, two after the first 32
-//   2  waves 0-3 right after the barrier, waves 4-7 (their SIMD partners) after their first 32 MFMAs
-//   3  mid-chunk barrier with fragments read one half chunk ahead (see the loop)
-//   4  = 3 with the SIMD partners' LDS-DMA issue staggered by 16 MFMAs
-template <bool LOWER, int VARIANT>
+template <bool LOWER>
 __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, int64_t ldc, const double *__restrict__ A,
                                                         int64_t lda, const double *__restrict__ B, int64_t ldb, int K,
-                                                        int nbx, int nby, int ntiles, int xcd, const int *__restrict__ info) {
-    if (info != nullptr && *info != 0) return;
+                                                        int nbx, int nby, int ntiles, const int *__restrict__ info,
+                                                        GemmBatch bt) {
+    {   // lock-step batch: matrix blockIdx.z
+        const int64_t z = blockIdx.z;
+        C += z * bt.sC;
+        A += z * bt.sA;
+        B += z * bt.sB;
+        if (info != nullptr) info += z * bt.sInfo;
+    }
+    if (wg_failed_before(info)) return;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x, nch = K / KC;
-    // Workgroup b runs on XCD b % 8.  xcd != 0 (one tile per workgroup): XCD x takes the x-th EIGHTH of the column-major
-    // tile list instead of every eighth tile, so that the workgroups that share an L2 share their panel columns.
-    const int bid = (xcd && G == ntiles) ? (int)(blockIdx.x & 7) * (ntiles >> 3) + min((int)(blockIdx.x & 7), ntiles & 7) + (int)(blockIdx.x >> 3)
-                                         : (int)blockIdx.x;
+    const int bid = (int)blockIdx.x;
     const int my_tiles = (ntiles - bid + G - 1) / G;
     const int total = my_tiles * nch;  // chunks this workgroup streams
 
@@ -495,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
     for (int r = 0; r < 4; r++) coff[r] = (unsigned)(((lane >> 4) + 4 * r) * (int)ldc + (lane & 15));
 
     int g = 0, stage = 0;  // global chunk counter of this workgroup, stage = g % 3
-    d2_t a0[4], b0[4];     // VARIANT 3: fragments of the coming half chunk, read one half ahead (live across tiles)
+    d2_t a0[4], b0[4];     // fragments of the coming half chunk, read one half ahead (live across tiles)
 #pragma unroll
     for (int i = 0; i < 4; i++) a0[i] = b0[i] = d2_t{0.0, 0.0};
     for (int t = bid; t < ntiles; t += G) {
@@ -515,106 +451,58 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         EGX_SSTAMP(t, 3, clock64());
-        if constexpr (VARIANT >= 3) {
-            // MID-CHUNK barrier: the synchronisation for chunk g + 1 sits between the two 8-deep halves of chunk g, the
-            // fragments of a half are read one half ahead, so the MFMA stream runs across the barrier and no LDS read
-            // latency is exposed behind it:
-            //   [read kb1(g)] [32 MFMA kb0(g)] [wait own loads of g + 1; barrier] [issue loads g + 2] [read kb0(g + 1)]
-            //   [32 MFMA kb1(g)]
-            // RAW: kb0/kb1(g + 1) are read after the barrier that follows every wave's wait for chunk g + 1.  WAR: the
-            // loads of g + 2 overwrite the stage of g - 1, whose last reads were issued before the previous barrier.
-            auto read_half = [&](int st, int kb, d2_t (&a)[4], d2_t (&b)[4]) {
-                const double *As = smem + st * ST_STAGE + aoff, *Bs = smem + st * ST_STAGE + boff;
+        // MID-CHUNK barrier (the survivor of five orderings, profiles/r02_run11_gemm_lab_variants_0_to_4.txt): the synchronisation for chunk g + 1 sits between the two 8-deep halves of chunk g, the
+        // fragments of a half are read one half ahead, so the MFMA stream runs across the barrier and no LDS read
+        // latency is exposed behind it:
+        //   [read kb1(g)] [32 MFMA kb0(g)] [wait own loads of g + 1; barrier] [issue loads g + 2] [read kb0(g + 1)]
+        //   [32 MFMA kb1(g)]
+        // RAW: kb0/kb1(g + 1) are read after the barrier that follows every wave's wait for chunk g + 1.  WAR: the
+        // loads of g + 2 overwrite the stage of g - 1, whose last reads were issued before the previous barrier.
+        auto read_half = [&](int st, int kb, d2_t (&a)[4], d2_t (&b)[4]) {
+            const double *As = smem + st * ST_STAGE + aoff, *Bs = smem + st * ST_STAGE + boff;
 #pragma unroll
-                for (int mi = 0; mi < 4; mi++) a[mi] = *reinterpret_cast<const d2_t *>(As + mi * 16 * KC + foff[kb]);
+            for (int mi = 0; mi < 4; mi++) a[mi] = *reinterpret_cast<const d2_t *>(As + mi * 16 * KC + foff[kb]);
 #pragma unroll
-                for (int ni = 0; ni < 4; ni++) b[ni] = *reinterpret_cast<const d2_t *>(Bs + ni * 16 * KC + foff[kb]);
-            };
-            auto mma_quarter = [&](const d2_t (&a)[4], const d2_t (&b)[4], int h) {
+            for (int ni = 0; ni < 4; ni++) b[ni] = *reinterpret_cast<const d2_t *>(Bs + ni * 16 * KC + foff[kb]);
+        };
+        auto mma_quarter = [&](const d2_t (&a)[4], const d2_t (&b)[4], int h) {
 #pragma unroll
-                for (int mi = 0; mi < 4; mi++)
+            for (int mi = 0; mi < 4; mi++)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ni++)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][h], b[ni][h], acc[mi][ni], 0, 0, 0);
-            };
-            auto mma_half = [&](const d2_t (&a)[4], const d2_t (&b)[4]) {
-                mma_quarter(a, b, 0);
-                mma_quarter(a, b, 1);
-            };
-            if (g == 0) {  // the workgroup's very first chunk: the classic wait + barrier in front of its first read
-                if (issued > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                read_half(0, 0, a0, b0);
-            }
-            for (int ch = 0; ch < nch; ch++, g++) {
-                d2_t a1[4], b1[4];
-                read_half(stage, 1, a1, b1);
-                mma_half(a0, b0);
-                __builtin_amdgcn_sched_barrier(0);
-                const bool next = g + 1 < total;   // another chunk follows (possibly the next tile's first)
-                const bool more = issued < total;  // ... and one more to prefetch
-                const int st1 = (stage == ST_NSTAGE - 1) ? 0 : stage + 1;
-                if (next) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own pieces of chunk g + 1 (the only ones in flight)
-                    __builtin_amdgcn_s_barrier();
-                    // chunk g + 2 -> stage of chunk g - 1; VARIANT 4: the SIMD partners (waves 4-7) issue theirs 16 MFMAs later
-                    if (more && (VARIANT == 3 || wave < 4)) issue_pieces(stage == 0 ? 2 : stage - 1, 0, 6);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                mma_quarter(a1, b1, 0);  // (fragments read before the first half: nothing to wait for behind the barrier)
-                __builtin_amdgcn_sched_barrier(0);
-                if (VARIANT == 4 && next && more && wave >= 4) issue_pieces(stage == 0 ? 2 : stage - 1, 0, 6);
-                if (next && more) issue_done();
-                if (next) read_half(st1, 0, a0, b0);
-                __builtin_amdgcn_sched_barrier(0);
-                mma_quarter(a1, b1, 1);
-                stage = st1;
-            }
-        } else
-        for (int ch = 0; ch < nch; ch++, g++) {
-            // chunk g has landed once this wave's own loads for it are done (the loads of chunk g + 1 may stay in
-            // flight) AND every other wave says the same (barrier).  The barrier also tells that every wave is done
-            // reading chunk g - 1, whose stage the loads of chunk g + 2 overwrite.
-            if (issued > g + 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                for (int ni = 0; ni < 4; ni++)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][h], b[ni][h], acc[mi][ni], 0, 0, 0);
+        };
+        auto mma_half = [&](const d2_t (&a)[4], const d2_t (&b)[4]) {
+            mma_quarter(a, b, 0);
+            mma_quarter(a, b, 1);
+        };
+        if (g == 0) {  // the workgroup's very first chunk: the classic wait + barrier in front of its first read
+            if (issued > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            const bool more = issued < total;
-            const int nst = stage == 0 ? 2 : stage - 1;  // (g + 2) % 3
-            if (more) {
-                if (VARIANT == 0) issue_pieces(nst, 0, 6);
-                else if (VARIANT == 1) issue_pieces(nst, 0, 2);
-                else if (VARIANT == 2 && wave < 4) issue_pieces(nst, 0, 6);
+            read_half(0, 0, a0, b0);
+        }
+        for (int ch = 0; ch < nch; ch++, g++) {
+            d2_t a1[4], b1[4];
+            read_half(stage, 1, a1, b1);
+            mma_half(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool next = g + 1 < total;   // another chunk follows (possibly the next tile's first)
+            const bool more = issued < total;  // ... and one more to prefetch
+            const int st1 = (stage == ST_NSTAGE - 1) ? 0 : stage + 1;
+            if (next) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own pieces of chunk g + 1 (the only ones in flight)
+                __builtin_amdgcn_s_barrier();
+                if (more) issue_pieces(stage == 0 ? 2 : stage - 1, 0, 6);  // chunk g + 2 -> stage of chunk g - 1
             }
-            const double *As = smem + stage * ST_STAGE + aoff, *Bs = smem + stage * ST_STAGE + boff;
-            stage = (stage == ST_NSTAGE - 1) ? 0 : stage + 1;
-#pragma unroll
-            for (int kb = 0; kb < 2; kb++) {
-                d2_t a[4], b[4];
-#pragma unroll
-                for (int mi = 0; mi < 4; mi++) a[mi] = *reinterpret_cast<const d2_t *>(As + mi * 16 * KC + foff[kb]);
-#pragma unroll
-                for (int ni = 0; ni < 4; ni++) b[ni] = *reinterpret_cast<const d2_t *>(Bs + ni * 16 * KC + foff[kb]);
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-#pragma unroll
-                    for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-                        for (int ni = 0; ni < 4; ni++)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi][h], b[ni][h], acc[mi][ni], 0, 0, 0);
-                    if (VARIANT == 1 && kb == 0 && more) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        issue_pieces(nst, 2 + 2 * h, 4 + 2 * h);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                if (VARIANT == 2 && kb == 0 && more && wave >= 4) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    issue_pieces(nst, 0, 6);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (more) issue_done();
+            __builtin_amdgcn_sched_barrier(0);
+            mma_quarter(a1, b1, 0);  // (fragments read before the first half: nothing to wait for behind the barrier)
+            __builtin_amdgcn_sched_barrier(0);
+            if (next && more) issue_done();
+            if (next) read_half(st1, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_quarter(a1, b1, 1);
+            stage = st1;
         }
         EGX_SSTAMP(t, 4, clock64());
         // (the 16 row pointers of the C tile are rebuilt here instead of staying live through the K loop: the opaque
@@ -644,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, i
                                                        const double *__restrict__ dinv, int nbk,
                                                        const int *__restrict__ info, const double *__restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    if (info != nullptr && *info != 0) return;  // failed pivot earlier: early exit (see k_gemm_nt_sub)
+    if (wg_failed_before(info)) return;  // failed pivot earlier: early exit (see k_gemm_nt_sub)
     __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double *Pw = P + (int64_t)blockIdx.x * 64 * ldp;  // this workgroup's 64 rows
@@ -711,117 +599,12 @@ __global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, i
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// A: diagonal block factorisation (nbk x nbk, nbk in {64,128,192,256}) by ONE workgroup.
-//    Per 64-column panel s of the block:
-//      1. the 64x64 tile (s,s) is staged in LDS; wave 0 factors it with one matrix row per lane, in
-//         16-column register strips (right-looking inside a strip, strip-by-strip trailing update);
-//         finished columns reach the other rows through a uniform-address (broadcast) LDS read.
-//         Loops over strips are NOT unrolled: a fully unrolled 64x64 version makes hipcc materialise
-//         thousands of uniform operands in SGPRs and spill them through VGPR lanes (measured 5x slower).
-//      2. wave 0 inverts the tile the same way (row of L^-1 per lane) -> dinv (used by k_panel_trsm and
-//         the triangular solves).
-//      3. tiles below: X_t = A(t,s) Linv^T with the MFMA core (K = 64), in place.
-//      4. remaining tiles A(t,u) -= X_t X_u^T with the MFMA core (K = 64).
-//    LDS: 70 KB, so the kernel can share a CU with one trailing-update workgroup on the look-ahead stream.
-// ---------------------------------------------------------------------------------------------
-#ifdef EGX_POTF2_PROFILE
-__device__ long long g_potf2_stamps[4][6];
-#define EGX_STAMP(i) \
-    if (threadIdx.x == 0) g_potf2_stamps[s][i] = (long long)__builtin_readcyclecounter()
-#else
-#define EGX_STAMP(i)
-#endif
 constexpr int TS = 64;
 constexpr int TLD = 65;  // padded LDS row (doubles): per-lane row accesses are conflict free
-constexpr int POTF2_AUX = TS * TLD + 2 * TS + TS;  // tile + two broadcast lines + reciprocal diagonal (doubles)
-constexpr int POTF2_LDS_BYTES = POTF2_AUX * 8 + GemmShape<192, 64, 48, 32, 512>::LDS_BYTES;  // staging of the 192-row phases
-static_assert((POTF2_AUX * 8) % 16 == 0, "MFMA staging must stay 16-byte aligned");
-static_assert(GemmShape<192, 64, 48, 32, 512>::LDS_BYTES >= TS * TLD * 8, "inverse scratch aliases the MFMA staging");
 
-// sqrt(p) and 1/sqrt(p) for p > 0 (normal range): v_rsq_f64 seed + 2 Newton steps + 1 correction.
-// ~12 dependent ops instead of the ~50 of IEEE sqrt() followed by a division; error <= ~1 ulp.
-__device__ __forceinline__ void sqrt_rsqrt(double p, double &d, double &r) {
-    double y = __builtin_amdgcn_rsq(p);
-    const double h = 0.5 * p;
-    y = y * __builtin_fma(-h * y, y, 1.5);
-    y = y * __builtin_fma(-h * y, y, 1.5);
-    double g = p * y;
-    g = __builtin_fma(__builtin_fma(-g, g, p), 0.5 * y, g);
-    d = g;
-    r = y;
-}
-
-// Workgroup (8 waves): in-place lower Cholesky of the 64x64 tile T (LDS, row stride TLD), matrix row `lane`
-// per lane.  Per 16-column strip: wave 0 factors the strip (sequential in the 16 columns: pivot by v_readlane,
-// multipliers through a broadcast LDS line), then waves 0..5 each update half of one of the remaining strips.
-template <int NW>
-__device__ __forceinline__ void wg_potf2_64(double *T, double *cb, double *rd, int tid, int *info, int gcol0,
-                                            int n_valid) {
-    const int wave = tid >> 6, lane = tid & 63;
-#pragma unroll 1
-    for (int jb = 0; jb < 4; jb++) {
-        if (wave == 0) {
-            double a[16];
-#pragma unroll
-            for (int c = 0; c < 16; c++) a[c] = T[lane * TLD + jb * 16 + c];
-            double pnext = a[0];  // lane gj holds the pivot of the coming column
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int gj = jb * 16 + j;
-                double piv = readlane_d(pnext, gj);
-                if (!(piv > 0.0) || !(piv < 1.0e300)) {  // wave-uniform: NaN, inf or non-positive pivot
-                    if (lane == 0 && (gcol0 + gj) < n_valid) atomicCAS(info, 0, gcol0 + gj + 1);
-                    piv = 1.0;
-                }
-                double dj, rinv;
-                sqrt_rsqrt(piv, dj, rinv);
-                const double lij = (lane == gj) ? dj : a[j] * rinv;
-                a[j] = lij;
-                // the NEXT pivot a[j+1] - l^2 of lane gj + 1 needs only that lane's own multiplier: it is formed here, off
-                // the LDS broadcast below, so the rsqrt chain of column j + 1 overlaps the broadcast round trip of column j
-                // (same operands as the regular update of a[j + 1] in that lane -> the same bits)
-                if (j + 1 < 16) pnext = __builtin_fma(-lij, lij, a[j + 1]);
-                double *colb = cb + (j & 1) * TS;  // two alternating broadcast lines (LDS is in-order per wave)
-                colb[lane] = lij;
-                if (lane == gj) rd[gj] = rinv;
-                // (v_readlane of the multipliers instead of this LDS broadcast was measured 14 % SLOWER: 38.6k vs 33.8k
-                //  cycles per 64x64 tile, tools/potf2_prof)
-#pragma unroll
-                for (int c = j + 1; c < 16; c++) a[c] = __builtin_fma(-lij, colb[jb * 16 + c], a[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < 16; c++) T[lane * TLD + jb * 16 + c] = ((jb * 16 + c) <= lane) ? a[c] : 0.0;
-        }
-        __syncthreads();
-        // trailing strips on the matrix cores: 16x16 tile (rt, sb), jb < sb <= rt, -= L(rt, jb) L(sb, jb)^T (K = 16);
-        // at most six tiles, one per wave (two per wave with four waves).  Tiles above the diagonal are never read.
-        {
-            const int frow = lane & 15, fk = lane >> 4;
-            int tcount = 0;
-            for (int sb = jb + 1; sb < 4; sb++)
-                for (int rt = sb; rt < 4; rt++, tcount++) {
-                    if (tcount % NW != wave) continue;
-                    const double *arow = T + (rt * 16 + frow) * TLD + jb * 16 + fk;
-                    const double *brow = T + (sb * 16 + frow) * TLD + jb * 16 + fk;
-                    double *ct = T + (rt * 16 + fk) * TLD + sb * 16 + frow;
-                    double4_t acc;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) acc[r] = ct[(4 * r) * TLD];
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-arow[kk * 4], brow[kk * 4], acc, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) ct[(4 * r) * TLD] = acc[r];
-                }
-        }
-        __syncthreads();
-    }
-}
-
-// Workgroup: X = L^-1 (lower) for the factored tile T; row `lane` of X per lane, into X (LDS, stride TLD).
-// Strips of 16 columns from the right; the contributions of the already finished strips are split over the
-// eight waves (2 columns each), the short in-strip back substitution is done by wave 0.
+// Workgroup: X = L^-1 (lower) for the factored 64x64 tile T (k_diag_tile_inverses); row `lane` of X per lane, into X
+// (LDS, stride TLD).  Strips of 16 columns from the right; the contributions of the already finished strips go through
+// the matrix cores, the short in-strip back substitution is done by wave 0.
 template <int NW>
 __device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, double *X, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
@@ -868,126 +651,8 @@ __device__ __forceinline__ void wg_inv_64(const double *T, const double *rd, dou
     }
 }
 
-// In-block MFMA phases of k_potf2_block on 64 R rows at once (R = 1..3 tiles below / at the current tile column):
-// 8 waves of (16 R) x 32 (4 waves: (16 R) x 64).  One staging pass per phase instead of one per 64x64 tile.
-template <int NT, int R>
-__device__ __forceinline__ void potf2_trsm_rows(double *A, int64_t ld, const double *linv, double *stage, int tid) {
-    constexpr int WN = 256 / (NT / 64);
-    using S = GemmShape<64 * R, 64, 16 * R, WN, NT>;
-    double4_t acc[R][WN / 16];
-#pragma unroll
-    for (int mi = 0; mi < R; mi++)
-#pragma unroll
-        for (int ni = 0; ni < WN / 16; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-    gemm_core<64 * R, 64, 16 * R, WN, NT>(A, ld, linv, TS, TS, acc, stage, tid);
-    const int wave = tid >> 6, lane = tid & 63;
-    double *xt = A + (int64_t)((wave / S::WAVES_N) * 16 * R + (lane >> 4)) * ld + (wave % S::WAVES_N) * WN + (lane & 15);
-#pragma unroll
-    for (int mi = 0; mi < R; mi++)
-#pragma unroll
-        for (int ni = 0; ni < WN / 16; ni++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) xt[(int64_t)(mi * 16 + 4 * r) * ld + ni * 16] = acc[mi][ni][r];
-}
-
-template <int NT, int R>
-__device__ __forceinline__ void potf2_syrk_col(double *C, const double *X, int64_t ld, double *stage, int tid) {
-    constexpr int WN = 256 / (NT / 64);
-    using S = GemmShape<64 * R, 64, 16 * R, WN, NT>;
-    double4_t acc[R][WN / 16];
-#pragma unroll
-    for (int mi = 0; mi < R; mi++)
-#pragma unroll
-        for (int ni = 0; ni < WN / 16; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-    gemm_core<64 * R, 64, 16 * R, WN, NT>(X, ld, X, ld, TS, acc, stage, tid);  // rows u.. times tile u (the first 64 rows)
-    const int wave = tid >> 6, lane = tid & 63;
-    double *ct = C + (int64_t)((wave / S::WAVES_N) * 16 * R + (lane >> 4)) * ld + (wave % S::WAVES_N) * WN + (lane & 15);
-#pragma unroll
-    for (int mi = 0; mi < R; mi++) {
-        double cv[WN / 16][4];
-#pragma unroll
-        for (int ni = 0; ni < WN / 16; ni++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) cv[ni][r] = ct[(int64_t)(mi * 16 + 4 * r) * ld + ni * 16];
-#pragma unroll
-        for (int ni = 0; ni < WN / 16; ni++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) ct[(int64_t)(mi * 16 + 4 * r) * ld + ni * 16] = cv[ni][r] - acc[mi][ni][r];
-    }
-}
-
-template <int NT>
-__global__ __launch_bounds__(NT, NT / 256) void k_potf2_block(double *__restrict__ D, int64_t ld, int nbk,
-                                                              double *__restrict__ dinv, int *__restrict__ info,
-                                                              int col0, int n_valid) {
-    constexpr int NW = NT / 64;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    if (*info != 0) return;  // a previous block of this factorisation already failed: early exit
-    __builtin_amdgcn_s_setprio(3);   // on the look-ahead stream this workgroup shares its CU with trailing-update waves
-    double *Ls = sm;                 // current diagonal tile / its factor, [64][65]
-    double *cb = sm + TS * TLD;      // 2 x 64 broadcast lines
-    double *rd = cb + 2 * TS;        // 64 reciprocal diagonal entries
-    double *stage = sm + POTF2_AUX;  // MFMA staging; aliased by the inverse scratch X [64][65]
-    const int tid = threadIdx.x;
-    const int nt = nbk / TS;
-    for (int s = 0; s < nt; s++) {
-        EGX_STAMP(0);
-        // ---- stage tile (s,s) into LDS (coalesced 16-byte pieces)
-        {
-            const double *src = D + (int64_t)(s * TS) * ld + s * TS;
-            for (int e = tid; e < TS * (TS / 2); e += NT) {
-                const int row = e >> 5, c2 = e & 31;
-                const d2_t v = *reinterpret_cast<const d2_t *>(src + (int64_t)row * ld + c2 * 2);
-                Ls[row * TLD + c2 * 2] = v[0];
-                Ls[row * TLD + c2 * 2 + 1] = v[1];
-            }
-        }
-        __syncthreads();
-        // ---- steps 1+2: factor and invert the tile (all four waves, see wg_potf2_64 / wg_inv_64)
-        wg_potf2_64<NW>(Ls, cb, rd, tid, info, col0 + s * TS, n_valid);
-        EGX_STAMP(5);
-        wg_inv_64<NW>(Ls, rd, stage, tid);
-        EGX_STAMP(1);
-        // ---- write the factor back (upper part zeroed) and the inverse to dinv
-        {
-            double *dstL = D + (int64_t)(s * TS) * ld + s * TS;
-            double *dstI = dinv + (int64_t)s * 4096;
-            for (int e = tid; e < TS * (TS / 2); e += NT) {
-                const int row = e >> 5, c2 = e & 31;
-                d2_t v, w;
-                v[0] = Ls[row * TLD + c2 * 2];
-                v[1] = Ls[row * TLD + c2 * 2 + 1];
-                w[0] = stage[row * TLD + c2 * 2];
-                w[1] = stage[row * TLD + c2 * 2 + 1];
-                *reinterpret_cast<d2_t *>(dstL + (int64_t)row * ld + c2 * 2) = v;
-                *reinterpret_cast<d2_t *>(dstI + row * TS + c2 * 2) = w;
-            }
-        }
-        __syncthreads();  // dinv visible (workgroup scope); the staging area is free again
-        EGX_STAMP(2);
-        // ---- step 3: ALL tiles below in one MFMA pass:  X = A(s+1.., s) Linv^T  (in place, 64 R rows)
-        const int rb = nt - s - 1;
-        if (rb == 3) potf2_trsm_rows<NT, 3>(D + (int64_t)(s + 1) * TS * ld + s * TS, ld, dinv + (int64_t)s * 4096, stage, tid);
-        else if (rb == 2) potf2_trsm_rows<NT, 2>(D + (int64_t)(s + 1) * TS * ld + s * TS, ld, dinv + (int64_t)s * 4096, stage, tid);
-        else if (rb == 1) potf2_trsm_rows<NT, 1>(D + (int64_t)(s + 1) * TS * ld + s * TS, ld, dinv + (int64_t)s * 4096, stage, tid);
-        __syncthreads();  // X tiles visible before they are re-read as MFMA operands
-        EGX_STAMP(3);
-        // ---- step 4: per tile column u: A(u.., u) -= X(u..) X_u^T  (64 (nt - u) rows in one MFMA pass)
-        for (int u = s + 1; u < nt; u++) {
-            double *Cu = D + (int64_t)u * TS * ld + u * TS;
-            const double *Xu = D + (int64_t)u * TS * ld + s * TS;
-            const int ru = nt - u;
-            if (ru == 3) potf2_syrk_col<NT, 3>(Cu, Xu, ld, stage, tid);
-            else if (ru == 2) potf2_syrk_col<NT, 2>(Cu, Xu, ld, stage, tid);
-            else potf2_syrk_col<NT, 1>(Cu, Xu, ld, stage, tid);
-        }
-        __syncthreads();
-        EGX_STAMP(4);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// A' (round 2): REGISTER-RESIDENT diagonal block factorisation.  The lower triangle of the 256x256 block is 136
+// A: REGISTER-RESIDENT diagonal block factorisation (nbk x nbk, nbk a multiple of 16 up to 256) by ONE workgroup.  The lower triangle of the 256x256 block is 136
 // tiles of 16x16; they live for the whole kernel as FP64-MFMA accumulators in the registers of seven "update" waves
 // (<= 20 tiles = 160 VGPRs per wave), wave 0 is the "chain" wave.  Per 16-column strip k, two workgroup barriers:
 //   phase A (waves 1-7)  TRSM_k: X_R = T(R,k) Linv_k^T for the tiles below the diagonal tile: ONE 4-MFMA chain per tile
@@ -1288,12 +953,21 @@ __device__ long long g_rb_stamps[2][16][8];  // [chain wave / update wave 1][str
 #else
 #define RB_STAMP(w, k, i)
 #endif
-template <int NW>  // waves: 1 chain wave + NW - 1 update waves (8, 12 or 16)
+template <int NW>  // waves: 1 chain wave + NW - 1 update waves (16 in the product; the tables also cover 8 and 12)
 __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D, int64_t ld, int nbk, double *__restrict__ lin,
-                                                          int *__restrict__ info, int col0, int n_valid) {
+                                                          int *__restrict__ info, int col0, int n_valid, int64_t bsD,
+                                                          int64_t bsL, int bsI) {
     constexpr int NU = NW - 1, RB_NS = rb_slots(NU);
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int failed_before = *info;  // examined once the loads of the block are on their way (below)
+    {   // lock-step batch: one workgroup per matrix
+        const int64_t z = blockIdx.z;
+        D += z * bsD;
+        lin += z * bsL;
+        info += z * bsI;
+    }
+    // examined once the loads of the block are on their way (below).  Only diagonal-block kernels SET the flag and the
+    // chain runs them one after the other, so every wave of this workgroup reads the same value.
+    const int failed_before = *info;
     __builtin_amdgcn_s_setprio(2);    // above the trailing-update workgroups this kernel may share its CU with
     double *P = sm;                   // X panel of the current strip, row = row of the block
     double *Dg = sm + RB_P_DOUBLES;   // hand-off of the next diagonal tile (update wave -> chain wave)
@@ -1503,9 +1177,17 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
 template <int RT>  // 16-row tiles per workgroup: 1 (panels of small matrices: n / 16 workgroups) or 2 (tall panels: the L
                     // fragments and the barrier serve two tiles, half the workgroups, less CU time per row)
 __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, int64_t ldp, const double *__restrict__ L, int64_t ldl,
-                                                      const double *__restrict__ lin, int nbk, const int *__restrict__ info) {
+                                                      const double *__restrict__ lin, int nbk, const int *__restrict__ info,
+                                                      int64_t bsM, int64_t bsL, int bsI) {
     __shared__ __attribute__((aligned(16))) double X[2][RT][16 * RB_LD];
-    if (info != nullptr && *info != 0) return;  // failed pivot earlier: early exit (see k_gemm_nt_sub)
+    {   // lock-step batch: matrix blockIdx.z
+        const int64_t z = blockIdx.z;
+        P += z * bsM;
+        L += z * bsM;
+        lin += z * bsL;
+        if (info != nullptr) info += z * bsI;
+    }
+    if (wg_failed_before(info)) return;  // failed pivot earlier: early exit (see k_gemm_nt_sub)
     __builtin_amdgcn_s_setprio(2);
     const int tid = threadIdx.x, lane = tid & 63, frow = lane & 15, fk = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1617,14 +1299,21 @@ __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, in
     }
 }
 
-// Inverses of all 64x64 diagonal tiles of a GIVEN lower factor (used when a fitted model is loaded instead of
-// factored here): one workgroup per tile, same row-per-lane strip algorithm as in k_potf2_block.
+// Inverses of all 64x64 diagonal tiles of a GIVEN lower factor (at the end of a factorisation, and when a fitted model
+// is loaded instead of factored here): one workgroup per tile, row-per-lane strips (wg_inv_64).
 __global__ __launch_bounds__(256, 1) void k_diag_tile_inverses(const double *__restrict__ M, int64_t ld,
-                                                               double *__restrict__ dinv, double *__restrict__ flags) {
+                                                               double *__restrict__ dinv, double *__restrict__ flags,
+                                                               int64_t bsM, int64_t bsL) {
     __shared__ double Ls[TS * TLD];
     __shared__ double X[TS * TLD];
     __shared__ double rd[TS];
     __shared__ double red[2][256];
+    {   // lock-step batch: matrix blockIdx.z
+        const int64_t z = blockIdx.z;
+        M += z * bsM;
+        dinv += z * bsL;
+        if (flags != nullptr) flags += z * bsL;
+    }
     const int tid = threadIdx.x, t = blockIdx.x;
     const double *src = M + (int64_t)(t * TS) * ld + t * TS;
     for (int e = tid; e < TS * TS; e += 256) {
@@ -1819,55 +1508,28 @@ __global__ void k_gram_reduce(const double *__restrict__ P, int rows, int nsplit
 // =============================================================================================
 // host launchers
 // =============================================================================================
-static int g_potf2_threads = 512;
-static int g_potf2_reg = 16;       // EGX_POTF2_REG: waves of the register-resident diagonal-block kernel (8, 12, 16); 0 = the
-                                   // LDS-tile kernel of round 1 (k_potf2_block)
-static int g_potrf_group = 2;    // panels per trailing update (EGX_POTRF_GROUP, 1..8)
-static bool g_potrf_group_set = false;  // EGX_POTRF_GROUP given: no size-dependent choice in launch_potrf
-static int g_gemm_wide_min = 512;
-static int g_potrf_diag_first = 1;   // EGX_POTRF_DIAG_FIRST=0: updates on the critical path are not split (round-1 order)
-static int g_gemm_stream = 1;        // EGX_GEMM_STREAM=0: the register-staged wide kernel instead of k_gemm_stream
-static int g_stream_tpw = 1;         // EGX_STREAM_TPW: tiles per workgroup of k_gemm_stream (0 = one workgroup per CU walks all;
-                                     // measured: the fully persistent form is the fastest kernel alone, 54 vs 50 TFLOP/s, but
-                                     // holds every CU for the whole update and starves the look-ahead chain)
-static int g_stream_variant = 3;      // EGX_STREAM_VARIANT: structure of a chunk (see k_gemm_stream; measured alone, n = 15872,
-                                      // persistent: v0 58.3, v1 58.9, v2 59.3, v3 60.3, v4 59.9 TFLOP/s; K loop 0.879 -> 0.909)
-static int g_stream_min_tiles = 512;  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles go to k_gemm_stream
-static int g_tail_lookahead = 0;      // EGX_TAIL_LOOKAHEAD=1: look-ahead also below 3072 trailing columns (measured: n = 4096 fit
-                                      // 3.37 -> 3.27 ms alone, but 460 -> 313 fits/s with two in flight: the extra hand-offs cost more)
-static int g_trsm_refine = 1;        // EGX_TRSM_REFINE=0: no refinement step in the solves after the factorisation
-static int g_panel_rt2_rows = 4096;  // EGX_PANEL_RT2: panels with at least this many rows use two 16-row tiles per workgroup
-static int g_stream_xcd = 0;         // EGX_STREAM_XCD=1: XCD-contiguous tile assignment in k_gemm_stream (one tile per workgroup)
-static int g_stream_wgs = 256;       // EGX_STREAM_WGS: workgroups of the fully persistent form
-static int g_gemm_pipe = 0;          // EGX_GEMM_PIPE=1: hand software-pipelined K loop (measured 3 % SLOWER, run 20)
-static int g_gemm_small_max = 1024;  // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used  // EGX_GEMM_WIDE: minimum number of 128x256 tiles for the wide-tile kernel (0 = off)
+// Tuning knobs that survive (each read once; everything else that was ever switchable has its A/B in profiles/ and
+// is gone -- DESIGN.md section 4 lists both):
+static int g_potrf_group = 0;         // EGX_POTRF_GROUP: panels per trailing update, 1..8 (0 = by size: 4 from n_pad 14336, else 2)
+static int g_stream_min_tiles = 128;  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles PER MATRIX go to k_gemm_stream
+static int g_stream_tpw = 1;          // EGX_STREAM_TPW: tiles a workgroup of k_gemm_stream walks (1: CUs turn over, the chain squeezes in)
+static int g_gemm_small_max = 1024;   // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used
+static int g_look_min_cols = 3072;    // EGX_LOOK_MIN: look-ahead while at least this many columns trail the next group
+static int g_stream_min_k = 32;       // EGX_STREAM_MINK (experiment): launches below 512 tiles take the stream kernel only from this K on
 
 int chol_init() {
     static std::once_flag once;
     static int rc_once = EGX_SUCCESS;
     std::call_once(once, [] {
-        if (const char *e = std::getenv("EGX_POTF2_THREADS")) g_potf2_threads = (std::atoi(e) == 256) ? 256 : 512;
-        if (const char *e = std::getenv("EGX_POTF2_REG")) g_potf2_reg = (std::atoi(e) == 1) ? 16 : std::atoi(e);
         if (const char *e = std::getenv("EGX_POTRF_GROUP")) {
             const int g = std::atoi(e);
-            if (g >= 1 && g <= 8) {
-                g_potrf_group = g;
-                g_potrf_group_set = true;
-            }
+            if (g >= 1 && g <= 8) g_potrf_group = g;
         }
-        if (const char *e = std::getenv("EGX_GEMM_WIDE")) g_gemm_wide_min = std::atoi(e);
         if (const char *e = std::getenv("EGX_GEMM_SMALL")) g_gemm_small_max = std::atoi(e);
-        if (const char *e = std::getenv("EGX_GEMM_PIPE")) g_gemm_pipe = std::atoi(e);
-        if (const char *e = std::getenv("EGX_GEMM_STREAM")) g_gemm_stream = std::atoi(e);
-        if (const char *e = std::getenv("EGX_POTRF_DIAG_FIRST")) g_potrf_diag_first = std::atoi(e);
-        if (const char *e = std::getenv("EGX_STREAM_TPW")) g_stream_tpw = std::atoi(e);
-        if (const char *e = std::getenv("EGX_STREAM_XCD")) g_stream_xcd = std::atoi(e);
-        if (const char *e = std::getenv("EGX_TRSM_REFINE")) g_trsm_refine = std::atoi(e);
-        if (const char *e = std::getenv("EGX_PANEL_RT2")) g_panel_rt2_rows = std::atoi(e) > 0 ? std::atoi(e) : (1 << 30);
-        if (const char *e = std::getenv("EGX_STREAM_MIN")) g_stream_min_tiles = std::atoi(e);
-        if (const char *e = std::getenv("EGX_STREAM_VARIANT")) g_stream_variant = std::atoi(e);
-        if (const char *e = std::getenv("EGX_TAIL_LOOKAHEAD")) g_tail_lookahead = std::atoi(e);
-        if (const char *e = std::getenv("EGX_STREAM_WGS")) g_stream_wgs = std::atoi(e) > 0 ? std::atoi(e) : 256;
+        if (const char *e = std::getenv("EGX_STREAM_TPW")) g_stream_tpw = std::atoi(e) > 0 ? std::atoi(e) : 1;
+        if (const char *e = std::getenv("EGX_STREAM_MIN")) g_stream_min_tiles = std::atoi(e) > 0 ? std::atoi(e) : 1;
+        if (const char *e = std::getenv("EGX_LOOK_MIN")) g_look_min_cols = std::atoi(e);
+        if (const char *e = std::getenv("EGX_STREAM_MINK")) g_stream_min_k = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -1875,101 +1537,65 @@ int chol_init() {
                 rc_once = EGX_ERR_HIP;
             }
         };
-        set(reinterpret_cast<const void *>(&k_potf2_block<256>), POTF2_LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_potf2_block<512>), POTF2_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 128, 32, 64, 512, true>), TrailShape::LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 128, 32, 64, 512, true>), TrailShape::LDS_BYTES);
-        constexpr int wide_lds = GemmShape<128, 256, 64, 64, 512>::LDS_BYTES;
-        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 256, 64, 64, 512, false, false>), wide_lds);
-        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 256, 64, 64, 512, false, false>), wide_lds);
-        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 256, 64, 64, 512, false, true>), wide_lds);
-        set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 256, 64, 64, 512, false, true>), wide_lds);
         set(reinterpret_cast<const void *>(&k_panel_trsm), PanelShape::LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_stream<true, 0>), ST_LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_stream<false, 0>), ST_LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_stream<true, 1>), ST_LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_stream<false, 1>), ST_LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_stream<true, 2>), ST_LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_stream<false, 2>), ST_LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_stream<true, 3>), ST_LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_stream<false, 3>), ST_LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_stream<true, 4>), ST_LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_gemm_stream<false, 4>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<true>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<false>), ST_LDS_BYTES);
     });
     return rc_once;
 }
 
-// Tile shape: 128x128 (64x64 per wave) when the launch fills the chip, 64x64 (32x32 per wave) otherwise: a
-// 128x128xK tile is one wave-chain of K/4*16 MFMAs (~43 us at K = 256), so small grids are latency bound.
+// Kernel choice by the size of ONE matrix' launch (never by the batch count: a matrix is factored by the same kernels
+// alone and in a lock-step batch, hence to the same bits):
+//   k_gemm_stream (128x256 tile, LDS-DMA ring)   >= g_stream_min_tiles wide tiles, N % 256 == 0, no ktri
+//   k_gemm_nt_sub 64x64 (register staged)        latency-bound launches: a 128x128xK tile is one wave chain of
+//                                                K/4*16 MFMAs (~43 us at K = 256)
+//   k_gemm_nt_sub 128x128, XCD-swizzled          the rest (the theta-gradient's R^-1 = W W^T with ktri, odd widths)
 int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
                        const double *B, int64_t ldb, int M, int N, int K, int lower, int ktri, bool *used_big_tile,
-                       const int *info) {
+                       const int *info, const GemmBatch *batch) {
     if (used_big_tile) *used_big_tile = false;
     if (M <= 0 || N <= 0 || K <= 0) return EGX_SUCCESS;
     if (M % 128 || N % 128 || K % KC) {
         set_error("gemm_nt_sub: M,N must be multiples of 128 and K of 16");
         return EGX_ERR_INVALID_VALUE;
     }
+    const GemmBatch bt = batch ? *batch : GemmBatch();
+    const unsigned nz = (unsigned)(bt.count > 0 ? bt.count : 1);
     const int64_t big_tiles = lower ? ((int64_t)(M / 128) * (N / 128) - (int64_t)(N / 128) * (N / 128 - 1) / 2)
                                     : (int64_t)(M / 128) * (N / 128);
     const bool small = big_tiles < g_gemm_small_max;  // fewer than 2 waves of workgroups over 256 CUs x 2
-    if (used_big_tile) *used_big_tile = !small;
     int64_t wide_tiles = 0;
-    if (N % 256 == 0) {
+    if (N % 256 == 0 && !ktri && (!lower || M >= N)) {
         if (lower)
             for (int c = 0; c < N / 256; c++) wide_tiles += (M / 128 - 2 * c > 0) ? M / 128 - 2 * c : 0;
         else
             wide_tiles = (int64_t)(M / 128) * (N / 256);
     }
-    const bool stream_ok = g_gemm_stream && K % KC == 0 && K >= 2 * KC && wide_tiles >= g_stream_min_tiles;
-    if (g_gemm_wide_min > 0 && (wide_tiles >= g_gemm_wide_min || stream_ok) && !ktri && (!lower || M >= N)) {
-        if (used_big_tile) *used_big_tile = wide_tiles >= g_gemm_wide_min;  // the chip-filling launches (roofline trace)
-        // 128x256 workgroup tile, 64x64 wave tiles (LDS operand reads per MFMA 0.5 instead of 0.75)
-        using WideShape = GemmShape<128, 256, 64, 64, 512>;
+    if (K >= 2 * KC && wide_tiles >= g_stream_min_tiles && (wide_tiles >= 512 || K >= g_stream_min_k)) {
+        // the launches that fill the chip on their own are the ones the roofline trace follows
+        if (used_big_tile) *used_big_tile = wide_tiles >= 512;
         const int nbx = M / 128, nby = N / 256;  // LOWER: column c holds nbx - 2 c tiles (M >= N in the factorisation)
-        if (stream_ok) {
-            const int nt = (int)wide_tiles;
-            int grid = g_stream_tpw > 0 ? (nt + g_stream_tpw - 1) / g_stream_tpw : (nt < g_stream_wgs ? nt : g_stream_wgs);
-            if (grid < 1) grid = 1;
-#define EGX_STREAM(LOW, V) \
-    hipLaunchKernelGGL((k_gemm_stream<LOW, V>), dim3(grid), dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx, nby, nt, g_stream_xcd, info)
-            if (lower) {
-                if (g_stream_variant == 1) EGX_STREAM(true, 1);
-                else if (g_stream_variant == 3) EGX_STREAM(true, 3);
-                else if (g_stream_variant == 4) EGX_STREAM(true, 4);
-                else if (g_stream_variant == 2) EGX_STREAM(true, 2);
-                else EGX_STREAM(true, 0);
-            } else {
-                if (g_stream_variant == 1) EGX_STREAM(false, 1);
-                else if (g_stream_variant == 3) EGX_STREAM(false, 3);
-                else if (g_stream_variant == 4) EGX_STREAM(false, 4);
-                else if (g_stream_variant == 2) EGX_STREAM(false, 2);
-                else EGX_STREAM(false, 0);
-            }
-#undef EGX_STREAM
-            EGX_HIP_CHECK(hipGetLastError());
-            return EGX_SUCCESS;
-        }
-        const dim3 g1((unsigned)wide_tiles), g2(M / 128, N / 256);
-#define EGX_WIDE(LOW, PIPE, GRID, FLAG)                                                                             \
-    hipLaunchKernelGGL((k_gemm_nt_sub<LOW, 128, 256, 64, 64, 512, false, PIPE>), GRID, dim3(512), WideShape::LDS_BYTES, s, \
-                       C, ldc, A, lda, B, ldb, K, nbx, nby, FLAG, info)
-        if (lower && g_gemm_pipe) EGX_WIDE(true, true, g1, 2);
-        else if (lower) EGX_WIDE(true, false, g1, 2);
-        else if (g_gemm_pipe) EGX_WIDE(false, true, g2, 0);
-        else EGX_WIDE(false, false, g2, 0);
-#undef EGX_WIDE
+        const int nt = (int)wide_tiles;
+        const dim3 grid((unsigned)((nt + g_stream_tpw - 1) / g_stream_tpw), 1, nz);
+        if (lower)
+            hipLaunchKernelGGL((k_gemm_stream<true>), grid, dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx, nby, nt,
+                               info, bt);
+        else
+            hipLaunchKernelGGL((k_gemm_stream<false>), grid, dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx, nby, nt,
+                               info, bt);
         EGX_HIP_CHECK(hipGetLastError());
         return EGX_SUCCESS;
     }
     if (small) {
-        dim3 grid(M / 64, N / 64);
+        const dim3 grid(M / 64, N / 64, nz);
         if (lower)
             hipLaunchKernelGGL((k_gemm_nt_sub<true, 64, 64, 32, 32, 256, false>), grid, dim3(256), SmallShape::LDS_BYTES, s,
-                               C, ldc, A, lda, B, ldb, K, M / 64, N / 64, ktri, info);
+                               C, ldc, A, lda, B, ldb, K, M / 64, N / 64, ktri, info, bt);
         else
             hipLaunchKernelGGL((k_gemm_nt_sub<false, 64, 64, 32, 32, 256, false>), grid, dim3(256), SmallShape::LDS_BYTES,
-                               s, C, ldc, A, lda, B, ldb, K, M / 64, N / 64, ktri, info);
+                               s, C, ldc, A, lda, B, ldb, K, M / 64, N / 64, ktri, info, bt);
     } else {
         const int nbx = M / 128, nby = N / 128;
         const int nsx = (nbx + 7) / 8, nsy = (nby + 7) / 8;
@@ -1982,13 +1608,13 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
             nst = nsx * nsy;
         }
         const int per_xcd = (nst + 7) / 8;
-        dim3 grid(8 * per_xcd * 64);
+        const dim3 grid(8 * per_xcd * 64, 1, nz);
         if (lower)
             hipLaunchKernelGGL((k_gemm_nt_sub<true, 128, 128, 32, 64, 512, true>), grid, dim3(512), TrailShape::LDS_BYTES, s,
-                               C, ldc, A, lda, B, ldb, K, nbx, nby, ktri, info);
+                               C, ldc, A, lda, B, ldb, K, nbx, nby, ktri, info, bt);
         else
             hipLaunchKernelGGL((k_gemm_nt_sub<false, 128, 128, 32, 64, 512, true>), grid, dim3(512), TrailShape::LDS_BYTES,
-                               s, C, ldc, A, lda, B, ldb, K, nbx, nby, ktri, info);
+                               s, C, ldc, A, lda, B, ldb, K, nbx, nby, ktri, info, bt);
     }
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
@@ -2021,8 +1647,8 @@ int launch_gram_lower(hipStream_t s, const double *W, int64_t ldw, int rows, int
     return EGX_SUCCESS;
 }
 
-// Right-looking factorisation, two-level blocking (kNB-wide panels inside groups of `g_potrf_group` panels, ONE trailing
-// update per group with K = group width) with a look-ahead whose CRITICAL PATH is kept narrow:
+// Right-looking factorisation, two-level blocking (kNB-wide panels inside groups of panels, ONE trailing update per
+// group with K = group width) with a look-ahead whose CRITICAL PATH is kept narrow:
 //   * the critical path of a right-looking Cholesky is  potf2(k) -> trsm(k) -> update of panel k+1 -> potf2(k+1) ...
 //     Only the DIAGONAL block of panel k+1 has to be up to date before potf2(k+1) may start, so every update on that
 //     path is split into the diagonal block (a 256x256 launch on the chain's stream) and the rest (on a side stream,
@@ -2031,8 +1657,10 @@ int launch_gram_lower(hipStream_t s, const double *W, int64_t ldw, int rows, int
 //     panel solves, in-group updates -- runs on the auxiliary high-priority streams (lk->s2 / lk->s3), concurrently with
 //     the rest of the look-ahead columns (LUr) and the trailing update (RU) on `s`.
 // lk == nullptr (or lk->s2 == nullptr) runs everything in order on `s`.
+// batch != nullptr: batch->count matrices in lock-step (matrix z at M + z sM, dinv + z sD, info + z sI); every launch
+// below covers all of them (grid.z), the schedule is the one a single matrix of this size gets.
 int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
-                 const PotrfLookahead *lk, GemmTrace *trace) {
+                 const PotrfLookahead *lk, GemmTrace *trace, const PotrfBatch *batch) {
     if (trace) trace->used = 0;
     int rc = chol_init();
     if (rc) return rc;
@@ -2040,52 +1668,43 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         set_error("potrf: padded sizes must be multiples of 128");
         return EGX_ERR_INVALID_VALUE;
     }
-    hipStream_t s2 = lk ? lk->s2 : nullptr, s3 = (lk && g_potrf_diag_first) ? lk->s3 : nullptr;
+    const PotrfBatch pb = batch ? *batch : PotrfBatch();
+    const unsigned nz = (unsigned)(pb.count > 0 ? pb.count : 1);
+    GemmBatch gb;
+    gb.count = (int)nz;
+    gb.sC = gb.sA = gb.sB = pb.sM;
+    gb.sInfo = pb.sI;
+    hipStream_t s2 = lk ? lk->s2 : nullptr, s3 = lk ? lk->s3 : nullptr;
     auto potf2 = [&](hipStream_t st, int k0, int nbk) {
         double *diag = M + (int64_t)k0 * ld + k0;
         double *dtiles = dinv + (int64_t)(k0 / 64) * 4096;
-        // 512 threads (two MFMA waves per SIMD) is ~10 % faster alone; the 256-thread variant (1 wave per SIMD) fits
-        // next to one resident trailing-update workgroup.  Measured end to end they are within 1.5 % (run 12);
-        // EGX_POTF2_THREADS=256 selects the latter for experiments.
-        if (g_potf2_reg) {
-            if (g_potf2_reg == 16)
-                hipLaunchKernelGGL(k_potf2_reg<16>, dim3(1), dim3(1024), RB_LDS_BYTES, st, diag, ld, nbk, dtiles, info, k0, n_pad);
-            else if (g_potf2_reg == 12)
-                hipLaunchKernelGGL(k_potf2_reg<12>, dim3(1), dim3(768), RB_LDS_BYTES, st, diag, ld, nbk, dtiles, info, k0, n_pad);
-            else
-                hipLaunchKernelGGL(k_potf2_reg<8>, dim3(1), dim3(512), RB_LDS_BYTES, st, diag, ld, nbk, dtiles, info, k0, n_pad);
-            // (the 64x64 tile inverses `dinv` -- for the solves AFTER the factorisation -- are built at the end, all at once)
-        } else if (g_potf2_threads == 512)
-            hipLaunchKernelGGL(k_potf2_block<512>, dim3(1), dim3(512), POTF2_LDS_BYTES, st, diag, ld, nbk, dtiles, info,
-                               k0, n_pad);
-        else
-            hipLaunchKernelGGL(k_potf2_block<256>, dim3(1), dim3(256), POTF2_LDS_BYTES, st, diag, ld, nbk, dtiles, info,
-                               k0, n_pad);
+        // (the 64x64 tile inverses `dinv` -- for the solves AFTER the factorisation -- are built at the end, all at once;
+        //  during the factorisation their slots carry the 16x16 inverses + refinement flags to the panel solve)
+        hipLaunchKernelGGL(k_potf2_reg<16>, dim3(1, 1, nz), dim3(1024), RB_LDS_BYTES, st, diag, ld, nbk, dtiles, info, k0, n_pad,
+                           pb.sM, pb.sD, pb.sI);
     };
     auto trsm = [&](hipStream_t st, int k0, int nbk) {
-        const int below = m_tot - (k0 + nbk);
-        if (below > 0 && g_potf2_reg && below >= g_panel_rt2_rows)  // (below is a multiple of 64)
-            hipLaunchKernelGGL(k_panel_trsm16<2>, dim3(below / 32), dim3(256), 0, st, M + (int64_t)(k0 + nbk) * ld + k0, ld,
-                               (const double *)(M + (int64_t)k0 * ld + k0), ld,
-                               (const double *)(dinv + (int64_t)(k0 / 64) * 4096), nbk, (const int *)info);
-        else if (below > 0 && g_potf2_reg)
-            hipLaunchKernelGGL(k_panel_trsm16<1>, dim3(below / 16), dim3(256), 0, st, M + (int64_t)(k0 + nbk) * ld + k0, ld,
-                               (const double *)(M + (int64_t)k0 * ld + k0), ld,
-                               (const double *)(dinv + (int64_t)(k0 / 64) * 4096), nbk, (const int *)info);
-        else if (below > 0)
-            hipLaunchKernelGGL(k_panel_trsm, dim3(below / 64), dim3(256), PanelShape::LDS_BYTES, st,
-                               M + (int64_t)(k0 + nbk) * ld + k0, ld, (const double *)(M + (int64_t)k0 * ld + k0), ld,
-                               (const double *)(dinv + (int64_t)(k0 / 64) * 4096), nbk, (const int *)info, (const double *)nullptr);
+        const int below = m_tot - (k0 + nbk);  // a multiple of 64
+        if (below <= 0) return;
+        double *P = M + (int64_t)(k0 + nbk) * ld + k0;
+        const double *L = M + (int64_t)k0 * ld + k0;
+        const double *lin = dinv + (int64_t)(k0 / 64) * 4096;
+        if (below >= 4096)  // tall panels: two 16-row tiles per workgroup (+1 %, profiles/r02_run34_*)
+            hipLaunchKernelGGL(k_panel_trsm16<2>, dim3(below / 32, 1, nz), dim3(256), 0, st, P, ld, L, ld, lin, nbk,
+                               (const int *)info, pb.sM, pb.sD, pb.sI);
+        else
+            hipLaunchKernelGGL(k_panel_trsm16<1>, dim3(below / 16, 1, nz), dim3(256), 0, st, P, ld, L, ld, lin, nbk,
+                               (const int *)info, pb.sM, pb.sD, pb.sI);
     };
     // C[r0.., c0..c0+N) -= P[r0.., k0..k0+K) P[c0..c0+N, k0..k0+K)^T for the M rows from r0
     auto update = [&](hipStream_t st, int r0, int c0, int Mr, int N, int k0, int K, int lower, bool *big) -> int {
         return launch_gemm_nt_sub(st, M + (int64_t)r0 * ld + c0, ld, M + (int64_t)r0 * ld + k0, ld,
-                                  M + (int64_t)c0 * ld + k0, ld, Mr, N, K, lower, 0, big, info);
+                                  M + (int64_t)c0 * ld + k0, ld, Mr, N, K, lower, 0, big, info, &gb);
     };
     // groups of four panels (K = 1024 per trailing update: half the C tile traffic and tile boundaries of K = 512) pay
     // from n ~ 14000 on (measured, profiles/r02_run13_group_by_size.txt: n = 16384 -2 %, n = 12288 even, n = 8192 +5 %:
     // the chain of a group gets longer while its trailing update shrinks)
-    const int GW = (g_potrf_group_set ? g_potrf_group : (n_pad >= 14336 ? 4 : 2)) * kNB;
+    const int GW = (g_potrf_group ? g_potrf_group : (n_pad >= 14336 ? 4 : 2)) * kNB;
     auto gwidth = [&](int g0) { return (n_pad - g0 < GW) ? (n_pad - g0) : GW; };
     // panels of one group on stream `st`; `side` != nullptr splits every in-group update into the next diagonal block
     // (on st) and the rest (on side); `first_wait` is waited for before the FIRST panel solve (the rest of the update
@@ -2130,10 +1749,9 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         const int r1 = g0 + gw;  // first row/col of the trailing matrix
         if (r1 >= n_pad) break;  // (right-hand-side rows below the last block were solved by its panel)
         const int gw1 = gwidth(r1);
-        // the cross-stream hand-off costs ~2 x 10 us; below ~3k trailing columns RU is shorter than that
-        // (with the diagonal-block-first split the hand-off pays down to the last group: the next diagonal block is
-        //  factored while the rest of this group's update runs)
-        const bool look = (s2 != nullptr) && (n_pad - r1 - gw1 >= 3072 || (s3 != nullptr && g_tail_lookahead));
+        // the cross-stream hand-off costs ~2 x 10 us; below ~3k trailing columns RU is shorter than that (and with
+        // several fits in flight the extra hand-offs cost more than they hide: profiles/r02_run23_tail_lookahead_ab.txt)
+        const bool look = (s2 != nullptr) && (n_pad - r1 - gw1 >= g_look_min_cols);
         const int nb1 = gw1 < kNB ? gw1 : kNB;
         if (look && s3) {
             // LUd: the next group's first diagonal block; its chain may start.  LUr: the rest of the next group's columns.
@@ -2170,7 +1788,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             if (timed && big) {
                 EGX_HIP_CHECK(hipEventRecord(trace->e1[trace->used], s));
                 const double nc = (double)(n_pad - r2);
-                trace->flops[trace->used] = 2.0 * gw * nc * (nc + 1.0) / 2.0;
+                trace->flops[trace->used] = (double)nz * 2.0 * gw * nc * (nc + 1.0) / 2.0;
                 trace->used++;
             }
         }
@@ -2181,11 +1799,9 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             if (rc) return rc;
         }
     }
-    if (g_potf2_reg)  // every stream has been joined into `s`: the 64x64 tile inverses of the complete factor, one launch
-        hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64), dim3(256), 0, s, (const double *)M, ld, dinv,
-                           dinv + (int64_t)(n_pad / 64) * 4096);
-    else  // round 1's kernels leave no flags: no refinement in the solves that follow
-        EGX_HIP_CHECK(hipMemsetAsync(dinv + (int64_t)(n_pad / 64) * 4096, 0, sizeof(double) * (size_t)(n_pad / 64), s));
+    // every stream has been joined into `s`: the 64x64 tile inverses of the complete factor(s), one launch
+    hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64, 1, nz), dim3(256), 0, s, (const double *)M, ld, dinv,
+                       dinv + (int64_t)(n_pad / 64) * 4096, pb.sM, pb.sD);
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }
@@ -2200,7 +1816,7 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
     }
     // same two-level blocking as launch_potrf: block forward substitution inside a group of panels, then ONE update
     // of the remaining columns per group (K = group width)
-    const int GW = g_potrf_group * kNB;
+    const int GW = (g_potrf_group ? g_potrf_group : 2) * kNB;
     for (int g0 = 0; g0 < n_pad; g0 += GW) {
         const int gw = (n_pad - g0 < GW) ? (n_pad - g0) : GW;
         const int gend = g0 + gw;
@@ -2213,7 +1829,7 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
             const int m_eff = tri_rows ? ((k0 + nbk < m) ? (k0 + nbk) : m) : m;
             hipLaunchKernelGGL(k_panel_trsm, dim3(m_eff / 64), dim3(256), PanelShape::LDS_BYTES, s, RT + k0, ldr, diag,
                                ldm, dtiles, nbk, (const int *)nullptr,
-                               (const double *)(g_trsm_refine ? dinv + (int64_t)(n_pad / 64) * 4096 + k0 / 64 : nullptr));
+                               (const double *)(dinv + (int64_t)(n_pad / 64) * 4096 + k0 / 64));
             const int ncols = gend - (k0 + nbk);
             if (ncols > 0) {
                 rc = launch_gemm_nt_sub(s, RT + (k0 + nbk), ldr, RT + k0, ldr, M + (int64_t)(k0 + nbk) * ldm + k0, ldm,
@@ -2234,7 +1850,8 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
 }
 
 int launch_diag_tile_inverses(hipStream_t s, const double *M, int64_t ld, int n_pad, double *dinv) {
-    hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64), dim3(256), 0, s, M, ld, dinv, dinv + (int64_t)(n_pad / 64) * 4096);
+    hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64), dim3(256), 0, s, M, ld, dinv, dinv + (int64_t)(n_pad / 64) * 4096,
+                       (int64_t)0, (int64_t)0);
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }

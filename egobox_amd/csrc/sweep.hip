@@ -98,7 +98,7 @@ struct egx_sweep {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     // staging of the all-gather, allocated once: kChunk doubles per rank
-    static constexpr int64_t kChunk = 8192;
+    static constexpr int64_t kChunk = 262144;  // 2 MiB per rank: a 100 000-point mean + variance pair goes in one piece
     double *d_send = nullptr, *d_recv = nullptr;
     double *h_send = nullptr, *h_recv = nullptr;  // pinned
     std::mutex mu;
@@ -476,6 +476,190 @@ int32_t egx_sweep_allgather(egx_sweep *sw, const double *send, int64_t count, do
         return dev_rc;
     }
     return rc;
+}
+
+// ---- mixture-of-experts recombination (BASELINE config 5: one expert per GPU) -----------------------
+// GpMixture::predict_smooth / predict_var_smooth (crates/moe/src/algorithm.rs:411-423, 670-685): val = sum_e p_e y_e,
+// var = sum_e p_e^2 v_e over ALL points; predict_hard / predict_var_hard (:879-935): every point is answered by the expert
+// of its cluster, argmax_e p_e.  The reference calls the expert once per ROW in hard mode (a full n^2 triangular solve per
+// point for the variance); here the points are routed once and every expert gets ONE batched call on its subset.
+// Multi-rank: every rank owns some of the experts, forms the partial sums of its own and ONE all-gather of the partial
+// (val, var) vectors + a sum in rank order (the same bits on every rank) replaces the reference's fold over experts.
+int32_t egx_moe_predict_valvar(egx_sweep *sw, egx_gp *const *experts, const int32_t *expert_ids, int64_t n_local,
+                               int64_t n_experts, const double *probas, const double *xq, int64_t m, int64_t d,
+                               int32_t smooth, double *val, double *var) {
+    if (n_local < 0 || n_experts < 1 || m < 0 || d < 1 || (m > 0 && (!probas || !xq)) || (n_local > 0 && (!experts || !expert_ids)) ||
+        (!val && !var)) {
+        set_error("egx_moe_predict_valvar: bad arguments");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (!sw && n_local != n_experts) {
+        set_error("egx_moe_predict_valvar: without a sweep handle (single process) every expert must be local");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (m == 0) return EGX_SUCCESS;
+    // ---- local part: failures are carried into the collective (a rank that left early would hang the others)
+    int local_rc = EGX_SUCCESS;
+    std::string local_msg;
+    std::vector<double> part((size_t)2 * m + 1, 0.0);  // [status | val (m) | var (m)]
+    double *pv = part.data() + 1, *pw = pv + m;
+    for (int64_t e = 0; e < n_local && !local_rc; e++)
+        if (!experts[e] || expert_ids[e] < 0 || expert_ids[e] >= n_experts) {
+            local_msg = "egx_moe_predict_valvar: NULL expert handle or expert id out of range";
+            local_rc = EGX_ERR_INVALID_VALUE;
+        }
+    std::vector<int32_t> cluster;
+    if (!smooth && !local_rc) {  // gmx.predict: first maximum of the responsibilities (ndarray / numpy argmax)
+        cluster.resize(m);
+        for (int64_t a = 0; a < m; a++) {
+            const double *pa = probas + a * n_experts;
+            int32_t best = 0;
+            for (int32_t j = 1; j < n_experts; j++)
+                if (pa[j] > pa[best]) best = j;
+            cluster[a] = best;
+        }
+    }
+    if (!local_rc) {
+        // experts of one rank: up to two in flight (each handle has its own streams: one's launch gaps hide in the other)
+        std::atomic<int64_t> next{0};
+        std::mutex acc_mu;
+        auto worker = [&]() {
+            std::vector<double> xs, ys, vs;
+            std::vector<int64_t> idx;
+            for (;;) {
+                const int64_t e = next.fetch_add(1);
+                if (e >= n_local) return;
+                {
+                    std::lock_guard<std::mutex> l(acc_mu);
+                    if (local_rc) return;
+                }
+                const int32_t g = expert_ids[e];
+                const double *xin = xq;
+                int64_t me = m;
+                if (!smooth) {
+                    idx.clear();
+                    for (int64_t a = 0; a < m; a++)
+                        if (cluster[a] == g) idx.push_back(a);
+                    me = (int64_t)idx.size();
+                    if (me == 0) continue;
+                    xs.resize((size_t)me * d);
+                    for (int64_t i = 0; i < me; i++) std::memcpy(&xs[(size_t)i * d], xq + idx[i] * d, sizeof(double) * d);
+                    xin = xs.data();
+                }
+                ys.resize(me);
+                vs.resize(me);
+                int rc;
+                if (val && var) rc = egx_gp_predict_valvar(experts[e], xin, me, ys.data(), vs.data());
+                else if (val) rc = egx_gp_predict(experts[e], xin, me, ys.data());
+                else rc = egx_gp_predict_var(experts[e], xin, me, vs.data());
+                std::lock_guard<std::mutex> l(acc_mu);
+                if (rc) {
+                    if (!local_rc) {
+                        local_rc = rc;
+                        local_msg = last_error_string();
+                    }
+                    return;
+                }
+                if (smooth) {
+                    for (int64_t a = 0; a < m; a++) {
+                        const double p = probas[a * n_experts + g];
+                        if (val) pv[a] += p * ys[a];
+                        if (var) pw[a] += p * p * vs[a];
+                    }
+                } else {
+                    for (int64_t i = 0; i < me; i++) {
+                        if (val) pv[idx[i]] = ys[i];
+                        if (var) pw[idx[i]] = vs[i];
+                    }
+                }
+            }
+        };
+        // (the accumulation of the smooth sums is ordered by completion, not by expert: addition of <= n_local terms per
+        //  point in a run-dependent order would not be reproducible to the bit -- so with two workers each owns its own
+        //  partial vectors and they are added in worker order below)
+        if (n_local > 1 && smooth) {
+            std::vector<double> part2((size_t)2 * m, 0.0);
+            double *pv0 = pv, *pw0 = pw;
+            // worker A takes the even local experts into part, worker B the odd ones into part2
+            auto fixed_worker = [&](int64_t first, double *tv, double *tw) {
+                std::vector<double> ys(m), vs(m);
+                for (int64_t e = first; e < n_local; e += 2) {
+                    {
+                        std::lock_guard<std::mutex> l(acc_mu);
+                        if (local_rc) return;
+                    }
+                    int rc;
+                    if (val && var) rc = egx_gp_predict_valvar(experts[e], xq, m, ys.data(), vs.data());
+                    else if (val) rc = egx_gp_predict(experts[e], xq, m, ys.data());
+                    else rc = egx_gp_predict_var(experts[e], xq, m, vs.data());
+                    if (rc) {
+                        std::lock_guard<std::mutex> l(acc_mu);
+                        if (!local_rc) {
+                            local_rc = rc;
+                            local_msg = last_error_string();
+                        }
+                        return;
+                    }
+                    const int32_t g = expert_ids[e];
+                    for (int64_t a = 0; a < m; a++) {
+                        const double p = probas[a * n_experts + g];
+                        if (val) tv[a] += p * ys[a];
+                        if (var) tw[a] += p * p * vs[a];
+                    }
+                }
+            };
+            std::thread tb(fixed_worker, (int64_t)1, part2.data(), part2.data() + m);
+            fixed_worker(0, pv0, pw0);
+            tb.join();
+            for (int64_t a = 0; a < m; a++) {
+                pv0[a] += part2[a];
+                pw0[a] += part2[(size_t)m + a];
+            }
+        } else if (n_local > 1) {
+            std::thread tb(worker);  // hard: disjoint subsets, no sums: completion order does not matter
+            worker();
+            tb.join();
+        } else {
+            worker();
+        }
+    }
+    part[0] = local_rc ? -(double)(kSweepPoison + local_rc) : 0.0;
+    // ---- the collective (multi-rank) and the sum over ranks, in rank order
+    const int world = sw ? sw->world : 1;
+    std::vector<double> all;
+    const double *src = part.data();
+    if (sw) {
+        std::lock_guard<std::mutex> lock(sw->mu);
+        all.resize(part.size() * (size_t)world);
+        (void)set_device(sw->gp);
+        const int coll_rc = sweep_allgather_doubles(sw, part.data(), (int64_t)part.size(), all.data());
+        if (coll_rc) {
+            if (local_rc) set_error(local_msg + " (and the collective failed: " + last_error_string() + ")");
+            return local_rc ? local_rc : coll_rc;
+        }
+        src = all.data();
+    }
+    if (local_rc) {
+        set_error(local_msg);
+        return local_rc;
+    }
+    for (int r = 0; r < world; r++)
+        if (src[(size_t)r * part.size()] != 0.0) {
+            set_error("egx_moe_predict_valvar: rank " + std::to_string(r) + " failed with egx_rc " +
+                      std::to_string((int)(-src[(size_t)r * part.size()]) - kSweepPoison));
+            return EGX_ERR_PEER;
+        }
+    for (int64_t a = 0; a < m; a++) {
+        double sv = 0.0, sw2 = 0.0;
+        for (int r = 0; r < world; r++) {
+            const double *pr = src + (size_t)r * part.size() + 1;
+            sv += pr[a];
+            sw2 += pr[m + a];
+        }
+        if (val) val[a] = sv;
+        if (var) var[a] = sw2;
+    }
+    return EGX_SUCCESS;
 }
 
 }  // extern "C"

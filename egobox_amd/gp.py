@@ -188,6 +188,12 @@ class GpHandle:
         self.close()
 
     # -- likelihood
+    def set_lockstep(self, width):
+        """Candidates of `likelihood_batch` factored in lock-step by one launch sequence (egx_gp_set_lockstep);
+        0 = the library's default, 1 = one stream set per candidate."""
+        L.check(self._lib.egx_gp_set_lockstep(self._h, int(width)))
+        return self._lib.egx_gp_get_lockstep(self._h)
+
     def likelihood(self, theta):
         theta = L.as_f64(np.atleast_1d(theta), 1)
         lk, st = C.c_double(), C.c_int32()
@@ -393,6 +399,18 @@ def mfma_probe():
     e = C.c_double()
     L.check(L.load().egx_mfma_probe(C.byref(e)))
     return e.value
+
+
+def trim():
+    """Free the device resources destroyed handles left in the library's pool (egx_trim); returns the bytes freed."""
+    return int(L.load().egx_trim())
+
+
+def pool_stats():
+    """(cached bytes, hits, misses) of the resource pool behind egx_gp_create / egx_gp_destroy."""
+    b, h, m = C.c_int64(), C.c_int64(), C.c_int64()
+    L.load().egx_pool_stats(C.byref(b), C.byref(h), C.byref(m))
+    return {"cached_bytes": b.value, "hits": h.value, "misses": m.value}
 
 
 # ---- builder (crates/gp/src/parameters.rs:93-313) ---------------------------------------------------

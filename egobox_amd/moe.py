@@ -94,8 +94,11 @@ class GaussianMixture:
 class GpMixture:
     """Experts + mixture, predict side only.  `experts[i]` is None for experts that live on another rank."""
 
-    def __init__(self, experts, gmx, recombination="hard", rank=0, world=1, device=None):
+    def __init__(self, experts, gmx, recombination="hard", rank=0, world=1, device=None, sweep=None):
+        """`sweep`: the rank's `egobox_amd.Sweep` (its RCCL communicator carries the recombination's one all-gather
+        inside the library, egx_moe_predict_valvar); without it a multi-rank mixture reduces through torch.distributed."""
         self.experts, self.gmx = list(experts), gmx
+        self.sweep = sweep
         self.recombination = recombination.lower()
         if self.recombination not in ("hard", "smooth"):
             raise ValueError("recombination must be 'hard' or 'smooth'")
@@ -119,9 +122,46 @@ class GpMixture:
         out = t.cpu().numpy()
         return tuple(out[i] for i in range(len(arrays)))
 
+    def _library_handles(self):
+        """The egx_gp* of this rank's experts when ALL of them are GPU handles (and the collective, if any, is the
+        library's): then the recombination runs inside libegx_gp_hip.so (egx_moe_predict_valvar)."""
+        if self.world > 1 and self.sweep is None:
+            return None
+        ids, hs = [], []
+        for i, e in enumerate(self.experts):
+            if not self._mine(i):
+                continue
+            h = getattr(getattr(e, "_h", None), "_h", None)
+            if h is None or not h:
+                return None
+            ids.append(i)
+            hs.append(h)
+        return ids, hs
+
+    def _predict_valvar_library(self, x, lib_handles, want_val, want_var):
+        import ctypes as C
+        from . import _lib as L
+        lib = L.load()
+        ids, hs = lib_handles
+        m, d = x.shape
+        k = len(self.experts)
+        probas = np.ascontiguousarray(self.gmx.predict_probas(x), dtype=np.float64)
+        harr = (C.c_void_p * max(1, len(hs)))(*[h.value if hasattr(h, "value") else h for h in hs])
+        iarr = np.asarray(ids, dtype=np.int32)
+        val = np.empty(m) if want_val else None
+        var = np.empty(m) if want_var else None
+        L.check(lib.egx_moe_predict_valvar(self.sweep._h if self.sweep is not None else None, harr,
+                                           iarr.ctypes.data_as(L.c_int32_p), len(hs), k, L.dptr(probas), L.dptr(x), m, d,
+                                           1 if self.recombination == "smooth" else 0,
+                                           L.dptr(val) if want_val else None, L.dptr(var) if want_var else None))
+        return (val if want_val else np.zeros(m)), (var if want_var else np.zeros(m))
+
     def predict_valvar(self, x, want_val=True, want_var=True):
-        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        x = np.ascontiguousarray(np.atleast_2d(np.asarray(x, dtype=np.float64)))
         m = x.shape[0]
+        lib_handles = self._library_handles()
+        if lib_handles is not None and m > 0:
+            return self._predict_valvar_library(x, lib_handles, want_val, want_var)
         val, var = np.zeros(m), np.zeros(m)
         smooth = self.recombination == "smooth"
         if smooth:

@@ -118,6 +118,12 @@ class Sweep:
                                                st.ctypes.data_as(L.c_int32_p)))
         return lk, st
 
+    def set_lockstep(self, width):
+        """Lock-step width of this rank's likelihood batches (egx_gp_set_lockstep on the sweep's handle)."""
+        h = self._lib.egx_sweep_handle(self._h)
+        self._L.check(self._lib.egx_gp_set_lockstep(h, int(width)))
+        return self._lib.egx_gp_get_lockstep(h)
+
     def set_assignment(self, dynamic):
         """0 / False: candidate c -> rank c mod world (default); 1 / True: ranks pull candidates from a node-wide counter
         as their workspaces free up.  Every rank must select the same mode."""

@@ -94,6 +94,14 @@ int32_t egx_abi_version(void);
 const char *egx_last_error(void); /* thread-local, never NULL */
 int32_t egx_device_count(void);   /* number of visible HIP devices (0 when none) */
 void egx_gp_config_default(egx_gp_config *cfg);
+/* Destroyed handles leave their device resources (the correlation-matrix workspaces with their streams and pinned
+ * buffers, the training-set buffers) in a per-process pool keyed by the handle's shape (device, padded n, d, trend
+ * columns, workspaces): the reference creates a new model per fit (GpValidParams::fit is one-shot, algorithm.rs:785-794;
+ * egobox-moe trains one per expert, crates/moe/src/algorithm.rs:167-177), and the next egx_gp_create of that shape
+ * starts warm instead of paying a multi-GiB allocation and a first factorisation on untouched memory.  Bounded by
+ * EGX_POOL_MAX_GB (environment, default 48, 0 = no pool).  egx_trim frees everything cached and returns the bytes. */
+int64_t egx_trim(void);
+void egx_pool_stats(int64_t *cached_bytes, int64_t *hits, int64_t *misses);
 
 /* ---- host-side helpers (no device needed) -------------------------------- */
 /* utils.rs:45-54 normalize(): column mean, sample std (ddof=1), zero std -> 1. */
@@ -129,6 +137,14 @@ int32_t egx_gp_likelihood(egx_gp *gp, const double *theta, int64_t theta_len, do
  * workspace 0 (and stays fitted) when n_workspaces > 1. */
 int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len,
                                 double *lkh /*k*/, int32_t *status /*k*/);
+/* Width of the LOCK-STEP groups of egx_gp_likelihood_batch / egx_sweep_likelihood: that many candidates (consecutive
+ * workspaces) are factored by ONE launch sequence -- the candidates of a sweep have the same n, hence the same
+ * schedule; the serial chain of the factorisation then costs its latency once per group and every launch has `width`
+ * times the tiles.  1 = every candidate on its own stream set (round 2's pipeline); 0 = the default
+ * (min(n_workspaces, 4), or the EGX_LOCKSTEP environment variable); at most n_workspaces.  A candidate's result does
+ * not depend on the width or on its companions (same kernels, same arithmetic: bit-identical). */
+int32_t egx_gp_set_lockstep(egx_gp *gp, int32_t width);
+int32_t egx_gp_get_lockstep(const egx_gp *gp);
 /* NEW capability (the reference has no theta-gradient, algorithm.rs:880):
  * dL/dtheta (length h); validated by finite differences of the parity-checked likelihood.
  * Runs on workspace 0 (it needs the factor, C^-T and R^-1 at this theta): a fitted model is un-fitted by the call. */
@@ -270,6 +286,22 @@ int32_t egx_sweep_last_balance(const egx_sweep *sw, int64_t *per_rank /*world*/,
  * concatenation over ranks of send (count), e.g. per-expert mean / variance vectors before the recombination of
  * crates/moe/src/algorithm.rs:670-685. */
 int32_t egx_sweep_allgather(egx_sweep *sw, const double *send, int64_t count, double *recv /*world*count*/);
+
+/* ---- mixture-of-experts recombination (BASELINE config 5) ----------------------------------
+ * GpMixture::predict_smooth / predict_var_smooth (crates/moe/src/algorithm.rs:411-423, 670-685):
+ *     val = sum_e p_e y_e,  var = sum_e p_e^2 v_e        over all m points, every expert sees every point;
+ * GpMixture::predict_hard / predict_var_hard (:879-935): a point is answered by the expert of its cluster,
+ * argmax_e p_e (first maximum) -- routed once, ONE batched call per expert (the reference calls the expert per row).
+ * `experts` are this process' fitted handles, expert_ids[e] in [0, n_experts) their columns in `probas`
+ * (m x n_experts row-major: the responsibilities GaussianMixture::predict_probas returns, gaussian_mixture.rs:114-121).
+ * xq is (m x d) in ORIGINAL units.  val / var (m): either may be NULL.
+ * sw == NULL: single process, every expert is local.  sw != NULL: COLLECTIVE -- every rank passes the same probas /
+ * xq and ITS OWN experts (expert e on rank e mod world in config 5; a rank may own none); the partial sums are exchanged
+ * by one all-gather on the sweep's communicator and added in rank order, so every rank returns the same bits.  Failure
+ * safety as for egx_sweep_likelihood (a failing rank still arrives, the others return EGX_ERR_PEER). */
+int32_t egx_moe_predict_valvar(egx_sweep *sw, egx_gp *const *experts, const int32_t *expert_ids, int64_t n_local,
+                               int64_t n_experts, const double *probas /*m*n_experts*/, const double *xq /*m*d*/,
+                               int64_t m, int64_t d, int32_t smooth, double *val /*m*/, double *var /*m*/);
 
 /* ---- measurement ------------------------------------------------------------
  * HIP-event durations (ms) of the stages of the most recent likelihood /

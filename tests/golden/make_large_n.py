@@ -13,6 +13,8 @@ tests/test_oracle_golden.py) needs ~100 s per likelihood at n = 16384 on 8 cores
                           (row 0, the first 13 LHS rows, the 14 rows with the smallest sum theta^2) and 3
                           extra lower-bound rows that exercise the not-positive-definite status
   expert_n8192_d16        config 5: one expert (seed 7) with 1000 predict / predict_var points
+  experts_1_to_7_n8192_d16  config 5: the other seven experts (seeds 8..14) on the first 100 query points, and the
+                          smooth / hard mixture of all eight oracle experts on those points (--only experts)
 
 Inputs are regenerated in the tests from the same seeds (oracle.lhs_classic / griewank ==
 egobox_amd.workload), so only thetas, scalars and the prediction vectors are stored.
@@ -140,6 +142,50 @@ def part_expert(out):
     print(f"expert: lkh {gp.likelihood!r} ({time.time() - t0:.0f}s)", flush=True)
 
 
+def part_experts(out):
+    """config 5, experts 1..7 (seeds 8..14) on the first 100 query points, and the mixture (smooth / hard recombination,
+    crates/moe/src/algorithm.rs:670-685, 894-910) of all eight ORACLE experts on those points, with the responsibilities
+    of oracle/moe_oracle.py (weights / means / covariances drawn as in tests/test_gpu_configs.py, seed 5)."""
+    from oracle import moe_oracle as MO
+    n, d, k, mq = 8192, 16, 8, 100
+    theta = np.full(d, 0.5 / math.sqrt(d))
+    xq = queries(100000, d, 7)[:mq]
+    e0 = out["expert_n8192_d16"]
+    per_y, per_v = [np.array(e0["predict"][:mq])], [np.array(e0["predict_var"][:mq])]
+    experts = {}
+    for e in range(1, k):
+        x = O.lhs_classic(n, d, 7 + e)
+        y = O.griewank(x)
+        t0 = time.time()
+        gp = O.fit_fixed(x, y, theta, O.CONSTANT, O.SQEXP)
+        yp, vp = gp.predict(xq), gp.predict_var(xq)
+        experts[str(e)] = {"seed": 7 + e, "likelihood": gp.likelihood, "sigma2": gp.inner.sigma2,
+                           "min_pivot": float(np.diag(gp.inner.r_chol).min()), "predict": yp.tolist(),
+                           "predict_var": vp.tolist()}
+        per_y.append(yp)
+        per_v.append(vp)
+        print(f"expert {e}: lkh {gp.likelihood!r} ({time.time() - t0:.0f}s)", flush=True)
+    per_y, per_v = np.array(per_y), np.array(per_v)
+    rng = np.random.default_rng(5)
+    w = rng.random(k) + 0.5
+    w /= w.sum()
+    means = rng.random((k, d))
+    covs = np.array([np.eye(d) * 0.3] * k)
+    gmo = MO.GaussianMixtureOracle(w, means, covs, 0.9)
+    p = gmo.predict_probas(xq)
+    c = gmo.predict(xq)
+    rows = np.arange(mq)
+    out["experts_1_to_7_n8192_d16"] = {
+        "n": n, "d": d, "theta": theta.tolist(), "corr": O.SQEXP, "m": mq,
+        "query": "np.random.default_rng(7).random((100000, 16))[:100]", "experts": experts,
+        "mixture": {"gmm": "rng = default_rng(5); w = rng.random(8) + 0.5; w /= w.sum(); means = rng.random((8, 16)); "
+                           "covs = 0.3 I; heaviside factor 0.9",
+                    "clusters": c.tolist(),
+                    "smooth_predict": (per_y * p.T).sum(axis=0).tolist(),
+                    "smooth_predict_var": (per_v * p.T * p.T).sum(axis=0).tolist(),
+                    "hard_predict": per_y[c, rows].tolist(), "hard_predict_var": per_v[c, rows].tolist()}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -160,6 +206,9 @@ def main():
     want = lambda p: args.only in ("", p)  # noqa: E731
     if want("expert"):
         part_expert(out)
+        save()
+    if args.only == "experts" or (args.only == "" and "experts_1_to_7_n8192_d16" not in out):
+        part_experts(out)
         save()
     if want("grad"):
         part_grad(out)

@@ -142,7 +142,7 @@ def test_config3_theta_gradient_n16384_directional_differences(egx):
 
 
 # ------------------------------------------------------------------ config 4
-def test_config4_sweep_candidates_n16384(egx, large):
+def test_config4_sweep_candidates_n16384(egx, large, arbiter):
     """33 candidates of the theta sweep at size -- 28 rows of theta_sweep_candidates(512, 32) (row 0, the first 13 LHS
     rows, the 14 rows with the smallest sum theta^2) + 5 corner rows -- through likelihood_batch AND the C-ABI sweep
     (egx_sweep_*, one-rank RCCL communicator), against the oracle's likelihoods and statuses:
@@ -168,12 +168,31 @@ def test_config4_sweep_candidates_n16384(egx, large):
     def check(lk, st):
         np.testing.assert_array_equal(st[well], 0)
         np.testing.assert_allclose(lk[well], want_lk[well], rtol=LK_RTOL)
-        np.testing.assert_array_equal(st[bad], 1)
-        assert np.all(np.isneginf(lk[bad]))
+        for i in np.flatnonzero(bad):
+            # all theta = 1e-3 / 1e-4: R = (all ones) - O(1e-5 .. 1e-7) + nugget.  In exact arithmetic it is positive definite
+            # (the arbiter factors it); in double the accumulated rounding of 16384-term dot products is of the size of
+            # the nugget, so whether every pivot stays positive depends on the summation order.  LAPACK (the reference's
+            # answer: an error, i.e. +inf) fails; the HIP path may fail too, or get through -- then its likelihood has to
+            # be near the extended-precision value.
+            assert st[i] in (0, 1)
+            if st[i] == 1:
+                assert np.isneginf(lk[i])
+            else:
+                truth = arbiter.get(f"sweep_extra_n16384_d32_theta_{thetas[i][0]}")
+                assert truth is not None and truth["truth_status"] == 0
+                print(f"theta {thetas[i][0]}: LAPACK not positive definite, HIP {lk[i]!r}, long double {truth['truth_likelihood']!r}")
+                assert lk[i] == pytest.approx(truth["truth_likelihood"], rel=5e-2)
         for i in np.flatnonzero(corner):
+            # all theta = 0.01 / 0.02 / 0.03: cond(R) ~ 1 / nugget, LAPACK gets through with pivots near rounding level.
+            # The extended-precision arbiter says how far LAPACK itself is from the exact value; the HIP path has to be
+            # within 10x of that distance (or 1e-8), or report not positive definite.
             assert st[i] in (0, 1)
             if st[i] == 0:
-                assert lk[i] == pytest.approx(want_lk[i], rel=1e-2)
+                truth = arbiter[f"sweep_extra_n16384_d32_theta_{thetas[i][0]}"]["truth_likelihood"]
+                lap_err = abs(want_lk[i] - truth) / abs(truth)
+                gpu_err = abs(lk[i] - truth) / abs(truth)
+                print(f"corner theta {thetas[i][0]}: long double {truth!r}; LAPACK rel err {lap_err:.2e}, HIP rel err {gpu_err:.2e}")
+                assert gpu_err <= max(LK_RTOL, 10.0 * lap_err)
             else:
                 assert np.isneginf(lk[i])
 

@@ -103,10 +103,10 @@ print("RESULT", out)
 """
 
 
-@pytest.mark.parametrize("variant", ["0", "8", "12", "16"])
-def test_every_variant_of_the_kernel(variant):
-    """EGX_POTF2_REG is read once per process: each variant gets its own."""
-    env = dict(os.environ, EGX_POTF2_REG=variant)
+@pytest.mark.parametrize("group", ["1", "2", "4"])
+def test_every_group_width_of_the_factorisation(group):
+    """EGX_POTRF_GROUP (panels per trailing update) is read once per process: each width gets its own."""
+    env = dict(os.environ, EGX_POTRF_GROUP=group)
     r = subprocess.run([sys.executable, "-c", _VARIANT % ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1]

@@ -232,26 +232,31 @@ def test_ill_conditioned_case_within_oracle_self_consistency(egx, O):
         assert st == egx._lib.STATUS_NOT_POSITIVE_DEFINITE
 
 
-def test_config2_dense_sqexp_n4096_d8(egx, O):
-    """BASELINE configs[1]: n=4096, d=8 squared exponential, theta_j = 0.5/sqrt(d).  The smallest oracle
-    pivot here is ~5e-6 (only ~30x sqrt(nugget)), so the tolerance is the larger of 1e-8 and 20x the
-    oracle's own disagreement with itself under a row permutation."""
+def test_config2_dense_sqexp_n4096_d8(egx, O, arbiter):
+    """BASELINE configs[1] exactly as SURVEY 8d states it: n=4096, d=8 squared exponential, theta_j = 0.5/sqrt(d).
+    The smallest pivot is ~5e-6 (only ~30x sqrt(nugget)): two double-precision evaluations of this likelihood differ
+    by ~1e-6 (LAPACK disagrees with itself under a row permutation), so the judge is the extended-precision ARBITER
+    (oracle/arbiter_ld.c, x87 long double end to end, tests/golden/arbiter.json): the HIP path must be no further from
+    it than 10x LAPACK's own distance (the larger of its two recorded ones), both printed."""
     x, y = _data(4096, 8, seed=42)
     theta = egx.workload.default_theta(8)
+    rec, recp = arbiter["config2_n4096_d8_sqexp"], arbiter["perm_n4096_d8_sqexp"]
+    np.testing.assert_array_equal(theta, np.array(rec["theta"]))
+    truth = rec["truth_likelihood"]
+    assert abs(recp["truth_likelihood"] - truth) / abs(truth) < 1e-8   # the arbiter does not care about the row order
     ref = O.fit_fixed(x, y, theta)
-    minpiv = np.diag(ref.inner.r_chol).min()
-    assert minpiv > 1e-6
-    perm = np.random.default_rng(1).permutation(4096)
-    ref2 = O.fit_fixed(x[perm], y[perm], theta)
-    self_err = abs(ref.likelihood - ref2.likelihood) / abs(ref.likelihood)
-    tol = max(LK_RTOL, 20.0 * self_err)
-    print(f"config2: oracle min pivot {minpiv:.3e}, oracle self-consistency {self_err:.2e}, tolerance {tol:.2e}")
+    lap_err = abs(ref.likelihood - truth) / abs(truth)
+    assert lap_err == pytest.approx(rec["lapack_rel_error"], rel=0.5)  # (what the fixture's generator saw; BLAS build dependent)
+    lap_worst = max(lap_err, rec["lapack_rel_error"], recp["lapack_rel_error"])
     with egx.GpHandle(x, y) as h:
         h.finalize(theta)
         lk, s2 = h.fitted_scalars()
-        print(f"config2: gpu {lk!r} oracle {ref.likelihood!r} rel {abs(lk - ref.likelihood) / abs(ref.likelihood):.2e}")
-        assert lk == pytest.approx(ref.likelihood, rel=tol)
-        assert s2 == pytest.approx(ref.inner.sigma2, rel=max(1e-7, 100 * tol))
+        gpu_err = abs(lk - truth) / abs(truth)
+        print(f"config2 at theta = 0.5/sqrt(d): long double {truth!r}; LAPACK {ref.likelihood!r} rel err {lap_err:.2e} "
+              f"(permuted rows {recp['lapack_rel_error']:.2e}); HIP {lk!r} rel err {gpu_err:.2e}")
+        assert gpu_err <= max(LK_RTOL, 10.0 * lap_worst)
+        tol = max(LK_RTOL, 10.0 * lap_worst)
+        assert s2 == pytest.approx(rec["truth_sigma2"], rel=max(1e-7, 100 * tol))
         xq = np.random.default_rng(3).random((1000, 8))
         yr, vr = ref.predict(xq), ref.predict_var(xq)
         np.testing.assert_allclose(h.predict(xq), yr, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(yr).max())
@@ -336,6 +341,80 @@ def test_batch_equals_single_and_uses_workspaces(egx):
             assert st == stb[i]
             if st == 0:
                 assert lk == lkb[i]  # same kernels, same order: bit identical
+
+
+@pytest.mark.parametrize("n,d,mean,corr", [(700, 6, 0, 0), (2100, 5, 1, 3), (4200, 8, 0, 0)])
+def test_lockstep_groups_are_bit_identical_to_single_candidates(egx, n, d, mean, corr):
+    """Round 3: the candidates of a batch are factored in LOCK-STEP groups by one launch sequence (grid.z = candidate).
+    A candidate must get the bits it gets alone -- whatever the group width, its slot in the group, a ragged last
+    group, a NaN theta or a not-positive-definite companion next to it (n = 4200 crosses the look-ahead and the
+    stream-kernel thresholds, the linear mean takes the device GLS route)."""
+    x, y = _data(n, d, seed=11)
+    k = 7 if n > 3000 else 11
+    thetas = egx.theta_sweep_candidates(k, d, seed=5)
+    thetas[3] = np.nan                      # answered at once, takes no slot
+    thetas[5] = 1e-3 if corr == 0 else thetas[5]   # sq-exp with tiny theta: R ~ all ones, not positive definite
+    with egx.GpHandle(x, y, mean=mean, corr=corr, n_workspaces=6) as h:
+        h.set_lockstep(1)
+        ref_lk, ref_st = h.likelihood_batch(thetas)
+        assert ref_st[3] == egx._lib.STATUS_NAN_THETA
+        for width in (2, 3, 4, 6):
+            assert h.set_lockstep(width) == width
+            lk, st = h.likelihood_batch(thetas)
+            np.testing.assert_array_equal(st, ref_st)
+            ok = st == 0
+            assert ok.sum() >= 3
+            np.testing.assert_array_equal(lk[ok], ref_lk[ok])   # bit identical
+        assert h.set_lockstep(0) == 4        # the default: min(n_workspaces, 4)
+        # a fit keeps workspace 0; the batch then uses slots of the remaining five
+        h.finalize(thetas[0])
+        lk, st = h.likelihood_batch(thetas)
+        np.testing.assert_array_equal(lk[st == 0], ref_lk[ref_st == 0])
+        assert h.fitted_scalars()[0] == ref_lk[0]
+
+
+def test_one_shot_fits_are_warm_fits_and_the_pool_is_bounded(egx):
+    """The reference creates a model per fit (algorithm.rs:785-794; one per expert in egobox-moe).  Destroyed handles
+    leave their device resources in the library's pool: 20 create -> fit -> destroy cycles on DIFFERENT data of one
+    shape must (a) hit the pool from the second cycle on, (b) cost at most 1.2x a fit on a resident handle plus the
+    upload, (c) not grow device memory, (d) give the results a fresh process gives; egx_trim returns the memory."""
+    import time
+    import torch
+    n, d = 4096, 8
+    theta = egx.workload.default_theta(d) * 4.0
+    egx.trim()
+    free0 = torch.cuda.mem_get_info()[0]
+    x0, y0 = _data(n, d, seed=100)
+    with egx.GpHandle(x0, y0) as h:           # resident handle: the yardstick
+        h.finalize(theta)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            h.finalize(theta)
+        resident = (time.perf_counter() - t0) / 5
+        ref_lk = h.fitted_scalars()[0]
+    stats0 = egx.pool_stats()
+    assert stats0["cached_bytes"] > 0
+    cycle, used = [], []
+    for c in range(20):
+        x, y = _data(n, d, seed=100 + c % 3)
+        t0 = time.perf_counter()
+        h = egx.GpHandle(x, y)
+        h.finalize(theta)
+        lk = h.fitted_scalars()[0]
+        h.close()
+        cycle.append(time.perf_counter() - t0)
+        used.append(free0 - torch.cuda.mem_get_info()[0])
+        if c % 3 == 0:
+            assert lk == ref_lk               # same data, same bits, whatever the workspace held before
+    stats = egx.pool_stats()
+    assert stats["hits"] - stats0["hits"] == 20 and stats["misses"] == stats0["misses"]
+    print(f"resident fit {resident * 1e3:.2f} ms, create+fit+destroy cycles {np.median(cycle) * 1e3:.2f} ms (median), "
+          f"{max(cycle) * 1e3:.2f} ms (max)")
+    assert np.median(cycle) <= 1.2 * resident + 2e-3   # + normalisation, the k-major copies and two uploads on the host
+    assert max(used) - min(used) < 64 << 20            # no growth
+    freed = egx.trim()
+    assert freed >= stats["cached_bytes"] > 0 and egx.pool_stats()["cached_bytes"] == 0
+    assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20
 
 
 def test_concurrent_likelihood_calls_on_one_handle(egx):
@@ -899,10 +978,12 @@ def test_no_device_memory_leak_over_handle_lifecycles(egx, O):
             s.predict_var(x[:10])
 
     cycle()
+    egx.trim()  # (destroyed handles park their device resources in the library's pool: compare with it emptied)
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info()
     for _ in range(25):
         cycle()
+    egx.trim()
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert abs(free0 - free1) < 64 << 20, (free0, free1)

@@ -254,3 +254,54 @@ def test_jacobian_with_kpls_weights_matches_finite_differences():
             dx[k] = 1e-6
             fd = (O.corr_value(kind, (x + dx)[None, :] - xt, theta, w) - O.corr_value(kind, (x - dx)[None, :] - xt, theta, w)) / 2e-6
             np.testing.assert_allclose(jac[:, k], fd[:, 0], rtol=1e-6, atol=1e-9)
+
+
+# ---------------------------------------------------------------- the extended-precision arbiter (oracle/arbiter_ld.c)
+@pytest.fixture(scope="module")
+def ARB():
+    import subprocess
+    from oracle import arbiter
+    if not arbiter.available():
+        subprocess.run(["make", "-C", os.path.dirname(arbiter.__file__)], check=True)
+    return arbiter
+
+
+def test_arbiter_reproduces_golden_a(golden_dir, ARB):
+    """The long double evaluation hits the reference's own notebook likelihood (Constant + sq-exp, 5 points)."""
+    g = _load(golden_dir, "golden_a.json")
+    r = ARB.likelihood(np.array(g["xt"]), np.array(g["yt"]), [g["theta_printed_8_digits"]], corr=O.SQEXP)
+    assert r["status"] == 0
+    assert r["likelihood"] == pytest.approx(g["likelihood"], abs=1e-12)
+    assert r["sigma2"] == pytest.approx(g["variance"], rel=1e-8)
+
+
+@pytest.mark.parametrize("kind", [O.SQEXP, O.ABSEXP, O.MATERN32, O.MATERN52])
+def test_arbiter_agrees_with_numpy_oracle_where_the_problem_is_well_posed(ARB, kind):
+    rng = np.random.default_rng(17)
+    x = rng.random((300, 3))
+    y = np.sin(3 * x[:, 0]) + x[:, 1] ** 2 - 0.5 * x[:, 2]
+    theta = np.array([1.5, 2.0, 1.0])
+    ref = O.fit_fixed(x, y, theta, mean=O.CONSTANT, corr=kind)
+    r = ARB.likelihood(x, y, theta, corr=kind)
+    assert r["status"] == 0
+    assert r["likelihood"] == pytest.approx(ref.likelihood, rel=1e-11)
+    assert r["sigma2"] == pytest.approx(ref.inner.sigma2, rel=1e-10)
+    assert r["min_pivot"] == pytest.approx(np.diag(ref.inner.r_chol).min(), rel=1e-9)
+
+
+def test_arbiter_fixture_is_what_the_arbiter_computes(golden_dir, ARB):
+    """tests/golden/arbiter.json was generated by this code: the control case reproduces bit for bit (the arithmetic is
+    x87 long double in a fixed order per row -- OpenMP only splits rows), and on it LAPACK and the arbiter agree; the
+    recorded LAPACK errors of the ill-posed cases are what this container's numpy gives, to within the BLAS build."""
+    fx = _load(golden_dir, "arbiter.json")
+    c = fx["control_n2048_d8_matern52"]
+    x = O.lhs_classic(c["n"], c["d"], c["seed"])
+    y = O.griewank(x)
+    r = ARB.likelihood(x, y, np.array(c["theta"]), corr=c["corr"])
+    assert r["status"] == 0 and r["likelihood"] == c["truth_likelihood"]
+    assert c["lapack_rel_error"] < 1e-10
+    # the ill-posed cases: LAPACK is 1e-9 .. 1e-5 away from the extended-precision value, and not consistently
+    assert 1e-7 < fx["config2_n4096_d8_sqexp"]["lapack_rel_error"] < 1e-4
+    a, b = fx["config2_n4096_d8_sqexp"], fx["perm_n4096_d8_sqexp"]
+    assert abs(a["truth_likelihood"] - b["truth_likelihood"]) / abs(a["truth_likelihood"]) < 1e-8
+    assert abs(a["lapack_likelihood"] - b["lapack_likelihood"]) / abs(a["truth_likelihood"]) > 1e-7
