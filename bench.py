@@ -7,20 +7,23 @@
      127.0.0.1; either way the line is only printed when the world size IS N and the RCCL communicator inside the
      library has N ranks)
 
-One "step" = one pass of the hot path over one batch of `--sweep-batch` (default 24 = 3 in flight on each of 8 GPUs)
-candidate thetas of a theta sweep: every candidate is one fit in north_star's sense --
+One "step" = one pass of the hot path over one batch of `--sweep-batch` (default 96 = three lock-step groups of four on
+each of 8 GPUs) candidate thetas of a theta sweep: every candidate is one fit in north_star's sense --
 correlation-matrix build (K1) + blocked FP64-MFMA Cholesky with fused forward solves (K3/K4) + GLS / reduced
 likelihood, i.e. one evaluation of the objective the reference's COBYLA multiplies
 (crates/gp/src/algorithm.rs:880-897, 988-1056).  The batch is FIXED as N grows (strong scaling): rank r evaluates
 candidates r, r + N, ... through `egx_sweep_likelihood` (include/egx_gp.h), whose RCCL all-gather of the
 (likelihood, status) pairs runs inside libegx_gp_hip.so, inside the timed region, every step -- also at N = 1
-(one-rank communicator), so the measured code path is the same at every N.  The training set is resident in HBM
-before the timed region starts.
+(one-rank communicator), so the measured code path is the same at every N.  On every GPU the candidates are factored
+in LOCK-STEP groups (egx_gp_set_lockstep: one launch sequence per group of 4, grid.z = candidate), three groups in
+flight.  The training set is resident in HBM before the timed region starts.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the Cholesky trailing update, FP64 MFMA
 bound), measured in a separate leg with ONE fit in flight; `cpu_baseline` is the blas-feature-shaped CPU path
-(oracle/cpu_baseline.py: OpenMP correlation build + LAPACK dpotrf, all host cores) MEASURED at the full size in its
-own process on the GPU box's host.
+(oracle/cpu_baseline.py: OpenMP correlation build + LAPACK dpotrf) MEASURED at the full size in its own process on the
+GPU box's host -- one fit at its best thread count (latency mode) -- and `cpu_baseline_concurrent` as many such fits
+side by side as the host holds (throughput mode, the shape of the reference's rayon multistart); the speed-ups are
+labelled by mode.  `other_configs`: bounded side measurements of BASELINE configs 3 and 5 and of d = 64.
 """
 import argparse
 import json
@@ -37,7 +40,9 @@ sys.path.insert(0, ROOT)
 # public MI355X figures (the CDNA4 guide in this image lists no FP64 matrix peak):
 FP64_MFMA_PEAK_TFLOPS = 78.6
 HBM_PEAK_GBPS = 8000.0
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_update_kernel.json")
+PMC_SUMMARY = next((p for p in (os.path.join(ROOT, "profiles", "r03_pmc_update_kernel.json"),
+                                os.path.join(ROOT, "profiles", "r02_pmc_update_kernel.json")) if os.path.exists(p)),
+                   os.path.join(ROOT, "profiles", "r02_pmc_update_kernel.json"))
 
 
 def cpu_baseline(n, d, timeout_s=900):
@@ -51,6 +56,45 @@ def cpu_baseline(n, d, timeout_s=900):
     if out.returncode != 0:
         return {"error": out.stderr[-400:]}
     return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def cpu_baseline_concurrent(n, d, threads_per_fit, timeout_s=900):
+    """The like-for-like CPU figure for a THROUGHPUT number: the reference's multistart is rayon-parallel over starts
+    (crates/gp/src/algorithm.rs:928-945), i.e. several fits side by side, each with a slice of the host's cores.  As
+    many oracle/cpu_baseline.py processes as fit the host at `threads_per_fit` threads each (the setting a single fit
+    is fastest with) start their fit at the same instant; value = processes / (last end - common start)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    procs = max(1, min(16, cores // max(1, threads_per_fit)))
+    start_at = time.time() + 12.0 + 0.25 * procs  # imports + LHS / Griewank generation + normalisation happen before it
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = str(threads_per_fit)
+    env["OPENBLAS_NUM_THREADS"] = str(threads_per_fit)
+    cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--n", str(n), "--d", str(d), "--blas-threads",
+           str(threads_per_fit), "--start-at", repr(start_at)]
+    ps = [subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+          for _ in range(procs)]
+    recs = []
+    for p in ps:
+        try:
+            so, se = p.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            return {"error": "timeout"}
+        if p.returncode != 0:
+            return {"error": se[-300:]}
+        recs.append(json.loads(so.strip().splitlines()[-1]))
+    late = max(r["wall_start"] for r in recs) - start_at
+    wall = max(r["wall_end"] for r in recs) - min(r["wall_start"] for r in recs)
+    return {"value": procs / wall, "unit": "fits/s", "cores": procs * threads_per_fit, "kind": "port",
+            "processes": procs, "threads_per_process": threads_per_fit, "host_threads": cores,
+            "wall_s_all_fits": wall, "fit_s_each": [r["seconds"]["fit"] for r in recs],
+            "start_skew_s": late,
+            "sample": (f"{procs} simultaneous fixed-theta fits at n={n} d={d}, one process each with {threads_per_fit} "
+                       f"OpenMP / OpenBLAS threads ({procs * threads_per_fit} of the host's {cores} hardware threads), common "
+                       f"start: {procs} fits in {wall:.2f} s")}
 
 
 def cpu_baseline_reference_shaped(n_full, d):
@@ -89,6 +133,65 @@ def measured_traffic(n, d):
         p = json.load(f)
     fetch, write, c_read = p["fetch_bytes_per_launch"], p["write_bytes_per_launch"], p["c_read_bytes_per_launch"]
     return write + c_read + 2.0 * max(0.0, fetch - c_read), p
+
+
+def other_configs(egx, workload, gpu):
+    """Bounded side measurements in the SAME driver-run line (never `value`): BASELINE config 3 (Matern-5/2 likelihood
+    and likelihood + theta-gradient at n = 16384, d = 32), config 5 (one expert n = 8192, d = 16: predict / predict_var on
+    100 000 points), and the metric's shape at d = 64 (north_star: "d up to 64").  ~10 s in all."""
+    res = {}
+    n, d = 16384, 32
+    x, y = workload.make_training_set(n, d, seed=42)
+    th = workload.default_theta(d)
+    h = egx.GpHandle(x, y, mean=0, corr=3, device=gpu, n_workspaces=1)
+    h.finalize(th)
+    t0 = time.perf_counter()
+    h.finalize(th * 1.01)
+    t_fit = time.perf_counter() - t0
+    tm = h.timings()
+    t0 = time.perf_counter()
+    lk, g, st = h.likelihood_grad(th)
+    t_grad = time.perf_counter() - t0
+    h.close()
+    res["config3_matern52_n16384_d32"] = {
+        "fixed_theta_fit_ms": t_fit * 1e3, "corr_build_ms": tm["corr_build_ms"],
+        "corr_build_gbps": tm["corr_bytes"] / tm["corr_build_ms"] / 1e6, "potrf_ms": tm["potrf_ms"],
+        "cholesky_tflops": tm["potrf_flops"] / tm["potrf_ms"] / 1e9, "likelihood_plus_theta_gradient_ms": t_grad * 1e3,
+        "gradient_status": int(st), "gradient_norm": float(np.linalg.norm(g))}
+    n5, d5, m5 = 8192, 16, 100000
+    x5, y5 = workload.make_training_set(n5, d5, seed=7)
+    h = egx.GpHandle(x5, y5, mean=0, corr=0, device=gpu, n_workspaces=1)
+    h.finalize(workload.default_theta(d5))
+    xq = np.random.default_rng(7).random((m5, d5))
+    h.predict_valvar(xq[:2000])
+    t0 = time.perf_counter()
+    h.predict(xq)
+    t_p = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    h.predict_var(xq)
+    t_v = time.perf_counter() - t0
+    h.close()
+    res["config5_expert_n8192_d16_m100000"] = {
+        "predict_points_per_s": m5 / t_p, "predict_var_points_per_s": m5 / t_v,
+        "predict_var_trsm_tflops": float(n5) * n5 * m5 / t_v / 1e12,
+        "predict_var_frac_of_fp64_peak": float(n5) * n5 * m5 / t_v / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+    d6 = 64
+    x6, y6 = workload.make_training_set(n, d6, seed=42)
+    h = egx.GpHandle(x6, y6, mean=0, corr=0, device=gpu, n_workspaces=1)
+    th6 = workload.default_theta(d6)
+    h.finalize(th6)
+    ts = []
+    for j in range(2):
+        t0 = time.perf_counter()
+        h.finalize(th6 * (1.0 + 0.01 * j))
+        ts.append(time.perf_counter() - t0)
+    tm = h.timings()
+    h.close()
+    res["metric_shape_d64_n16384_sqexp"] = {"single_fit_in_flight_fits_per_s": 1.0 / float(np.mean(ts)),
+                                            "corr_build_ms": tm["corr_build_ms"],
+                                            "corr_build_gbps": tm["corr_bytes"] / tm["corr_build_ms"] / 1e6,
+                                            "potrf_ms": tm["potrf_ms"]}
+    return res
 
 
 def spawn_ranks(n_ranks):
@@ -157,11 +260,15 @@ def main():
     ap.add_argument("--npoints", dest="n", type=int, default=16384)
     ap.add_argument("--dim", dest="d", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=12,
                     help="candidates in flight per GPU (correlation-matrix workspaces of the sweep handle, 2 GiB each at "
-                         "n = 16384)")
-    ap.add_argument("--sweep-batch", type=int, default=24,
-                    help="candidate thetas per step, summed over ALL GPUs (fixed as N grows: strong scaling)")
+                         "n = 16384): 3 lock-step groups of 4 (measured 36.0 / 37.5 / 39.8 / 40.2 fits/s with 3 / 3 / 8 / 12 in "
+                         "flight and lock-step widths 1 / 3 / 4 / 4, profiles/r03_run1_*, r03_run2_*)")
+    ap.add_argument("--sweep-batch", type=int, default=96,
+                    help="candidate thetas per step, summed over ALL GPUs (fixed as N grows: strong scaling; 96 = 12 per GPU "
+                         "at N = 8, i.e. every GPU still has its three lock-step groups of four)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the bounded side measurements of BASELINE configs 3 / 5 and d = 64 (other_configs in the line)")
     ap.add_argument("--lockstep", type=int, default=0,
                     help="candidates factored in lock-step by one launch sequence (0 = library default: min(in-flight, 4))")
     ap.add_argument("--assignment", choices=("static", "dynamic"), default="static",
@@ -281,6 +388,12 @@ def main():
         ok = stats[args.warmup * nb:] == 0
         out = {
             "metric": "gp_fixed_theta_fits_per_sec", "value": fits / elapsed, "unit": "fits/s",
+            "metric_note": "one fit = correlation build + Cholesky with fused forward solves + GLS + reduced likelihood = one "
+                           "evaluation of the objective the reference's optimiser multiplies (algorithm.rs:880-897, 988-1056), "
+                           "timed through egx_sweep_likelihood; the gamma back-substitution of algorithm.rs:1034 (1 ms, once "
+                           "per tuned fit, for the winner) is in stage_ms_single_fit.gamma_solve and in "
+                           "single_fit_in_flight_fits_per_s / pcie_inclusive, which time egx_gp_finalize; the CPU baselines "
+                           "include it (n^2 flops beside n^3/3)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -307,13 +420,16 @@ def main():
                          "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic,
                          "kernel": "k_gemm_stream<LOWER> (Cholesky trailing update C -= P P^T, 128x256 tiles, once per group "
-                                   "of four 256-wide panels, K = 1024, at this size; the launches with >= 512 tiles, ~80% "
-                                   "of the factorisation's flops)",
+                                   "of four 256-wide panels, K = 1024, at this size; the launches with >= 512 tiles: "
+                                   f"{100.0 * syrk_flops / flops:.0f} % of the factorisation's n^3/3 flops)",
+                         "share_of_potrf_flops": syrk_flops / flops,
                          "launches_per_fit": syrk_launches, "launch_ms_avg": syrk_ms / max(1, syrk_launches),
                          "flops_per_launch_avg": syrk_flops / max(1, syrk_launches),
                          "how": "algorithmic flops (2*K*ncols*(ncols+1)/2 per launch, K = group width) / HIP-event durations around every "
                                 "launch on the stream it is launched on, one fit in flight (separate leg after the timed "
                                 "region; in the timed region the candidates in flight overlap and share the GPU)",
+                         "traffic_measured": "offline: separate rocprofv3 --pmc passes (tools/gpu_pmc_r03.sh), committed under "
+                                             "profiles/ and READ here, not measured by this run",
                          "traffic_source": (None if pmc is None else
                                             {"file": os.path.relpath(PMC_SUMMARY, ROOT),
                                              "fetch_bytes_per_launch_raw": pmc["fetch_bytes_per_launch"],
@@ -360,13 +476,23 @@ def main():
                                      "note": "x, y (4 MiB) cross PCIe once per handle; every further fit on the handle "
                                              "moves (p + 2) n doubles back (0.4 MB); destroyed handles leave their "
                                              "device resources in the library's pool (egx_trim frees it)"}
+        if world == 1 and not args.no_extra_configs:
+            out["other_configs"] = other_configs(egx, workload, gpu)
         if not args.no_cpu_baseline and world == 1:
             torch.cuda.synchronize()
             cb = cpu_baseline(n, d)
             out["cpu_baseline"] = cb
             if "value" in cb:
-                out["speedup_vs_cpu_baseline"] = out["value"] / cb["value"]
-                out["speedup_single_fit_in_flight_vs_cpu_baseline"] = out["single_fit_in_flight_fits_per_s"] / cb["value"]
+                # LATENCY mode against latency mode: one fit in flight on the GPU, one fit on the CPU's best thread count
+                out["speedup_latency_mode_single_fit_vs_cpu_baseline"] = out["single_fit_in_flight_fits_per_s"] / cb["value"]
+                best_threads = min(cb.get("thread_settings_tried", [{"blas_threads": 16, "fit_s": 0}]),
+                                   key=lambda r: r["fit_s"])["blas_threads"]
+                cc = cpu_baseline_concurrent(n, d, int(best_threads) if str(best_threads).isdigit() else 16)
+                out["cpu_baseline_concurrent"] = cc
+                if "value" in cc:
+                    # THROUGHPUT mode against throughput mode: `value` (several candidates in flight) / simultaneous CPU fits
+                    out["speedup_throughput_mode_vs_cpu_baseline_concurrent"] = out["value"] / cc["value"]
+                out["speedup_mixed_modes_value_vs_single_cpu_fit"] = out["value"] / cb["value"]
             rs = cpu_baseline_reference_shaped(n, d)
             if rs is not None:
                 out["cpu_baseline_reference_shaped"] = rs

@@ -37,8 +37,17 @@ struct DevBuf {
     ~DevBuf() {
         if (p) (void)hipFree(p);
     }
+    size_t cap = 0;  // doubles
+    // grow-only: a buffer declared outside a chunk loop is allocated once (a hipMalloc / hipFree pair of a 1 GiB block per
+    // 16 384 query points used to sit inside predict_var's loop)
     int alloc(size_t n_doubles) {
-        EGX_HIP_CHECK(hipMalloc(&p, sizeof(double) * (n_doubles ? n_doubles : 1)));
+        if (n_doubles == 0) n_doubles = 1;
+        if (p && cap >= n_doubles) return EGX_SUCCESS;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        EGX_HIP_CHECK(hipMalloc(&p, sizeof(double) * n_doubles));
+        cap = n_doubles;
         return EGX_SUCCESS;
     }
 };

@@ -77,10 +77,10 @@ int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *
     if (cap > 16384) cap = 16384;
     if (!vout) cap = 65536;
     std::vector<double> f(p), rhs(p), u(p), xn, racc, s0, sl;
+    DevBuf d_xqT, d_racc, d_RT, d_s0, d_sl;  // sized by the first (largest) chunk, reused by the others
     for (int64_t m0 = 0; m0 < m; m0 += cap) {
         const int mc = (int)((m - m0 < cap) ? (m - m0) : cap);
         const int m_pad = (int)round_up(mc, kTile);
-        DevBuf d_xqT, d_racc, d_RT, d_s0, d_sl;
         EGX_RC(upload_queries(gp, xq, m0, mc, m_pad, xn, d_xqT, w.stream));
         // few queries: split the training range so that ~1024 workgroups exist (partial sums added below)
         int msplit = 1;
@@ -335,6 +335,7 @@ int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv) 
     if (cap > 16384) cap = 16384;
     if (!gv) cap = 65536;
     std::vector<double> xn, part, sl, f(p), a_vec(p), u(p), dd(p), dneg, df(d);
+    DevBuf d_xqT, d_out, d_RT, d_s0, d_sl, d_Wt, d_D;  // sized by the first (largest) chunk, reused by the others
     for (int64_t m0 = 0; m0 < m; m0 += cap) {
         const int mc = (int)((m - m0 < cap) ? (m - m0) : cap);
         const int m_pad = (int)round_up(mc, kTile);
@@ -346,7 +347,6 @@ int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv) 
         if (nsplit > slabs) nsplit = slabs;
         const int per = (slabs + nsplit - 1) / nsplit;
         nsplit = (slabs + per - 1) / per;
-        DevBuf d_xqT, d_out, d_RT, d_s0, d_sl, d_Wt, d_D;
         EGX_RC(upload_queries(gp, xq, m0, mc, m_pad, xn, d_xqT, w.stream));
         const size_t out_sz = (size_t)nsplit * m_pad * d;
         EGX_RC(d_out.alloc(out_sz));

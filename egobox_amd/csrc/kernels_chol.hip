@@ -10,8 +10,9 @@
 //                       FP64-MFMA accumulator registers; 16-column strips; the 16x16 diagonal tile by a DPP-broadcast
 //                       pivot chain on one wave, fused with its inverse.
 //   B  k_panel_trsm16 : rows below the block:  X = P * L_kk^-T, one 16-row tile per workgroup, strip by strip with the
-//                       16x16 inverses A left behind (+ one refinement step for ill-conditioned tiles).  k_panel_trsm
-//                       (64-row slabs, explicit 64x64 tile inverses) serves the solves after the factorisation.
+//                       16x16 inverses A left behind (+ one refinement step for ill-conditioned tiles); the solves after
+//                       the factorisation (launch_trsm_rows) use it too, with the 16x16 diagonal blocks of the 64x64 tile
+//                       inverses.
 //   C  k_gemm_stream  : chip-filling trailing updates  C -= P P^T  (lower tiles only) -- the n^3/3 flops -- 128x256
 //      k_gemm_nt_sub    tiles, LDS-DMA ring; smaller launches by the register-staged 128x128 / 64x64 kernel:
 //                       v_mfma_f64_16x16x4_f64, A/B staged through LDS in 16-deep K chunks.
@@ -517,85 +518,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
                 for (int r = 0; r < 4; r++) Ct[(int64_t)mi * 16 * ldc + ni * 16 + coff[r]] = -acc[mi][ni][r];
         EGX_SSTAMP(t, 5, clock64());
         EGX_SSTAMP(t, 1, wall_clock64());
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// B: panel triangular solve  X = P * L^-T  for the 64-row slab of one workgroup.
-//    P: rows of the panel (ldp), columns [0, nbk) ; L: diagonal block (ldl) ; dinv: inverses of the
-//    64x64 diagonal tiles of L (row-major 64x64 each).  Block forward substitution over 64-col tiles.
-// ---------------------------------------------------------------------------------------------
-using PanelShape = GemmShape<64, 64, 16, 64>;
-
-__global__ __launch_bounds__(256, 2) void k_panel_trsm(double *__restrict__ P, int64_t ldp,
-                                                       const double *__restrict__ L, int64_t ldl,
-                                                       const double *__restrict__ dinv, int nbk,
-                                                       const int *__restrict__ info, const double *__restrict__ flags) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    if (wg_failed_before(info)) return;  // failed pivot earlier: early exit (see k_gemm_nt_sub)
-    __builtin_amdgcn_s_setprio(2);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double *Pw = P + (int64_t)blockIdx.x * 64 * ldp;  // this workgroup's 64 rows
-    const int row = wave * 16 + (lane >> 4);          // + 4 r
-    const int colf = lane & 15;                       // + 16 ni
-    const int nt = nbk / 64;
-    for (int c = 0; c < nt; c++) {
-        double4_t acc[1][4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-        // sum_{t<c} X_t L[c,t]^T  (K = 64 c): X_t were written to global by this workgroup
-        gemm_core<64, 64, 16, 64>(Pw, ldp, L + (int64_t)c * 64 * ldl, ldl, 64 * c, acc, smem, tid);
-        // rhs = P_c - acc, in place
-        double rhs[4][4];
-        {
-            double cv[4][4];
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) cv[ni][r] = Pw[(int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf];
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    rhs[ni][r] = cv[ni][r] - acc[0][ni][r];
-                    Pw[(int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf] = rhs[ni][r];
-                }
-        }
-        __syncthreads();  // workgroup-scope visibility of rhs before it is re-read as an operand
-#pragma unroll
-        for (int ni = 0; ni < 4; ni++) acc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-        // X_c = rhs * Linv_cc^T   (K = 64)
-        gemm_core<64, 64, 16, 64>(Pw + c * 64, ldp, dinv + (int64_t)c * 4096, 64, 64, acc, smem, tid);
-#pragma unroll
-        for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                Pw[(int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf] = acc[0][ni][r];
-        __syncthreads();
-        if (flags != nullptr && flags[c] != 0.0) {
-            // Ill-conditioned diagonal tile (k_diag_tile_inverses: max |Linv| max L_ii >= 32): the explicit inverse leaves a
-            // residual rhs - X L_cc^T of order eps cond(L_cc) |rhs|; one refinement step, X += (rhs - X L_cc^T) Linv_cc^T,
-            // brings it back to eps |rhs| (as long as eps cond^2 < 1) -- see the TRSM phase of k_potf2_reg.
-            double4_t racc[1][4];
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++) racc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-            gemm_core<64, 64, 16, 64>(Pw + c * 64, ldp, L + (int64_t)c * 64 * ldl + c * 64, ldl, 64, racc, smem, tid);  // X L_cc^T
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    Pw[(int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf] = rhs[ni][r] - racc[0][ni][r];
-            __syncthreads();
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++) racc[0][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-            gemm_core<64, 64, 16, 64>(Pw + c * 64, ldp, dinv + (int64_t)c * 4096, 64, 64, racc, smem, tid);
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++)
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    Pw[(int64_t)(row + 4 * r) * ldp + c * 64 + ni * 16 + colf] = acc[0][ni][r] + racc[0][ni][r];
-            __syncthreads();
-        }
     }
 }
 
@@ -1170,15 +1092,20 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
 // refinement step is the diagonal-block kernel's), puts it into LDS (two buffers, one barrier per strip) and global;
 // every wave then applies  T_C -= X_k L(C,k)^T  to its strips right of k, the L(C,k) fragments (rows pi(frow), 32
 // contiguous bytes per lane) straight from the factored block in L2 and already in flight when the barrier opens.
-// No global round trip between the strips (the round-1 kernel, k_panel_trsm, re-reads its 64-row slab from global four
-// times per block: 38 us whatever the panel's height); 16-row workgroups keep n / 16 of them in flight, which is what a
+// No global round trip between the strips (the round-1 kernel re-read its 64-row slab from global four times per block:
+// 38 us whatever the panel's height); 16-row workgroups keep n / 16 of them in flight, which is what a
 // 256-column panel of a small matrix needs to be spread over the chip at all.
 // ---------------------------------------------------------------------------------------------
-template <int RT>  // 16-row tiles per workgroup: 1 (panels of small matrices: n / 16 workgroups) or 2 (tall panels: the L
-                    // fragments and the barrier serve two tiles, half the workgroups, less CU time per row)
+// POST = false: during a factorisation (lin = the slots k_potf2_reg filled: four 16x16 inverses of 256 doubles + four flags
+// per 64x64 tile slot).  POST = true: the solves AFTER it (launch_trsm_rows: predict_var, theta-gradient, x-gradients),
+// when the slots hold the 64x64 tile inverses: the inverse of a lower triangular matrix has the inverses of its diagonal
+// blocks on its block diagonal, so strip C reads the 16x16 block (C % 4, C % 4) of tile C / 4 (row stride 64) and takes
+// that tile's refinement flag (`tflags`, one per 64x64 tile, from k_diag_tile_inverses).
+template <int RT, bool POST = false>  // RT: 16-row tiles per workgroup: 1 (panels of small matrices: n / 16 workgroups) or 2
+                                      // (tall panels: the L fragments and the barrier serve two tiles, half the workgroups)
 __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, int64_t ldp, const double *__restrict__ L, int64_t ldl,
                                                       const double *__restrict__ lin, int nbk, const int *__restrict__ info,
-                                                      int64_t bsM, int64_t bsL, int bsI) {
+                                                      int64_t bsM, int64_t bsL, int bsI, const double *__restrict__ tflags) {
     __shared__ __attribute__((aligned(16))) double X[2][RT][16 * RB_LD];
     {   // lock-step batch: matrix blockIdx.z
         const int64_t z = blockIdx.z;
@@ -1211,10 +1138,11 @@ __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, in
             acc[r][4 * t + 3] = v1[1];
         }
         // everything a solve needs besides its tile comes from L2 (~1 us): fetched here, not when the strip comes up
-        const double *lk = lin + (int64_t)(Cc >> 2) * 4096 + (Cc & 3) * 256;
-        n01[t] = *reinterpret_cast<const d2_t *>(lk + prow * 16 + 4 * fk);
-        n23[t] = *reinterpret_cast<const d2_t *>(lk + prow * 16 + 4 * fk + 2);
-        refine[t] = lin[(int64_t)(Cc >> 2) * 4096 + 1024 + (Cc & 3)] != 0.0;
+        constexpr int LS = POST ? 64 : 16;  // row stride of the 16x16 inverse
+        const double *lk = lin + (int64_t)(Cc >> 2) * 4096 + (Cc & 3) * (POST ? 16 * 64 + 16 : 256);
+        n01[t] = *reinterpret_cast<const d2_t *>(lk + prow * LS + 4 * fk);
+        n23[t] = *reinterpret_cast<const d2_t *>(lk + prow * LS + 4 * fk + 2);
+        refine[t] = POST ? (tflags != nullptr && tflags[Cc >> 2] != 0.0) : (lin[(int64_t)(Cc >> 2) * 4096 + 1024 + (Cc & 3)] != 0.0);
         const double *ld16 = Lp + (int64_t)(16 * Cc) * ldl + 16 * Cc;
         const d2_t r01 = *reinterpret_cast<const d2_t *>(ld16), r23 = *reinterpret_cast<const d2_t *>(ld16 + 2);
         l01[t] = d2_t{(4 * fk <= prow) ? r01[0] : 0.0, (4 * fk + 1 <= prow) ? r01[1] : 0.0};
@@ -1515,7 +1443,7 @@ static int g_stream_min_tiles = 128;  // EGX_STREAM_MIN: launches with at least 
 static int g_stream_tpw = 1;          // EGX_STREAM_TPW: tiles a workgroup of k_gemm_stream walks (1: CUs turn over, the chain squeezes in)
 static int g_gemm_small_max = 1024;   // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used
 static int g_look_min_cols = 3072;    // EGX_LOOK_MIN: look-ahead while at least this many columns trail the next group
-static int g_stream_min_k = 32;       // EGX_STREAM_MINK (experiment): launches below 512 tiles take the stream kernel only from this K on
+static int g_lur_side = 1;            // EGX_LUR_SIDE (experiment): LUr on the side stream, beside RU
 
 int chol_init() {
     static std::once_flag once;
@@ -1529,7 +1457,7 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_STREAM_TPW")) g_stream_tpw = std::atoi(e) > 0 ? std::atoi(e) : 1;
         if (const char *e = std::getenv("EGX_STREAM_MIN")) g_stream_min_tiles = std::atoi(e) > 0 ? std::atoi(e) : 1;
         if (const char *e = std::getenv("EGX_LOOK_MIN")) g_look_min_cols = std::atoi(e);
-        if (const char *e = std::getenv("EGX_STREAM_MINK")) g_stream_min_k = std::atoi(e);
+        if (const char *e = std::getenv("EGX_LUR_SIDE")) g_lur_side = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -1539,7 +1467,6 @@ int chol_init() {
         };
         set(reinterpret_cast<const void *>(&k_gemm_nt_sub<true, 128, 128, 32, 64, 512, true>), TrailShape::LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 128, 32, 64, 512, true>), TrailShape::LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_panel_trsm), PanelShape::LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<true>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<false>), ST_LDS_BYTES);
     });
@@ -1573,7 +1500,7 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         else
             wide_tiles = (int64_t)(M / 128) * (N / 256);
     }
-    if (K >= 2 * KC && wide_tiles >= g_stream_min_tiles && (wide_tiles >= 512 || K >= g_stream_min_k)) {
+    if (K >= 2 * KC && wide_tiles >= g_stream_min_tiles) {
         // the launches that fill the chip on their own are the ones the roofline trace follows
         if (used_big_tile) *used_big_tile = wide_tiles >= 512;
         const int nbx = M / 128, nby = N / 256;  // LOWER: column c holds nbx - 2 c tiles (M >= N in the factorisation)
@@ -1690,11 +1617,11 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         const double *L = M + (int64_t)k0 * ld + k0;
         const double *lin = dinv + (int64_t)(k0 / 64) * 4096;
         if (below >= 4096)  // tall panels: two 16-row tiles per workgroup (+1 %, profiles/r02_run34_*)
-            hipLaunchKernelGGL(k_panel_trsm16<2>, dim3(below / 32, 1, nz), dim3(256), 0, st, P, ld, L, ld, lin, nbk,
-                               (const int *)info, pb.sM, pb.sD, pb.sI);
+            hipLaunchKernelGGL((k_panel_trsm16<2, false>), dim3(below / 32, 1, nz), dim3(256), 0, st, P, ld, L, ld, lin, nbk,
+                               (const int *)info, pb.sM, pb.sD, pb.sI, (const double *)nullptr);
         else
-            hipLaunchKernelGGL(k_panel_trsm16<1>, dim3(below / 16, 1, nz), dim3(256), 0, st, P, ld, L, ld, lin, nbk,
-                               (const int *)info, pb.sM, pb.sD, pb.sI);
+            hipLaunchKernelGGL((k_panel_trsm16<1, false>), dim3(below / 16, 1, nz), dim3(256), 0, st, P, ld, L, ld, lin, nbk,
+                               (const int *)info, pb.sM, pb.sD, pb.sI, (const double *)nullptr);
     };
     // C[r0.., c0..c0+N) -= P[r0.., k0..k0+K) P[c0..c0+N, k0..k0+K)^T for the M rows from r0
     auto update = [&](hipStream_t st, int r0, int c0, int Mr, int N, int k0, int K, int lower, bool *big) -> int {
@@ -1759,9 +1686,13 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             if (rc) return rc;
             EGX_HIP_CHECK(hipEventRecord(lk->ev_lu, s));
             EGX_HIP_CHECK(hipStreamWaitEvent(s2, lk->ev_lu, 0));
-            rc = update(s, r1 + nb1, r1, m_tot - r1 - nb1, gw1, g0, gw, 0, nullptr);
+            // LUr writes the next group's columns, RU the columns right of them, both only READ this group's panel: LUr goes
+            // to the (high-priority) side stream so that RU fills the CUs its last, partly filled round of tiles leaves idle
+            hipStream_t slu = g_lur_side ? s3 : s;
+            if (slu != s) EGX_HIP_CHECK(hipStreamWaitEvent(slu, lk->ev_lu, 0));
+            rc = update(slu, r1 + nb1, r1, m_tot - r1 - nb1, gw1, g0, gw, 0, nullptr);
             if (rc) return rc;
-            EGX_HIP_CHECK(hipEventRecord(lk->ev_lur, s));
+            EGX_HIP_CHECK(hipEventRecord(lk->ev_lur, slu));
             rc = inner_factor(s2, r1, gw1, s3, lk->ev_lur);
             if (rc) return rc;
             EGX_HIP_CHECK(hipEventRecord(lk->ev_panel, s2));
@@ -1827,9 +1758,14 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
             // tri_rows: the right-hand sides are the rows of the identity, so the solution (C^-T) is upper triangular:
             // rows below the current block are still zero in these columns and are skipped
             const int m_eff = tri_rows ? ((k0 + nbk < m) ? (k0 + nbk) : m) : m;
-            hipLaunchKernelGGL(k_panel_trsm, dim3(m_eff / 64), dim3(256), PanelShape::LDS_BYTES, s, RT + k0, ldr, diag,
-                               ldm, dtiles, nbk, (const int *)nullptr,
-                               (const double *)(dinv + (int64_t)(n_pad / 64) * 4096 + k0 / 64));
+            // the same register-resident 16-row-tile solve as inside the factorisation (POST layout of the tile inverses)
+            const double *tfl = dinv + (int64_t)(n_pad / 64) * 4096 + k0 / 64;
+            if (m_eff >= 4096)
+                hipLaunchKernelGGL((k_panel_trsm16<2, true>), dim3(m_eff / 32), dim3(256), 0, s, RT + k0, ldr, diag, ldm, dtiles,
+                                   nbk, (const int *)nullptr, (int64_t)0, (int64_t)0, 0, tfl);
+            else
+                hipLaunchKernelGGL((k_panel_trsm16<1, true>), dim3(m_eff / 16), dim3(256), 0, s, RT + k0, ldr, diag, ldm, dtiles,
+                                   nbk, (const int *)nullptr, (int64_t)0, (int64_t)0, 0, tfl);
             const int ncols = gend - (k0 + nbk);
             if (ncols > 0) {
                 rc = launch_gemm_nt_sub(s, RT + (k0 + nbk), ldr, RT + k0, ldr, M + (int64_t)(k0 + nbk) * ldm + k0, ldm,

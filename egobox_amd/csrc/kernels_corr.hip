@@ -18,6 +18,32 @@ constexpr double kSqrt3 = 1.7320508075688772;
 constexpr double kSqrt5 = 2.23606797749979;
 constexpr double k5over3 = 5.0 / 3.0;
 
+// exp(x) for x <= 0 (every correlation is exp of a non-positive sum): round-to-nearest range reduction x = k ln2 + r,
+// |r| <= ln2 / 2, degree-13 Taylor polynomial in Horner form (truncation 4e-18, all FMA), one v_ldexp_f64: ~20 VALU
+// instructions and no branches or selects, against ~30 of the library exp with its special-case handling.  K1 is bound
+// by FP64 VALU issue (profiles/r03_*_pmc_corr_*), so instructions per pair are what counts.  Error <= 2 ulp; underflow
+// goes through ldexp (gradual, then 0); NaN propagates.
+__device__ __forceinline__ double exp_nonpos(double x) {
+    const double kf = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821614599e-10;                  // 1 / 13!
+    p = __builtin_fma(p, r, 2.0876756987868098979e-09);    // 1 / 12!
+    p = __builtin_fma(p, r, 2.5052108385441718775e-08);    // 1 / 11!
+    p = __builtin_fma(p, r, 2.7557319223985890653e-07);    // 1 / 10!
+    p = __builtin_fma(p, r, 2.7557319223985892511e-06);    // 1 / 9!
+    p = __builtin_fma(p, r, 2.4801587301587301566e-05);    // 1 / 8!
+    p = __builtin_fma(p, r, 1.9841269841269841253e-04);    // 1 / 7!
+    p = __builtin_fma(p, r, 1.3888888888888889419e-03);    // 1 / 6!
+    p = __builtin_fma(p, r, 8.3333333333333332177e-03);    // 1 / 5!
+    p = __builtin_fma(p, r, 4.1666666666666664354e-02);    // 1 / 4!
+    p = __builtin_fma(p, r, 1.6666666666666665741e-01);    // 1 / 3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)kf);
+}
+
 // Accumulator for one (i, j) pair, updated one input dimension at a time.
 template <int CORR>
 struct PairAcc {
@@ -45,25 +71,46 @@ struct PairAcc {
             }
         }
     }
+    // the same with the coefficient already applied to both coordinates (hcols == 1: diff = c x_i - c x_j, so that
+    // c |x_i - x_j| costs no instruction per pair; the rounding of the two products perturbs the exponent by
+    // <= 2 eps sum_k |t_k| max |c x|, below 1e-13 wherever r is not negligible): 2 VALU instructions per pair and dimension
+    // for the squared exponential instead of 3, 5 instead of 8 for Matern-5/2
+    __device__ __forceinline__ void add_scaled(double diff) {
+        if (CORR == EGX_CORR_SQUARED_EXPONENTIAL) {
+            s = __builtin_fma(diff, diff, s);
+        } else if (CORR == EGX_CORR_ABSOLUTE_EXPONENTIAL) {
+            s += fabs(diff);
+        } else if (CORR == EGX_CORR_MATERN32) {
+            const double t = fabs(diff);
+            s += t;
+            a *= __builtin_fma(kSqrt3, t, 1.0);
+        } else {
+            const double t = fabs(diff);
+            s += t;
+            a *= __builtin_fma(__builtin_fma(k5over3, t, kSqrt5), t, 1.0);
+        }
+    }
     __device__ __forceinline__ double value() const {
-        if (CORR == EGX_CORR_SQUARED_EXPONENTIAL) return exp(-0.5 * s);
-        if (CORR == EGX_CORR_ABSOLUTE_EXPONENTIAL) return exp(-s);
-        if (CORR == EGX_CORR_MATERN32) return a * exp(-kSqrt3 * s);
-        return a * exp(-kSqrt5 * s);
+        if (CORR == EGX_CORR_SQUARED_EXPONENTIAL) return exp_nonpos(-0.5 * s);
+        if (CORR == EGX_CORR_ABSOLUTE_EXPONENTIAL) return exp_nonpos(-s);
+        if (CORR == EGX_CORR_MATERN32) return a * exp_nonpos(-kSqrt3 * s);
+        return a * exp_nonpos(-kSqrt5 * s);
     }
 };
 
-// Stage a 64-point slab (all d dimensions, k-major) into LDS: dst[k*64 + i].
+// Stage a 64-point slab (all d dimensions, k-major) into LDS: dst[k*64 + i]; scale != nullptr: times scale[k]
+// (PairAcc::add_scaled, hcols == 1).
 __device__ __forceinline__ void stage_slab(double *dst, const double *__restrict__ xT, int64_t ldx, int i0,
-                                           int d, int tid) {
+                                           int d, int tid, const double *__restrict__ scale = nullptr) {
     for (int e = tid; e < d * 64; e += 256) {
         const int k = e >> 6, i = e & 63;
-        dst[e] = xT[(int64_t)k * ldx + i0 + i];
+        const double v = xT[(int64_t)k * ldx + i0 + i];
+        dst[e] = scale ? scale[k] * v : v;
     }
 }
 
 // 4x4 micro-tile of pair accumulators from two staged slabs.
-template <int CORR>
+template <int CORR, bool PRE = false>  // PRE: the slabs were staged with the coefficients applied (hcols == 1)
 __device__ __forceinline__ void tile_pairs(const double *xi, const double *xj, const double *__restrict__ coef,
                                            int hcols, int d, int ty, int tx, double (&r)[4][4]) {
     PairAcc<CORR> acc[4][4];
@@ -77,7 +124,10 @@ __device__ __forceinline__ void tile_pairs(const double *xi, const double *xj, c
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++) acc[a][b].add(vi[a] - vj[b], ck, hcols);
+            for (int b = 0; b < 4; b++) {
+                if (PRE) acc[a][b].add_scaled(vi[a] - vj[b]);
+                else acc[a][b].add(vi[a] - vj[b], ck, hcols);
+            }
     }
 #pragma unroll
     for (int a = 0; a < 4; a++)
@@ -86,7 +136,7 @@ __device__ __forceinline__ void tile_pairs(const double *xi, const double *xj, c
 }
 
 // K1: symmetric training correlation matrix, 64x64 tiles, 128x128-granular lower triangle.
-template <int CORR>
+template <int CORR, bool PRE>
 __global__ __launch_bounds__(256) void k_corr_sym(const double *__restrict__ xT, int64_t ldx, int n, int d,
                                                   const double *__restrict__ coef, int hcols, double diag,
                                                   double *__restrict__ M, int64_t ld) {
@@ -101,11 +151,11 @@ __global__ __launch_bounds__(256) void k_corr_sym(const double *__restrict__ xT,
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *xi = sm, *xj = sm + d * 64;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    stage_slab(xi, xT, ldx, bi * 64, d, tid);
-    stage_slab(xj, xT, ldx, bj * 64, d, tid);
+    stage_slab(xi, xT, ldx, bi * 64, d, tid, PRE ? coef : nullptr);
+    stage_slab(xj, xT, ldx, bj * 64, d, tid, PRE ? coef : nullptr);
     __syncthreads();
     double r[4][4];
-    tile_pairs<CORR>(xi, xj, coef, hcols, d, ty, tx, r);
+    tile_pairs<CORR, PRE>(xi, xj, coef, hcols, d, ty, tx, r);
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         const int i = bi * 64 + ty * 4 + a;
@@ -125,7 +175,7 @@ __global__ __launch_bounds__(256) void k_corr_sym(const double *__restrict__ xT,
 }
 
 // K2: rectangular cross-correlation block (queries x training points), full grid.
-template <int CORR>
+template <int CORR, bool PRE>
 __global__ __launch_bounds__(256) void k_cross_corr(const double *__restrict__ xqT, int64_t ldq,
                                                     const double *__restrict__ xT, int64_t ldx, int d,
                                                     const double *__restrict__ coef, int hcols,
@@ -133,11 +183,11 @@ __global__ __launch_bounds__(256) void k_cross_corr(const double *__restrict__ x
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *xi = sm, *xj = sm + d * 64;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    stage_slab(xi, xqT, ldq, blockIdx.x * 64, d, tid);
-    stage_slab(xj, xT, ldx, blockIdx.y * 64, d, tid);
+    stage_slab(xi, xqT, ldq, blockIdx.x * 64, d, tid, PRE ? coef : nullptr);
+    stage_slab(xj, xT, ldx, blockIdx.y * 64, d, tid, PRE ? coef : nullptr);
     __syncthreads();
     double r[4][4];
-    tile_pairs<CORR>(xi, xj, coef, hcols, d, ty, tx, r);
+    tile_pairs<CORR, PRE>(xi, xj, coef, hcols, d, ty, tx, r);
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         double *p = R + (int64_t)(blockIdx.x * 64 + ty * 4 + a) * ld + blockIdx.y * 64 + tx * 4;
@@ -147,7 +197,7 @@ __global__ __launch_bounds__(256) void k_cross_corr(const double *__restrict__ x
 }
 
 // K2+K6 fused: racc[q] = sum_i k(xq, x_i) gamma_i ; one workgroup per 64 queries, loop over slabs.
-template <int CORR>
+template <int CORR, bool PRE>
 __global__ __launch_bounds__(256) void k_predict_mean(const double *__restrict__ xqT, int64_t ldq,
                                                       const double *__restrict__ xT, int64_t ldx, int n_pad,
                                                       int d, const double *__restrict__ coef, int hcols,
@@ -156,7 +206,7 @@ __global__ __launch_bounds__(256) void k_predict_mean(const double *__restrict__
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *xi = sm, *xj = sm + d * 64, *gs = sm + 2 * d * 64;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    stage_slab(xi, xqT, ldq, blockIdx.x * 64, d, tid);
+    stage_slab(xi, xqT, ldq, blockIdx.x * 64, d, tid, PRE ? coef : nullptr);
     double sum[4] = {0.0, 0.0, 0.0, 0.0};
     // grid.y splits the training range (a few queries must still fill the chip); partial sums per split
     const int j_lo = blockIdx.y * slabs_per_split * 64;
@@ -164,11 +214,11 @@ __global__ __launch_bounds__(256) void k_predict_mean(const double *__restrict__
     if (j_hi > n_pad) j_hi = n_pad;
     for (int j0 = j_lo; j0 < j_hi; j0 += 64) {
         __syncthreads();
-        stage_slab(xj, xT, ldx, j0, d, tid);
+        stage_slab(xj, xT, ldx, j0, d, tid, PRE ? coef : nullptr);
         if (tid < 64) gs[tid] = gamma[j0 + tid];
         __syncthreads();
         double r[4][4];
-        tile_pairs<CORR>(xi, xj, coef, hcols, d, ty, tx, r);
+        tile_pairs<CORR, PRE>(xi, xj, coef, hcols, d, ty, tx, r);
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -531,8 +581,13 @@ int launch_corr_sym(hipStream_t s, int corr, const double *xT, int64_t ldx, int 
     const int nt2 = n_pad / 128;  // n_pad is a multiple of 128
     dim3 grid((unsigned)(4 * (nt2 * (nt2 + 1) / 2)));
     const size_t lds = (size_t)2 * d * 64 * sizeof(double);
-    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_corr_sym<C_>, grid, dim3(256), lds, s, xT, ldx, n, d, coef, hcols,
-                                               1.0 + nugget, M, ld));
+    if (hcols == 1) {
+        EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_corr_sym<C_, true>), grid, dim3(256), lds, s, xT, ldx, n, d, coef, hcols,
+                                                   1.0 + nugget, M, ld));
+    } else {
+        EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_corr_sym<C_, false>), grid, dim3(256), lds, s, xT, ldx, n, d, coef, hcols,
+                                                   1.0 + nugget, M, ld));
+    }
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }
@@ -541,8 +596,13 @@ int launch_cross_corr(hipStream_t s, int corr, const double *xqT, int64_t ldq, i
                       int64_t ldx, int n_pad, int d, const double *coef, int hcols, double *R, int64_t ld) {
     dim3 grid(m_pad / 64, n_pad / 64);
     const size_t lds = (size_t)2 * d * 64 * sizeof(double);
-    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_cross_corr<C_>, grid, dim3(256), lds, s, xqT, ldq, xT, ldx, d, coef,
-                                               hcols, R, ld));
+    if (hcols == 1) {
+        EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_cross_corr<C_, true>), grid, dim3(256), lds, s, xqT, ldq, xT, ldx, d, coef,
+                                                   hcols, R, ld));
+    } else {
+        EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_cross_corr<C_, false>), grid, dim3(256), lds, s, xqT, ldq, xT, ldx, d, coef,
+                                                   hcols, R, ld));
+    }
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }
@@ -556,8 +616,13 @@ int launch_predict_mean(hipStream_t s, int corr, const double *xqT, int64_t ldq,
     if (nsplit > slabs) nsplit = slabs;
     const int per = (slabs + nsplit - 1) / nsplit;
     nsplit = (slabs + per - 1) / per;
-    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_predict_mean<C_>, dim3(m_pad / 64, nsplit), dim3(256), lds, s, xqT, ldq, xT,
-                                               ldx, n_pad, d, coef, hcols, gamma, racc, per, m_pad));
+    if (hcols == 1) {
+        EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_predict_mean<C_, true>), dim3(m_pad / 64, nsplit), dim3(256), lds, s, xqT,
+                                                   ldq, xT, ldx, n_pad, d, coef, hcols, gamma, racc, per, m_pad));
+    } else {
+        EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_predict_mean<C_, false>), dim3(m_pad / 64, nsplit), dim3(256), lds, s, xqT,
+                                                   ldq, xT, ldx, n_pad, d, coef, hcols, gamma, racc, per, m_pad));
+    }
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }

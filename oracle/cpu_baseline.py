@@ -50,7 +50,7 @@ def corr_matrix(kind, xn, theta, nugget):
     return r
 
 
-def measure(n, d, seed=42, blas_threads=None):
+def measure(n, d, seed=42, blas_threads=None, start_at=None):
     from scipy.linalg import lapack
     from threadpoolctl import threadpool_info, threadpool_limits
     sys.path.insert(0, os.path.dirname(_HERE))
@@ -61,6 +61,9 @@ def measure(n, d, seed=42, blas_threads=None):
     y = O.griewank(x)
     theta = np.full(d, 0.5 / math.sqrt(d))
     _, _, xn, _, _, yn, _, ys, fx = O.prepare_training(x, y)
+    if start_at is not None:  # concurrent mode: every process starts its fit at the same wall-clock instant
+        time.sleep(max(0.0, float(start_at) - time.time()))
+    wall0 = time.time()
     t0 = time.perf_counter()
     r = corr_matrix(0, xn, theta, O.DEFAULT_NUGGET)
     t1 = time.perf_counter()
@@ -101,7 +104,7 @@ def measure(n, d, seed=42, blas_threads=None):
                     "blas": [{k: p.get(k) for k in ("internal_api", "version", "num_threads", "threading_layer")}
                              for p in blas],
                     "os_cpu_count": os.cpu_count(), "sched_affinity": affinity},
-        "likelihood": lkh, "n": n, "d": d,
+        "likelihood": lkh, "n": n, "d": d, "wall_start": wall0, "wall_end": wall0 + t_fit,
     }
 
 
@@ -113,10 +116,13 @@ def main():
                     help="comma list of OpenBLAS thread counts to try (0 = library default); the BEST fit is reported, "
                          "all are listed: OpenBLAS' dpotrf does not scale to every core of a 2 x 64-core host "
                          "(measured on the GPU box at n = 8192: 16 threads 709 GFLOP/s, 64 threads 236)")
+    ap.add_argument("--start-at", type=float, default=None,
+                    help="unix time at which the (single) timed fit starts: bench.py's cpu_baseline_concurrent runs several "
+                         "of these processes side by side, the reference's rayon-parallel multistart shape")
     args = ap.parse_args()
     best, tried = None, []
     for t in [int(v) for v in str(args.blas_threads).split(",") if v.strip() != ""]:
-        m = measure(args.n, args.d, blas_threads=t)
+        m = measure(args.n, args.d, blas_threads=t, start_at=args.start_at)
         tried.append({"blas_threads": t if t else "default", "fit_s": m["seconds"]["fit"],
                       "dpotrf_gflops": m["dpotrf_gflops"]})
         if best is None or m["value"] > best["value"]:

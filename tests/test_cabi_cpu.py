@@ -140,7 +140,7 @@ def test_header_is_valid_c_and_cpp(tmp_path):
     hpp = tmp_path / "t2.cpp"  # the header-only C++ mirror of the reference's builder and the host tests that use it
     hpp.write_text('#include "egx_gp.hpp"\nint main() { auto p = egobox::Kriging::params(); (void)p; return 0; }\n')
     subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", f"-I{inc}", str(hpp)], check=True)
-    for src in ("golden_a_driver.c", "reference_style_tests.cpp"):
+    for src in ("golden_a_driver.c", "sweep_driver.c", "moe_driver.c", "reference_style_tests.cpp"):
         comp = ["gcc", "-std=c99"] if src.endswith(".c") else ["g++", "-std=c++17"]
         subprocess.run(comp + ["-Wall", "-Werror", "-fsyntax-only", f"-I{inc}", os.path.join(ROOT, "tests", "c_host", src)],
                        check=True)

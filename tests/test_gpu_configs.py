@@ -251,6 +251,22 @@ def test_sweep_c_host_drives_the_collective(tmp_path):
     assert out.stdout.startswith("OK"), out.stdout  # RCCL's version banner goes to stderr (sweep.hip)
 
 
+def test_moe_c_host_drives_the_recombination(tmp_path):
+    """tests/c_host/moe_driver.c: a C99 host (no Python) trains three experts, then calls egx_moe_predict_valvar -- the
+    mixture recombination inside the library -- in both recombinations, single-process and through a one-rank RCCL
+    communicator, against crates/moe/src/algorithm.rs:411-423, 670-685, 879-935 applied to the experts' own outputs."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "moe_driver"
+    libdir = os.path.join(root, "egobox_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", f"-I{os.path.join(root, 'include')}",
+                    os.path.join(root, "tests", "c_host", "moe_driver.c"), f"-L{libdir}", "-legx_gp_hip", "-lm",
+                    f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert out.stdout.startswith("OK"), out.stdout
+
+
 # ------------------------------------------------------------------ config 5
 def test_config5_eight_experts_n8192_d16_m100000(egx, large):
     """8 experts x n = 8192, d = 16 (disjoint LHS draws, seeds 7..14), m = 100 000 query points, smooth and hard

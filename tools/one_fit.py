@@ -13,9 +13,10 @@ import egobox_amd as egx  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+corr = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # 0 sq-exp, 1 abs-exp, 2 Matern-3/2, 3 Matern-5/2
 x, y = egx.workload.make_training_set(n, d, 42)
 th = egx.workload.default_theta(d)
-h = egx.GpHandle(x, y)
+h = egx.GpHandle(x, y, corr=corr)
 for i in range(reps):
     t0 = time.perf_counter()
     h.finalize(th * (1 + 0.01 * i))

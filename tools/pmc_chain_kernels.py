@@ -24,6 +24,12 @@ for k, a in acc.items():
     r = {"dispatches": n, **{c: v / n for c, v in a.items()}}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in a and "SQ_BUSY_CYCLES" in a and a["SQ_BUSY_CYCLES"]:
         r["mfma_busy_over_sq_busy"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / a["SQ_BUSY_CYCLES"]
+    if "SQ_INSTS_VALU" in a and a.get("SQ_WAVES"):
+        r["valu_insts_per_wave"] = a["SQ_INSTS_VALU"] / a["SQ_WAVES"]
+    if "SQ_ACTIVE_INST_VALU" in a and a.get("SQ_WAVE_CYCLES"):
+        r["valu_active_over_wave_cycles"] = a["SQ_ACTIVE_INST_VALU"] / a["SQ_WAVE_CYCLES"]
+    if "SQ_ACTIVE_INST_VALU" in a and a.get("SQ_BUSY_CYCLES"):
+        r["valu_active_over_sq_busy"] = a["SQ_ACTIVE_INST_VALU"] / a["SQ_BUSY_CYCLES"]
     if "SQ_LDS_BANK_CONFLICT" in a and a.get("SQ_LDS_IDX_ACTIVE"):
         r["lds_bank_conflict_frac"] = a["SQ_LDS_BANK_CONFLICT"] / a["SQ_LDS_IDX_ACTIVE"]
     res[k] = r
