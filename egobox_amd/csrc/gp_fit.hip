@@ -1,6 +1,6 @@
 // Optimiser drivers above the likelihood (GpValidParams::fit with ThetaTuning::Full / Partial,
 // crates/gp/src/algorithm.rs:873-960, optimization.rs:26-169): multistart COBYLA (cobyla.h: Powell's method restated, all
-// starts in lock-step through one likelihood batch per round; EGX_FIT_OPTIMIZER=nelder-mead keeps the round-1 stand-in),
+// starts in lock-step through one likelihood batch per round),
 // the new theta-gradient of the likelihood and a projected L-BFGS on it.
 #include "gp_handle.h"
 
@@ -48,11 +48,9 @@ static int32_t fit_nm_core(egx_gp *gp, const double *theta_base /*h*/, const std
             set_error("theta start points must be > 0");
             return EGX_ERR_INVALID_VALUE;
         }
-    std::vector<NmResult> results((size_t)n_starts);
+    std::vector<StartResult> results((size_t)n_starts);
     gp->fitted = false;
-    const char *opt_env = std::getenv("EGX_FIT_OPTIMIZER");
-    const bool use_nm = opt_env && std::string(opt_env) == "nelder-mead";
-    if (!use_nm) {
+    {
         // COBYLA (cobyla.h), one machine per start, rhobeg 0.5 / ftol_rel 1e-4 (optimization.rs:16-24), all machines
         // advanced in LOCK-STEP: their trial points form one likelihood batch per round, pipelined over the
         // handle's workspaces (the reference runs the starts as rayon tasks, algorithm.rs:928-945)
@@ -89,51 +87,7 @@ static int32_t fit_nm_core(egx_gp *gp, const double *theta_base /*h*/, const std
             const CobylaBox &m = mach[(size_t)s];
             double fb = m.best_f();
             if (std::isnan(fb) || fb >= 1e30) fb = std::numeric_limits<double>::infinity();  // optimization.rs:153-157
-            results[(size_t)s] = NmResult{fb, m.best_x(), m.evals()};
-        }
-    } else {
-    // EGX_FIT_OPTIMIZER=nelder-mead: the round-1 stand-in, one host thread per workspace, start s on workspace s % n_threads
-    const int nthreads = (int)std::min<int64_t>((int64_t)gp->ws.size(), n_starts);
-    std::vector<int> rcs((size_t)nthreads, EGX_SUCCESS);
-    std::vector<std::string> errs((size_t)nthreads);
-    auto worker = [&](int t) {
-        if (hipSetDevice(gp->device) != hipSuccess) {
-            rcs[t] = EGX_ERR_HIP;
-            errs[t] = "hipSetDevice failed in optimiser thread";
-            return;
-        }
-        auto objective = [&](const std::vector<double> &x) -> double {
-            std::vector<double> th(theta_base, theta_base + hfull);
-            for (int i = 0; i < h; i++) th[active[i]] = std::pow(10.0, x[i]);
-            EvalResult res;
-            int rc = eval_one(gp, t, th.data(), hfull, res, false);
-            if (rc) {
-                if (!rcs[t]) {
-                    rcs[t] = rc;
-                    errs[t] = last_error_string();
-                }
-                return std::numeric_limits<double>::infinity();
-            }
-            if (res.status != EGX_STATUS_OK || std::isnan(res.lkh)) return std::numeric_limits<double>::infinity();
-            return -res.lkh;
-        };
-        for (int64_t s = t; s < n_starts; s += nthreads) {
-            std::vector<double> x0(h);
-            for (int i = 0; i < h; i++) x0[i] = std::log10(theta0s[s * h + i]);
-            results[(size_t)s] = nelder_mead(objective, x0, blo, bhi, per_start);
-        }
-    };
-    if (nthreads <= 1) {
-        worker(0);
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; t++) pool.emplace_back(worker, t);
-        for (auto &th : pool) th.join();
-    }
-    for (int t = 0; t < nthreads; t++)
-        if (rcs[t]) {
-            set_error(errs[t]);
-            return rcs[t];
+            results[(size_t)s] = StartResult{fb, m.best_x(), m.evals()};
         }
     }
     for (int64_t s = 0; s < n_starts; s++) {

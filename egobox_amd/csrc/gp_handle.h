@@ -17,7 +17,6 @@
 
 #include "egx_internal.h"
 #include "host_math.h"
-#include "nelder_mead.h"
 #include "cobyla.h"
 
 #define EGX_RC(call)              \
@@ -81,6 +80,13 @@ struct Workspace {
     int *h_info = nullptr;     // pinned
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     GemmTrace trace;
+};
+
+// outcome of one start of a multistart optimisation: objective (-likelihood), its minimiser in log10 theta, evaluations
+struct StartResult {
+    double f;
+    std::vector<double> x;
+    int64_t evals;
 };
 
 struct EvalResult {

@@ -334,10 +334,10 @@ int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coef, int 
 // Householder route, < 0 = -(egx_rc) on a HIP failure.
 //   A = ft^T ft = L L^T,  z = L^-1 ft^T yt  (device, enqueue_eval)  ->  R = L^T (algorithm.rs:1007 `qr`, positive
 //   diagonal), beta = R^-1 z (:1030), rho = yt - ft beta and sum rho^2 on the device (:1031-1032).
-// The conditioning test of :1010-1027 compares sigma_min / sigma_max of R with 1e-10.  Here the ratio is ESTIMATED in
-// O(p^2) (a few steps of power iteration on R^T R and of inverse iteration through two triangular solves); the Gram
-// route is taken only when the estimate is >= 1e-8 and the factor's diagonal ratio >= 1e-4 (normal equations keep
-// at least half the digits there).  Anything closer to the threshold goes to the host Householder + SVD route, which
+// The conditioning test of :1010-1027 compares sigma_min / sigma_max of R with 1e-10.  For p <= 64 the singular values
+// are computed exactly (Jacobi on the p x p factor); wider trends estimate the ratio in O(p^2) by power / inverse
+// iteration and keep two decades of margin.  The Gram route is taken only when the ratio is >= 1e-7 (1e-6 estimated) and
+// the factor's diagonal ratio >= 1e-4; anything closer to the threshold goes to the host Householder + SVD route, which
 // decides exactly as for p = 1.
 static int finish_eval_device_gls(egx_gp *gp, Workspace &w, EvalResult &out, bool keep) {
     const int n = gp->n, p = gp->p, n_pad = gp->n_pad, g = gp->rhs_pad;
@@ -384,7 +384,20 @@ static int finish_eval_device_gls(egx_gp *gp, Workspace &w, EvalResult &out, boo
             for (int l = 0; l < i; l++) v[l] -= row[l] * wi;
         }
     };
-    {   // sigma_max^2 by power iteration on R^T R = L L^T (R = L^T), 1 / sigma_min^2 by inverse iteration
+    if (p <= 64) {
+        // the reference's own test, exactly (algorithm.rs:1010-1027): singular values of the p x p factor R = L^T by
+        // one-sided Jacobi, O(p^3) on a tiny matrix.  A ratio below 1e-10 is the reference's error; the Gram route is
+        // taken down to 1e-7 only (normal equations square the condition number), the Householder route decides below
+        std::vector<double> Rm((size_t)p * p, 0.0);
+        for (int i = 0; i < p; i++)
+            for (int l = i; l < p; l++) Rm[(size_t)i * p + l] = L[(size_t)l * g + i];
+        const std::vector<double> sv = hm::singular_values(Rm, p);
+        if (!(sv[p - 1] / sv[0] >= 1e-7)) return 1;
+    } else {
+        // wide trends (quadratic in d = 32: p = 561): sigma_max^2 by power iteration on R^T R = L L^T (R = L^T),
+        // 1 / sigma_min^2 by inverse iteration.  Both UNDER-estimate their target, so the ratio is OVER-estimated: the
+        // Gram route is taken only with two decades of margin (>= 1e-6), anything closer to the reference's 1e-10
+        // threshold goes to the host Householder + SVD route, which decides exactly as for p = 1
         std::vector<double> v(p), u(p);
         auto normalize = [&](std::vector<double> &t) {
             double s = 0.0;
@@ -396,20 +409,20 @@ static int finish_eval_device_gls(egx_gp *gp, Workspace &w, EvalResult &out, boo
         for (int i = 0; i < p; i++) v[i] = 1.0 + 0.37 * ((i * 2654435761u) % 1000) / 1000.0;
         normalize(v);
         double smax2 = 0.0, sinv2 = 0.0;
-        for (int it = 0; it < 5; it++) {
+        for (int it = 0; it < 12; it++) {
             mul_lt(v, u);
             mul_l(u, v);
             smax2 = normalize(v);
         }
         for (int i = 0; i < p; i++) v[i] = 1.0 - 0.29 * ((i * 40503u) % 1000) / 1000.0;
         normalize(v);
-        for (int it = 0; it < 5; it++) {
+        for (int it = 0; it < 12; it++) {
             solve_l(v);
             solve_lt(v);
             sinv2 = normalize(v);
         }
         const double ratio = 1.0 / std::sqrt(sinv2 * smax2);  // ~ sigma_min / sigma_max
-        if (!(ratio >= 1e-8)) return 1;
+        if (!(ratio >= 1e-6)) return 1;
     }
     // beta = L^-T z   (z = row p of the factor)
     std::vector<double> beta(L + (size_t)p * g, L + (size_t)p * g + p);

@@ -76,12 +76,26 @@ int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *
     if (cap < kTile) cap = kTile;
     if (cap > 16384) cap = 16384;
     if (!vout) cap = 65536;
-    std::vector<double> f(p), rhs(p), u(p), xn, racc, s0, sl;
-    DevBuf d_xqT, d_racc, d_RT, d_s0, d_sl;  // sized by the first (largest) chunk, reused by the others
-    for (int64_t m0 = 0; m0 < m; m0 += cap) {
+    // Two chunks in flight on two streams: while the GPU works on chunk i the host post-processes chunk i - 1 and
+    // normalises / uploads chunk i + 1, and the tail of one chunk's solve overlaps the head of the next (the (m x n)
+    // block of a chunk is bounded at 1 GiB, so 100 000 query points at n = 8192 are 7 chunks).
+    struct Slot {
+        DevBuf d_xqT, d_racc, d_RT, d_s0, d_sl;  // sized by the first (largest) chunk, reused by the later ones
+        std::vector<double> xn, racc, s0, sl;
+        int64_t m0 = 0;
+        int mc = 0, m_pad = 0, msplit = 1;
+        hipStream_t stream = nullptr;
+    } slots[2];
+    slots[0].stream = w.stream;
+    slots[1].stream = w.lk.s2 ? w.lk.s2 : w.stream;
+    auto enqueue = [&](Slot &sl_, int64_t m0) -> int {
         const int mc = (int)((m - m0 < cap) ? (m - m0) : cap);
         const int m_pad = (int)round_up(mc, kTile);
-        EGX_RC(upload_queries(gp, xq, m0, mc, m_pad, xn, d_xqT, w.stream));
+        sl_.m0 = m0;
+        sl_.mc = mc;
+        sl_.m_pad = m_pad;
+        hipStream_t st = sl_.stream;
+        EGX_RC(upload_queries(gp, xq, m0, mc, m_pad, sl_.xn, sl_.d_xqT, st));
         // few queries: split the training range so that ~1024 workgroups exist (partial sums added below)
         int msplit = 1;
         if (m_pad / 64 < 1024) msplit = (1024 + m_pad / 64 - 1) / (m_pad / 64);
@@ -90,32 +104,43 @@ int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *
             const int per = (n_pad / 64 + msplit - 1) / msplit;
             msplit = (n_pad / 64 + per - 1) / per;
         }
+        sl_.msplit = msplit;
         if (yout) {
-            racc.resize((size_t)msplit * m_pad);
-            EGX_RC(d_racc.alloc((size_t)msplit * m_pad));
-            EGX_RC(launch_predict_mean(w.stream, gp->corr, d_xqT.p, m_pad, m_pad, gp->d_xT, n_pad, n_pad, d,
-                                       gp->d_fit_coef, gp->fit_hcols, gp->d_gamma, d_racc.p, msplit));
-            EGX_HIP_CHECK(hipMemcpyAsync(racc.data(), d_racc.p, sizeof(double) * (size_t)msplit * m_pad,
-                                         hipMemcpyDeviceToHost, w.stream));
+            EGX_RC(sl_.d_racc.alloc((size_t)msplit * m_pad));
+            EGX_RC(launch_predict_mean(st, gp->corr, sl_.d_xqT.p, m_pad, m_pad, gp->d_xT, n_pad, n_pad, d, gp->d_fit_coef,
+                                       gp->fit_hcols, gp->d_gamma, sl_.d_racc.p, msplit));
         }
         if (vout) {
-            s0.resize(m_pad);
-            sl.resize((size_t)m_pad * p);
-            EGX_RC(d_RT.alloc((size_t)m_pad * n_pad));
-            EGX_RC(d_s0.alloc(m_pad));
-            EGX_RC(d_sl.alloc((size_t)m_pad * p));
+            EGX_RC(sl_.d_RT.alloc((size_t)m_pad * n_pad));
+            EGX_RC(sl_.d_s0.alloc(m_pad));
+            EGX_RC(sl_.d_sl.alloc((size_t)m_pad * p));
             // corr (m x n): algorithm.rs:372-380 ; rt = C^-1 corr^T: :337-350 (held transposed, row per query)
-            EGX_RC(launch_cross_corr(w.stream, gp->corr, d_xqT.p, m_pad, m_pad, gp->d_xT, n_pad, n_pad, d,
-                                     gp->d_fit_coef, gp->fit_hcols, d_RT.p, n_pad));
-            EGX_RC(launch_trsm_rows(w.stream, w.M, gp->ld, n_pad, w.dinv, d_RT.p, n_pad, m_pad));
+            EGX_RC(launch_cross_corr(st, gp->corr, sl_.d_xqT.p, m_pad, m_pad, gp->d_xT, n_pad, n_pad, d, gp->d_fit_coef,
+                                     gp->fit_hcols, sl_.d_RT.p, n_pad));
+            EGX_RC(launch_trsm_rows(st, w.M, gp->ld, n_pad, w.dinv, sl_.d_RT.p, n_pad, m_pad));
             // sum rt^2 and ft^T rt (:352): ft^T rows live below the factor in the workspace
-            EGX_RC(launch_row_reduce(w.stream, d_RT.p, n_pad, m_pad, n, w.M + (size_t)n_pad * gp->ld, gp->ld, p,
-                                     d_s0.p, d_sl.p));
-            EGX_HIP_CHECK(hipMemcpyAsync(s0.data(), d_s0.p, sizeof(double) * m_pad, hipMemcpyDeviceToHost, w.stream));
-            EGX_HIP_CHECK(hipMemcpyAsync(sl.data(), d_sl.p, sizeof(double) * (size_t)m_pad * p, hipMemcpyDeviceToHost,
-                                         w.stream));
+            EGX_RC(launch_row_reduce(st, sl_.d_RT.p, n_pad, m_pad, n, w.M + (size_t)n_pad * gp->ld, gp->ld, p, sl_.d_s0.p,
+                                     sl_.d_sl.p));
         }
-        EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+        return EGX_SUCCESS;
+    };
+    std::vector<double> f(p), rhs(p), u(p);
+    auto finish = [&](Slot &sl_) -> int {
+        const int mc = sl_.mc, m_pad = sl_.m_pad, msplit = sl_.msplit;
+        const int64_t m0 = sl_.m0;
+        EGX_HIP_CHECK(hipStreamSynchronize(sl_.stream));
+        // (the copies go to pageable memory: issued after the wait, they cost their transfer time only)
+        if (yout) {
+            sl_.racc.resize((size_t)msplit * m_pad);
+            EGX_HIP_CHECK(hipMemcpy(sl_.racc.data(), sl_.d_racc.p, sizeof(double) * (size_t)msplit * m_pad, hipMemcpyDeviceToHost));
+        }
+        if (vout) {
+            sl_.s0.resize(m_pad);
+            sl_.sl.resize((size_t)m_pad * p);
+            EGX_HIP_CHECK(hipMemcpy(sl_.s0.data(), sl_.d_s0.p, sizeof(double) * m_pad, hipMemcpyDeviceToHost));
+            EGX_HIP_CHECK(hipMemcpy(sl_.sl.data(), sl_.d_sl.p, sizeof(double) * (size_t)m_pad * p, hipMemcpyDeviceToHost));
+        }
+        const std::vector<double> &xn = sl_.xn, &racc = sl_.racc, &s0 = sl_.s0, &sl = sl_.sl;
         for (int a = 0; a < mc; a++) {
             hm::regression_row(gp->mean, &xn[(size_t)a * d], d, f.data());
             if (yout) {
@@ -138,8 +163,23 @@ int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *
                 vout[m0 + a] = (mse < 0.0) ? 0.0 : mse;         // :278
             }
         }
+        return EGX_SUCCESS;
+    };
+    int cur = 0, rc = EGX_SUCCESS;
+    bool pending = false;
+    for (int64_t m0 = 0; m0 < m && !rc; m0 += cap) {
+        rc = enqueue(slots[cur], m0);
+        if (!rc && pending) rc = finish(slots[cur ^ 1]);
+        pending = !rc;
+        cur ^= 1;
     }
-    return EGX_SUCCESS;
+    if (!rc && pending) rc = finish(slots[cur ^ 1]);
+    if (rc) {  // nothing may still run on the buffers the slots are about to free
+        (void)hipStreamSynchronize(slots[0].stream);
+        (void)hipStreamSynchronize(slots[1].stream);
+        (void)hipGetLastError();
+    }
+    return rc;
 }
 
 // d_W <- C^-T (upper triangular, rows of the identity through the forward block substitution) and

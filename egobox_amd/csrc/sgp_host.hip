@@ -19,12 +19,18 @@
 #include <vector>
 
 #include "egx_internal.h"
-#include "nelder_mead.h"
 #include "cobyla.h"
 
 using namespace egx;
 
 namespace {
+
+// outcome of one start of the multistart optimisation (objective, minimiser in log10 parameters, evaluations)
+struct StartResult {
+    double f;
+    std::vector<double> x;
+    int64_t evals;
+};
 
 struct Dev {
     double *p = nullptr;
@@ -528,18 +534,15 @@ int32_t egx_sgp_fit(egx_sgp *g, const double *params0s, int64_t n_starts, const 
         std::vector<double> x0(np);
         for (int i = 0; i < np; i++) x0[i] = std::log10(params0s[st * np + i]);
         // COBYLA as the reference configures it for the sparse model too (sparse_algorithm.rs:597-611 ->
-        // optimization.rs:122-169); EGX_FIT_OPTIMIZER=nelder-mead keeps the round-1 stand-in
-        const char *opt_env = std::getenv("EGX_FIT_OPTIMIZER");
-        NmResult r;
-        if (opt_env && std::string(opt_env) == "nelder-mead") {
-            r = nelder_mead(objective, x0, blo, bhi, per_start);
-        } else {
+        // optimization.rs:122-169)
+        StartResult r;
+        {
             CobylaBox m(x0, blo, bhi, 0.5, 1e-4, per_start);
             std::vector<double> xv;
             while (m.ask(xv)) m.tell(objective(xv));
             double fb = m.best_f();
             if (std::isnan(fb) || fb >= 1e30) fb = std::numeric_limits<double>::infinity();
-            r = NmResult{fb, m.best_x(), m.evals()};
+            r = StartResult{fb, m.best_x(), m.evals()};
         }
         evals += r.evals;
         if (r.f < best_f) {

@@ -111,28 +111,6 @@ class ThetaTuning:
 
 
 # ---- low level handle --------------------------------------------------------------------------
-class _fit_optimizer_env:
-    """egx_gp_fit / egx_gp_fit_partial run COBYLA; EGX_FIT_OPTIMIZER=nelder-mead selects the round-1 stand-in."""
-
-    def __init__(self, name):
-        self.name = name
-
-    def __enter__(self):
-        import os
-        self.old = os.environ.get("EGX_FIT_OPTIMIZER")
-        if self.name == "nelder-mead":
-            os.environ["EGX_FIT_OPTIMIZER"] = "nelder-mead"
-        else:
-            os.environ.pop("EGX_FIT_OPTIMIZER", None)
-
-    def __exit__(self, *a):
-        import os
-        if self.old is None:
-            os.environ.pop("EGX_FIT_OPTIMIZER", None)
-        else:
-            os.environ["EGX_FIT_OPTIMIZER"] = self.old
-
-
 class GpHandle:
     """One training set resident on one GPU (opaque `egx_gp*`)."""
 
@@ -485,11 +463,10 @@ class GpParams:
         return self
 
     def optimizer(self, name):
-        """"cobyla" (default: Powell's COBYLA as the reference uses it, csrc/cobyla.h), or the extensions "lbfgs"
-        (projected L-BFGS on log10 theta driven by the new likelihood gradient) and "nelder-mead" (the round-1
-        derivative-free stand-in, kept for A/B runs)."""
-        if name not in ("cobyla", "nelder-mead", "lbfgs"):
-            raise ValueError("optimizer must be 'cobyla', 'nelder-mead' or 'lbfgs'")
+        """"cobyla" (default: Powell's COBYLA as the reference uses it, csrc/cobyla.h), or the extension "lbfgs"
+        (projected L-BFGS on log10 theta driven by the new likelihood gradient)."""
+        if name not in ("cobyla", "lbfgs"):
+            raise ValueError("optimizer must be 'cobyla' or 'lbfgs'")
         self._optimizer = name
         return self
 
@@ -557,8 +534,7 @@ class GpParams:
                 n_evals = h.fit_lbfgs(10.0 ** starts_log10, [lo for lo, _ in b], [hi for _, hi in b],
                                       max(5, min(100, self._max_eval // 4)))
             else:
-                with _fit_optimizer_env(self._optimizer):
-                    n_evals = h.fit(10.0 ** starts_log10, [lo for lo, _ in b], [hi for _, hi in b], self._max_eval)
+                n_evals = h.fit(10.0 ** starts_log10, [lo for lo, _ in b], [hi for _, hi in b], self._max_eval)
         else:  # ThetaTuning::Partial, algorithm.rs:822-826, 873-960: only the active components move
             theta0 = np.full(dim, t.init[0]) if t.init.size == 1 else np.array(t.init, dtype=np.float64)
             b = t.bounds
@@ -574,9 +550,8 @@ class GpParams:
                 raise L.InvalidValueError(L.ERR_INVALID_VALUE, f"active components must be indices in [0, {dim})")
             ab = [b[i] for i in active]
             starts_log10, _ = prepare_multistart(self._n_start, theta0[active], ab, seed=self._seed)
-            with _fit_optimizer_env(self._optimizer):
-                n_evals = h.fit_partial(theta0, active, 10.0 ** starts_log10, [lo for lo, _ in ab],
-                                        [hi for _, hi in ab], self._max_eval)
+            n_evals = h.fit_partial(theta0, active, 10.0 ** starts_log10, [lo for lo, _ in ab],
+                                    [hi for _, hi in ab], self._max_eval)
         return GaussianProcess(h, self, n_evals)
 
 

@@ -270,9 +270,11 @@ def test_moe_c_host_drives_the_recombination(tmp_path):
 # ------------------------------------------------------------------ config 5
 def test_config5_eight_experts_n8192_d16_m100000(egx, large):
     """8 experts x n = 8192, d = 16 (disjoint LHS draws, seeds 7..14), m = 100 000 query points, smooth and hard
-    recombination (crates/moe/src/algorithm.rs:670-685, 894-910).  Expert 0 is pinned to the oracle fixture on the
-    first 1000 queries; the mixture is pinned to the recombination formulas applied to the experts' own outputs
-    with the ORACLE's mixture responsibilities (whose pdfs are pinned to gaussian_mixture.rs KATs)."""
+    recombination (crates/moe/src/algorithm.rs:670-685, 894-910).  EVERY expert is pinned to the oracle: expert 0 on the
+    first 1000 queries, experts 1..7 on the first 100 (likelihood, variance, predictions, variances); both
+    recombinations are pinned to the mixture of the eight ORACLE experts on those 100 points, and at m = 100 000 to the
+    recombination formulas applied to the experts' own outputs with the oracle's responsibilities (whose pdfs are pinned
+    to gaussian_mixture.rs KATs).  The recombination itself runs inside the library (egx_moe_predict_valvar)."""
     from egobox_amd.moe import GaussianMixture, GpMixture
     from oracle import moe_oracle as MO
     rec = large["expert_n8192_d16"]
@@ -287,6 +289,17 @@ def test_config5_eight_experts_n8192_d16_m100000(egx, large):
     try:
         assert experts[0].likelihood() == pytest.approx(rec["likelihood"], rel=LK_RTOL)
         assert experts[0].variance() == pytest.approx(rec["sigma2"], rel=1e-8)
+        # experts 1..7: the oracle's likelihood, variance and 100 predictions each (tests/golden/make_large_n.py --only experts)
+        rec17 = large["experts_1_to_7_n8192_d16"]
+        mq = rec17["m"]
+        for e in range(1, k):
+            re_ = rec17["experts"][str(e)]
+            assert re_["seed"] == 7 + e
+            assert experts[e].likelihood() == pytest.approx(re_["likelihood"], rel=LK_RTOL)
+            assert experts[e].variance() == pytest.approx(re_["sigma2"], rel=1e-8)
+            ye, ve = experts[e].predict_valvar(xq[:mq])
+            np.testing.assert_allclose(ye, re_["predict"], rtol=PRED_RTOL, atol=PRED_RTOL * max(np.abs(re_["predict"]).max(), 1.0))
+            np.testing.assert_allclose(ve, re_["predict_var"], rtol=PRED_RTOL, atol=1e-9 * re_["sigma2"])
         t0 = time.perf_counter()
         per_y, per_v = zip(*[e.predict_valvar(xq) for e in experts])
         dt = time.perf_counter() - t0
@@ -309,8 +322,15 @@ def test_config5_eight_experts_n8192_d16_m100000(egx, large):
         val, var = smooth.predict_valvar(xq)
         np.testing.assert_allclose(val, (per_y * p.T).sum(axis=0), rtol=1e-9, atol=1e-9 * ymax)
         np.testing.assert_allclose(var, (per_v * p.T * p.T).sum(axis=0), rtol=1e-9, atol=1e-12 * per_v.max())
+        # ... and against the mixture of the eight ORACLE experts on the fixture's 100 points (both recombinations)
+        mixr = rec17["mixture"]
+        np.testing.assert_array_equal(c[:mq], mixr["clusters"])
+        np.testing.assert_allclose(val[:mq], mixr["smooth_predict"], rtol=PRED_RTOL, atol=PRED_RTOL * ymax)
+        np.testing.assert_allclose(var[:mq], mixr["smooth_predict_var"], rtol=PRED_RTOL, atol=1e-9 * rec["sigma2"])
         hard = GpMixture(experts, GaussianMixture(w, means, covs, 0.9), "hard")
         val_h, var_h = hard.predict_valvar(xq)
+        np.testing.assert_allclose(val_h[:mq], mixr["hard_predict"], rtol=PRED_RTOL, atol=PRED_RTOL * ymax)
+        np.testing.assert_allclose(var_h[:mq], mixr["hard_predict_var"], rtol=PRED_RTOL, atol=1e-9 * rec["sigma2"])
         rows = np.arange(m)
         # routed subsets run through the same kernels in a different batch composition: values agree to rounding
         np.testing.assert_allclose(val_h, per_y[c, rows], rtol=1e-9, atol=1e-9 * ymax)
@@ -318,6 +338,37 @@ def test_config5_eight_experts_n8192_d16_m100000(egx, large):
     finally:
         for e in experts:
             e.close()
+
+
+@pytest.mark.parametrize("eps_col", [1e-8, 1e-10, 1e-12, 1e-13, 1e-15, 0.0])
+def test_nearly_collinear_trend_is_decided_as_the_reference_decides(egx, O, eps_col):
+    """algorithm.rs:1010-1027: the fit fails when sigma_min / sigma_max of the p x p QR factor of ft drops below 1e-10.
+    A Linear trend whose last two input columns agree to eps_col makes ft that ill conditioned.  The device GLS route
+    (Gram matrix, normal equations) may only be taken with margin -- the singular values of the factor are computed
+    exactly for p <= 64 -- and the status must be the oracle's in every regime (sigma_min / sigma_max of the oracle's
+    factor in brackets): comfortably fine (1e-8 [1.5e-4], 1e-10 [1.5e-6]), fine but too ill conditioned for normal
+    equations (1e-12 [1.5e-8], 1e-13 [1.5e-9]: the Householder route answers), failed with "ft is too ill conditioned"
+    (1e-15) and with "F is too ill conditioned" (0: a duplicated column)."""
+    rng = np.random.default_rng(12)
+    n, d = 600, 3
+    x = rng.random((n, d))
+    x[:, 2] = x[:, 1] + eps_col * rng.standard_normal(n)
+    y = np.sin(3.0 * x[:, 0]) + 2.0 * x[:, 1] + 0.1 * rng.standard_normal(n)
+    theta = np.array([1.0, 0.8, 0.8])
+    ref_lk, ref_st = O.likelihood_at(x, y, theta, mean=O.LINEAR, corr=O.MATERN52)
+    with egx.GpHandle(x, y, mean=1, corr=3) as h:
+        lk, st = h.likelihood(theta)
+    print(f"eps_col {eps_col:g}: oracle status {ref_st} lkh {ref_lk!r}; HIP status {st} lkh {lk!r}")
+    if eps_col >= 1e-13:
+        assert ref_st == 0
+    else:
+        assert ref_st in (2, 3)
+    assert (st == 0) == (ref_st == 0)
+    if st == 0:
+        # (beta along the nearly collinear pair is determined to eps / ratio only: the likelihood inherits some of it)
+        assert lk == pytest.approx(ref_lk, rel=1e-8 if eps_col >= 1e-10 else 1e-5)
+    else:
+        assert st in (egx._lib.STATUS_ILL_CONDITIONED_F, egx._lib.STATUS_ILL_CONDITIONED_FT) and np.isneginf(lk)
 
 
 # ------------------------------------------------------------------ device-side GLS for p > 1 trend columns

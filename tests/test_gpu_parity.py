@@ -986,7 +986,9 @@ def test_no_device_memory_leak_over_handle_lifecycles(egx, O):
     egx.trim()
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
-    assert abs(free0 - free1) < 64 << 20, (free0, free1)
+    # no GROWTH (the runtime's own sub-allocator may hand back a few 2 MiB blocks more or less than before: observed
+    # +68 MiB free after the 25 cycles)
+    assert free0 - free1 < 64 << 20, (free0, free1)
 
 
 def test_randomised_parity_sweep(egx, O):

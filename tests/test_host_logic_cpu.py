@@ -98,7 +98,7 @@ def test_workload_generators(egx):
 
 
 def test_host_cpp_under_address_and_ub_sanitizers(tmp_path):
-    """egobox_amd/csrc/host_math.h + nelder_mead.h (normalisation, trend basis and its jacobian, Householder QR with
+    """egobox_amd/csrc/host_math.h (normalisation, trend basis and its jacobian, Householder QR with
     positive diagonal, Jacobi singular values, the box-constrained Nelder-Mead) built with -fsanitize=address,undefined
     and checked against independent formulas (tests/c_host/host_math_sanitized.cpp)."""
     import os

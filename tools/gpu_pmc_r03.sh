@@ -6,9 +6,9 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 CORR=${1:-0}
 i=0; dbs=""
-for CTRS in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT"; do
+for CTRS in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F64" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES"; do
   i=$((i+1))
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $CTRS -d "$GRAFT_REPO_ROOT/gpurun_out/pmc3_$i" -o pmc -- python "$GRAFT_REPO_ROOT/tools/one_fit.py" 16384 32 3 $CORR > gpurun_out/pmc3_$i.log 2>&1)
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $CTRS -d "$GRAFT_REPO_ROOT/gpurun_out/pmc3_$i" -o pmc -- python "$GRAFT_REPO_ROOT/tools/one_fit.py" 16384 32 3 $CORR > "$GRAFT_REPO_ROOT/gpurun_out/pmc3_$i.log" 2>&1)
   db=$(find "$GRAFT_REPO_ROOT/gpurun_out/pmc3_$i" -name "*_results.db" | head -1)
   if [ -n "$db" ]; then
     python tools/pmc_chain_kernels.py gpurun_out/r03_pmc_per_kernel_corr${CORR}_$i.json "$db" > /dev/null
