@@ -177,92 +177,6 @@ __global__ __launch_bounds__(256) void k_corr_sym(const double *__restrict__ xT,
     }
 }
 
-// K1, round 3: the same result from 128x128 tiles with an 8x4 REGISTER tile per lane and pass (two passes per 64x64
-// quadrant).  The 4x4 form above reads 8 doubles from LDS per 16 pairs and dimension: 4 ds_read_b128
-// per 32 VALU instructions per wave, which at 8 cycles per read and 4 per FP64 instruction keeps the CU's one LDS pipe
-// exactly as busy as its four VALUs (the kernel ran at ~55 % of its VALU-issue bound, profiles/r03_run4_*).  8x4 pairs
-// per lane need 12 doubles per 32 pairs: 6 reads per 64 instructions, under a fifth of the VALU time.  One wave = one
-// 64x64 quadrant (lane = (ty, tx) in 8 x 8, rows 8 ty + a, columns 32 pass + 4 tx + b), four waves = the 128x128 tile,
-// two 128-point slabs in LDS.
-template <int CORR, bool PRE, int RJ>
-__device__ __forceinline__ void quad_pairs(const double *xi, const double *xj, const double *__restrict__ coef, int hcols,
-                                           int d, double (&r)[8][RJ]) {
-    PairAcc<CORR> acc[8][RJ];
-    for (int k = 0; k < d; k++) {
-        double vi[8], vj[RJ];
-#pragma unroll
-        for (int a = 0; a < 8; a++) vi[a] = xi[k * 128 + a];
-#pragma unroll
-        for (int b = 0; b < RJ; b++) vj[b] = xj[k * 128 + b];
-        const double *ck = coef + k * hcols;
-#pragma unroll
-        for (int a = 0; a < 8; a++)
-#pragma unroll
-            for (int b = 0; b < RJ; b++) {
-                if (PRE) acc[a][b].add_scaled(vi[a] - vj[b]);
-                else acc[a][b].add(vi[a] - vj[b], ck, hcols);
-            }
-    }
-#pragma unroll
-    for (int a = 0; a < 8; a++)
-#pragma unroll
-        for (int b = 0; b < RJ; b++) r[a][b] = acc[a][b].value();
-}
-
-__device__ __forceinline__ void stage_slab128(double *dst, const double *__restrict__ xT, int64_t ldx, int i0, int d, int tid,
-                                              const double *__restrict__ scale) {
-    for (int e = tid; e < d * 128; e += 256) {
-        const int k = e >> 7, i = e & 127;
-        const double v = xT[(int64_t)k * ldx + i0 + i];
-        dst[e] = scale ? scale[k] * v : v;
-    }
-}
-
-template <int CORR, bool PRE>
-__global__ __launch_bounds__(256, 2) void k_corr_sym128(const double *__restrict__ xT, int64_t ldx, int n, int d,
-                                                     const double *__restrict__ coef, int hcols, double diag,
-                                                     double *__restrict__ M, int64_t ld) {
-    // 1-D grid over the 128x128 tiles of the LOWER triangle
-    const int t = blockIdx.x;
-    int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
-    while (I * (I + 1) / 2 > t) I--;
-    while ((I + 1) * (I + 2) / 2 <= t) I++;
-    const int J = t - I * (I + 1) / 2;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *xi = sm, *xj = sm + d * 128;
-    const int tid = threadIdx.x, lane = tid & 63, ty = lane >> 3, tx = lane & 7;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wi = wave >> 1, wj = wave & 1;
-    stage_slab128(xi, xT, ldx, I * 128, d, tid, PRE ? coef : nullptr);
-    stage_slab128(xj, xT, ldx, J * 128, d, tid, PRE ? coef : nullptr);
-    __syncthreads();
-    // columns per lane and pass: 8x4 pairs per pass, two passes (an 8x8 accumulator array is not promoted to registers by
-    // hipcc -- 1 KiB of scratch per lane --, and Matern's two accumulators per pair would not fit anyway; at 8x4 the LDS
-    // pipe is busy 48 cycles per 256 cycles of FP64 issue)
-    constexpr int RJ = 4;
-#pragma unroll 1
-    for (int pass = 0; pass < 8 / RJ; pass++) {
-        const int i0 = I * 128 + wi * 64 + ty * 8;
-        const int j0 = J * 128 + wj * 64 + pass * (8 * RJ) + tx * RJ;
-        double r[8][RJ];
-        quad_pairs<CORR, PRE, RJ>(xi + wi * 64 + ty * 8, xj + wj * 64 + pass * (8 * RJ) + tx * RJ, coef, hcols, d, r);
-#pragma unroll
-        for (int a = 0; a < 8; a++) {
-            const int i = i0 + a;
-            double *p = M + (int64_t)i * ld + j0;
-#pragma unroll
-            for (int b = 0; b < RJ; b += 2) {
-                double v0 = r[a][b], v1 = r[a][b + 1];
-                const int ja = j0 + b, jb = j0 + b + 1;
-                if (i >= n || ja >= n) v0 = (i == ja) ? 1.0 : 0.0;  // identity padding
-                else if (i == ja) v0 = diag;                        // 1 + nugget, algorithm.rs:997
-                if (i >= n || jb >= n) v1 = (i == jb) ? 1.0 : 0.0;
-                else if (i == jb) v1 = diag;
-                *reinterpret_cast<double2 *>(p + b) = make_double2(v0, v1);
-            }
-        }
-    }
-}
-
 // K2: rectangular cross-correlation block (queries x training points), full grid.
 template <int CORR, bool PRE>
 __global__ __launch_bounds__(256) void k_cross_corr(const double *__restrict__ xqT, int64_t ldq,
@@ -670,32 +584,10 @@ int launch_corr_sym(hipStream_t s, int corr, const double *xT, int64_t ldx, int 
     const int nt2 = n_pad / 128;  // n_pad is a multiple of 128
     dim3 grid((unsigned)(4 * (nt2 * (nt2 + 1) / 2)));
     const size_t lds = (size_t)2 * d * 64 * sizeof(double);
-    // 128x128 tiles with 8x8 register tiles (k_corr_sym128) whenever their two 128-point slabs fit the LDS (d <= 64 does);
-    // EGX_CORR_TILE=64 keeps the 64x64 / 4x4 form of rounds 1-2 for A/B runs
-    static const int tile = [] {
-        const char *e = std::getenv("EGX_CORR_TILE");
-        return (e && std::atoi(e) == 64) ? 64 : 128;
-    }();
-    if (tile == 128 && (size_t)2 * d * 128 * sizeof(double) <= 150 * 1024) {
-        const dim3 g128((unsigned)(nt2 * (nt2 + 1) / 2));
-        const size_t lds128 = (size_t)2 * d * 128 * sizeof(double);
-        if (lds128 > 64 * 1024) {
-            static std::once_flag once;
-            std::call_once(once, [] {
-#define EGX_LDS_ATTR(C, P) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_corr_sym128<C, P>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)
-                EGX_LDS_ATTR(0, true); EGX_LDS_ATTR(1, true); EGX_LDS_ATTR(2, true); EGX_LDS_ATTR(3, true);
-                EGX_LDS_ATTR(0, false); EGX_LDS_ATTR(1, false); EGX_LDS_ATTR(2, false); EGX_LDS_ATTR(3, false);
-#undef EGX_LDS_ATTR
-            });
-        }
-        if (hcols == 1) {
-            EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_corr_sym128<C_, true>), g128, dim3(256), lds128, s, xT, ldx, n, d, coef,
-                                                       hcols, 1.0 + nugget, M, ld));
-        } else {
-            EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_corr_sym128<C_, false>), g128, dim3(256), lds128, s, xT, ldx, n, d, coef,
-                                                       hcols, 1.0 + nugget, M, ld));
-        }
-    } else if (hcols == 1) {
+    // (a 128x128-tile form with 8x4 pairs per lane -- a quarter less LDS traffic per VALU instruction -- was measured
+    //  SLOWER: 0.58 vs 0.52 ms at d = 32, 1.46 vs 1.11 ms at d = 64; its 64 / 128 KB of slabs leave 2 / 1 workgroups per CU
+    //  and nothing to overlap the staging with: profiles/r03_run5_k1_tile128_discarded.jsonl)
+    if (hcols == 1) {
         EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_corr_sym<C_, true>), grid, dim3(256), lds, s, xT, ldx, n, d, coef, hcols,
                                                    1.0 + nugget, M, ld));
     } else {
