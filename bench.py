@@ -178,6 +178,31 @@ def other_configs(egx, workload, gpu):
         "predict_points_per_s": m5 / t_p, "predict_var_points_per_s": m5 / t_v,
         "predict_var_trsm_tflops": float(n5) * n5 * m5 / t_v / 1e12,
         "predict_var_frac_of_fp64_peak": float(n5) * n5 * m5 / t_v / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+    # config 5 as a MIXTURE: 8 experts x n = 8192 resident on this GPU, smooth recombination of predict_var on 100 000
+    # points INSIDE the library (egx_moe_predict_valvar; with N ranks expert e lives on rank e mod N and the same call
+    # carries one all-gather of the partial sums)
+    from egobox_amd.moe import GaussianMixture, GpMixture
+    k = 8
+    rng = np.random.default_rng(5)
+    experts = []
+    for e in range(k):
+        xe, ye = workload.make_training_set(n5, d5, seed=7 + e)
+        experts.append(egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr())
+                       .theta_tuning(egx.ThetaTuning.Fixed(workload.default_theta(d5))).fit(xe, ye))
+    w = rng.random(k) + 0.5
+    w /= w.sum()
+    gmx = GaussianMixture(w, rng.random((k, d5)), np.array([np.eye(d5) * 0.3] * k), 0.9)
+    mix = GpMixture(experts, gmx, "smooth")
+    mix.predict_var(xq[:4000])
+    t0 = time.perf_counter()
+    vm = mix.predict_var(xq)
+    t_m = time.perf_counter() - t0
+    for e in experts:
+        e.close()
+    res["config5_mixture_8_experts_1gpu"] = {"predict_var_smooth_points_per_s": m5 / t_m,
+                                             "expert_points_per_s": k * m5 / t_m,
+                                             "trsm_tflops": k * float(n5) * n5 * m5 / t_m / 1e12,
+                                             "checksum": float(vm.sum())}
     d6 = 64
     x6, y6 = workload.make_training_set(n, d6, seed=42)
     h = egx.GpHandle(x6, y6, mean=0, corr=0, device=gpu, n_workspaces=1)

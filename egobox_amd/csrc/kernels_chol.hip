@@ -1440,7 +1440,6 @@ __global__ void k_gram_reduce(const double *__restrict__ P, int rows, int nsplit
 // is gone -- DESIGN.md section 4 lists both):
 static int g_potrf_group = 0;         // EGX_POTRF_GROUP: panels per trailing update, 1..8 (0 = by size: 4 from n_pad 14336, else 2)
 static int g_stream_min_tiles = 128;  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles PER MATRIX go to k_gemm_stream
-static int g_stream_min_lower = 128;  // EGX_STREAM_MIN_LOWER (experiment): the same for the LOWER (trailing-matrix) launches
 static int g_stream_tpw = 1;          // EGX_STREAM_TPW: tiles a workgroup of k_gemm_stream walks (1: CUs turn over, the chain squeezes in)
 static int g_gemm_small_max = 1024;   // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used
 static int g_look_min_cols = 3072;    // EGX_LOOK_MIN: look-ahead while at least this many columns trail the next group
@@ -1457,7 +1456,6 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_GEMM_SMALL")) g_gemm_small_max = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_TPW")) g_stream_tpw = std::atoi(e) > 0 ? std::atoi(e) : 1;
         if (const char *e = std::getenv("EGX_STREAM_MIN")) g_stream_min_tiles = std::atoi(e) > 0 ? std::atoi(e) : 1;
-        if (const char *e = std::getenv("EGX_STREAM_MIN_LOWER")) g_stream_min_lower = std::atoi(e) > 0 ? std::atoi(e) : 1;
         if (const char *e = std::getenv("EGX_LOOK_MIN")) g_look_min_cols = std::atoi(e);
         if (const char *e = std::getenv("EGX_TRSM_GROUP")) g_trsm_group = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
@@ -1502,7 +1500,7 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         else
             wide_tiles = (int64_t)(M / 128) * (N / 256);
     }
-    if (K >= 2 * KC && wide_tiles >= (lower ? g_stream_min_lower : g_stream_min_tiles)) {
+    if (K >= 2 * KC && wide_tiles >= g_stream_min_tiles) {
         // the launches that fill the chip on their own are the ones the roofline trace follows
         if (used_big_tile) *used_big_tile = wide_tiles >= 512;
         const int nbx = M / 128, nby = N / 256;  // LOWER: column c holds nbx - 2 c tiles (M >= N in the factorisation)

@@ -251,6 +251,31 @@ def test_sweep_c_host_drives_the_collective(tmp_path):
     assert out.stdout.startswith("OK"), out.stdout  # RCCL's version banner goes to stderr (sweep.hip)
 
 
+def test_sweep_dynamic_assignment_gives_the_static_results(egx):
+    """egx_sweep_set_assignment(1): candidates are pulled from the node-wide counter instead of the c mod world shard.
+    On one rank the counter is process-local; the results must be those of the static assignment bit for bit, call after
+    call (the counter slots rotate), NaN thetas included, and the balance report must account for every candidate."""
+    x, y = _data(900, 5, 3)
+    thetas = egx.theta_sweep_candidates(13, 5, seed=2)
+    thetas[4] = np.nan
+    with egx.Sweep(x, y, corr=0, rank=0, world=1, id_bytes="new", n_workspaces=4) as sw:
+        lk0, st0 = sw.likelihood(thetas)
+        assert st0[4] == egx._lib.STATUS_NAN_THETA and (st0 == 0).sum() >= 8
+        sw.set_assignment(True)
+        for _ in range(70):  # more calls than counter slots (64): the slots are recycled
+            lk1, st1 = sw.likelihood(thetas[:5])
+            np.testing.assert_array_equal(st1, st0[:5])
+            np.testing.assert_array_equal(lk1[st1 == 0], lk0[:5][st0[:5] == 0])
+        lk1, st1 = sw.likelihood(thetas)
+        np.testing.assert_array_equal(st1, st0)
+        np.testing.assert_array_equal(lk1[st1 == 0], lk0[st0 == 0])
+        per, sec = sw.last_balance()
+        assert per.tolist() == [13] and sec > 0.0
+        sw.set_assignment(False)
+        lk2, st2 = sw.likelihood(thetas)
+        np.testing.assert_array_equal(lk2[st2 == 0], lk0[st0 == 0])
+
+
 def test_moe_c_host_drives_the_recombination(tmp_path):
     """tests/c_host/moe_driver.c: a C99 host (no Python) trains three experts, then calls egx_moe_predict_valvar -- the
     mixture recombination inside the library -- in both recombinations, single-process and through a one-rank RCCL

@@ -18,6 +18,20 @@ def main(path, per_fit=1):
     print(f"{'kernel':<72} {'calls':>6} {'total_ms':>10} {'avg_us':>10} {'min_us':>9} {'max_us':>10} {'pct':>6}")
     for r in rows:
         print(f"{r[0][:72]:<72} {r[1]:>6} {r[2]:>10.3f} {r[3]:>10.1f} {r[4]:>9.1f} {r[5]:>10.1f} {100 * r[2] / tot:>6.1f}")
+    # The roofline of bench.py follows the launches of the trailing-update kernel that fill the chip on their own
+    # (>= 512 workgroups of one 128x256 tile each, ONE matrix per launch): the same selection here, so that the average
+    # duration below is the one its HIP events must agree with.  (Since round 3 the kernel also serves smaller launches.)
+    try:
+        q2 = """select count(*), sum(d.end-d.start)/1e6, avg(d.end-d.start)/1e3, min(d.end-d.start)/1e3, max(d.end-d.start)/1e3
+                from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+                where s.kernel_name like '%k_gemm_streamILb1E%' and d.grid_size_x / d.workgroup_size_x >= 512
+                      and d.grid_size_z <= 1"""
+        c, t, a, lo, hi = list(cur.execute(q2))[0]
+        if c:
+            print(f"{'k_gemm_stream<LOWER>, launches of >= 512 workgroups, one matrix (the roofline set)':<72}"[:100])
+            print(f"{'':<72} {c:>6} {t:>10.3f} {a:>10.1f} {lo:>9.1f} {hi:>10.1f} {100 * t / tot:>6.1f}")
+    except sqlite3.OperationalError as e:  # older rocpd schema without grid sizes
+        print(f"# (no grid-size columns in this database: {e})")
 
 
 if __name__ == "__main__":
