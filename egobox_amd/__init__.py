@@ -6,7 +6,7 @@ no CPU or PyTorch fallback for the compute path.
 """
 from . import _lib
 from ._lib import (EgxError, InvalidValueError, LikelihoodComputationError, LinalgError, NoDeviceError,
-                   NotFittedError)
+                   NotFittedError, PeerError)
 
 _lib.load()  # fail loudly at import when the HIP library is missing
 

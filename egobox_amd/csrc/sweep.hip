@@ -89,6 +89,12 @@ using namespace egx;
 struct SweepCounters {
     static constexpr int kSlots = 64;
     std::atomic<int64_t> next[kSlots];
+    // HOST TRANSPORT of the all-gather (EGX_SWEEP_TRANSPORT=shm, see egx_sweep_create): two monotonic arrival counters
+    // (a barrier = "add one, wait until the count reaches generation x world") and one slab per rank
+    static constexpr int kMaxWorld = 16;
+    static constexpr int64_t kSlab = 8192;  // doubles per rank and round
+    std::atomic<int64_t> arrived_a, arrived_b;
+    double gather[kMaxWorld * kSlab];
 };
 static_assert(std::atomic<int64_t>::is_always_lock_free, "the shared counters must be plain lock-free words");
 
@@ -107,6 +113,8 @@ struct egx_sweep {
     int dynamic = 0;
     SweepCounters *counters = nullptr;  // shared memory (world > 1) or heap (world == 1)
     bool counters_shared = false;
+    bool shm_transport = false;  // the all-gather goes through `counters->gather` instead of RCCL (test transport)
+    int64_t shm_generation = 0;
     std::string shm_name;
     int64_t call_seq = 0;
     // balance of the last call
@@ -173,6 +181,41 @@ int sweep_wait(egx_sweep *sw) {
 
 }  // namespace
 
+// The HOST transport (EGX_SWEEP_TRANSPORT=shm): the same all-gather through the ranks' shared-memory segment.  It
+// exists so that the world > 1 logic of this file -- sharding, the dynamic counter, poisoned payloads, the deadline --
+// can EXECUTE where RCCL cannot build a communicator: several ranks on ONE GPU (RCCL refuses duplicate devices), i.e. the
+// one-GPU box the test-suite runs on (tests/test_gpu_configs.py::test_sweep_two_ranks_*).  The payload is 16 bytes per
+// candidate either way; the product transport is RCCL (ncclAllGather over xGMI), which every run with a communicator uses.
+static int shm_barrier(egx_sweep *sw, std::atomic<int64_t> &ctr, int64_t generation) {
+    ctr.fetch_add(1, std::memory_order_acq_rel);
+    const int64_t want = generation * sw->world;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int64_t spins = 0; ctr.load(std::memory_order_acquire) < want; spins++) {
+        if (spins > 4000) std::this_thread::sleep_for(std::chrono::microseconds(20));
+        if ((spins & 4095) == 4095 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > sw->timeout_s) {
+            set_error("sweep collective (host transport): no answer from the other ranks within " +
+                      std::to_string((int)sw->timeout_s) + " s (EGX_SWEEP_TIMEOUT_S)");
+            return EGX_ERR_PEER;
+        }
+    }
+    return EGX_SUCCESS;
+}
+static int shm_allgather_doubles(egx_sweep *sw, const double *send, int64_t count, double *recv) {
+    SweepCounters *sc = sw->counters;
+    for (int64_t off = 0; off < count; off += SweepCounters::kSlab) {
+        const int64_t len = std::min<int64_t>(SweepCounters::kSlab, count - off);
+        const int64_t gen = ++sw->shm_generation;
+        std::memcpy(sc->gather + (size_t)sw->rank * SweepCounters::kSlab, send + off, sizeof(double) * len);
+        EGX_RC(shm_barrier(sw, sc->arrived_a, gen));  // every slab of this round is written
+        for (int r = 0; r < sw->world; r++)
+            std::memcpy(recv + (size_t)r * count + off, sc->gather + (size_t)r * SweepCounters::kSlab, sizeof(double) * len);
+        EGX_RC(shm_barrier(sw, sc->arrived_b, gen));  // ... and read by everybody before the next round overwrites it
+        sw->n_allgathers++;
+    }
+    return EGX_SUCCESS;
+}
+
 // all ranks: recv (world x count doubles) <- concatenation over ranks of send (count doubles); host buffers, pinned
 // staging allocated in egx_sweep_create, one ncclAllGather per kChunk doubles on the sweep's stream
 static int sweep_allgather_doubles(egx_sweep *sw, const double *send, int64_t count, double *recv) {
@@ -180,6 +223,7 @@ static int sweep_allgather_doubles(egx_sweep *sw, const double *send, int64_t co
         std::memcpy(recv, send, sizeof(double) * count);
         return EGX_SUCCESS;
     }
+    if (sw->shm_transport) return shm_allgather_doubles(sw, send, count, recv);
     if (!sw->comm) {
         set_error("sweep collective: the communicator was aborted by an earlier failure");
         return EGX_ERR_PEER;
@@ -289,7 +333,17 @@ int32_t egx_sweep_create(const egx_gp_config *cfg_in, const double *x, const dou
         sw->counters = new SweepCounters();
         for (auto &c : sw->counters->next) c.store(0);
     }
-    if (nccl_id) {
+    {
+        const char *tr = std::getenv("EGX_SWEEP_TRANSPORT");
+        if (tr && std::string(tr) == "shm" && world > 1) {
+            if (!sw->counters_shared || world > SweepCounters::kMaxWorld) {
+                set_error("egx_sweep_create: the host transport needs the shared-memory segment and world <= 16");
+                return fail(EGX_ERR_UNSUPPORTED);
+            }
+            sw->shm_transport = true;
+        }
+    }
+    if (nccl_id && !sw->shm_transport) {
         RcclApi &api = rccl();
         if (!api.err.empty()) {
             set_error(api.err);

@@ -107,15 +107,19 @@ class Sweep:
         return {"rank": r.value, "world": w.value, "rccl_ranks": rr.value, "rccl_version": v.value,
                 "n_allgathers": na.value}
 
-    def likelihood(self, thetas):
-        """COLLECTIVE: (k x h) candidates -> (lkh (k,), status (k,)), complete on every rank."""
+    def likelihood(self, thetas, raise_on_peer_failure=True):
+        """COLLECTIVE: (k x h) candidates -> (lkh (k,), status (k,)), complete on every rank.
+        When ANOTHER rank failed the call raises `PeerError` -- or, with raise_on_peer_failure=False, returns the arrays
+        anyway: the survivors' candidates are valid, the failed rank's carry STATUS_RANK_FAILED."""
         L = self._L
         thetas = L.as_f64(thetas, 2)
         k = thetas.shape[0]
         lk = np.empty(k)
         st = np.empty(k, dtype=np.int32)
-        L.check(self._lib.egx_sweep_likelihood(self._h, L.dptr(thetas), k, thetas.shape[1], L.dptr(lk),
-                                               st.ctypes.data_as(L.c_int32_p)))
+        rc = self._lib.egx_sweep_likelihood(self._h, L.dptr(thetas), k, thetas.shape[1], L.dptr(lk),
+                                            st.ctypes.data_as(L.c_int32_p))
+        if not (rc == L.ERR_PEER and not raise_on_peer_failure):
+            L.check(rc)
         return lk, st
 
     def set_lockstep(self, width):

@@ -276,6 +276,97 @@ def test_sweep_dynamic_assignment_gives_the_static_results(egx):
         np.testing.assert_array_equal(lk2[st2 == 0], lk0[st0 == 0])
 
 
+def _two_rank_worker(rank, token, q):
+    """One rank of a world = 2 sweep on the ONE GPU of the test box (host transport, see sweep.hip)."""
+    os.environ["EGX_SWEEP_TRANSPORT"] = "shm"
+    os.environ["EGX_SWEEP_TIMEOUT_S"] = "8"
+    import numpy as np
+    import egobox_amd as egx
+    from egobox_amd import workload
+    x, y = workload.make_training_set(900, 5, seed=3)
+    thetas = egx.theta_sweep_candidates(14, 5, seed=2)
+    thetas[4] = np.nan
+    thetas[9] = 1e-4  # not positive definite: returns ~10x sooner than the others
+    out = {}
+    sw = egx.Sweep(x, y, corr=0, device=0, rank=rank, world=2, id_bytes=token, n_workspaces=4)
+    try:
+        out["info"] = sw.info()
+        out["static"] = sw.likelihood(thetas)
+        out["balance_static"] = sw.last_balance()[0].tolist()
+        sw.set_assignment(True)
+        out["dynamic"] = [sw.likelihood(thetas) for _ in range(3)][-1]
+        out["balance_dynamic"] = sw.last_balance()[0].tolist()
+        sw.set_assignment(False)
+        out["allgather"] = sw.allgather(np.arange(5.0) + 10.0 * rank)
+        # a LOCAL failure on rank 1 only (its theta matrix has one column too many): both ranks must come back
+        bad = thetas if rank == 0 else np.hstack([thetas, thetas[:, :1]])
+        try:
+            lk, st = sw.likelihood(bad, raise_on_peer_failure=False)
+            out["fail"] = ("returned", lk, st, egx._lib.load().egx_last_error().decode())
+        except egx.EgxError as e:
+            out["fail"] = (type(e).__name__, e.rc, str(e))
+        out["after"] = sw.likelihood(thetas)  # the collective completed on both ranks: the sweep is still usable
+        if rank == 0:  # rank 1 never arrives at this call: the deadline (8 s) must end it
+            import time
+            t0 = time.time()
+            try:
+                sw.likelihood(thetas)
+                out["deadline"] = ("returned", time.time() - t0)
+            except egx.EgxError as e:
+                out["deadline"] = (type(e).__name__, e.rc, time.time() - t0)
+    finally:
+        q.put((rank, out))
+        sw.close()
+
+
+@pytest.mark.timeout(300)
+def test_sweep_two_ranks_share_one_gpu_through_the_host_transport(egx):
+    """The world > 1 logic of csrc/sweep.hip EXECUTED on the one-GPU box: two processes, both on GPU 0, rendezvous
+    through the shared-memory segment (EGX_SWEEP_TRANSPORT=shm: RCCL refuses two ranks on one device; the payload and
+    everything around the all-gather are the product's).  Static and dynamic assignment return the single-process
+    results bit for bit on both ranks; a rank that fails locally still arrives (the survivor gets EGX_ERR_PEER with the
+    failed rank's candidates marked, its own valid); a rank that never arrives is given up after the deadline."""
+    import torch.multiprocessing as mp
+    x, y = _data(900, 5, 3)
+    thetas = egx.theta_sweep_candidates(14, 5, seed=2)
+    thetas[4] = np.nan
+    thetas[9] = 1e-4
+    with egx.GpHandle(x, y, corr=0, n_workspaces=4) as h:
+        ref_lk, ref_st = h.likelihood_batch(thetas)
+    assert ref_st[4] == egx._lib.STATUS_NAN_THETA and ref_st[9] == egx._lib.STATUS_NOT_POSITIVE_DEFINITE
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    token = os.urandom(128)
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, token, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ok = ref_st == 0
+    for r in range(2):
+        assert res[r]["info"]["world"] == 2 and res[r]["info"]["rccl_ranks"] == 0
+        for mode in ("static", "dynamic", "after"):
+            lk, st = res[r][mode]
+            np.testing.assert_array_equal(st, ref_st)
+            np.testing.assert_array_equal(lk[ok], ref_lk[ok])
+        assert res[r]["balance_static"] == [7, 7]
+        assert sum(res[r]["balance_dynamic"]) == 14 and min(res[r]["balance_dynamic"]) >= 1
+        np.testing.assert_array_equal(res[r]["allgather"], [[0, 1, 2, 3, 4], [10, 11, 12, 13, 14]])
+    print("dynamic balance:", res[0]["balance_dynamic"])
+    # the failing rank reports ITS error, the survivor a peer error with the survivors' candidates intact
+    assert res[1]["fail"][0] == "InvalidValueError"
+    kind, lk, st, msg = res[0]["fail"]
+    assert kind == "returned" and "rank 1 failed" in msg
+    mine = np.arange(14) % 2 == 0
+    np.testing.assert_array_equal(st[mine], ref_st[mine])
+    np.testing.assert_array_equal(lk[mine & ok], ref_lk[mine & ok])
+    assert np.all(st[~mine] == egx._lib.STATUS_RANK_FAILED) and np.all(np.isneginf(lk[~mine]))
+    kind, rc, waited = res[0]["deadline"]
+    assert kind == "PeerError" and rc == egx._lib.ERR_PEER and 6.0 < waited < 40.0
+
+
 def test_moe_c_host_drives_the_recombination(tmp_path):
     """tests/c_host/moe_driver.c: a C99 host (no Python) trains three experts, then calls egx_moe_predict_valvar -- the
     mixture recombination inside the library -- in both recombinations, single-process and through a one-rank RCCL
