@@ -17,7 +17,7 @@ from .gpx import CorrelationSpec, GpMix, Gpx, Recombination, RegressionSpec  # n
 from .multistart import prepare_multistart, theta_sweep_candidates  # noqa: E402
 from .sgp import (Inducings, ParamTuning, SgpHandle, SgpParams, SparseGaussianProcess, SparseGpMix, SparseGpx,  # noqa: E402
                   SparseMethod)
-from . import workload  # noqa: E402
+from . import moe, workload  # noqa: E402
 from .sweep import Sweep, best_candidate, rendezvous_sweep, shard_indices, sweep_likelihood  # noqa: E402
 
 __all__ = [n for n in dir() if not n.startswith("_")]
