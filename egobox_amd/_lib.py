@@ -60,6 +60,7 @@ SIGNATURES = [
                                   C.POINTER(C.c_void_p)]),
     ("egx_gp_destroy", None, [C.c_void_p]),
     ("egx_gp_dims", C.c_int32, [C.c_void_p, c_int64_p, c_int64_p, c_int64_p, c_int64_p]),
+    ("egx_gp_get_training_data", C.c_int32, [C.c_void_p, c_double_p, c_double_p]),
     ("egx_gp_likelihood", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_int32_p]),
     ("egx_gp_likelihood_batch", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_int32_p]),
     ("egx_gp_set_lockstep", C.c_int32, [C.c_void_p, C.c_int32]),

@@ -947,8 +947,13 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
     if (rc) return fail(rc);
     // k-major, zero padded copies
     std::vector<double> xT((size_t)d * gp->n_pad, 0.0), rhsT((size_t)gp->q * gp->n_pad, 0.0);
-    for (int64_t i = 0; i < n; i++)
-        for (int64_t j = 0; j < d; j++) xT[(size_t)j * gp->n_pad + i] = gp->xnorm[i * d + j];
+    for (int64_t i0 = 0; i0 < n; i0 += 64) {  // 64-point blocks: the d write streams stay within a few cache lines each
+        const int64_t i1 = std::min<int64_t>(n, i0 + 64);
+        for (int64_t j = 0; j < d; j++) {
+            double *dst = &xT[(size_t)j * gp->n_pad];
+            for (int64_t i = i0; i < i1; i++) dst[i] = gp->xnorm[i * d + j];
+        }
+    }
     for (int64_t l = 0; l < p; l++)
         for (int64_t i = 0; i < n; i++) rhsT[(size_t)l * gp->n_pad + i] = gp->F[i * p + l];
     for (int64_t i = 0; i < n; i++) rhsT[(size_t)p * gp->n_pad + i] = gp->ynorm[i];
@@ -1020,6 +1025,16 @@ int32_t egx_gp_dims(const egx_gp *gp, int64_t *n, int64_t *d, int64_t *p, int64_
     if (d) *d = gp->d;
     if (p) *p = gp->p;
     if (h) *h = gp->h;
+    return EGX_SUCCESS;
+}
+
+int32_t egx_gp_get_training_data(const egx_gp *gp, double *x_out, double *y_out) {
+    if (!gp) {
+        set_error("NULL handle");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (x_out) std::memcpy(x_out, gp->x_raw.data(), sizeof(double) * gp->x_raw.size());
+    if (y_out) std::memcpy(y_out, gp->y_raw.data(), sizeof(double) * gp->y_raw.size());
     return EGX_SUCCESS;
 }
 

@@ -4,6 +4,7 @@
 // factorisation that runs on the GPU.  The reference takes these from linfa-linalg 0.2.1
 // (`qr().into_decomp()`, `svd(false,false)`, `solve_triangular`).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -11,22 +12,32 @@
 namespace egx {
 namespace hm {
 
-// utils.rs:45-54
+// utils.rs:45-54.  Row-major passes with one accumulator per column: every column sees exactly the additions of the
+// column-by-column form, in the same order (the same bits), without its d strided sweeps over the (n, d) array.
 inline void normalize(const double *x, int64_t n, int64_t d, double *xn, double *mean, double *sd) {
-    for (int64_t j = 0; j < d; j++) {
-        double s = 0.0;
-        for (int64_t i = 0; i < n; i++) s += x[i * d + j];
-        const double m = s / (double)n;
-        double v = 0.0;
-        for (int64_t i = 0; i < n; i++) {
-            const double t = x[i * d + j] - m;
-            v += t * t;
+    std::vector<double> acc((size_t)d, 0.0);
+    for (int64_t i = 0; i < n; i++) {
+        const double *row = x + i * d;
+        for (int64_t j = 0; j < d; j++) acc[j] += row[j];
+    }
+    for (int64_t j = 0; j < d; j++) mean[j] = acc[j] / (double)n;
+    std::fill(acc.begin(), acc.end(), 0.0);
+    for (int64_t i = 0; i < n; i++) {
+        const double *row = x + i * d;
+        for (int64_t j = 0; j < d; j++) {
+            const double t = row[j] - mean[j];
+            acc[j] += t * t;
         }
-        double sdev = std::sqrt(v / (double)(n - 1));
+    }
+    for (int64_t j = 0; j < d; j++) {
+        double sdev = std::sqrt(acc[j] / (double)(n - 1));
         if (sdev == 0.0) sdev = 1.0;
-        mean[j] = m;
         sd[j] = sdev;
-        for (int64_t i = 0; i < n; i++) xn[i * d + j] = (x[i * d + j] - m) / sdev;
+    }
+    for (int64_t i = 0; i < n; i++) {
+        const double *row = x + i * d;
+        double *out = xn + i * d;
+        for (int64_t j = 0; j < d; j++) out[j] = (row[j] - mean[j]) / sd[j];
     }
 }
 

@@ -146,7 +146,14 @@ class GpHandle:
         n, d, p, h = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         L.check(lib.egx_gp_dims(self._h, C.byref(n), C.byref(d), C.byref(p), C.byref(h)))
         self.n, self.d, self.p, self.h = n.value, d.value, p.value, h.value
-        self.training_data = (x.copy(), y.copy())
+
+    @property
+    def training_data(self):
+        """(x, y) as given to the fit: the handle's own copy (the fitted model owns its training data,
+        algorithm.rs:969-978), fetched from the library when asked for instead of being duplicated in Python."""
+        x, y = np.empty((self.n, self.d)), np.empty(self.n)
+        L.check(self._lib.egx_gp_get_training_data(self._h, L.dptr(x), L.dptr(y)))
+        return x, y
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:

@@ -121,6 +121,9 @@ int32_t egx_gp_create(const egx_gp_config *cfg, const double *x, const double *y
 void egx_gp_destroy(egx_gp *gp);
 /* dims: n, d (dims().0, algorithm.rs:437-439), p = basis columns, h = theta length */
 int32_t egx_gp_dims(const egx_gp *gp, int64_t *n, int64_t *d, int64_t *p, int64_t *h);
+/* the handle's own copy of the raw training set (GaussianProcess::training_data, algorithm.rs:969-978: the fitted model
+ * owns copies of x and y); x_out (n*d), y_out (n), either may be NULL */
+int32_t egx_gp_get_training_data(const egx_gp *gp, double *x_out, double *y_out);
 
 /* ---- likelihood (the unit COBYLA multiplies) ------------------------------
  * One evaluation of `reduced_likelihood(fx, corr.value(d, theta, w), ...)`
