@@ -771,6 +771,13 @@ int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t t
 // =================================================================================================
 // C ABI
 // =================================================================================================
+// lock-step width of a handle with nws workspaces: min(nws, 4), or the EGX_LOCKSTEP environment variable
+static int default_lockstep(int nws) {
+    int ls = nws < 4 ? nws : 4;
+    if (const char *e = std::getenv("EGX_LOCKSTEP")) ls = std::atoi(e);
+    return ls < 1 ? 1 : (ls > nws ? nws : ls);
+}
+
 extern "C" {
 
 int32_t egx_abi_version(void) { return EGX_GP_ABI_VERSION; }
@@ -986,11 +993,7 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
     }
     EGX_HIPF(hipMemcpy(gp->d_xT, xT.data(), sizeof(double) * xT.size(), hipMemcpyHostToDevice));
     EGX_HIPF(hipMemcpy(gp->d_rhsT, rhsT.data(), sizeof(double) * rhsT.size(), hipMemcpyHostToDevice));
-    {   // candidates of a likelihood batch factored in lock-step: see egx_gp_set_lockstep
-        int ls = nws < 4 ? nws : 4;
-        if (const char *e = std::getenv("EGX_LOCKSTEP")) ls = std::atoi(e);
-        gp->lockstep = ls < 1 ? 1 : (ls > nws ? nws : ls);
-    }
+    gp->lockstep = default_lockstep(nws);  // candidates of a likelihood batch factored in lock-step: egx_gp_set_lockstep
     *out = gp;
     return EGX_SUCCESS;
 }
@@ -1083,12 +1086,6 @@ int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int
     std::unique_lock<std::shared_mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
     return likelihood_batch_core(gp, thetas, k, theta_len, lkh, status);
-}
-
-static int default_lockstep(int nws) {
-    int ls = nws < 4 ? nws : 4;
-    if (const char *e = std::getenv("EGX_LOCKSTEP")) ls = std::atoi(e);
-    return ls < 1 ? 1 : (ls > nws ? nws : ls);
 }
 
 int32_t egx_gp_set_lockstep(egx_gp *gp, int32_t width) {
