@@ -702,7 +702,8 @@ int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t t
     const int ws_lo = (gp->fitted && gp->ws.size() > 1) ? 1 : 0;
     const int nws = (int)gp->ws.size() - ws_lo;
     const int B = gp->lockstep < nws ? (gp->lockstep < 1 ? 1 : gp->lockstep) : nws;
-    const int nslots = nws / B;
+    const int nslots = (nws + B - 1) / B;  // the last slot may hold fewer workspaces (11 starts: 4 + 4 + 3)
+    auto slot_cap = [&](int i) { return std::min(B, nws - i * B); };
     std::vector<std::vector<int64_t>> cand(nslots);  // candidates in flight on slot i (workspaces ws_lo + i B ...)
     bool exhausted = false;
     int busy = 0;
@@ -743,7 +744,7 @@ int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t t
                 busy--;
             }
             int hcols = 1;
-            while (!exhausted && (int)cand[i].size() < B) {
+            while (!exhausted && (int)cand[i].size() < slot_cap(i)) {
                 int64_t c;
                 EGX_RC(next_valid(c, coefs[cand[i].size()], hcols));
                 if (c >= 0) cand[i].push_back(c);
@@ -771,9 +772,12 @@ int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t t
 // =================================================================================================
 // C ABI
 // =================================================================================================
-// lock-step width of a handle with nws workspaces: min(nws, 4), or the EGX_LOCKSTEP environment variable
-static int default_lockstep(int nws) {
-    int ls = nws < 4 ? nws : 4;
+// Lock-step width of a handle with nws workspaces (or the EGX_LOCKSTEP environment variable): 4 for large matrices --
+// measured at n = 16384: 3 / 4 / 6 / 8 wide 37.5 / 38.4-40.5 / 38.9-40.1 / 39.6-40.3 fits/s, several groups in flight
+// matter more than their width --; up to 12 for n_pad <= 4096, where an evaluation is bound by launch latency and the
+// chain (a tuned fit's 11 COBYLA starts are then ONE launch sequence per round)
+static int default_lockstep(int nws, int n_pad) {
+    int ls = n_pad <= 4096 ? 12 : 4;
     if (const char *e = std::getenv("EGX_LOCKSTEP")) ls = std::atoi(e);
     return ls < 1 ? 1 : (ls > nws ? nws : ls);
 }
@@ -993,7 +997,7 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
     }
     EGX_HIPF(hipMemcpy(gp->d_xT, xT.data(), sizeof(double) * xT.size(), hipMemcpyHostToDevice));
     EGX_HIPF(hipMemcpy(gp->d_rhsT, rhsT.data(), sizeof(double) * rhsT.size(), hipMemcpyHostToDevice));
-    gp->lockstep = default_lockstep(nws);  // candidates of a likelihood batch factored in lock-step: egx_gp_set_lockstep
+    gp->lockstep = default_lockstep(nws, gp->n_pad);  // candidates of a likelihood batch factored in lock-step: egx_gp_set_lockstep
     *out = gp;
     return EGX_SUCCESS;
 }
@@ -1095,7 +1099,7 @@ int32_t egx_gp_set_lockstep(egx_gp *gp, int32_t width) {
     }
     std::unique_lock<std::shared_mutex> lock(gp->mu);
     const int nws = (int)gp->ws.size();
-    gp->lockstep = width == 0 ? default_lockstep(nws) : (width > nws ? nws : width);
+    gp->lockstep = width == 0 ? default_lockstep(nws, gp->n_pad) : (width > nws ? nws : width);
     return EGX_SUCCESS;
 }
 

@@ -410,7 +410,7 @@ class GpParams:
         self._max_eval = GP_COBYLA_MAX_EVAL
         self._nugget = DEFAULT_NUGGET
         self._device = -1
-        self._n_workspaces = 2  # concurrent likelihood evaluations (multistart threads) during a tuned fit
+        self._n_workspaces = None  # concurrent likelihood evaluations during a tuned fit; None = all starts (see fit)
         self._optimizer = "cobyla"  # the reference's optimiser (optimization.rs:122-169); "lbfgs" uses the new gradient
         self._seed = 42  # optimization.rs:62: multistart LHS is seeded with 42
 
@@ -514,7 +514,16 @@ class GpParams:
                 w = pls_rotations(x, y, self._kpls_dim)
             else:
                 w = self._kpls_weights
-        nws = 1 if self._theta_tuning.kind == "Fixed" else min(self._n_workspaces, self._n_start + 1)
+        if self._theta_tuning.kind == "Fixed":
+            nws = 1
+        elif self._n_workspaces is not None:
+            nws = min(self._n_workspaces, self._n_start + 1)
+        else:
+            # every start of the multistart gets a workspace (the reference runs them on a rayon pool, algorithm.rs:928-945):
+            # COBYLA advances all starts in lock-step, so a round's trial points are ONE likelihood batch, factored in
+            # lock-step groups of four -- bounded by 12 workspaces and 16 GiB of correlation matrices
+            n_pad = -(-x.shape[0] // 128) * 128
+            nws = max(1, min(self._n_start + 1, 12, int((16 << 30) // max(1, 8 * n_pad * (n_pad + 128)))))
         h = GpHandle(x, y, mean=self._mean.code, corr=self._corr.code, nugget=self._nugget, device=self._device,
                      n_workspaces=max(1, nws), w_star=w)
         t = self._theta_tuning
