@@ -163,18 +163,6 @@ __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t 
 // ---------------------------------------------------------------------------------------------
 // C: trailing update / general  C -= A B^T.  grid = (M/128, N/128).
 // ---------------------------------------------------------------------------------------------
-#ifdef EGX_GEMM_PROFILE
-__device__ long long g_gemm_stamps[1 << 16][4];
-__device__ long long g_gemm_cycles[1 << 16][2];  // shader-clock ticks (s_memtime) at the K-loop boundaries
-#define EGX_GSTAMP(i)                                                                                     \
-    if (threadIdx.x == 0) {                                                                               \
-        g_gemm_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 0xffff][i] = (long long)wall_clock64();    \
-        if (i < 2) g_gemm_cycles[(blockIdx.y * gridDim.x + blockIdx.x) & 0xffff][i] = (long long)clock64(); \
-        if (i == 0) g_gemm_stamps[(blockIdx.y * gridDim.x + blockIdx.x) & 0xffff][3] = __smid();          \
-    }
-#else
-#define EGX_GSTAMP(i)
-#endif
 using TrailShape = GemmShape<128, 128, 32, 64, 512>;  // 8 waves, 2 workgroups per CU -> 4 MFMA waves per SIMD
 using SmallShape = GemmShape<64, 64, 32, 32, 256>;    // 4x lower per-tile latency: look-ahead column + small trailing matrices
 
@@ -256,7 +244,6 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt
     if (LOWER && (bx + 1) * BM <= by * BN) return;  // tile entirely above the diagonal
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x;
-    EGX_GSTAMP(0);
     double4_t acc[S::MT][S::NT];
 #pragma unroll
     for (int mi = 0; mi < S::MT; mi++)
@@ -267,7 +254,6 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt
     const int koff = (ktri & 1) ? bx * BM : 0;
     gemm_core<BM, BN, WM, WN, NTHREADS>(A + (int64_t)bx * BM * lda + koff, lda, B + (int64_t)by * BN * ldb + koff, ldb,
                                         K - koff, acc, smem, tid);
-    EGX_GSTAMP(1);
     const int wave = tid >> 6, lane = tid & 63;
     const int r0 = bx * BM + (wave / S::WAVES_N) * WM + (lane >> 4);
     const int c0 = by * BN + (wave % S::WAVES_N) * WN + (lane & 15);
@@ -294,7 +280,6 @@ __global__ __launch_bounds__(NTHREADS, (NTHREADS == 512 ? 4 : 2)) void k_gemm_nt
             for (int r = 0; r < 4; r++)
                 C[(int64_t)(r0 + mi * 16 + 4 * r) * ldc + (c0 + ni * 16)] = cv[mi & 1][ni][r] - acc[mi][ni][r];
     }
-    EGX_GSTAMP(2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -337,13 +322,6 @@ __device__ __forceinline__ void stream_tile_coords(int t, int nbx, int nby, int 
     }
 }
 
-#ifdef EGX_STREAM_PROFILE
-__device__ long long g_stream_stamps[1 << 14][6];  // per tile: wall start, wall end, cycles start / after C load / after K loop / end
-#define EGX_SSTAMP(slot, i, v)                                     \
-    if (threadIdx.x == 0) g_stream_stamps[(slot) & 0x3fff][i] = (long long)(v)
-#else
-#define EGX_SSTAMP(slot, i, v)
-#endif
 template <bool LOWER>
 __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, int64_t ldc, const double *__restrict__ A,
                                                         int64_t lda, const double *__restrict__ B, int64_t ldb, int K,
@@ -439,8 +417,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
         int bx, by;
         stream_tile_coords<LOWER>(t, nbx, nby, bx, by);
         double *Ct = C + (int64_t)(bx * 128 + wm0) * ldc + by * 256 + wn0;
-        EGX_SSTAMP(t, 0, wall_clock64());
-        EGX_SSTAMP(t, 2, clock64());
         double4_t acc[4][4];
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
@@ -448,10 +424,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
             for (int ni = 0; ni < 4; ni++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) acc[mi][ni][r] = -Ct[(int64_t)mi * 16 * ldc + ni * 16 + coff[r]];
-#ifdef EGX_STREAM_PROFILE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        EGX_SSTAMP(t, 3, clock64());
         // MID-CHUNK barrier (the survivor of five orderings, profiles/r02_run11_gemm_lab_variants_0_to_4.txt): the synchronisation for chunk g + 1 sits between the two 8-deep halves of chunk g, the
         // fragments of a half are read one half ahead, so the MFMA stream runs across the barrier and no LDS read
         // latency is exposed behind it:
@@ -505,7 +477,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
             mma_quarter(a1, b1, 1);
             stage = st1;
         }
-        EGX_SSTAMP(t, 4, clock64());
         // (the 16 row pointers of the C tile are rebuilt here instead of staying live through the K loop: the opaque
         //  pass through an empty asm keeps the compiler from carrying 32 address VGPRs across 2048 MFMAs)
 #pragma unroll
@@ -516,8 +487,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
             for (int ni = 0; ni < 4; ni++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) Ct[(int64_t)mi * 16 * ldc + ni * 16 + coff[r]] = -acc[mi][ni][r];
-        EGX_SSTAMP(t, 5, clock64());
-        EGX_SSTAMP(t, 1, wall_clock64());
     }
 }
 
@@ -868,13 +837,6 @@ __device__ __forceinline__ void rb_chain_run(RbChain &ch, double *NL, double *LR
     c = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b2, c, 0, 0, NEG);           \
     c = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b3, c, 0, 0, NEG)
 
-#ifdef EGX_POTF2_PROFILE
-__device__ long long g_rb_stamps[2][16][8];  // [chain wave / update wave 1][strip][event]
-#define RB_STAMP(w, k, i) \
-    if (lane == 0) g_rb_stamps[w][k][i] = (long long)__builtin_readcyclecounter()
-#else
-#define RB_STAMP(w, k, i)
-#endif
 template <int NW>  // waves: 1 chain wave + NW - 1 update waves (16 in the product; the tables also cover 8 and 12)
 __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D, int64_t ld, int nbk, double *__restrict__ lin,
                                                           int *__restrict__ info, int col0, int n_valid, int64_t bsD,
@@ -914,14 +876,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
             ch.a[c + 1] = v[1];
         }
         if (failed_before != 0) return;  // a previous block of this factorisation already failed: early exit
-        RB_STAMP(0, 0, 0);
         rb_chain_run(ch, NL, LR, rd, lane, frow, fk, info, col0, n_valid, flag, flag + 1);
-        RB_STAMP(0, 0, 1);
         __syncthreads();
         if (*flag) return;
         for (int k = 0; k + 1 < nb16; k++) {
             __syncthreads();  // phase A of strip k done: tile (k+1, k+1) is in Dg
-            RB_STAMP(0, k + 1, 0);
 #pragma unroll
             for (int c = 0; c < 16; c += 2) {
                 const d2_t v = *reinterpret_cast<const d2_t *>(Dg + frow * RB_LD + c);
@@ -929,9 +888,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
                 ch.a[c + 1] = v[1];
             }
             rb_chain_run(ch, NL, LR, rd, lane, frow, fk, info, col0 + (k + 1) * 16, n_valid, flag, flag + 1);
-            RB_STAMP(0, k + 1, 1);
             __syncthreads();
-            RB_STAMP(0, k + 1, 2);
             if (*flag) return;
         }
         return;
@@ -1002,7 +959,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
         int fr = frow, pr = prow, f4 = 4 * fk;
         asm volatile("" : "+v"(fr), "+v"(pr), "+v"(f4));
         // ---- phase A: TRSM_k (the tiles (R, k), R > k, become X_R); tile (k+1, k+1) is updated by its owner at once
-        if (wave == 1) RB_STAMP(1, k, 0);
         if (wave == 1 + k % NU) store_diag(k);
         if (m_trsm) {
             const d2_t n01 = *reinterpret_cast<const d2_t *>(NL + pr * RB_LD + f4);
@@ -1049,10 +1005,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
                 }
             }
         }
-        if (wave == 1) RB_STAMP(1, k, 1);
         __syncthreads();
         // ---- phase B: all other tiles right of column k, while wave 0 factors tile (k+1, k+1)
-        if (wave == 1) RB_STAMP(1, k, 2);
 #pragma unroll
         for (int s = 0; s < RB_NS; s++) {
             if (m_upd & (1u << s)) {
@@ -1069,9 +1023,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D
                 acc[4 * s + 3] = c4[3];
             }
         }
-        if (wave == 1) RB_STAMP(1, k, 3);
         __syncthreads();
-        if (wave == 1) RB_STAMP(1, k, 4);
         if (*flag) return false;
         m_trsm = n_trsm;
         m_pair = n_pair;
