@@ -1396,6 +1396,7 @@ static int g_stream_tpw = 1;          // EGX_STREAM_TPW: tiles a workgroup of k_
 static int g_gemm_small_max = 1024;   // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used
 static int g_look_min_cols = 3072;    // EGX_LOOK_MIN: look-ahead while at least this many columns trail the next group
 static int g_trsm_group = 0;          // EGX_TRSM_GROUP: panels per update in the solves after the factorisation (0 = 4)
+static int g_lur_side = 1;            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU also in lock-step batches
 
 int chol_init() {
     static std::once_flag once;
@@ -1410,6 +1411,7 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_STREAM_MIN")) g_stream_min_tiles = std::atoi(e) > 0 ? std::atoi(e) : 1;
         if (const char *e = std::getenv("EGX_LOOK_MIN")) g_look_min_cols = std::atoi(e);
         if (const char *e = std::getenv("EGX_TRSM_GROUP")) g_trsm_group = std::atoi(e);
+        if (const char *e = std::getenv("EGX_LUR_SIDE")) g_lur_side = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -1638,12 +1640,16 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             if (rc) return rc;
             EGX_HIP_CHECK(hipEventRecord(lk->ev_lu, s));
             EGX_HIP_CHECK(hipStreamWaitEvent(s2, lk->ev_lu, 0));
-            // (LUr beside RU on the side stream -- they write disjoint columns -- gained 0.8 % on the sweep and 1 % on a lone
-            //  fit, profiles/r03_run4_lur_side_ab.txt, but RU's own launches then share the chip with LUr and cannot be
-            //  timed per launch any more: not kept)
-            rc = update(s, r1 + nb1, r1, m_tot - r1 - nb1, gw1, g0, gw, 0, nullptr);
+            // LUr writes the next group's columns, RU the columns right of them, both only READ this group's panel.  In a
+            // lock-step batch LUr goes to the (high-priority) side stream, so that RU fills the CUs LUr's last, partly filled
+            // round of tiles leaves idle (+0.8 % on the sweep, profiles/r03_run4_lur_side_ab.txt).  A lone matrix keeps LUr in
+            // front of RU on `s`: its RU launches are the ones the roofline times per launch, and they would share the chip
+            // with LUr.  Streams only: the arithmetic of a matrix is the same either way.
+            hipStream_t slu = (nz > 1 && g_lur_side) ? s3 : s;
+            if (slu != s) EGX_HIP_CHECK(hipStreamWaitEvent(slu, lk->ev_lu, 0));
+            rc = update(slu, r1 + nb1, r1, m_tot - r1 - nb1, gw1, g0, gw, 0, nullptr);
             if (rc) return rc;
-            EGX_HIP_CHECK(hipEventRecord(lk->ev_lur, s));
+            EGX_HIP_CHECK(hipEventRecord(lk->ev_lur, slu));
             rc = inner_factor(s2, r1, gw1, s3, lk->ev_lur);
             if (rc) return rc;
             EGX_HIP_CHECK(hipEventRecord(lk->ev_panel, s2));
