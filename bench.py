@@ -222,6 +222,40 @@ def other_configs(egx, workload, gpu):
     return res
 
 
+def moe_sharded_leg(egx, workload, sw, rank, world, gpu):
+    """8 experts x n = 8192, d = 16, expert e trained and kept on rank e mod world; predict_var of the smooth mixture on
+    100 000 points: every rank evaluates its own experts, ONE all-gather of the partial sums inside the library
+    (crates/moe/src/algorithm.rs:167-177 trains the experts serially, :670-685 folds them)."""
+    from egobox_amd.moe import GaussianMixture, GpMixture
+    k, n5, d5, m5 = 8, 8192, 16, 100000
+    rng = np.random.default_rng(5)
+    experts = []
+    t0 = time.perf_counter()
+    for e in range(k):
+        if e % world == rank:
+            xe, ye = workload.make_training_set(n5, d5, seed=7 + e)
+            experts.append(egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr())
+                           .theta_tuning(egx.ThetaTuning.Fixed(workload.default_theta(d5))).fit(xe, ye))
+        else:
+            experts.append(None)
+    t_fit = time.perf_counter() - t0
+    w = rng.random(k) + 0.5
+    w /= w.sum()
+    gmx = GaussianMixture(w, rng.random((k, d5)), np.array([np.eye(d5) * 0.3] * k), 0.9)
+    xq = np.random.default_rng(7).random((m5, d5))
+    mix = GpMixture(experts, gmx, "smooth", rank=rank, world=world, sweep=sw)
+    mix.predict_var(xq[:4000])
+    t0 = time.perf_counter()
+    vm = mix.predict_var(xq)
+    t_m = time.perf_counter() - t0
+    for e in experts:
+        if e is not None:
+            e.close()
+    return {"experts": k, "experts_on_rank_0": sum(1 for e in range(k) if e % world == 0), "fit_own_experts_s": t_fit,
+            "predict_var_smooth_points_per_s": m5 / t_m, "expert_points_per_s": k * m5 / t_m,
+            "trsm_tflops_all_gpus": k * float(n5) * n5 * m5 / t_m / 1e12, "checksum": float(vm.sum())}
+
+
 def spawn_ranks(n_ranks):
     """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run on
     127.0.0.1 (one process per GPU, algorithm.rs:928-945's rayon workers at node scale) and pass its exit code on."""
@@ -317,6 +351,7 @@ def main():
     if args.dry_launch:
         sys.exit(dry_launch(args, rank, world))
 
+    os.environ.setdefault("EGX_SWEEP_TIMEOUT_S", "300")  # a benchmark: a peer that is 5 minutes late is gone
     import torch
     import torch.distributed as dist
 
@@ -324,11 +359,19 @@ def main():
         sys.stderr.write("bench.py: no GPU visible (the product has no CPU path; --dry-launch rehearses the launch only)\n")
         sys.exit(3)
     gpu = local_rank % torch.cuda.device_count()
+    # REHEARSAL of the N > 1 path on a box with fewer GPUs than ranks (EGX_SWEEP_TRANSPORT=shm: the library's all-gather goes
+    # through the ranks' shared-memory segment, several ranks share a GPU, torch.distributed runs on gloo).  The line is
+    # marked and its throughput means nothing; it exists so that every statement of the N > 1 path has executed once.
+    rehearsal = os.environ.get("EGX_SWEEP_TRANSPORT", "") == "shm"
+    tdev = "cpu" if rehearsal else f"cuda:{gpu}"
     torch.cuda.set_device(gpu)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{gpu}"))
+        if rehearsal:
+            dist.init_process_group("gloo")  # only carries the 128 id bytes and the per-rank times
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{gpu}"))
 
     import egobox_amd as egx
     from egobox_amd import workload
@@ -371,7 +414,7 @@ def main():
     elapsed = time.perf_counter() - t0
     rank_seconds = [elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{gpu}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         parts = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
         rank_seconds = [float(p.item()) for p in parts]
@@ -379,13 +422,22 @@ def main():
     per_rank_last, eval_s_last = sw.last_balance()
     eval_seconds = [eval_s_last]
     if world > 1:
-        t = torch.tensor([eval_s_last], dtype=torch.float64, device=f"cuda:{gpu}")
+        t = torch.tensor([eval_s_last], dtype=torch.float64, device=tdev)
         parts = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
         eval_seconds = [float(p.item()) for p in parts]
     info = sw.info()
+    # BASELINE config 5 sharded over the ranks (one expert per GPU at N = 8): a bounded side leg AFTER the timed region, on
+    # every rank (it is a collective): expert e on rank e mod N, smooth recombination of predict_var on 100 000 points
+    # through egx_moe_predict_valvar and the sweep's communicator.  Never part of `value`; any failure becomes a string.
+    moe_sharded = None
+    if world > 1 and not args.no_extra_configs:
+        try:
+            moe_sharded = moe_sharded_leg(egx, workload, sw, rank, world, gpu)
+        except Exception as e:  # noqa: BLE001 - reported in the line, must not take the headline number down
+            moe_sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
     sw.close()
-    if info["rccl_ranks"] != world:
+    if info["rccl_ranks"] != world and not rehearsal:
         sys.stderr.write(f"bench.py: the library's RCCL communicator has {info['rccl_ranks']} ranks, world is {world}\n")
         sys.exit(4)
 
@@ -433,6 +485,8 @@ def main():
                        "fits_in_flight_per_gpu": max(1, args.in_flight), "lockstep_width": lockstep},
             "fits_per_step": nb,
             "rccl_ranks": info["rccl_ranks"], "rccl_version": info["rccl_version"],
+            **({"rehearsal": "EGX_SWEEP_TRANSPORT=shm: host transport instead of RCCL, ranks share GPUs -- NOT a measurement"}
+               if rehearsal else {}),
             "allgathers_in_timed_region": args.steps, "assignment": args.assignment,
             "rank_seconds": rank_seconds,
             "last_step_balance": {"candidates_per_rank": [int(v) for v in per_rank_last],
@@ -506,6 +560,8 @@ def main():
                                              "device resources in the library's pool (egx_trim frees it)"}
         if world == 1 and not args.no_extra_configs:
             out["other_configs"] = other_configs(egx, workload, gpu)
+        if moe_sharded is not None:
+            out["other_configs"] = {"config5_mixture_8_experts_sharded": moe_sharded}
         if not args.no_cpu_baseline and world == 1:
             torch.cuda.synchronize()
             cb = cpu_baseline(n, d)

@@ -298,6 +298,20 @@ def _two_rank_worker(rank, token, q):
         out["balance_dynamic"] = sw.last_balance()[0].tolist()
         sw.set_assignment(False)
         out["allgather"] = sw.allgather(np.arange(5.0) + 10.0 * rank)
+        # the mixture recombination sharded over the two ranks (expert e on rank e mod 2), both recombinations
+        from egobox_amd.moe import GaussianMixture, GpMixture
+        experts = []
+        for e in range(3):
+            xe, ye = workload.make_training_set(400, 2, seed=20 + e)
+            experts.append(egx.GaussianProcess.params(egx.ConstantMean(), egx.Matern52Corr())
+                           .theta_tuning(egx.ThetaTuning.Fixed([1.2, 0.9])).fit(xe, ye) if e % 2 == rank else None)
+        gmx = GaussianMixture([0.3, 0.3, 0.4], [[0.2, 0.5], [0.5, 0.5], [0.8, 0.5]], [np.eye(2) * 0.05] * 3, 0.8)
+        xq = np.random.default_rng(2).random((333, 2))
+        for recomb in ("smooth", "hard"):
+            out["moe_" + recomb] = GpMixture(experts, gmx, recomb, rank=rank, world=2, sweep=sw).predict_valvar(xq)
+        for e in experts:
+            if e is not None:
+                e.close()
         # a LOCAL failure on rank 1 only (its theta matrix has one column too many): both ranks must come back
         bad = thetas if rank == 0 else np.hstack([thetas, thetas[:, :1]])
         try:
@@ -355,6 +369,23 @@ def test_sweep_two_ranks_share_one_gpu_through_the_host_transport(egx):
         assert sum(res[r]["balance_dynamic"]) == 14 and min(res[r]["balance_dynamic"]) >= 1
         np.testing.assert_array_equal(res[r]["allgather"], [[0, 1, 2, 3, 4], [10, 11, 12, 13, 14]])
     print("dynamic balance:", res[0]["balance_dynamic"])
+    # the sharded mixture against the same three experts in this process
+    from egobox_amd.moe import GaussianMixture, GpMixture
+    experts = []
+    for e in range(3):
+        xe, ye = _data(400, 2, 20 + e)
+        experts.append(egx.GaussianProcess.params(egx.ConstantMean(), egx.Matern52Corr())
+                       .theta_tuning(egx.ThetaTuning.Fixed([1.2, 0.9])).fit(xe, ye))
+    gmx = GaussianMixture([0.3, 0.3, 0.4], [[0.2, 0.5], [0.5, 0.5], [0.8, 0.5]], [np.eye(2) * 0.05] * 3, 0.8)
+    xq = np.random.default_rng(2).random((333, 2))
+    for recomb in ("smooth", "hard"):
+        want = GpMixture(experts, gmx, recomb).predict_valvar(xq)
+        for r in range(2):
+            np.testing.assert_allclose(res[r]["moe_" + recomb][0], want[0], rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(res[r]["moe_" + recomb][1], want[1], rtol=1e-12, atol=1e-14)
+        np.testing.assert_array_equal(res[0]["moe_" + recomb][0], res[1]["moe_" + recomb][0])  # the same bits on both ranks
+    for e in experts:
+        e.close()
     # the failing rank reports ITS error, the survivor a peer error with the survivors' candidates intact
     assert res[1]["fail"][0] == "InvalidValueError"
     kind, lk, st, msg = res[0]["fail"]
@@ -365,6 +396,34 @@ def test_sweep_two_ranks_share_one_gpu_through_the_host_transport(egx):
     assert np.all(st[~mine] == egx._lib.STATUS_RANK_FAILED) and np.all(np.isneginf(lk[~mine]))
     kind, rc, waited = res[0]["deadline"]
     assert kind == "PeerError" and rc == egx._lib.ERR_PEER and 6.0 < waited < 40.0
+
+
+@pytest.mark.timeout(600)
+def test_bench_gpus_2_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on the one-GPU box: bench.py starts its two ranks itself, both on GPU 0, the
+    library's all-gather goes through the host transport (EGX_SWEEP_TRANSPORT=shm; RCCL refuses two ranks on one device),
+    torch.distributed on gloo.  Every statement of the N > 1 path runs: rendezvous, sharded sweep, per-rank times, the
+    sharded mixture leg (expert e on rank e mod 2).  The line is marked as a rehearsal and carries no performance claim."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EGX_SWEEP_TRANSPORT="shm")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--sweep-batch", "10", "--in-flight", "4", "--npoints", "2048", "--dim", "6", "--no-cpu-baseline",
+                          "--assignment", "dynamic"], cwd=root, env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and "rehearsal" in rec and rec["rccl_ranks"] == 0 and rec["assignment"] == "dynamic"
+    assert rec["candidates_ok"] == 20 and rec["candidates_failed"] == 0 and len(rec["rank_seconds"]) == 2
+    assert sum(rec["last_step_balance"]["candidates_per_rank"]) == 10
+    moe = rec["other_configs"]["config5_mixture_8_experts_sharded"]
+    assert "error" not in moe and moe["experts_on_rank_0"] == 4 and math.isfinite(moe["checksum"])
+    # the sharded mixture is the single-process mixture (bench.py's other_configs at N = 1 prints the same checksum)
+    assert moe["checksum"] == pytest.approx(5774.94659384006, rel=1e-9)
 
 
 def test_moe_c_host_drives_the_recombination(tmp_path):
