@@ -14,3 +14,5 @@ python tools/rocpd_stats.py "$DB" > gpurun_out/${T}_bench_sweepbatch1_kernel_sta
 python tools/timeline.py "$DB" gpurun_out/${T}_timeline_n16384_one_fit.txt
 timeout 300 python tools/small_n_latency.py > gpurun_out/${T}_small_n_latency.jsonl 2>/dev/null; tail -2 gpurun_out/${T}_small_n_latency.jsonl
 rm -rf gpurun_out/prof_${T}_default gpurun_out/prof_${T}_b1
+timeout 600 python bench_configs.py > gpurun_out/${T}_bench_configs.jsonl 2>/dev/null; wc -l gpurun_out/${T}_bench_configs.jsonl
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
