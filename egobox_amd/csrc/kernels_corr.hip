@@ -104,8 +104,8 @@ struct PairAcc {
 // Stage a 64-point slab (all d dimensions, k-major) into LDS: dst[k*64 + i]; scale != nullptr: times scale[k]
 // (PairAcc::add_scaled, hcols == 1).
 __device__ __forceinline__ void stage_slab(double *dst, const double *__restrict__ xT, int64_t ldx, int i0,
-                                           int d, int tid, const double *__restrict__ scale = nullptr) {
-    for (int e = tid; e < d * 64; e += 256) {
+                                           int d, int tid, const double *__restrict__ scale = nullptr, int nthreads = 256) {
+    for (int e = tid; e < d * 64; e += nthreads) {
         const int k = e >> 6, i = e & 63;
         const double v = xT[(int64_t)k * ldx + i0 + i];
         dst[e] = scale ? scale[k] * v : v;
@@ -113,19 +113,20 @@ __device__ __forceinline__ void stage_slab(double *dst, const double *__restrict
 }
 
 // 4x4 micro-tile of pair accumulators from two staged slabs.
-template <int CORR, bool PRE = false>  // PRE: the slabs were staged with the coefficients applied (hcols == 1)
+template <int CORR, bool PRE = false, int RI = 4>  // PRE: the slabs were staged with the coefficients applied (hcols == 1);
+                                                    // RI x 4 pairs per lane (rows RI ty + a, columns 4 tx + b)
 __device__ __forceinline__ void tile_pairs(const double *xi, const double *xj, const double *__restrict__ coef,
-                                           int hcols, int d, int ty, int tx, double (&r)[4][4]) {
-    PairAcc<CORR> acc[4][4];
+                                           int hcols, int d, int ty, int tx, double (&r)[RI][4]) {
+    PairAcc<CORR> acc[RI][4];
     for (int k = 0; k < d; k++) {
-        double vi[4], vj[4];
+        double vi[RI], vj[4];
 #pragma unroll
-        for (int a = 0; a < 4; a++) vi[a] = xi[k * 64 + ty * 4 + a];
+        for (int a = 0; a < RI; a++) vi[a] = xi[k * 64 + ty * RI + a];
 #pragma unroll
         for (int b = 0; b < 4; b++) vj[b] = xj[k * 64 + tx * 4 + b];
         const double *ck = coef + k * hcols;
 #pragma unroll
-        for (int a = 0; a < 4; a++)
+        for (int a = 0; a < RI; a++)
 #pragma unroll
             for (int b = 0; b < 4; b++) {
                 if (PRE) acc[a][b].add_scaled(vi[a] - vj[b]);
@@ -133,18 +134,19 @@ __device__ __forceinline__ void tile_pairs(const double *xi, const double *xj, c
             }
     }
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int a = 0; a < RI; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) r[a][b] = acc[a][b].value();
 }
 
 // K1: symmetric training correlation matrix, 64x64 tiles, 128x128-granular lower triangle.
-template <int CORR, bool PRE>
-__global__ __launch_bounds__(256) void k_corr_sym(const double *__restrict__ xT, int64_t ldx, int n, int d,
-                                                  const double *__restrict__ coef, int hcols, double diag,
-                                                  double *__restrict__ M, int64_t ld) {
+template <int CORR, bool PRE, int RI>  // 64 x 64 tile per workgroup of 1024 / RI threads, RI x 4 pairs per lane
+__global__ __launch_bounds__(1024 / RI) void k_corr_sym(const double *__restrict__ xT, int64_t ldx, int n, int d,
+                                                        const double *__restrict__ coef, int hcols, double diag,
+                                                        double *__restrict__ M, int64_t ld) {
     // 1-D grid over the 128x128 tiles of the LOWER triangle only (4 workgroups per tile): a 2-D grid with an early exit
     // for the strictly-upper tiles launches twice the workgroups and leaves the real ones unevenly spread over the CUs
+    constexpr int NT = 1024 / RI;
     const int t = blockIdx.x >> 2, sub = blockIdx.x & 3;
     int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while (I * (I + 1) / 2 > t) I--;
@@ -154,14 +156,14 @@ __global__ __launch_bounds__(256) void k_corr_sym(const double *__restrict__ xT,
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *xi = sm, *xj = sm + d * 64;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    stage_slab(xi, xT, ldx, bi * 64, d, tid, PRE ? coef : nullptr);
-    stage_slab(xj, xT, ldx, bj * 64, d, tid, PRE ? coef : nullptr);
+    stage_slab(xi, xT, ldx, bi * 64, d, tid, PRE ? coef : nullptr, NT);
+    stage_slab(xj, xT, ldx, bj * 64, d, tid, PRE ? coef : nullptr, NT);
     __syncthreads();
-    double r[4][4];
-    tile_pairs<CORR, PRE>(xi, xj, coef, hcols, d, ty, tx, r);
+    double r[RI][4];
+    tile_pairs<CORR, PRE, RI>(xi, xj, coef, hcols, d, ty, tx, r);
 #pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const int i = bi * 64 + ty * 4 + a;
+    for (int a = 0; a < RI; a++) {
+        const int i = bi * 64 + ty * RI + a;
         double out[4];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -176,8 +178,6 @@ __global__ __launch_bounds__(256) void k_corr_sym(const double *__restrict__ xT,
         *reinterpret_cast<double2 *>(p + 2) = make_double2(out[2], out[3]);
     }
 }
-
-// K2: rectangular cross-correlation block (queries x training points), full grid.
 template <int CORR, bool PRE>
 __global__ __launch_bounds__(256) void k_cross_corr(const double *__restrict__ xqT, int64_t ldq,
                                                     const double *__restrict__ xT, int64_t ldx, int d,
@@ -587,11 +587,13 @@ int launch_corr_sym(hipStream_t s, int corr, const double *xT, int64_t ldx, int 
     // (a 128x128-tile form with 8x4 pairs per lane -- a quarter less LDS traffic per VALU instruction -- was measured
     //  SLOWER: 0.58 vs 0.52 ms at d = 32, 1.46 vs 1.11 ms at d = 64; its 64 / 128 KB of slabs leave 2 / 1 workgroups per CU
     //  and nothing to overlap the staging with: profiles/r03_run5_k1_tile128_discarded.jsonl)
+    // (8 x 4 pairs per lane in the same tile -- 128 threads, a quarter less LDS traffic per instruction -- is SLOWER too:
+    //  0.745 vs 0.52 ms; the kernel wants its 16 waves per CU more than it wants fewer LDS reads: profiles/r03_run10_*)
     if (hcols == 1) {
-        EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_corr_sym<C_, true>), grid, dim3(256), lds, s, xT, ldx, n, d, coef, hcols,
+        EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_corr_sym<C_, true, 4>), grid, dim3(256), lds, s, xT, ldx, n, d, coef, hcols,
                                                    1.0 + nugget, M, ld));
     } else {
-        EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_corr_sym<C_, false>), grid, dim3(256), lds, s, xT, ldx, n, d, coef, hcols,
+        EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_corr_sym<C_, false, 4>), grid, dim3(256), lds, s, xT, ldx, n, d, coef, hcols,
                                                    1.0 + nugget, M, ld));
     }
     EGX_HIP_CHECK(hipGetLastError());
