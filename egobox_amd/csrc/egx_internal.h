@@ -34,8 +34,10 @@ inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 // coef is (d x hcols) row-major: per-dimension scale (w = I: hcols = 1, coef[j] = theta_j;
 // KPLS: sq-exp/abs-exp collapse to hcols = 1, Matern keeps theta_l*|w_jl|).
 // xT is k-major (d x ldx): xT[k*ldx + i] = xnorm[i][k]; rows >= n are padding.
+// xs_scratch (optional, d x ldx doubles): with it and hcols == 1 the scalar-row kernel runs on prescaled inputs
 int launch_corr_sym(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d,
-                    const double *coef, int hcols, double nugget, double *M, int64_t ld, int n_pad);
+                    const double *coef, int hcols, double nugget, double *M, int64_t ld, int n_pad,
+                    double *xs_scratch = nullptr);
 // full (m_pad x n_pad) cross correlation block, row-major into R (ld), no diagonal handling
 int launch_cross_corr(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad,
                       const double *xT, int64_t ldx, int n_pad, int d, const double *coef,

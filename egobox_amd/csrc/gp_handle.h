@@ -62,6 +62,7 @@ struct Workspace {
     double *dinv = nullptr;    // (n_pad/64) x 64 x 64 inverses of the diagonal tiles
     double *dW = nullptr;      // (n_pad/256) x 256 x 256 transposed inverses of the diagonal blocks (lazy)
     double *d_coef = nullptr;  // d x hcols
+    double *d_xs = nullptr;    // d x n_pad: the inputs times this candidate's coefficients (K1's scalar-row form)
     double *d_diag = nullptr;  // n
     double *d_vec = nullptr;   // n_pad (gamma)
     double *d_rhs = nullptr;   // n_pad (rho, destroyed by the back-substitution)

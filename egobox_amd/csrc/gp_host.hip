@@ -26,6 +26,7 @@ static void free_workspace(Workspace &w) {
     // (M, dinv, d_info are views into the handle's slabs)
     if (w.dW) hipFree(w.dW);
     if (w.d_coef) hipFree(w.d_coef);
+    if (w.d_xs) hipFree(w.d_xs);
     if (w.d_diag) hipFree(w.d_diag);
     if (w.d_vec) hipFree(w.d_vec);
     if (w.d_rhs) hipFree(w.d_rhs);
@@ -74,6 +75,7 @@ static int alloc_workspace(egx_gp *gp, Workspace &w, int index) {
     }
     const int hmax = gp->has_w ? gp->h : 1;
     EGX_HIP_CHECK(hipMalloc(&w.d_coef, sizeof(double) * (size_t)gp->d * hmax));
+    EGX_HIP_CHECK(hipMalloc(&w.d_xs, sizeof(double) * (size_t)gp->d * gp->n_pad));
     EGX_HIP_CHECK(hipMalloc(&w.d_diag, sizeof(double) * (size_t)gp->n_pad));
     EGX_HIP_CHECK(hipMalloc(&w.d_vec, sizeof(double) * (size_t)gp->n_pad));
     EGX_HIP_CHECK(hipMalloc(&w.d_rhs, sizeof(double) * (size_t)gp->n_pad));
@@ -287,7 +289,7 @@ int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> 
     for (int j = 0; j < count; j++) {
         Workspace &w = gp->ws[w0 + j];
         EGX_RC(launch_corr_sym(st, gp->corr, gp->d_xT, gp->n_pad, gp->n, gp->d, w.d_coef, hcols, gp->nugget, w.M, gp->ld,
-                               gp->n_pad));
+                               gp->n_pad, w.d_xs));
         EGX_RC(launch_fill_rows(st, w.M, gp->ld, gp->n_pad, gp->rhs_pad, gp->d_rhsT, gp->n_pad, gp->q, gp->n_pad));
     }
     EGX_HIP_CHECK(hipEventRecord(lead.ev[1], st));

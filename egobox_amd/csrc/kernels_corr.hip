@@ -178,6 +178,74 @@ __global__ __launch_bounds__(1024 / RI) void k_corr_sym(const double *__restrict
         *reinterpret_cast<double2 *>(p + 2) = make_double2(out[2], out[3]);
     }
 }
+// K1, scalar-row form (round 3).  The 4x4-pairs-per-lane kernel above reads 8 doubles from LDS per 16 pairs and dimension:
+// 4 ds_read_b128 per 32 FP64 instructions per wave keep the CU's one LDS pipe as busy as its four SIMDs, and the kernel
+// sits at 0.78 of its FP64 VALU-issue bound.  Here a wave owns 16 ROWS x 64 columns (lane = column): the row coordinates
+// are WAVE-UNIFORM, so they are fetched by the scalar unit (s_load) into SGPRs and enter the FP64 instructions as their
+// scalar operand; only the lane's own column coordinate comes from LDS -- one ds_read_b64 per 32 instructions.  The inputs
+// are read PRESCALED (xs[k][i] = c_k x[k][i], one tiny launch per candidate) so that nothing but the subtraction and the
+// accumulation is left per pair and dimension.  Same 64x64 tile per workgroup, same grid, same stores (a row of 64 results
+// per wave instruction: 512 contiguous bytes).
+template <int CORR>
+__global__ __launch_bounds__(256) void k_corr_sym_srow(const double *__restrict__ xs, int64_t ldx, int n, int d, double diag,
+                                                       double *__restrict__ M, int64_t ld) {
+    const int t = blockIdx.x >> 2, sub = blockIdx.x & 3;
+    int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while (I * (I + 1) / 2 > t) I--;
+    while ((I + 1) * (I + 2) / 2 <= t) I++;
+    const int J = t - I * (I + 1) / 2;
+    const int bi = 2 * I + (sub >> 1), bj = 2 * J + (sub & 1);
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *xj = sm;  // the 64 column points, k-major
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    stage_slab(xj, xs, ldx, bj * 64, d, tid);
+    __syncthreads();
+    const int i0 = bi * 64 + wave * 16;
+    const double *xr = xs + i0;  // wave-uniform: rows i0 .. i0 + 15 of dimension k at xr[k * ldx + a]
+    PairAcc<CORR> acc[16];
+    for (int k = 0; k < d; k++) {
+        const double v = xj[k * 64 + lane];
+        const double4 r0 = *reinterpret_cast<const double4 *>(xr + (int64_t)k * ldx);
+        const double4 r1 = *reinterpret_cast<const double4 *>(xr + (int64_t)k * ldx + 4);
+        const double4 r2 = *reinterpret_cast<const double4 *>(xr + (int64_t)k * ldx + 8);
+        const double4 r3 = *reinterpret_cast<const double4 *>(xr + (int64_t)k * ldx + 12);
+        acc[0].add_scaled(r0.x - v);
+        acc[1].add_scaled(r0.y - v);
+        acc[2].add_scaled(r0.z - v);
+        acc[3].add_scaled(r0.w - v);
+        acc[4].add_scaled(r1.x - v);
+        acc[5].add_scaled(r1.y - v);
+        acc[6].add_scaled(r1.z - v);
+        acc[7].add_scaled(r1.w - v);
+        acc[8].add_scaled(r2.x - v);
+        acc[9].add_scaled(r2.y - v);
+        acc[10].add_scaled(r2.z - v);
+        acc[11].add_scaled(r2.w - v);
+        acc[12].add_scaled(r3.x - v);
+        acc[13].add_scaled(r3.y - v);
+        acc[14].add_scaled(r3.z - v);
+        acc[15].add_scaled(r3.w - v);
+    }
+    const int j = bj * 64 + lane;
+#pragma unroll
+    for (int a = 0; a < 16; a++) {
+        const int i = i0 + a;
+        double vv = acc[a].value();
+        if (i >= n || j >= n) vv = (i == j) ? 1.0 : 0.0;  // identity padding
+        else if (i == j) vv = diag;                       // 1 + nugget, algorithm.rs:997
+        M[(int64_t)i * ld + j] = vv;
+    }
+}
+
+// xs[k][i] = coef[k] * xT[k][i] over the (d x ldx) k-major array (hcols == 1)
+__global__ void k_scale_rows(const double *__restrict__ xT, int64_t ldx, int d, const double *__restrict__ coef,
+                             double *__restrict__ xs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ldx) return;
+    for (int k = 0; k < d; k++) xs[(int64_t)k * ldx + i] = coef[k] * xT[(int64_t)k * ldx + i];
+}
+
 template <int CORR, bool PRE>
 __global__ __launch_bounds__(256) void k_cross_corr(const double *__restrict__ xqT, int64_t ldq,
                                                     const double *__restrict__ xT, int64_t ldx, int d,
@@ -580,15 +648,24 @@ __global__ __launch_bounds__(256) void k_grad_accum(const double *__restrict__ x
     }
 
 int launch_corr_sym(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d, const double *coef,
-                    int hcols, double nugget, double *M, int64_t ld, int n_pad) {
+                    int hcols, double nugget, double *M, int64_t ld, int n_pad, double *xs_scratch) {
     const int nt2 = n_pad / 128;  // n_pad is a multiple of 128
     dim3 grid((unsigned)(4 * (nt2 * (nt2 + 1) / 2)));
     const size_t lds = (size_t)2 * d * 64 * sizeof(double);
-    // (a 128x128-tile form with 8x4 pairs per lane -- a quarter less LDS traffic per VALU instruction -- was measured
-    //  SLOWER: 0.58 vs 0.52 ms at d = 32, 1.46 vs 1.11 ms at d = 64; its 64 / 128 KB of slabs leave 2 / 1 workgroups per CU
-    //  and nothing to overlap the staging with: profiles/r03_run5_k1_tile128_discarded.jsonl)
-    // (8 x 4 pairs per lane in the same tile -- 128 threads, a quarter less LDS traffic per instruction -- is SLOWER too:
-    //  0.745 vs 0.52 ms; the kernel wants its 16 waves per CU more than it wants fewer LDS reads: profiles/r03_run10_*)
+    static const int srow = [] {  // EGX_CORR_SROW=0: the LDS-only form (0.51 vs 0.42 ms sq-exp, 1.10 vs 0.76 at d = 64:
+        const char *e = std::getenv("EGX_CORR_SROW");  // profiles/r03_run11_k1_scalar_rows_ab.txt)
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    if (hcols == 1 && xs_scratch != nullptr && srow) {
+        // scalar-row form on prescaled inputs (xs_scratch: d x ldx doubles, owned by the caller's workspace)
+        hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((ldx + 255) / 256)), dim3(256), 0, s, xT, ldx, d, coef, xs_scratch);
+        EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_corr_sym_srow<C_>), grid, dim3(256), lds / 2, s, (const double *)xs_scratch, ldx,
+                                                   n, d, 1.0 + nugget, M, ld));
+        EGX_HIP_CHECK(hipGetLastError());
+        return EGX_SUCCESS;
+    }
+    // (forms with more pairs per lane -- 8 x 4 in a 128x128 tile or in the same tile with 128 threads -- were measured SLOWER:
+    //  profiles/r03_run5_k1_tile128_discarded.jsonl, profiles/r03_run10_k1_rows8_discarded.txt)
     if (hcols == 1) {
         EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_corr_sym<C_, true, 4>), grid, dim3(256), lds, s, xT, ldx, n, d, coef, hcols,
                                                    1.0 + nugget, M, ld));
