@@ -44,6 +44,9 @@ int launch_cross_corr(hipStream_t s, int corr, const double *xqT, int64_t ldq, i
                       int hcols, double *R, int64_t ld);
 // racc[split * m_pad + q] = partial sum_i k(xq, x_i) * gamma[i] over the split's training range (gamma zero padded to
 // n_pad); nsplit > 1 spreads a few queries over the chip, the caller adds the partial sums (racc: nsplit * m_pad)
+// raw row-major queries -> normalised k-major (d x ldq, zero padded to m_pad); par = x_mean (d) | x_std (d) on the device
+int launch_normalize_queries(hipStream_t s, const double *xq, int m, int d, const double *par, double *xqT, int64_t ldq,
+                             int m_pad);
 int launch_predict_mean(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad,
                         const double *xT, int64_t ldx, int n_pad, int d, const double *coef,
                         int hcols, const double *gamma, double *racc, int nsplit = 1);

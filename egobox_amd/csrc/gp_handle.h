@@ -137,7 +137,7 @@ struct egx_gp {
     std::vector<double> fit_coef;
     int fit_hcols = 1;
     double *d_gamma = nullptr;  // n_pad
-    double *d_fit_coef = nullptr;
+    double *d_fit_coef = nullptr;  // d x hcols coefficients of the fit, then x_mean (d) | x_std (d): dev_xnorm()
     // gradient scratch (allocated on first use)
     double *d_W = nullptr, *d_Rinv = nullptr, *d_gout = nullptr, *d_theta = nullptr;
     // x-gradient state (lazy, per fitted factor): d_W = C^-T (shared with the theta-gradient scratch) and
@@ -153,6 +153,9 @@ struct egx_gp {
     uint64_t winv_fail_epoch = ~(uint64_t)0;  // fit for which the C^-T cache could not be built (batched path serves it)
     egx_timings timings{};
 };
+
+// x_mean (d) | x_std (d) on the device, behind the coefficients of the fit in the same allocation
+inline double *dev_xnorm(const egx_gp *gp) { return gp->d_fit_coef + (size_t)gp->d * (gp->has_w ? gp->h : 1); }
 
 namespace egx {
 

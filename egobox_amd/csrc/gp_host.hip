@@ -987,7 +987,7 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
         EGX_HIPF(hipMalloc(&gp->d_xT, sizeof(double) * xT.size()));
         EGX_HIPF(hipMalloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
         EGX_HIPF(hipMalloc(&gp->d_gamma, sizeof(double) * gp->n_pad));
-        EGX_HIPF(hipMalloc(&gp->d_fit_coef, sizeof(double) * (size_t)d * (gp->has_w ? gp->h : 1)));
+        EGX_HIPF(hipMalloc(&gp->d_fit_coef, sizeof(double) * ((size_t)d * (gp->has_w ? gp->h : 1) + 2 * (size_t)d)));
         EGX_HIPF(hipMalloc(&gp->slab_M, sizeof(double) * (size_t)gp->stride_M * nws));
         EGX_HIPF(hipMalloc(&gp->slab_D, sizeof(double) * (size_t)gp->stride_D * nws));
         EGX_HIPF(hipMalloc(&gp->slab_I, sizeof(int) * (size_t)nws));
@@ -999,6 +999,11 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
     }
     EGX_HIPF(hipMemcpy(gp->d_xT, xT.data(), sizeof(double) * xT.size(), hipMemcpyHostToDevice));
     EGX_HIPF(hipMemcpy(gp->d_rhsT, rhsT.data(), sizeof(double) * rhsT.size(), hipMemcpyHostToDevice));
+    {  // normalisation parameters for the query-side kernel (gp_predict.hip upload_queries)
+        std::vector<double> par(gp->x_mean);
+        par.insert(par.end(), gp->x_std.begin(), gp->x_std.end());
+        EGX_HIPF(hipMemcpy(dev_xnorm(gp), par.data(), sizeof(double) * par.size(), hipMemcpyHostToDevice));
+    }
     gp->lockstep = default_lockstep(nws, gp->n_pad);  // candidates of a likelihood batch factored in lock-step: egx_gp_set_lockstep
     *out = gp;
     return EGX_SUCCESS;

@@ -9,21 +9,25 @@ namespace egx {
 
 
 // ---- prediction -------------------------------------------------------------------------------
-// Normalise a chunk of query points (algorithm.rs:254) and upload it k-major (d x m_pad, zero padded).
+// Upload a chunk of query points as the caller holds it and normalise it (algorithm.rs:254) into the k-major layout
+// (d x m_pad, zero padded) ON THE DEVICE: the host loop this replaces (a division and a strided store per coordinate) cost
+// four times the prediction kernel for 100 000 points.  xn (the normalised rows on the host) is filled only when the trend
+// needs the coordinates (Linear / Quadratic).  xq outlives the call, so nothing waits for the copy here.
 static int upload_queries(egx_gp *gp, const double *xq, int64_t m0, int m, int m_pad, std::vector<double> &xn,
-                          DevBuf &d_xqT, hipStream_t s) {
+                          DevBuf &d_xraw, DevBuf &d_xqT, hipStream_t s) {
     const int d = gp->d;
-    xn.resize((size_t)m * d);
-    std::vector<double> xt((size_t)d * m_pad, 0.0);
-    for (int a = 0; a < m; a++)
-        for (int j = 0; j < d; j++) {
-            const double v = (xq[(size_t)(m0 + a) * d + j] - gp->x_mean[j]) / gp->x_std[j];
-            xn[(size_t)a * d + j] = v;
-            xt[(size_t)j * m_pad + a] = v;
-        }
-    EGX_RC(d_xqT.alloc(xt.size()));
-    EGX_HIP_CHECK(hipMemcpyAsync(d_xqT.p, xt.data(), sizeof(double) * xt.size(), hipMemcpyHostToDevice, s));
-    EGX_HIP_CHECK(hipStreamSynchronize(s));  // xt is a pageable buffer owned by this frame
+    EGX_RC(d_xraw.alloc((size_t)m * d));
+    EGX_RC(d_xqT.alloc((size_t)d * m_pad));
+    EGX_HIP_CHECK(hipMemcpyAsync(d_xraw.p, xq + (size_t)m0 * d, sizeof(double) * (size_t)m * d, hipMemcpyHostToDevice, s));
+    EGX_RC(launch_normalize_queries(s, d_xraw.p, m, d, dev_xnorm(gp), d_xqT.p, m_pad, m_pad));
+    if (gp->mean >= 1) {
+        xn.resize((size_t)m * d);
+        const double *src = xq + (size_t)m0 * d;
+        for (int a = 0; a < m; a++)
+            for (int j = 0; j < d; j++) xn[(size_t)a * d + j] = (src[(size_t)a * d + j] - gp->x_mean[j]) / gp->x_std[j];
+    } else {
+        xn.clear();
+    }
     return EGX_SUCCESS;
 }
 
@@ -80,7 +84,7 @@ int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *
     // normalises / uploads chunk i + 1, and the tail of one chunk's solve overlaps the head of the next (the (m x n)
     // block of a chunk is bounded at 1 GiB, so 100 000 query points at n = 8192 are 7 chunks).
     struct Slot {
-        DevBuf d_xqT, d_racc, d_RT, d_s0, d_sl;  // sized by the first (largest) chunk, reused by the later ones
+        DevBuf d_xraw, d_xqT, d_racc, d_RT, d_s0, d_sl;  // sized by the first (largest) chunk, reused by the later ones
         std::vector<double> xn, racc, s0, sl;
         int64_t m0 = 0;
         int mc = 0, m_pad = 0, msplit = 1;
@@ -95,7 +99,7 @@ int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *
         sl_.mc = mc;
         sl_.m_pad = m_pad;
         hipStream_t st = sl_.stream;
-        EGX_RC(upload_queries(gp, xq, m0, mc, m_pad, sl_.xn, sl_.d_xqT, st));
+        EGX_RC(upload_queries(gp, xq, m0, mc, m_pad, sl_.xn, sl_.d_xraw, sl_.d_xqT, st));
         // few queries: split the training range so that ~1024 workgroups exist (partial sums added below)
         int msplit = 1;
         if (m_pad / 64 < 1024) msplit = (1024 + m_pad / 64 - 1) / (m_pad / 64);
@@ -142,7 +146,7 @@ int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *
         }
         const std::vector<double> &xn = sl_.xn, &racc = sl_.racc, &s0 = sl_.s0, &sl = sl_.sl;
         for (int a = 0; a < mc; a++) {
-            hm::regression_row(gp->mean, &xn[(size_t)a * d], d, f.data());
+            hm::regression_row(gp->mean, xn.empty() ? nullptr : &xn[(size_t)a * d], d, f.data());
             if (yout) {
                 double fb = 0.0, rg = 0.0;
                 for (int l = 0; l < p; l++) fb += f[l] * gp->beta[l];
@@ -375,7 +379,7 @@ int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv) 
     if (cap > 16384) cap = 16384;
     if (!gv) cap = 65536;
     std::vector<double> xn, part, sl, f(p), a_vec(p), u(p), dd(p), dneg, df(d);
-    DevBuf d_xqT, d_out, d_RT, d_s0, d_sl, d_Wt, d_D;  // sized by the first (largest) chunk, reused by the others
+    DevBuf d_xraw, d_xqT, d_out, d_RT, d_s0, d_sl, d_Wt, d_D;  // sized by the first (largest) chunk, reused by the others
     for (int64_t m0 = 0; m0 < m; m0 += cap) {
         const int mc = (int)((m - m0 < cap) ? (m - m0) : cap);
         const int m_pad = (int)round_up(mc, kTile);
@@ -387,7 +391,7 @@ int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv) 
         if (nsplit > slabs) nsplit = slabs;
         const int per = (slabs + nsplit - 1) / nsplit;
         nsplit = (slabs + per - 1) / per;
-        EGX_RC(upload_queries(gp, xq, m0, mc, m_pad, xn, d_xqT, w.stream));
+        EGX_RC(upload_queries(gp, xq, m0, mc, m_pad, xn, d_xraw, d_xqT, w.stream));
         const size_t out_sz = (size_t)nsplit * m_pad * d;
         EGX_RC(d_out.alloc(out_sz));
         part.resize(out_sz);
@@ -402,7 +406,7 @@ int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv) 
             EGX_HIP_CHECK(hipMemcpyAsync(part.data(), d_out.p, sizeof(double) * out_sz, hipMemcpyDeviceToHost, w.stream));
             EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
             for (int a = 0; a < mc; a++) {
-                hm::regression_jac_dot(gp->mean, &xn[(size_t)a * d], d, gp->beta.data(), df.data());
+                hm::regression_jac_dot(gp->mean, xn.empty() ? nullptr : &xn[(size_t)a * d], d, gp->beta.data(), df.data());
                 for (int k = 0; k < d; k++)
                     gy[(size_t)(m0 + a) * d + k] = (df[k] + reduce_out(a, k)) * gp->y_std / gp->x_std[k];
             }
@@ -428,7 +432,7 @@ int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv) 
             // D = B^-1 A^T per query (p x p work on the host), uploaded negated and zero padded to rhs_pad columns
             dneg.assign((size_t)m_pad * rp, 0.0);
             for (int a = 0; a < mc; a++) {
-                hm::regression_row(gp->mean, &xn[(size_t)a * d], d, f.data());
+                hm::regression_row(gp->mean, xn.empty() ? nullptr : &xn[(size_t)a * d], d, f.data());
                 for (int l = 0; l < p; l++) a_vec[l] = f[l] - sl[(size_t)a * p + l];
                 for (int i = 0; i < p; i++) {  // Rq^T u = A^T (Rq^T lower)
                     double sacc = a_vec[i];
@@ -451,7 +455,7 @@ int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv) 
             EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
             for (int a = 0; a < mc; a++) {
                 for (int l = 0; l < p; l++) dd[l] = -dneg[(size_t)a * rp + l];
-                hm::regression_jac_dot(gp->mean, &xn[(size_t)a * d], d, dd.data(), df.data());
+                hm::regression_jac_dot(gp->mean, xn.empty() ? nullptr : &xn[(size_t)a * d], d, dd.data(), df.data());
                 for (int k = 0; k < d; k++)
                     gv[(size_t)(m0 + a) * d + k] = 2.0 * gp->sigma2 * (df[k] + reduce_out(a, k)) / gp->x_std[k];
             }

@@ -246,6 +246,28 @@ __global__ void k_scale_rows(const double *__restrict__ xT, int64_t ldx, int d, 
     for (int k = 0; k < d; k++) xs[(int64_t)k * ldx + i] = coef[k] * xT[(int64_t)k * ldx + i];
 }
 
+// Queries as the caller holds them (m x d row-major, raw) -> normalised and k-major (d x ldq, zero padded): what
+// GaussianProcess::predict does first ((x - x_mean) / x_std, algorithm.rs:254).  The same IEEE subtraction and division
+// as the host loop this replaces, so the bits are the same; a 64-query slab goes through LDS so that both the reads and
+// the writes are contiguous.  par = x_mean (d) then x_std (d).
+__global__ __launch_bounds__(256) void k_normalize_queries(const double *__restrict__ xq, int m, int d,
+                                                           const double *__restrict__ par, double *__restrict__ xqT,
+                                                           int64_t ldq) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int q0 = blockIdx.x * 64, tid = threadIdx.x;
+    const int rows = (m - q0 < 64) ? (m - q0) : 64;
+    const int ds = d | 1;  // odd row stride: the transposed reads below spread over the banks
+    for (int e = tid; e < rows * d; e += 256) {
+        const int i = e / d, k = e - i * d;
+        sm[i * ds + k] = xq[(int64_t)q0 * d + e];
+    }
+    __syncthreads();
+    for (int e = tid; e < d * 64; e += 256) {
+        const int k = e >> 6, i = e & 63;
+        xqT[(int64_t)k * ldq + q0 + i] = (i < rows) ? (sm[i * ds + k] - par[k]) / par[d + k] : 0.0;
+    }
+}
+
 template <int CORR, bool PRE>
 __global__ __launch_bounds__(256) void k_cross_corr(const double *__restrict__ xqT, int64_t ldq,
                                                     const double *__restrict__ xT, int64_t ldx, int d,
@@ -688,6 +710,14 @@ int launch_cross_corr(hipStream_t s, int corr, const double *xqT, int64_t ldq, i
         EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_cross_corr<C_, false>), grid, dim3(256), lds, s, xqT, ldq, xT, ldx, d, coef,
                                                    hcols, R, ld));
     }
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_normalize_queries(hipStream_t s, const double *xq, int m, int d, const double *par, double *xqT, int64_t ldq,
+                             int m_pad) {
+    const size_t lds = (size_t)64 * (d | 1) * sizeof(double);
+    hipLaunchKernelGGL(k_normalize_queries, dim3(m_pad / 64), dim3(256), lds, s, xq, m, d, par, xqT, ldq);
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }
