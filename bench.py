@@ -335,6 +335,11 @@ def main():
                     help="candidates factored in lock-step by one launch sequence (0 = library default: min(in-flight, 4))")
     ap.add_argument("--assignment", choices=("static", "dynamic"), default="static",
                     help="candidates -> ranks: c mod N, or pulled from the node-wide counter (egx_sweep_set_assignment)")
+    ap.add_argument("--collective", choices=("library", "torch"), default="library",
+                    help="who gathers the ranks' results at N > 1: the library's own RCCL all-gather inside "
+                         "egx_sweep_likelihood (default), or torch.distributed's (also RCCL) around egx_gp_likelihood_batch. "
+                         "The library path is probed once before the warm-up; if it fails on any rank, all ranks switch to "
+                         "torch and the line says so (`collective`)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="CPU rehearsal of the launch path: gloo + a stub evaluator, no GPU, no performance number")
     args = ap.parse_args()
@@ -351,7 +356,7 @@ def main():
     if args.dry_launch:
         sys.exit(dry_launch(args, rank, world))
 
-    os.environ.setdefault("EGX_SWEEP_TIMEOUT_S", "300")  # a benchmark: a peer that is 5 minutes late is gone
+    os.environ.setdefault("EGX_SWEEP_TIMEOUT_S", "120")  # a benchmark: a peer that is 2 minutes late is gone
     import torch
     import torch.distributed as dist
 
@@ -387,22 +392,77 @@ def main():
     total = (args.steps + args.warmup) * nb
     cands = base * 10.0 ** rng.uniform(-0.15, 0.15, size=(total, d))
 
+    def any_rank(err):  # the first rank's error string when one has any (the same answer on every rank), else None
+        if world == 1:
+            return err
+        box = [None] * world
+        dist.all_gather_object(box, err)
+        for r, e in enumerate(box):
+            if e is not None:
+                return f"rank {r}: {e}"
+        return None
+
     # uploads happen here: inputs resident.  Rank 0 draws the RCCL unique id; torch's store carries its 128 bytes
-    sw = egx.rendezvous_sweep(x, y, device=gpu, n_workspaces=max(1, args.in_flight))
+    use_lib = args.collective == "library" or world == 1
+    collective = "library: ncclAllGather inside egx_sweep_likelihood" if use_lib else "torch.distributed all_gather (--collective torch)"
+    sw, create_err = None, None
+    if use_lib:
+        try:
+            sw = egx.rendezvous_sweep(x, y, device=gpu, n_workspaces=max(1, args.in_flight))
+        except Exception as e:  # noqa: BLE001 - at N > 1 the ranks agree on the torch path below
+            if world == 1:
+                raise
+            create_err = f"{type(e).__name__}: {e}"[:200]
+        create_err = any_rank(create_err)
+        if create_err is not None:
+            use_lib = False
+            collective = f"torch.distributed all_gather (egx_sweep_create failed on a rank: {create_err})"
+            if sw is not None:
+                sw.close()
+                sw = None
+    if sw is None:  # this rank's replica without a communicator of the library's own
+        sw = egx.Sweep(x, y, device=gpu, rank=0, world=1, id_bytes=None, n_workspaces=max(1, args.in_flight))
     lockstep = sw.set_lockstep(args.lockstep)
-    if args.assignment == "dynamic":
+    if args.assignment == "dynamic" and use_lib:
         sw.set_assignment(True)
     lkhs = np.zeros(total)
     stats = np.zeros(total, dtype=np.int32)
+    torch_eval_s = [0.0]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def torch_evaluate(th):
+        te0 = time.perf_counter()
+        r = sw.local_likelihood_batch(th)
+        torch_eval_s[0] = time.perf_counter() - te0
+        return r
+
     def step(i):
         sl = slice(i * nb, (i + 1) * nb)
-        lkhs[sl], stats[sl] = sw.likelihood(cands[sl])  # collective: shard k mod N + ncclAllGather inside the library
+        if use_lib:
+            lkhs[sl], stats[sl] = sw.likelihood(cands[sl])  # collective: shard k mod N + ncclAllGather inside the library
+        else:  # the same shard (k mod N) evaluated by egx_gp_likelihood_batch, gathered by torch's RCCL
+            lkhs[sl], stats[sl] = egx.sweep_likelihood(torch_evaluate, cands[sl], rank, world,
+                                                             device=None if rehearsal else tdev)
+
+    if world > 1 and use_lib:
+        # PROBE, untimed: one candidate per rank through the library's collective.  The world > 1 RCCL path of the library
+        # cannot be exercised on the one-GPU boxes it is developed on; if it fails HERE, on any rank, every rank switches to
+        # torch's all-gather so that the run still yields its line -- and the line names what happened.
+        probe_err = None
+        try:
+            sw.likelihood(cands[:world])
+            if os.environ.get("EGX_BENCH_FAIL_PROBE") == str(rank):  # test hook (tests/test_gpu_sweep.py)
+                raise RuntimeError("injected probe failure")
+        except Exception as e:  # noqa: BLE001
+            probe_err = f"{type(e).__name__}: {e}"[:200]
+        probe_err = any_rank(probe_err)
+        if probe_err is not None:
+            use_lib = False
+            collective = f"torch.distributed all_gather (the library's collective failed its probe on a rank: {probe_err})"
 
     for i in range(args.warmup):
         step(i)
@@ -419,7 +479,10 @@ def main():
         dist.all_gather(parts, t)
         rank_seconds = [float(p.item()) for p in parts]
         elapsed = max(rank_seconds)  # MAX over ranks
-    per_rank_last, eval_s_last = sw.last_balance()
+    if use_lib:
+        per_rank_last, eval_s_last = sw.last_balance()
+    else:
+        per_rank_last, eval_s_last = [len(range(r, nb, world)) for r in range(world)], torch_eval_s[0]
     eval_seconds = [eval_s_last]
     if world > 1:
         t = torch.tensor([eval_s_last], dtype=torch.float64, device=tdev)
@@ -431,13 +494,13 @@ def main():
     # every rank (it is a collective): expert e on rank e mod N, smooth recombination of predict_var on 100 000 points
     # through egx_moe_predict_valvar and the sweep's communicator.  Never part of `value`; any failure becomes a string.
     moe_sharded = None
-    if world > 1 and not args.no_extra_configs:
+    if world > 1 and not args.no_extra_configs and use_lib:
         try:
             moe_sharded = moe_sharded_leg(egx, workload, sw, rank, world, gpu)
         except Exception as e:  # noqa: BLE001 - reported in the line, must not take the headline number down
             moe_sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
     sw.close()
-    if info["rccl_ranks"] != world and not rehearsal:
+    if use_lib and info["rccl_ranks"] != world and not rehearsal:
         sys.stderr.write(f"bench.py: the library's RCCL communicator has {info['rccl_ranks']} ranks, world is {world}\n")
         sys.exit(4)
 
@@ -484,7 +547,7 @@ def main():
                        "parallelism": f"sweep-dp{world}", "sweep_batch_per_step": nb,
                        "fits_in_flight_per_gpu": max(1, args.in_flight), "lockstep_width": lockstep},
             "fits_per_step": nb,
-            "rccl_ranks": info["rccl_ranks"], "rccl_version": info["rccl_version"],
+            "rccl_ranks": info["rccl_ranks"], "rccl_version": info["rccl_version"], "collective": collective,
             **({"rehearsal": "EGX_SWEEP_TRANSPORT=shm: host transport instead of RCCL, ranks share GPUs -- NOT a measurement"}
                if rehearsal else {}),
             "allgathers_in_timed_region": args.steps, "assignment": args.assignment,

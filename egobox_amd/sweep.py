@@ -122,6 +122,18 @@ class Sweep:
             L.check(rc)
         return lk, st
 
+    def local_likelihood_batch(self, thetas):
+        """NOT a collective: `egx_gp_likelihood_batch` on this rank's handle (the evaluation a rank does inside
+        `likelihood`, without the all-gather) -> (lkh (k,), status (k,))."""
+        L = self._L
+        thetas = L.as_f64(thetas, 2)
+        k = thetas.shape[0]
+        lk = np.empty(k)
+        st = np.empty(k, dtype=np.int32)
+        L.check(self._lib.egx_gp_likelihood_batch(self._lib.egx_sweep_handle(self._h), L.dptr(thetas), k, thetas.shape[1],
+                                                  L.dptr(lk), st.ctypes.data_as(L.c_int32_p)))
+        return lk, st
+
     def set_lockstep(self, width):
         """Lock-step width of this rank's likelihood batches (egx_gp_set_lockstep on the sweep's handle)."""
         h = self._lib.egx_sweep_handle(self._h)

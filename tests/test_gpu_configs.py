@@ -426,6 +426,38 @@ def test_bench_gpus_2_rehearsal_on_one_gpu():
     assert moe["checksum"] == pytest.approx(5774.94659384006, rel=1e-9)
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("how", ["flag", "probe_failure"])
+def test_bench_gpus_2_falls_back_to_torch_collective(how):
+    """The N > 1 line must survive a library collective that does not work on the driver's node: `--collective torch`
+    gathers through torch.distributed around egx_gp_likelihood_batch, and a failed PROBE of the library's all-gather on one
+    rank (injected here) switches every rank to that path.  Same likelihood checksum as the library's collective."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EGX_SWEEP_TRANSPORT="shm")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--sweep-batch", "10",
+            "--in-flight", "4", "--npoints", "2048", "--dim", "6", "--no-cpu-baseline", "--no-extra-configs"]
+    recs = {}
+    for name, extra, e in (("library", [], env),
+                           ("fallback", ["--collective", "torch"] if how == "flag" else [],
+                            env if how == "flag" else dict(env, EGX_BENCH_FAIL_PROBE="1"))):
+        out = subprocess.run(base + extra, cwd=root, env=e, capture_output=True, text=True, timeout=280)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, out.stdout[-2000:]
+        recs[name] = json.loads(lines[0])
+    lib, fb = recs["library"], recs["fallback"]
+    assert lib["collective"].startswith("library") and fb["collective"].startswith("torch.distributed")
+    if how == "probe_failure":
+        assert "injected probe failure" in fb["collective"]
+    assert fb["n_gpus"] == 2 and fb["candidates_ok"] == 20 and len(fb["rank_seconds"]) == 2
+    assert fb["last_step_balance"]["candidates_per_rank"] == [5, 5]
+    assert fb["likelihood_checksum"] == lib["likelihood_checksum"]
+
+
 def test_moe_c_host_drives_the_recombination(tmp_path):
     """tests/c_host/moe_driver.c: a C99 host (no Python) trains three experts, then calls egx_moe_predict_valvar -- the
     mixture recombination inside the library -- in both recombinations, single-process and through a one-rank RCCL
