@@ -49,7 +49,10 @@ int launch_normalize_queries(hipStream_t s, const double *xq, int m, int d, cons
                              int m_pad);
 int launch_predict_mean(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad,
                         const double *xT, int64_t ldx, int n_pad, int d, const double *coef,
-                        int hcols, const double *gamma, double *racc, int nsplit = 1);
+                        int hcols, const double *gamma, double *racc, int nsplit = 1,
+                        const double *xs_prescaled = nullptr);  // (d x ldx) training inputs times coef (hcols == 1): scalar-row form
+// xs[k][i] = coef[k] * xT[k][i] over a (d x ldx) k-major array
+int launch_scale_rows(hipStream_t s, const double *xT, int64_t ldx, int d, const double *coef, double *xs);
 // x-gradient contraction out[split][a][k] = sum_j w(j, a) d r(x_a, x_j) / d x_ak over the split's training range;
 // Wt = gamma (vec != 0, ldw ignored) or the transposed (n x m_pad) weight matrix; m_pad multiple of 128
 int launch_xgrad(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad, const double *xT, int64_t ldx,

@@ -114,7 +114,7 @@ struct egx_gp {
     std::vector<double> w_star;  // d x h
     std::vector<double> x_raw, y_raw, xnorm, x_mean, x_std, ynorm, F;
     double y_mean = 0.0, y_std = 1.0;
-    double *d_xT = nullptr;    // d x n_pad (k-major normalised inputs, zero padded)
+    double *d_xT = nullptr;    // d x n_pad (k-major normalised inputs, zero padded), then the same times the fit's coefficients
     double *d_rhsT = nullptr;  // q x n_pad: columns of F then y (normalised), as rows
     std::vector<egx::Workspace> ws;
     // one allocation each for all workspaces' matrices, tile inverses and failure flags (strides in elements)
@@ -155,6 +155,9 @@ struct egx_gp {
 };
 
 // x_mean (d) | x_std (d) on the device, behind the coefficients of the fit in the same allocation
+// the training inputs times the coefficients of the fit (d x n_pad, k-major; valid when fit_hcols == 1), behind d_xT in
+// the same allocation: what the scalar-row prediction kernel reads (kernels_corr.hip k_predict_mean_srow)
+inline double *dev_xs_fit(const egx_gp *gp) { return gp->d_xT + (size_t)gp->d * gp->n_pad; }
 inline double *dev_xnorm(const egx_gp *gp) { return gp->d_fit_coef + (size_t)gp->d * (gp->has_w ? gp->h : 1); }
 
 namespace egx {

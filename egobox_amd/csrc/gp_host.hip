@@ -662,6 +662,7 @@ int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     EGX_HIP_CHECK(hipMemcpyAsync(w.h_vec, w.d_vec, sizeof(double) * n_pad, hipMemcpyDeviceToHost, w.stream));
     EGX_HIP_CHECK(hipMemcpyAsync(gp->d_fit_coef, w.d_coef, sizeof(double) * coef.size(), hipMemcpyDeviceToDevice,
                                  w.stream));
+    if (hcols == 1) EGX_RC(launch_scale_rows(w.stream, gp->d_xT, gp->n_pad, gp->d, gp->d_fit_coef, dev_xs_fit(gp)));
     EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
     auto t2 = std::chrono::steady_clock::now();
     gp->gamma.assign(w.h_vec, w.h_vec + n);
@@ -984,7 +985,7 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
     gp->stride_M = (int64_t)gp->m_tot * gp->ld;
     gp->stride_D = round_up((int64_t)dinv_doubles(gp->n_pad), 64);
     if (!pool_take(gp, nws)) {  // no destroyed handle of this shape left its resources behind: allocate
-        EGX_HIPF(hipMalloc(&gp->d_xT, sizeof(double) * xT.size()));
+        EGX_HIPF(hipMalloc(&gp->d_xT, sizeof(double) * 2 * xT.size()));  // + dev_xs_fit()
         EGX_HIPF(hipMalloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
         EGX_HIPF(hipMalloc(&gp->d_gamma, sizeof(double) * gp->n_pad));
         EGX_HIPF(hipMalloc(&gp->d_fit_coef, sizeof(double) * ((size_t)d * (gp->has_w ? gp->h : 1) + 2 * (size_t)d)));
@@ -1191,6 +1192,7 @@ int32_t egx_gp_set_inner(egx_gp *gp, const egx_gp_inner_view *v) {
     EGX_HIP_CHECK(hipMemcpyAsync(gp->d_gamma, w.h_vec, sizeof(double) * n_pad, hipMemcpyHostToDevice, w.stream));
     std::memcpy(w.h_coef, coef.data(), sizeof(double) * coef.size());
     EGX_HIP_CHECK(hipMemcpyAsync(gp->d_fit_coef, w.h_coef, sizeof(double) * coef.size(), hipMemcpyHostToDevice, w.stream));
+    if (hcols == 1) EGX_RC(launch_scale_rows(w.stream, gp->d_xT, gp->n_pad, gp->d, gp->d_fit_coef, dev_xs_fit(gp)));
     EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
     gp->theta = thfull;
     gp->likelihood = *v->likelihood;

@@ -112,7 +112,8 @@ int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *
         if (yout) {
             EGX_RC(sl_.d_racc.alloc((size_t)msplit * m_pad));
             EGX_RC(launch_predict_mean(st, gp->corr, sl_.d_xqT.p, m_pad, m_pad, gp->d_xT, n_pad, n_pad, d, gp->d_fit_coef,
-                                       gp->fit_hcols, gp->d_gamma, sl_.d_racc.p, msplit));
+                                       gp->fit_hcols, gp->d_gamma, sl_.d_racc.p, msplit,
+                                       gp->fit_hcols == 1 ? dev_xs_fit(gp) : nullptr));
         }
         if (vout) {
             EGX_RC(sl_.d_RT.alloc((size_t)m_pad * n_pad));

@@ -329,6 +329,67 @@ __global__ __launch_bounds__(256) void k_predict_mean(const double *__restrict__
     }
 }
 
+// K2+K6, scalar-row form (round 3; see k_corr_sym_srow): a lane owns ONE query of the workgroup's 64 (its prescaled
+// coordinates in LDS, one ds_read_b64 per 32 FP64 instructions), the training points are the wave-uniform rows -- 16 at a
+// time, fetched from the PRESCALED training inputs of the fit (xs = c_k x, k-major) by the scalar unit, gamma with them --
+// and r . gamma accumulates in the lane's own register: no cross-lane reduction, no barrier inside the loop.  The four waves
+// of a workgroup take every fourth 16-row block of the split's training range; their partial sums meet in LDS at the end.
+template <int CORR>
+__global__ __launch_bounds__(256) void k_predict_mean_srow(const double *__restrict__ xqT, int64_t ldq,
+                                                           const double *__restrict__ xs, int64_t ldx, int n_pad, int d,
+                                                           const double *__restrict__ coef,
+                                                           const double *__restrict__ gamma, double *__restrict__ racc,
+                                                           int slabs_per_split, int m_pad) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *xq = sm, *part = sm + d * 64;  // 64 queries k-major, prescaled; 4 x 64 partial sums
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    stage_slab(xq, xqT, ldq, blockIdx.x * 64, d, tid, coef);
+    __syncthreads();
+    const int j_lo = blockIdx.y * slabs_per_split * 64;
+    int j_hi = j_lo + slabs_per_split * 64;
+    if (j_hi > n_pad) j_hi = n_pad;
+    double sum = 0.0;
+    for (int j0 = j_lo + wave * 16; j0 < j_hi; j0 += 64) {
+        const double *xr = xs + j0;  // wave-uniform
+        PairAcc<CORR> acc[16];
+        for (int k = 0; k < d; k++) {
+            const double v = xq[k * 64 + lane];
+            const double4 r0 = *reinterpret_cast<const double4 *>(xr + (int64_t)k * ldx);
+            const double4 r1 = *reinterpret_cast<const double4 *>(xr + (int64_t)k * ldx + 4);
+            const double4 r2 = *reinterpret_cast<const double4 *>(xr + (int64_t)k * ldx + 8);
+            const double4 r3 = *reinterpret_cast<const double4 *>(xr + (int64_t)k * ldx + 12);
+            acc[0].add_scaled(r0.x - v);
+            acc[1].add_scaled(r0.y - v);
+            acc[2].add_scaled(r0.z - v);
+            acc[3].add_scaled(r0.w - v);
+            acc[4].add_scaled(r1.x - v);
+            acc[5].add_scaled(r1.y - v);
+            acc[6].add_scaled(r1.z - v);
+            acc[7].add_scaled(r1.w - v);
+            acc[8].add_scaled(r2.x - v);
+            acc[9].add_scaled(r2.y - v);
+            acc[10].add_scaled(r2.z - v);
+            acc[11].add_scaled(r2.w - v);
+            acc[12].add_scaled(r3.x - v);
+            acc[13].add_scaled(r3.y - v);
+            acc[14].add_scaled(r3.z - v);
+            acc[15].add_scaled(r3.w - v);
+        }
+        const double4 g0 = *reinterpret_cast<const double4 *>(gamma + j0);
+        const double4 g1 = *reinterpret_cast<const double4 *>(gamma + j0 + 4);
+        const double4 g2 = *reinterpret_cast<const double4 *>(gamma + j0 + 8);
+        const double4 g3 = *reinterpret_cast<const double4 *>(gamma + j0 + 12);
+        const double g[16] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w, g3.x, g3.y, g3.z, g3.w};
+#pragma unroll
+        for (int a = 0; a < 16; a++) sum = __builtin_fma(acc[a].value(), g[a], sum);
+    }
+    part[wave * 64 + lane] = sum;
+    __syncthreads();
+    if (tid < 64)
+        racc[(int64_t)blockIdx.y * m_pad + blockIdx.x * 64 + tid] = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // x-gradients of the predictions (CorrelationModel::jacobian, correlation_models.rs:106-123, 198-214,
 // 355-413, 524-586, contracted as predict_jacobian / predict_var_gradients_single do, algorithm.rs:523-617):
@@ -722,15 +783,32 @@ int launch_normalize_queries(hipStream_t s, const double *xq, int m, int d, cons
     return EGX_SUCCESS;
 }
 
+int launch_scale_rows(hipStream_t s, const double *xT, int64_t ldx, int d, const double *coef, double *xs) {
+    hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((ldx + 255) / 256)), dim3(256), 0, s, xT, ldx, d, coef, xs);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
 int launch_predict_mean(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad, const double *xT,
                         int64_t ldx, int n_pad, int d, const double *coef, int hcols, const double *gamma,
-                        double *racc, int nsplit) {
+                        double *racc, int nsplit, const double *xs_prescaled) {
     const size_t lds = (size_t)(2 * d * 64 + 64) * sizeof(double);
     const int slabs = n_pad / 64;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > slabs) nsplit = slabs;
     const int per = (slabs + nsplit - 1) / nsplit;
     nsplit = (slabs + per - 1) / per;
+    static const int srow = [] {  // EGX_CORR_SROW=0: the LDS-only forms here and in launch_corr_sym
+        const char *e = std::getenv("EGX_CORR_SROW");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    if (hcols == 1 && xs_prescaled != nullptr && srow) {
+        const size_t lds_s = (size_t)(d * 64 + 256) * sizeof(double);
+        EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_predict_mean_srow<C_>), dim3(m_pad / 64, nsplit), dim3(256), lds_s, s, xqT,
+                                                   ldq, xs_prescaled, ldx, n_pad, d, coef, gamma, racc, per, m_pad));
+        EGX_HIP_CHECK(hipGetLastError());
+        return EGX_SUCCESS;
+    }
     if (hcols == 1) {
         EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_predict_mean<C_, true>), dim3(m_pad / 64, nsplit), dim3(256), lds, s, xqT,
                                                    ldq, xT, ldx, n_pad, d, coef, hcols, gamma, racc, per, m_pad));
