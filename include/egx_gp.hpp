@@ -41,6 +41,7 @@ struct GpError : std::runtime_error {
 struct InvalidValueError : GpError { using GpError::GpError; };
 struct LinalgError : GpError { using GpError::GpError; };
 struct LikelihoodComputationError : GpError { using GpError::GpError; };
+struct PeerError : GpError { using GpError::GpError; };  // another rank of a collective failed (EGX_ERR_PEER)
 
 inline void check(int32_t rc) {
     if (rc == EGX_SUCCESS) return;
@@ -49,6 +50,7 @@ inline void check(int32_t rc) {
         case EGX_ERR_INVALID_VALUE: throw InvalidValueError(rc, msg);
         case EGX_ERR_LINALG: throw LinalgError(rc, msg);
         case EGX_ERR_LIKELIHOOD: throw LikelihoodComputationError(rc, msg);
+        case EGX_ERR_PEER: throw PeerError(rc, msg);
         default: throw GpError(rc, msg);
     }
 }
@@ -138,6 +140,30 @@ class GaussianProcess {
         check(egx_gp_predict_var_gradients(h_.get(), x, m, g.data()));
         return g;
     }
+    // algorithm.rs:711-727 -> the two (m x d) row-major gradients from one pass
+    std::pair<std::vector<double>, std::vector<double>> predict_valvar_gradients(const double *x, int64_t m) const {
+        std::vector<double> gy((size_t)(m * d_)), gv((size_t)(m * d_));
+        check(egx_gp_predict_valvar_gradients(h_.get(), x, m, gy.data(), gv.data()));
+        return {std::move(gy), std::move(gv)};
+    }
+    // reduced likelihood at k candidate thetas (k x theta_len row-major) -> (values, status per candidate): the evaluations
+    // the reference's multistart closures make (algorithm.rs:880-897, 928-945), factored in lock-step groups on the GPU
+    std::pair<std::vector<double>, std::vector<int32_t>> likelihood_batch(const double *thetas, int64_t k, int64_t theta_len) {
+        std::vector<double> lk((size_t)k);
+        std::vector<int32_t> st((size_t)k);
+        check(egx_gp_likelihood_batch(h_.get(), thetas, k, theta_len, lk.data(), st.data()));
+        return {std::move(lk), std::move(st)};
+    }
+    int32_t set_lockstep(int32_t width) {  // candidates per launch sequence (0 = the library's choice); returns the width in force
+        check(egx_gp_set_lockstep(h_.get(), width));
+        return egx_gp_get_lockstep(h_.get());
+    }
+    // GaussianProcess::training_data (algorithm.rs:969-978): the (n x d) inputs and (n) outputs the model was trained on
+    std::pair<std::vector<double>, std::vector<double>> training_data(int64_t n) const {
+        std::vector<double> x((size_t)(n * d_)), y((size_t)n);
+        check(egx_gp_get_training_data(h_.get(), x.data(), y.data()));
+        return {std::move(x), std::move(y)};
+    }
     const std::vector<double> &theta() const { return theta_; }   // :413-416
     double variance() const { return sigma2_; }                   // :418-421
     double likelihood() const { return likelihood_; }             // :428-431
@@ -164,7 +190,7 @@ inline GaussianProcess GpParams::fit(const double *x, int64_t n, int64_t d, cons
     cfg.nugget = nugget_;
     cfg.device = device_;
     const bool tuned = tuning_.kind != ThetaTuning::Kind::Fixed;
-    cfg.n_workspaces = tuned ? std::max(1, std::min(n_workspaces_, n_start_ + 1)) : 1;
+    cfg.n_workspaces = tuned ? std::max(1, std::min(n_workspaces_, n_start_ + 1)) : std::max(1, n_workspaces_);
     egx_gp *raw = nullptr;
     check(egx_gp_create(&cfg, x, y, n, d, &raw));
     GaussianProcess gp;
@@ -229,6 +255,32 @@ inline GaussianProcess GpParams::fit(const double *x, int64_t n, int64_t d, cons
     view.likelihood = &gp.likelihood_;
     check(egx_gp_get_inner(raw, &view));
     return gp;
+}
+
+// GpMixture::predict / predict_var over fitted experts of THIS process (crates/moe/src/algorithm.rs:411-423, 670-685 smooth;
+// :879-935 hard): probas (m x n_experts row-major) are the responsibilities, xq (m x d) in original units.
+inline std::pair<std::vector<double>, std::vector<double>> moe_predict_valvar(const std::vector<const GaussianProcess *> &experts,
+                                                                              const double *probas, const double *xq,
+                                                                              int64_t m, int64_t d, bool smooth) {
+    std::vector<egx_gp *> hs;
+    std::vector<int32_t> ids;
+    for (size_t e = 0; e < experts.size(); e++) {
+        hs.push_back(experts[e]->handle());
+        ids.push_back((int32_t)e);
+    }
+    std::vector<double> val((size_t)m), var((size_t)m);
+    check(egx_moe_predict_valvar(nullptr, hs.data(), ids.data(), (int64_t)hs.size(), (int64_t)hs.size(), probas, xq, m, d,
+                                 smooth ? 1 : 0, val.data(), var.data()));
+    return {std::move(val), std::move(var)};
+}
+
+// device resources destroyed models left in the library's pool (a model of the same shape created next reuses them)
+inline int64_t trim() { return egx_trim(); }  // bytes freed
+struct PoolStats { int64_t cached_bytes = 0, hits = 0, misses = 0; };
+inline PoolStats pool_stats() {
+    PoolStats s;
+    egx_pool_stats(&s.cached_bytes, &s.hits, &s.misses);
+    return s;
 }
 
 // Kriging = constant mean + squared exponential, algorithm.rs:244-249

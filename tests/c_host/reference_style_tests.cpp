@@ -3,6 +3,7 @@
 //   test_bug_var_derivatives      :1723-1797   fixed theta, d var / dx against central differences (1e-5)
 //   golden A                      doc/Gpx_Tutorial.ipynb cell 14 (theta printed, likelihood / variance to full precision)
 //   theta0 length check           :829-838     (a panic in the reference, InvalidValueError here)
+//   the round-3 members of the mirror (value + variance gradients in one pass, likelihood batch, mixture recombination, pool)
 // through include/egx_gp.hpp -> C ABI -> GPU.  Exit code = number of failed checks.
 #include <cmath>
 #include <cstdio>
@@ -96,6 +97,61 @@ static void test_errors() {
     EXPECT(gp.theta()[1] == 1.3);
 }
 
+// The round-3 entry points through the C++ mirror: one-pass value + variance gradients, the likelihood batch with its
+// lock-step width, training_data, the mixture recombination of crates/moe/src/algorithm.rs:411-423, 670-685, 879-935 applied
+// to the experts' own outputs, and the resource pool.
+static void test_round3_mirror() {
+    const double xt[24] = {6.875, -4.375, -3.125, 1.875, 1.875, -1.875, -4.375, 3.125, 8.125, 9.375, 4.375, 4.375,
+                           0.625, 0.625,  9.375,  6.875, 5.625, 8.125,  -0.625, -3.125, 3.125, 5.625, -1.875, -0.625};
+    const double yt[12] = {2.43286801,  13.10840811, 5.32908578,  17.81862219, 74.08849877, 39.68137781,
+                           14.96009727, 63.17475741, 61.26331775, -7.46009727, 44.39159189, 2.17091422};
+    auto a = Kriging::params().theta_tuning(ThetaTuning::Fixed({0.3, 0.12})).n_workspaces(4).fit(xt, 12, 2, yt);
+    auto b = GaussianProcess::params(Mean::Linear, Corr::Matern52).theta_tuning(ThetaTuning::Fixed({0.2, 0.4})).fit(xt, 12, 2, yt);
+    const double xq[6] = {-1.3, 2.5, 4.0, 4.0, 0.0, 7.5};
+    auto gy = a.predict_gradients(xq, 3);
+    auto gv = a.predict_var_gradients(xq, 3);
+    auto both = a.predict_valvar_gradients(xq, 3);
+    for (int i = 0; i < 6; i++) {
+        EXPECT(std::fabs(both.first[i] - gy[i]) <= 1e-12 * (1.0 + std::fabs(gy[i])));
+        EXPECT(std::fabs(both.second[i] - gv[i]) <= 1e-12 * (1.0 + std::fabs(gv[i])));
+    }
+    // likelihood batch: the fitted theta among the candidates gives the fitted likelihood, any lock-step width the same bits
+    const double thetas[8] = {0.3, 0.12, 0.5, 0.5, 0.05, 0.9, 2.0, 0.01};
+    EXPECT(a.set_lockstep(1) == 1);
+    auto l1 = a.likelihood_batch(thetas, 4, 2);
+    EXPECT(a.set_lockstep(4) == 4);
+    auto l4 = a.likelihood_batch(thetas, 4, 2);
+    for (int c = 0; c < 4; c++) EXPECT(l1.second[c] == l4.second[c] && l1.first[c] == l4.first[c]);
+    EXPECT(l1.second[0] == EGX_STATUS_OK && std::fabs(l1.first[0] - a.likelihood()) <= 1e-12 * std::fabs(a.likelihood()));
+    auto td = a.training_data(12);
+    for (int i = 0; i < 24; i++) EXPECT(td.first[i] == xt[i]);
+    for (int i = 0; i < 12; i++) EXPECT(td.second[i] == yt[i]);
+    // mixture of the two experts
+    const double probas[6] = {0.7, 0.3, 0.2, 0.8, 0.5, 0.5};
+    auto ya = a.predict_valvar(xq, 3), yb = b.predict_valvar(xq, 3);
+    auto smooth = moe_predict_valvar({&a, &b}, probas, xq, 3, 2, true);
+    auto hard = moe_predict_valvar({&a, &b}, probas, xq, 3, 2, false);
+    for (int i = 0; i < 3; i++) {
+        const double pa = probas[2 * i], pb = probas[2 * i + 1];
+        const double sv = pa * ya.first[i] + pb * yb.first[i], svar = pa * pa * ya.second[i] + pb * pb * yb.second[i];
+        EXPECT(std::fabs(smooth.first[i] - sv) <= 1e-12 * (1.0 + std::fabs(sv)));
+        EXPECT(std::fabs(smooth.second[i] - svar) <= 1e-12 * (1.0 + std::fabs(svar)));
+        const bool first = pa >= pb;  // argmax, first maximum
+        EXPECT(std::fabs(hard.first[i] - (first ? ya.first[i] : yb.first[i])) <= 1e-12 * (1.0 + std::fabs(sv)));
+        EXPECT(std::fabs(hard.second[i] - (first ? ya.second[i] : yb.second[i])) <= 1e-12 * (1.0 + std::fabs(svar)));
+    }
+    const PoolStats before = pool_stats();
+    {
+        auto c = Kriging::params().theta_tuning(ThetaTuning::Fixed({0.3, 0.12})).fit(xt, 12, 2, yt);
+    }  // destroyed: its resources are cached
+    {
+        auto c = Kriging::params().theta_tuning(ThetaTuning::Fixed({0.3, 0.12})).fit(xt, 12, 2, yt);
+    }
+    const PoolStats after = pool_stats();
+    EXPECT(after.hits > before.hits && after.cached_bytes > 0);
+    EXPECT(trim() > 0 && pool_stats().cached_bytes == 0);
+}
+
 int main() {
     if (egx_device_count() < 1) {
         std::fprintf(stderr, "no HIP device\n");
@@ -106,6 +162,7 @@ int main() {
     test_golden_a();
     test_bug_var_derivatives();
     test_errors();
+    test_round3_mirror();
     std::printf("%s (%d failed checks)\n", failures ? "FAILED" : "OK", failures);
     return failures;
 }
