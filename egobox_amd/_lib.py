@@ -97,6 +97,9 @@ SIGNATURES = [
     ("egx_sweep_allgather", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
     ("egx_moe_predict_valvar", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), c_int32_p, C.c_int64, C.c_int64, c_double_p,
                                            c_double_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_double_p]),
+    ("egx_gmx_precisions_chol", C.c_int32, [c_double_p, C.c_int64, C.c_int64, c_double_p]),
+    ("egx_gmx_predict_probas", C.c_int32, [C.c_int32, c_double_p, c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_double,
+                                           c_double_p, C.c_int64, c_double_p]),
     ("egx_gp_last_timings", C.c_int32, [C.c_void_p, C.POINTER(Timings)]),
     ("egx_mfma_probe", C.c_int32, [c_double_p]),
     ("egx_sgp_config_default", None, [C.POINTER(SgpConfig)]),

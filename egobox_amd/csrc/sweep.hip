@@ -243,6 +243,45 @@ static int sweep_allgather_doubles(egx_sweep *sw, const double *send, int64_t co
     return EGX_SUCCESS;
 }
 
+namespace egx {
+// Responsibilities of a Gaussian mixture at m points (GaussianMixture::predict_probas, crates/moe/src/gaussian_mixture.rs:
+// 114-121, 231-283): one lane per point, the workgroup's 64 points staged in LDS (row stride d | 1: a lane walks its own
+// row), the k x d x d scaled precision factors and the means read as wave-uniform operands.  par = [log w_c + log det_c -
+// 0.5 d ln 2 pi] (k).  q_c = || (x - mu_c) P_c ||^2; weighted log probability, the sum of the exponentials above
+// f64::MIN_10_EXP, its logarithm unless the sum is below epsilon (:236-251), exp of the difference (:119).
+__global__ __launch_bounds__(64) void k_gmx_probas(const double *__restrict__ xq, int64_t m, int d, int k,
+                                                  const double *__restrict__ means, const double *__restrict__ precs,
+                                                  const double *__restrict__ par, double *__restrict__ probas) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int64_t q0 = (int64_t)blockIdx.x * 64;
+    const int lane = threadIdx.x, ds = d | 1;
+    const int rows = (int)((m - q0 < 64) ? (m - q0) : 64);
+    for (int e = lane; e < rows * d; e += 64) {
+        const int i = e / d, j = e - i * d;
+        sm[i * ds + j] = xq[q0 * d + e];
+    }
+    __syncthreads();
+    if (lane >= rows) return;
+    const double *x = sm + lane * ds;
+    double *out = probas + (q0 + lane) * k;
+    double s = 0.0;
+    for (int c = 0; c < k; c++) {
+        const double *mu = means + (size_t)c * d, *P = precs + (size_t)c * d * d;
+        double q = 0.0;
+        for (int j = 0; j < d; j++) {
+            double acc = 0.0;
+            for (int i = 0; i < d; i++) acc = __builtin_fma(x[i] - mu[i], P[(size_t)i * d + j], acc);
+            q = __builtin_fma(acc, acc, q);
+        }
+        const double wlp = par[c] - 0.5 * q;
+        out[c] = wlp;
+        s += (wlp <= -307.0) ? 0.0 : exp(wlp);
+    }
+    const double norm = (fabs(s) < 2.220446049250313e-16) ? 0.0 : log(s);
+    for (int c = 0; c < k; c++) out[c] = exp(out[c] - norm);
+}
+}  // namespace egx
+
 extern "C" {
 
 int32_t egx_sweep_unique_id(void *id_out) {
@@ -713,6 +752,101 @@ int32_t egx_moe_predict_valvar(egx_sweep *sw, egx_gp *const *experts, const int3
         if (val) val[a] = sv;
         if (var) var[a] = sw2;
     }
+    return EGX_SUCCESS;
+}
+
+// ---- Gaussian mixture responsibilities ----------------------------------------------------------
+// precisions_chol[c] = (chol(cov_c)^-1)^T, crates/moe/src/gaussian_mixture.rs:182-205: d x d host arithmetic.
+int32_t egx_gmx_precisions_chol(const double *covariances, int64_t k, int64_t d, double *precisions_chol) {
+    if (!covariances || !precisions_chol || k < 1 || d < 1) {
+        set_error("egx_gmx_precisions_chol: bad arguments");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::vector<double> L((size_t)d * d), Li((size_t)d * d);
+    for (int64_t c = 0; c < k; c++) {
+        const double *A = covariances + (size_t)c * d * d;
+        std::fill(L.begin(), L.end(), 0.0);
+        for (int64_t j = 0; j < d; j++) {  // lower Cholesky factor, column by column
+            double dj = A[j * d + j];
+            for (int64_t l = 0; l < j; l++) dj -= L[j * d + l] * L[j * d + l];
+            if (!(dj > 0.0) || !std::isfinite(dj)) {
+                set_error("egx_gmx_precisions_chol: covariance " + std::to_string((long long)c) + " is not positive definite");
+                return EGX_ERR_LINALG;
+            }
+            L[j * d + j] = std::sqrt(dj);
+            for (int64_t i = j + 1; i < d; i++) {
+                double v = A[i * d + j];
+                for (int64_t l = 0; l < j; l++) v -= L[i * d + l] * L[j * d + l];
+                L[i * d + j] = v / L[j * d + j];
+            }
+        }
+        std::fill(Li.begin(), Li.end(), 0.0);  // L^-1 by forward substitution on the identity
+        for (int64_t col = 0; col < d; col++)
+            for (int64_t i = col; i < d; i++) {
+                double v = (i == col) ? 1.0 : 0.0;
+                for (int64_t l = col; l < i; l++) v -= L[i * d + l] * Li[l * d + col];
+                Li[i * d + col] = v / L[i * d + i];
+            }
+        double *out = precisions_chol + (size_t)c * d * d;
+        for (int64_t i = 0; i < d; i++)
+            for (int64_t j = 0; j < d; j++) out[i * d + j] = Li[j * d + i];  // transposed: upper triangular
+    }
+    return EGX_SUCCESS;
+}
+
+int32_t egx_gmx_predict_probas(int32_t device, const double *weights, const double *means, const double *precisions_chol,
+                               int64_t k, int64_t d, double heaviside_factor, const double *xq, int64_t m, double *probas) {
+    if (!weights || !means || !precisions_chol || k < 1 || d < 1 || d > 4096 || m < 0 || (m > 0 && (!xq || !probas)) ||
+        !(heaviside_factor > 0.0)) {
+        set_error("egx_gmx_predict_probas: bad arguments");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (m == 0) return EGX_SUCCESS;
+    if (k == 1) {  // gaussian_mixture.rs:115-116
+        for (int64_t a = 0; a < m; a++) probas[a] = 1.0;
+        return EGX_SUCCESS;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        (void)hipGetLastError();
+        set_error("egx_gmx_predict_probas: no HIP device");
+        return EGX_ERR_NO_DEVICE;
+    }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;  // the calling thread's current device
+    if (device >= ndev) {
+        set_error("egx_gmx_predict_probas: device out of range");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    EGX_HIP_CHECK(hipSetDevice(device));
+    // scaled factors and the per-cluster constant (:105-110, 253-283): precs = P * hf^-0.5, log det = sum log diag(precs)
+    const double factor = std::pow(heaviside_factor, -0.5);
+    std::vector<double> precs((size_t)k * d * d), par(k);
+    const double cst = (double)d * std::log(2.0 * M_PI);
+    for (int64_t c = 0; c < k; c++) {
+        double ld = 0.0;
+        for (int64_t i = 0; i < d * d; i++) precs[(size_t)c * d * d + i] = precisions_chol[(size_t)c * d * d + i] * factor;
+        for (int64_t i = 0; i < d; i++) ld += std::log(precs[(size_t)c * d * d + i * d + i]);
+        par[c] = (-0.5 * cst + ld) + std::log(weights[c]);
+    }
+    egx::DevBuf d_x, d_mu, d_p, d_par, d_out;
+    EGX_RC(d_x.alloc((size_t)m * d));
+    EGX_RC(d_mu.alloc((size_t)k * d));
+    EGX_RC(d_p.alloc(precs.size()));
+    EGX_RC(d_par.alloc(k));
+    EGX_RC(d_out.alloc((size_t)m * k));
+    EGX_HIP_CHECK(hipMemcpy(d_x.p, xq, sizeof(double) * (size_t)m * d, hipMemcpyHostToDevice));
+    EGX_HIP_CHECK(hipMemcpy(d_mu.p, means, sizeof(double) * (size_t)k * d, hipMemcpyHostToDevice));
+    EGX_HIP_CHECK(hipMemcpy(d_p.p, precs.data(), sizeof(double) * precs.size(), hipMemcpyHostToDevice));
+    EGX_HIP_CHECK(hipMemcpy(d_par.p, par.data(), sizeof(double) * k, hipMemcpyHostToDevice));
+    const size_t lds = sizeof(double) * 64 * (size_t)(d | 1);
+    if (lds > 160 * 1024) {
+        set_error("egx_gmx_predict_probas: d too large for one workgroup's LDS");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    hipLaunchKernelGGL(egx::k_gmx_probas, dim3((unsigned)((m + 63) / 64)), dim3(64), lds, 0, d_x.p, m, (int)d, (int)k, d_mu.p,
+                       d_p.p, d_par.p, d_out.p);
+    EGX_HIP_CHECK(hipGetLastError());
+    EGX_HIP_CHECK(hipMemcpy(probas, d_out.p, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost));
     return EGX_SUCCESS;
 }
 

@@ -71,6 +71,20 @@ class GaussianMixture:
             return np.ones((x.shape[0], 1))
         return np.exp(self._log_resp(x))
 
+    def predict_probas_device(self, x, device=-1):
+        """The same responsibilities from the library (egx_gmx_predict_probas: one lane per point on the GPU); what the
+        library-side recombination of `GpMixture` consumes."""
+        from . import _lib as L
+        lib = L.load()
+        x = np.ascontiguousarray(np.atleast_2d(np.asarray(x, dtype=np.float64)))
+        k, nx = self.means.shape
+        out = np.empty((x.shape[0], k))
+        L.check(lib.egx_gmx_predict_probas(int(device), L.dptr(np.ascontiguousarray(self.weights)),
+                                           L.dptr(np.ascontiguousarray(self.means)),
+                                           L.dptr(np.ascontiguousarray(self.precisions_chol)), k, nx,
+                                           self.heaviside_factor, L.dptr(x), x.shape[0], L.dptr(out)))
+        return out
+
     def predict(self, x):
         x = np.atleast_2d(np.asarray(x, dtype=np.float64))
         return np.argmax(np.exp(self._log_resp(x)), axis=1)
@@ -145,7 +159,8 @@ class GpMixture:
         ids, hs = lib_handles
         m, d = x.shape
         k = len(self.experts)
-        probas = np.ascontiguousarray(self.gmx.predict_probas(x), dtype=np.float64)
+        dev = getattr(self.gmx, "predict_probas_device", None)  # the library's kernel; a duck-typed mixture keeps its own
+        probas = np.ascontiguousarray(dev(x) if dev is not None else self.gmx.predict_probas(x), dtype=np.float64)
         harr = (C.c_void_p * max(1, len(hs)))(*[h.value if hasattr(h, "value") else h for h in hs])
         iarr = np.asarray(ids, dtype=np.int32)
         val = np.empty(m) if want_val else None

@@ -307,6 +307,17 @@ int32_t egx_moe_predict_valvar(egx_sweep *sw, egx_gp *const *experts, const int3
                                int64_t n_experts, const double *probas /*m*n_experts*/, const double *xq /*m*d*/,
                                int64_t m, int64_t d, int32_t smooth, double *val /*m*/, double *var /*m*/);
 
+/* Responsibilities of a fitted Gaussian mixture at m points: GaussianMixture::predict_probas (crates/moe/src/
+ * gaussian_mixture.rs:114-121, with compute_log_prob_resp :231-251 and compute_log_gaussian_prob :253-283) -- the `probas`
+ * egx_moe_predict_valvar consumes.  weights (k), means (k x d), precisions_chol (k x d x d row-major: (chol(cov_c)^-1)^T as
+ * the reference stores it, :182-205; egx_gmx_precisions_chol builds it from covariances (k x d x d), EGX_ERR_LINALG for a
+ * covariance that is not positive definite), heaviside_factor > 0 (:105-110: scales the precision factors by its power
+ * -1/2; 1 = none).  xq (m x d) in original units, probas (m x k).  One cluster: all ones (:115-116).  Runs on `device`
+ * (< 0: the calling thread's current device); the d x d factorisations of egx_gmx_precisions_chol are host arithmetic. */
+int32_t egx_gmx_precisions_chol(const double *covariances, int64_t k, int64_t d, double *precisions_chol);
+int32_t egx_gmx_predict_probas(int32_t device, const double *weights, const double *means, const double *precisions_chol,
+                               int64_t k, int64_t d, double heaviside_factor, const double *xq, int64_t m, double *probas);
+
 /* ---- measurement ------------------------------------------------------------
  * HIP-event durations (ms) of the stages of the most recent likelihood /
  * finalize call on workspace 0, measured on the stream the kernels ran on. */

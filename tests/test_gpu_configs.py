@@ -458,6 +458,30 @@ def test_bench_gpus_2_falls_back_to_torch_collective(how):
     assert fb["likelihood_checksum"] == lib["likelihood_checksum"]
 
 
+@pytest.mark.parametrize("k,nx,hf", [(1, 3, 1.0), (2, 1, 1.0), (3, 2, 0.99), (8, 16, 0.9), (8, 16, 0.3), (4, 64, 1.0)])
+def test_gmx_responsibilities_on_the_device(k, nx, hf):
+    """egx_gmx_predict_probas (one lane per point) against the oracle's GaussianMixture::predict_probas
+    (crates/moe/src/gaussian_mixture.rs:114-121, 231-283), including points so far out that every weighted log probability is
+    below f64::MIN_10_EXP (the reference then leaves the normaliser at 0, :244-250) and a ragged last workgroup."""
+    from egobox_amd.moe import GaussianMixture
+    from oracle import moe_oracle as MO
+    rng = np.random.default_rng(100 * k + nx)
+    means = rng.standard_normal((k, nx)) * 2
+    a = rng.standard_normal((k, nx, nx))
+    covs = np.einsum("kij,klj->kil", a, a) / nx + 0.5 * np.eye(nx)
+    w = rng.random(k) + 0.2
+    w /= w.sum()
+    x = rng.standard_normal((1000 + 37, nx)) * 3
+    x[:5] *= 40.0  # far outside every cluster
+    g, go = GaussianMixture(w, means, covs, hf), MO.GaussianMixtureOracle(w, means, covs, hf)
+    got = g.predict_probas_device(x)
+    want = go.predict_probas(x)
+    np.testing.assert_allclose(got, want, rtol=2e-11, atol=1e-300)
+    if k > 1:
+        np.testing.assert_array_equal(np.argmax(got, axis=1), go.predict(x))
+    assert g.predict_probas_device(x[:0]).shape == (0, k)
+
+
 def test_moe_c_host_drives_the_recombination(tmp_path):
     """tests/c_host/moe_driver.c: a C99 host (no Python) trains three experts, then calls egx_moe_predict_valvar -- the
     mixture recombination inside the library -- in both recombinations, single-process and through a one-rank RCCL

@@ -147,3 +147,23 @@ def test_gradient_recombination_with_oracle_experts(recomb):
             fv = (mix.predict_var(xq + dq) - mix.predict_var(xq - dq)) / (2 * e)
             np.testing.assert_allclose(gy[:, k], fy, rtol=1e-5, atol=1e-6)
             np.testing.assert_allclose(gv[:, k], fv, rtol=1e-5, atol=1e-7)
+
+
+def test_precisions_chol_through_the_c_abi():
+    """egx_gmx_precisions_chol is host arithmetic (no GPU): (chol(cov)^-1)^T per cluster as gaussian_mixture.rs:182-205,
+    against the oracle's; a covariance that is not positive definite is a LinalgError."""
+    from egobox_amd import _lib as L
+    lib = L.load()
+    rng = np.random.default_rng(3)
+    for k, nx in ((1, 1), (3, 2), (8, 16), (2, 40)):
+        a = rng.standard_normal((k, nx, nx))
+        covs = np.ascontiguousarray(np.einsum("kij,klj->kil", a, a) + 0.5 * np.eye(nx))
+        out = np.empty((k, nx, nx))
+        L.check(lib.egx_gmx_precisions_chol(L.dptr(covs), k, nx, L.dptr(out)))
+        w = np.full(k, 1.0 / k)
+        ref = MO.GaussianMixtureOracle(w, np.zeros((k, nx)), covs).precisions_chol
+        np.testing.assert_allclose(out, ref, rtol=1e-11, atol=1e-13 * np.abs(ref).max())
+        assert np.all(np.tril(out, -1) == 0.0)  # upper triangular, as the reference stores it
+    bad = np.array([[[1.0, 2.0], [2.0, 1.0]]])
+    with pytest.raises(L.LinalgError):
+        L.check(lib.egx_gmx_precisions_chol(L.dptr(bad), 1, 2, L.dptr(np.empty((1, 2, 2)))))
