@@ -95,6 +95,7 @@ SIGNATURES = [
     ("egx_sweep_set_assignment", C.c_int32, [C.c_void_p, C.c_int32]),
     ("egx_sweep_last_balance", C.c_int32, [C.c_void_p, c_int64_p, c_double_p]),
     ("egx_sweep_allgather", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p]),
+    ("egx_sweep_fit", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_int64, C.c_int64, c_int64_p]),
     ("egx_moe_predict_valvar", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), c_int32_p, C.c_int64, C.c_int64, c_double_p,
                                            c_double_p, C.c_int64, C.c_int64, C.c_int32, c_double_p, c_double_p]),
     ("egx_gmx_precisions_chol", C.c_int32, [c_double_p, C.c_int64, C.c_int64, c_double_p]),

@@ -6,13 +6,15 @@
 
 using namespace egx;
 
-extern "C" {
+namespace egx {
 
 // Multistart derivative-free fit over the ACTIVE theta components (all of them for ThetaTuning::Full; a subset for
-// ThetaTuning::Partial, algorithm.rs:822-826, 873-960: the inactive components stay at theta_base).
-static int32_t fit_nm_core(egx_gp *gp, const double *theta_base /*h*/, const std::vector<int> &active,
-                           const double *theta0s /*n_starts x k*/, int64_t n_starts, const double *lo,
-                           const double *hi, int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out) {
+// ThetaTuning::Partial, algorithm.rs:822-826, 873-960: the inactive components stay at theta_base), in two halves so that
+// the starts can be SHARDED over the ranks of a sweep (egx_sweep_fit): fit_run_starts runs the COBYLA machines of the starts
+// s with s mod world == rank, fit_reduce_finalize reduces all starts' results and keeps the winner's factor resident.
+int fit_run_starts(egx_gp *gp, const double *theta_base /*h*/, const std::vector<int> &active,
+                   const double *theta0s /*n_starts x k*/, int64_t n_starts, const double *lo, const double *hi,
+                   int64_t bounds_len, int64_t max_eval, int rank, int world, std::vector<StartResult> &results) {
     if (!theta0s || !lo || !hi || n_starts < 1 || active.empty()) {
         set_error("NULL argument / no start point");
         return EGX_ERR_INVALID_VALUE;
@@ -40,61 +42,67 @@ static int32_t fit_nm_core(egx_gp *gp, const double *theta_base /*h*/, const std
     int64_t per_start = 10 * (int64_t)h;
     if (per_start < 25) per_start = 25;
     if (max_eval >= 25 && per_start > max_eval) per_start = max_eval;
-    double best_f = std::numeric_limits<double>::infinity();
-    std::vector<double> best_x(h, 0.0);
-    int64_t evals = 0;
     for (int64_t s = 0; s < n_starts * h; s++)
         if (!(theta0s[s] > 0.0)) {
             set_error("theta start points must be > 0");
             return EGX_ERR_INVALID_VALUE;
         }
-    std::vector<StartResult> results((size_t)n_starts);
+    results.assign((size_t)n_starts, StartResult{std::numeric_limits<double>::quiet_NaN(), std::vector<double>(h, 0.0), 0});
     gp->fitted = false;
-    {
-        // COBYLA (cobyla.h), one machine per start, rhobeg 0.5 / ftol_rel 1e-4 (optimization.rs:16-24), all machines
-        // advanced in LOCK-STEP: their trial points form one likelihood batch per round, pipelined over the
-        // handle's workspaces (the reference runs the starts as rayon tasks, algorithm.rs:928-945)
-        std::vector<CobylaBox> mach;
-        mach.reserve((size_t)n_starts);
-        for (int64_t s = 0; s < n_starts; s++) {
-            std::vector<double> x0(h);
-            for (int i = 0; i < h; i++) x0[i] = std::log10(theta0s[s * h + i]);
-            mach.emplace_back(x0, blo, bhi, 0.5, 1e-4, per_start);
-        }
-        std::vector<double> thetas, lk, x;
-        std::vector<int32_t> st;
-        std::vector<int64_t> who;
-        for (;;) {
-            thetas.clear();
-            who.clear();
-            for (int64_t s = 0; s < n_starts; s++)
-                if (mach[(size_t)s].ask(x)) {
-                    who.push_back(s);
-                    const size_t off = thetas.size();
-                    thetas.insert(thetas.end(), theta_base, theta_base + hfull);
-                    for (int i = 0; i < h; i++) thetas[off + active[i]] = std::pow(10.0, x[i]);
-                }
-            if (who.empty()) break;
-            lk.assign(who.size(), 0.0);
-            st.assign(who.size(), 0);
-            EGX_RC(likelihood_batch_core(gp, thetas.data(), (int64_t)who.size(), hfull, lk.data(), st.data()));
-            for (size_t q = 0; q < who.size(); q++) {
-                const bool ok = st[q] == EGX_STATUS_OK && !std::isnan(lk[q]);
-                mach[(size_t)who[q]].tell(ok ? -lk[q] : std::numeric_limits<double>::infinity());  // algorithm.rs:893-896
+    // COBYLA (cobyla.h), one machine per start, rhobeg 0.5 / ftol_rel 1e-4 (optimization.rs:16-24), all machines
+    // advanced in LOCK-STEP: their trial points form one likelihood batch per round, pipelined over the
+    // handle's workspaces (the reference runs the starts as rayon tasks, algorithm.rs:928-945)
+    std::vector<int64_t> mine;
+    for (int64_t s = rank; s < n_starts; s += world) mine.push_back(s);
+    std::vector<CobylaBox> mach;
+    mach.reserve(mine.size());
+    for (int64_t s : mine) {
+        std::vector<double> x0(h);
+        for (int i = 0; i < h; i++) x0[i] = std::log10(theta0s[s * h + i]);
+        mach.emplace_back(x0, blo, bhi, 0.5, 1e-4, per_start);
+    }
+    std::vector<double> thetas, lk, x;
+    std::vector<int32_t> st;
+    std::vector<size_t> who;
+    for (;;) {
+        thetas.clear();
+        who.clear();
+        for (size_t q = 0; q < mach.size(); q++)
+            if (mach[q].ask(x)) {
+                who.push_back(q);
+                const size_t off = thetas.size();
+                thetas.insert(thetas.end(), theta_base, theta_base + hfull);
+                for (int i = 0; i < h; i++) thetas[off + active[i]] = std::pow(10.0, x[i]);
             }
-        }
-        for (int64_t s = 0; s < n_starts; s++) {
-            const CobylaBox &m = mach[(size_t)s];
-            double fb = m.best_f();
-            if (std::isnan(fb) || fb >= 1e30) fb = std::numeric_limits<double>::infinity();  // optimization.rs:153-157
-            results[(size_t)s] = StartResult{fb, m.best_x(), m.evals()};
+        if (who.empty()) break;
+        lk.assign(who.size(), 0.0);
+        st.assign(who.size(), 0);
+        EGX_RC(likelihood_batch_core(gp, thetas.data(), (int64_t)who.size(), hfull, lk.data(), st.data()));
+        for (size_t q = 0; q < who.size(); q++) {
+            const bool ok = st[q] == EGX_STATUS_OK && !std::isnan(lk[q]);
+            mach[who[q]].tell(ok ? -lk[q] : std::numeric_limits<double>::infinity());  // algorithm.rs:893-896
         }
     }
-    for (int64_t s = 0; s < n_starts; s++) {
-        evals += results[(size_t)s].evals;
-        if (results[(size_t)s].f < best_f) {  // algorithm.rs:942-945 reduce to min (first wins ties)
-            best_f = results[(size_t)s].f;
-            best_x = results[(size_t)s].x;
+    for (size_t q = 0; q < mach.size(); q++) {
+        const CobylaBox &m = mach[q];
+        double fb = m.best_f();
+        if (std::isnan(fb) || fb >= 1e30) fb = std::numeric_limits<double>::infinity();  // optimization.rs:153-157
+        results[(size_t)mine[q]] = StartResult{fb, m.best_x(), m.evals()};
+    }
+    return EGX_SUCCESS;
+}
+
+int fit_reduce_finalize(egx_gp *gp, const double *theta_base, const std::vector<int> &active, const double *theta0s,
+                        const std::vector<StartResult> &results, int64_t *n_evals_out) {
+    const int hfull = gp->h, h = (int)active.size();
+    double best_f = std::numeric_limits<double>::infinity();
+    std::vector<double> best_x(h, 0.0);
+    int64_t evals = 0;
+    for (size_t s = 0; s < results.size(); s++) {
+        evals += results[s].evals;
+        if (results[s].f < best_f) {  // algorithm.rs:942-945 reduce to min (first wins ties)
+            best_f = results[s].f;
+            best_x = results[s].x;
         }
     }
     if (n_evals_out) *n_evals_out = evals;
@@ -103,7 +111,21 @@ static int32_t fit_nm_core(egx_gp *gp, const double *theta_base /*h*/, const std
         for (int i = 0; i < h; i++) th[active[i]] = std::pow(10.0, best_x[i]);
     else  // every start failed: the reference falls through with ones (algorithm.rs:943) -> 10^1... keep start 0
         for (int i = 0; i < h; i++) th[active[i]] = theta0s[i];
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
+    EGX_RC(set_device(gp));
     return do_finalize(gp, th.data(), hfull);
+}
+
+}  // namespace egx
+
+extern "C" {
+
+static int32_t fit_nm_core(egx_gp *gp, const double *theta_base /*h*/, const std::vector<int> &active,
+                           const double *theta0s /*n_starts x k*/, int64_t n_starts, const double *lo,
+                           const double *hi, int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out) {
+    std::vector<StartResult> results;
+    EGX_RC(fit_run_starts(gp, theta_base, active, theta0s, n_starts, lo, hi, bounds_len, max_eval, 0, 1, results));
+    return fit_reduce_finalize(gp, theta_base, active, theta0s, results, n_evals_out);
 }
 
 int32_t egx_gp_fit(egx_gp *gp, const double *theta0s, int64_t n_starts, const double *lo, const double *hi,

@@ -154,6 +154,16 @@ struct egx_gp {
     egx_timings timings{};
 };
 
+namespace egx {
+// the two halves of the multistart COBYLA fit (gp_fit.hip): the starts s = rank, rank + world, ... of this rank, then the
+// reduction over ALL starts (results of the other ranks filled in by the caller) and the final factorisation
+int fit_run_starts(egx_gp *gp, const double *theta_base, const std::vector<int> &active, const double *theta0s,
+                   int64_t n_starts, const double *lo, const double *hi, int64_t bounds_len, int64_t max_eval, int rank,
+                   int world, std::vector<StartResult> &results);
+int fit_reduce_finalize(egx_gp *gp, const double *theta_base, const std::vector<int> &active, const double *theta0s,
+                        const std::vector<StartResult> &results, int64_t *n_evals_out);
+}  // namespace egx
+
 // x_mean (d) | x_std (d) on the device, behind the coefficients of the fit in the same allocation
 // the training inputs times the coefficients of the fit (d x n_pad, k-major; valid when fit_hcols == 1), behind d_xT in
 // the same allocation: what the scalar-row prediction kernel reads (kernels_corr.hip k_predict_mean_srow)

@@ -755,6 +755,67 @@ int32_t egx_moe_predict_valvar(egx_sweep *sw, egx_gp *const *experts, const int3
     return EGX_SUCCESS;
 }
 
+// ---- tuned fit over the ranks of a sweep (SURVEY 8e x 8f rank 2) --------------------------------------------------
+// GpValidParams::fit with ThetaTuning::Full (crates/gp/src/algorithm.rs:873-960): the reference runs its n_start + 1 COBYLA
+// runs as rayon tasks on one host (:928-945).  Here start s belongs to rank s mod world; a rank advances the machines of
+// its starts in lock-step on its own GPU (fit_run_starts), ONE all-gather carries every start's (objective, evaluations,
+// minimiser) to every rank, all ranks reduce in start order (first minimum wins, :942-945) and factor the winner on their
+// replica.  An evaluation returns the same bits wherever and in whichever batch it runs, so every start walks the trajectory
+// it walks on one GPU and the fitted model is bit for bit the one egx_gp_fit returns.
+int32_t egx_sweep_fit(egx_sweep *sw, const double *theta0s, int64_t n_starts, const double *lo, const double *hi,
+                      int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out) {
+    if (!sw || !theta0s || !lo || !hi || n_starts < 1) {
+        set_error("egx_sweep_fit: NULL argument / no start point");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    egx_gp *gp = sw->gp;
+    const int h = gp->h, world = sw->world;
+    std::vector<int> active(h);
+    for (int i = 0; i < h; i++) active[i] = i;
+    std::vector<StartResult> results;
+    int local_rc = fit_run_starts(gp, theta0s, active, theta0s, n_starts, lo, hi, bounds_len, max_eval, sw->rank, world, results);
+    const std::string local_msg = local_rc ? last_error_string() : std::string();
+    // payload: [status | per start: objective, evaluations, minimiser (h)], NaN objective for the starts of other ranks
+    const size_t per = (size_t)h + 2;
+    std::vector<double> part(1 + (size_t)n_starts * per, std::numeric_limits<double>::quiet_NaN());
+    part[0] = local_rc ? -(double)(kSweepPoison + local_rc) : 0.0;
+    if (!local_rc)
+        for (int64_t s = sw->rank; s < n_starts; s += world) {
+            double *q = part.data() + 1 + (size_t)s * per;
+            q[0] = results[(size_t)s].f;
+            q[1] = (double)results[(size_t)s].evals;
+            for (int i = 0; i < h; i++) q[2 + i] = results[(size_t)s].x[(size_t)i];
+        }
+    std::vector<double> all(part.size() * (size_t)world);
+    {
+        std::lock_guard<std::mutex> lock(sw->mu);
+        (void)set_device(gp);
+        const int coll_rc = sweep_allgather_doubles(sw, part.data(), (int64_t)part.size(), all.data());
+        if (coll_rc) {
+            if (local_rc) set_error(local_msg + " (and the collective failed: " + last_error_string() + ")");
+            return local_rc ? local_rc : coll_rc;
+        }
+    }
+    if (local_rc) {
+        set_error(local_msg);
+        return local_rc;
+    }
+    for (int r = 0; r < world; r++)
+        if (all[(size_t)r * part.size()] != 0.0) {
+            set_error("egx_sweep_fit: rank " + std::to_string(r) + " failed with egx_rc " +
+                      std::to_string((int)(-all[(size_t)r * part.size()]) - kSweepPoison));
+            return EGX_ERR_PEER;
+        }
+    results.assign((size_t)n_starts, StartResult{std::numeric_limits<double>::infinity(), std::vector<double>(h, 0.0), 0});
+    for (int64_t s = 0; s < n_starts; s++) {
+        const double *q = all.data() + (size_t)(s % world) * part.size() + 1 + (size_t)s * per;
+        results[(size_t)s].f = q[0];
+        results[(size_t)s].evals = (int64_t)q[1];
+        results[(size_t)s].x.assign(q + 2, q + 2 + h);
+    }
+    return fit_reduce_finalize(gp, theta0s, active, theta0s, results, n_evals_out);
+}
+
 // ---- Gaussian mixture responsibilities ----------------------------------------------------------
 // precisions_chol[c] = (chol(cov_c)^-1)^T, crates/moe/src/gaussian_mixture.rs:182-205: d x d host arithmetic.
 int32_t egx_gmx_precisions_chol(const double *covariances, int64_t k, int64_t d, double *precisions_chol) {

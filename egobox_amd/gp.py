@@ -147,6 +147,20 @@ class GpHandle:
         L.check(lib.egx_gp_dims(self._h, C.byref(n), C.byref(d), C.byref(p), C.byref(h)))
         self.n, self.d, self.p, self.h = n.value, d.value, p.value, h.value
 
+    @classmethod
+    def _borrow(cls, raw, owner):
+        """A view of an egx_gp* owned by something else (the replica inside an `egx_sweep`): every method works, closing it
+        does nothing; `owner` is kept alive as long as the view is."""
+        self = cls.__new__(cls)
+        self._lib = L.load()
+        self._h = C.c_void_p(raw if isinstance(raw, int) else raw.value)
+        self._w = None
+        self._owner = owner
+        n, d, p, h = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        L.check(self._lib.egx_gp_dims(self._h, C.byref(n), C.byref(d), C.byref(p), C.byref(h)))
+        self.n, self.d, self.p, self.h = n.value, d.value, p.value, h.value
+        return self
+
     @property
     def training_data(self):
         """(x, y) as given to the fit: the handle's own copy (the fitted model owns its training data,
@@ -157,7 +171,8 @@ class GpHandle:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.egx_gp_destroy(self._h)
+            if getattr(self, "_owner", None) is None:
+                self._lib.egx_gp_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

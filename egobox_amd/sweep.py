@@ -134,6 +134,25 @@ class Sweep:
                                                   L.dptr(lk), st.ctypes.data_as(L.c_int32_p)))
         return lk, st
 
+    def fit(self, theta0s, lo, hi, max_eval=1000):  # GP_COBYLA_MAX_EVAL, crates/gp/src/lib.rs
+        """COLLECTIVE tuned fit (egx_sweep_fit): the multistart COBYLA runs of `GpHandle.fit` with start s on rank
+        s mod world, one all-gather of the starts' results, every rank's replica finalized at the winner -- the same bits
+        as the one-GPU fit.  Returns the evaluations of all starts; `model()` is the fitted replica."""
+        L, C = self._L, self._C
+        theta0s = L.as_f64(theta0s, 2)
+        lo = L.as_f64(np.atleast_1d(lo), 1)
+        hi = L.as_f64(np.atleast_1d(hi), 1)
+        ne = C.c_int64()
+        L.check(self._lib.egx_sweep_fit(self._h, L.dptr(theta0s), theta0s.shape[0], L.dptr(lo), L.dptr(hi), lo.size,
+                                        int(max_eval), C.byref(ne)))
+        return ne.value
+
+    def model(self):
+        """This rank's replica (egx_sweep_handle) as a `GpHandle` view: predict / fitted_scalars / inner on the model a
+        `fit` or the caller's `finalize` left resident.  Owned by the sweep."""
+        from .gp import GpHandle
+        return GpHandle._borrow(self._lib.egx_sweep_handle(self._h), self)
+
     def set_lockstep(self, width):
         """Lock-step width of this rank's likelihood batches (egx_gp_set_lockstep on the sweep's handle)."""
         h = self._lib.egx_sweep_handle(self._h)

@@ -291,6 +291,15 @@ int32_t egx_sweep_last_balance(const egx_sweep *sw, int64_t *per_rank /*world*/,
  * crates/moe/src/algorithm.rs:670-685. */
 int32_t egx_sweep_allgather(egx_sweep *sw, const double *send, int64_t count, double *recv /*world*count*/);
 
+/* COLLECTIVE tuned fit: egx_gp_fit with the starts sharded over the ranks (start s on rank s mod world; the reference runs
+ * them as rayon tasks on one host, crates/gp/src/algorithm.rs:928-945).  Every rank passes the same arguments; one
+ * all-gather carries each start's (objective, evaluations, minimiser); every rank reduces in start order (:942-945) and
+ * finalizes ITS replica at the winner, so afterwards egx_sweep_handle(sw) is the same fitted model on every rank -- bit
+ * for bit the model egx_gp_fit returns on one GPU (an evaluation gives the same bits wherever it runs).  n_evals_out: the
+ * evaluations of all starts.  Failure semantics as egx_sweep_likelihood. */
+int32_t egx_sweep_fit(egx_sweep *sw, const double *theta0s /*n_starts x h*/, int64_t n_starts, const double *lo,
+                      const double *hi, int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out);
+
 /* ---- mixture-of-experts recombination (BASELINE config 5) ----------------------------------
  * GpMixture::predict_smooth / predict_var_smooth (crates/moe/src/algorithm.rs:411-423, 670-685):
  *     val = sum_e p_e y_e,  var = sum_e p_e^2 v_e        over all m points, every expert sees every point;

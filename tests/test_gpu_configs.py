@@ -312,6 +312,12 @@ def _two_rank_worker(rank, token, q):
         for e in experts:
             if e is not None:
                 e.close()
+        # the tuned fit with its five starts sharded over the two ranks (egx_sweep_fit), then predictions on the replica
+        starts = egx.theta_sweep_candidates(5, 5, seed=11)
+        out["fit_evals"] = sw.fit(starts, [1e-2], [1e1], max_eval=60)
+        mdl = sw.model()
+        out["fit"] = ({k_: v for k_, v in mdl.inner().items() if k_ in ("theta", "likelihood", "sigma2", "beta", "gamma")},
+                      mdl.predict_valvar(x[:50] + 0.01))
         # a LOCAL failure on rank 1 only (its theta matrix has one column too many): both ranks must come back
         bad = thetas if rank == 0 else np.hstack([thetas, thetas[:, :1]])
         try:
@@ -386,6 +392,18 @@ def test_sweep_two_ranks_share_one_gpu_through_the_host_transport(egx):
         np.testing.assert_array_equal(res[0]["moe_" + recomb][0], res[1]["moe_" + recomb][0])  # the same bits on both ranks
     for e in experts:
         e.close()
+    # the sharded tuned fit IS the one-GPU tuned fit: same evaluations, same theta, same predictions, bit for bit, on both ranks
+    starts = egx.theta_sweep_candidates(5, 5, seed=11)
+    with egx.GpHandle(x, y, corr=0, n_workspaces=4) as h:
+        ne = h.fit(starts, [1e-2], [1e1], max_eval=60)
+        want_sc, want_pred = h.inner(), h.predict_valvar(x[:50] + 0.01)
+    for r in range(2):
+        assert res[r]["fit_evals"] == ne
+        got_sc, got_pred = res[r]["fit"]
+        for key in ("theta", "likelihood", "sigma2", "beta", "gamma"):
+            np.testing.assert_array_equal(np.asarray(got_sc[key]), np.asarray(want_sc[key]))
+        np.testing.assert_array_equal(got_pred[0], want_pred[0])
+        np.testing.assert_array_equal(got_pred[1], want_pred[1])
     # the failing rank reports ITS error, the survivor a peer error with the survivors' candidates intact
     assert res[1]["fail"][0] == "InvalidValueError"
     kind, lk, st, msg = res[0]["fail"]
@@ -396,6 +414,27 @@ def test_sweep_two_ranks_share_one_gpu_through_the_host_transport(egx):
     assert np.all(st[~mine] == egx._lib.STATUS_RANK_FAILED) and np.all(np.isneginf(lk[~mine]))
     kind, rc, waited = res[0]["deadline"]
     assert kind == "PeerError" and rc == egx._lib.ERR_PEER and 6.0 < waited < 40.0
+
+
+def test_sweep_fit_on_one_rank_is_the_handle_fit(egx):
+    """egx_sweep_fit with world = 1 (a one-rank RCCL communicator): the same machines, evaluations and fitted model as
+    egx_gp_fit; more starts than workspaces, a trend with p > 1 and a Matern kernel."""
+    x, y = _data(700, 3, 5)
+    starts = egx.theta_sweep_candidates(7, 3, seed=4)
+    with egx.GpHandle(x, y, mean=1, corr=3, n_workspaces=3) as h:
+        ne = h.fit(starts, [1e-2], [1e1], max_eval=40)
+        want_sc, want_pred = h.inner(), h.predict_valvar(x[:40] * 0.99)
+    with egx.Sweep(x, y, mean=1, corr=3, device=0, rank=0, world=1, id_bytes="new", n_workspaces=3) as sw:
+        assert sw.fit(starts, [1e-2], [1e1], max_eval=40) == ne
+        m = sw.model()
+        got_sc, got_pred = m.inner(), m.predict_valvar(x[:40] * 0.99)
+        m.close()  # a view: the sweep still owns the handle
+        assert sw.model().fitted_scalars()[0] == got_sc["likelihood"]
+    for key in ("theta", "likelihood", "sigma2", "beta", "gamma", "ft_qr_r"):
+        np.testing.assert_array_equal(np.asarray(got_sc[key]), np.asarray(want_sc[key]))
+    np.testing.assert_array_equal(got_pred[0], want_pred[0])
+    np.testing.assert_array_equal(got_pred[1], want_pred[1])
+    assert ne >= 7 * 25  # every start ran at least GP_COBYLA_MIN_EVAL evaluations
 
 
 @pytest.mark.timeout(600)
