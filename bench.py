@@ -256,6 +256,23 @@ def moe_sharded_leg(egx, workload, sw, rank, world, gpu):
             "trsm_tflops_all_gpus": k * float(n5) * n5 * m5 / t_m / 1e12, "checksum": float(vm.sum())}
 
 
+def tuned_fit_leg(egx, sw, d, world):
+    """A TUNED fit of the metric's training set through egx_sweep_fit: the reference's 11 multistart COBYLA runs
+    (GP_OPTIM_N_START + 1, crates/gp/src/algorithm.rs:928-945) with start s on rank s mod world, bounded at the reference's
+    MINIMUM of 25 evaluations per start (GP_COBYLA_MIN_EVAL; its default at d = 32 is 320) so that the leg takes seconds.
+    Collective; the fitted model is the same bits for every N."""
+    starts = egx.theta_sweep_candidates(11, d, seed=9)  # row 0 = the default theta0 = 0.1, rows 1.. LHS in log10 bounds
+    t0 = time.perf_counter()
+    evals = sw.fit(starts, [1e-2], [1e1], max_eval=25)
+    dt = time.perf_counter() - t0
+    m = sw.model()
+    lk, s2 = m.fitted_scalars()
+    th = m.inner()["theta"]
+    return {"starts": 11, "max_eval_per_start": 25, "evaluations": int(evals), "seconds": dt,
+            "evaluations_per_s_all_gpus": evals / dt, "n_gpus": world, "likelihood": lk, "sigma2": s2,
+            "theta_checksum": float(np.sum(np.log10(th)))}
+
+
 def spawn_ranks(n_ranks):
     """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run on
     127.0.0.1 (one process per GPU, algorithm.rs:928-945's rayon workers at node scale) and pass its exit code on."""
@@ -499,6 +516,13 @@ def main():
             moe_sharded = moe_sharded_leg(egx, workload, sw, rank, world, gpu)
         except Exception as e:  # noqa: BLE001 - reported in the line, must not take the headline number down
             moe_sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # the tuned fit with its starts sharded over the ranks (every N, also 1): bounded, after the timed region, collective
+    tuned = None
+    if not args.no_extra_configs and use_lib:
+        try:
+            tuned = tuned_fit_leg(egx, sw, d, world)
+        except Exception as e:  # noqa: BLE001
+            tuned = {"error": f"{type(e).__name__}: {e}"[:300]}
     sw.close()
     if use_lib and info["rccl_ranks"] != world and not rehearsal:
         sys.stderr.write(f"bench.py: the library's RCCL communicator has {info['rccl_ranks']} ranks, world is {world}\n")
@@ -625,6 +649,8 @@ def main():
             out["other_configs"] = other_configs(egx, workload, gpu)
         if moe_sharded is not None:
             out["other_configs"] = {"config5_mixture_8_experts_sharded": moe_sharded}
+        if tuned is not None:
+            out.setdefault("other_configs", {})["tuned_fit_11_starts_sharded"] = tuned
         if not args.no_cpu_baseline and world == 1:
             torch.cuda.synchronize()
             cb = cpu_baseline(n, d)

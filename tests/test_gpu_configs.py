@@ -463,6 +463,8 @@ def test_bench_gpus_2_rehearsal_on_one_gpu():
     assert "error" not in moe and moe["experts_on_rank_0"] == 4 and math.isfinite(moe["checksum"])
     # the sharded mixture is the single-process mixture (bench.py's other_configs at N = 1 prints the same checksum)
     assert moe["checksum"] == pytest.approx(5774.94659384006, rel=1e-9)
+    tuned = rec["other_configs"]["tuned_fit_11_starts_sharded"]
+    assert "error" not in tuned and tuned["evaluations"] >= 11 * 25 and math.isfinite(tuned["likelihood"])
 
 
 @pytest.mark.timeout(600)
