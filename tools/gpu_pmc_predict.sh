@@ -11,7 +11,7 @@ q = """select s.kernel_name, p.name, e.value, d.event_id from rocpd_pmc_event e 
        join rocpd_kernel_dispatch d on e.event_id = d.event_id join rocpd_info_kernel_symbol s on d.kernel_id = s.id"""
 acc = {}
 for name, ctr, val, ev in cur.execute(q):
-    key = next((k for k in ("k_predict_mean", "k_cross_corr", "k_row_reduce") if k in name), None)
+    key = next((k for k in ("k_predict_mean_srow", "k_predict_mean", "k_normalize_queries", "k_cross_corr", "k_row_reduce") if k in name), None)
     if key is None:
         continue
     a = acc.setdefault(key, {"dispatches": set()})
