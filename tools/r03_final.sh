@@ -12,6 +12,10 @@ python tools/rocpd_stats.py "$(find gpurun_out/prof_${T}_default -name '*_result
 DB=$(find gpurun_out/prof_${T}_b1 -name '*_results.db' | head -1)
 python tools/rocpd_stats.py "$DB" > gpurun_out/${T}_bench_sweepbatch1_kernel_stats.txt; tail -4 gpurun_out/${T}_bench_sweepbatch1_kernel_stats.txt
 python tools/timeline.py "$DB" gpurun_out/${T}_timeline_n16384_one_fit.txt
+# one lock-step group in flight: kernel stats of the batched launches without another group's kernels beside them
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/gpurun_out/prof_${T}_g4" -o prof -- python "$GRAFT_REPO_ROOT/bench.py" --sweep-batch 4 --in-flight 4 --lockstep 4 --steps 8 --warmup 2 --no-cpu-baseline --no-extra-configs > "$GRAFT_REPO_ROOT/gpurun_out/${T}_prof_g4_bench.json" 2>/dev/null)
+python tools/rocpd_stats.py "$(find gpurun_out/prof_${T}_g4 -name '*_results.db' | head -1)" > gpurun_out/${T}_bench_one_group_kernel_stats.txt; tail -6 gpurun_out/${T}_bench_one_group_kernel_stats.txt
+rm -rf gpurun_out/prof_${T}_g4
 timeout 300 python tools/small_n_latency.py > gpurun_out/${T}_small_n_latency.jsonl 2>/dev/null; tail -2 gpurun_out/${T}_small_n_latency.jsonl
 rm -rf gpurun_out/prof_${T}_default gpurun_out/prof_${T}_b1
 timeout 600 python bench_configs.py > gpurun_out/${T}_bench_configs.jsonl 2>/dev/null; wc -l gpurun_out/${T}_bench_configs.jsonl
