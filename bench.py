@@ -273,6 +273,48 @@ def tuned_fit_leg(egx, sw, d, world):
             "theta_checksum": float(np.sum(np.log10(th)))}
 
 
+def kernel_alone_leg(args):
+    """Child process of the roofline leg: the same chip-filling launches of one fit, timed the same way, but with the
+    look-ahead switched off (EGX_LOOK_MIN beyond n) so that no chain kernel of the next group shares the GPU with them."""
+    import egobox_amd as egx
+    from egobox_amd import workload
+    x, y = workload.make_training_set(args.n, args.d, seed=42)
+    base = workload.default_theta(args.d)
+    gp = egx.GpHandle(x, y, mean=0, corr=0, device=int(os.environ.get("EGX_BENCH_DEVICE", "0")), n_workspaces=1)
+    tims = []
+    for j in range(4):
+        gp.finalize(base * (1.0 + 0.01 * j))
+        tims.append(gp.timings())
+    tims = tims[1:]
+    ms = float(np.mean([t["potrf_syrk_ms"] for t in tims]))
+    fl = float(np.mean([t["syrk_flops"] for t in tims]))
+    nl = int(tims[0]["syrk_launches"])
+    print(json.dumps({"tflops": fl / (ms * 1e-3) / 1e12, "launch_ms_avg": ms / max(1, nl), "launches_per_fit": nl,
+                      "potrf_ms": float(np.mean([t["potrf_ms"] for t in tims]))}), flush=True)
+    gp.close()
+    return 0
+
+
+def run_kernel_alone_leg(args, gpu):
+    import subprocess
+    env = dict(os.environ, EGX_LOOK_MIN="1000000000", EGX_BENCH_DEVICE=str(gpu))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--kernel-alone-leg", "--npoints", str(args.n),
+                              "--dim", str(args.d)], env=env, capture_output=True, text=True, timeout=300)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+        r = json.loads(line)
+    except Exception as e:  # noqa: BLE001 - a side figure
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+    return {"bound": "mfma", "achieved": r["tflops"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": r["tflops"] / FP64_MFMA_PEAK_TFLOPS, "launch_ms_avg": r["launch_ms_avg"],
+            "launches_per_fit": r["launches_per_fit"], "potrf_ms_with_lookahead_off": r["potrf_ms"],
+            "how": "the launches of `roofline`, timed the same way in a child process with EGX_LOOK_MIN beyond n: no look-ahead, "
+                   "so the chain kernels of the next group do not share the GPU with the trailing update (and the fit as a "
+                   "whole is slower: potrf_ms_with_lookahead_off).  What the kernel does with the chip to itself"}
+
+
 def spawn_ranks(n_ranks):
     """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run on
     127.0.0.1 (one process per GPU, algorithm.rs:928-945's rayon workers at node scale) and pass its exit code on."""
@@ -346,6 +388,9 @@ def main():
     ap.add_argument("--sweep-batch", type=int, default=96,
                     help="candidate thetas per step, summed over ALL GPUs (fixed as N grows: strong scaling; 96 = 12 per GPU "
                          "at N = 8, i.e. every GPU still has its three lock-step groups of four)")
+    ap.add_argument("--kernel-alone-leg", action="store_true",
+                    help="internal: the roofline launches of one fit with the look-ahead OFF (run as a child process with "
+                         "EGX_LOOK_MIN set, the library reads its knobs once); prints one JSON object")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the bounded side measurements of BASELINE configs 3 / 5 and d = 64 (other_configs in the line)")
     ap.add_argument("--lockstep", type=int, default=0,
@@ -361,6 +406,8 @@ def main():
                     help="CPU rehearsal of the launch path: gloo + a stub evaluator, no GPU, no performance number")
     args = ap.parse_args()
 
+    if args.kernel_alone_leg:
+        sys.exit(kernel_alone_leg(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -626,6 +673,7 @@ def main():
                                              "correction": "gfx950 FETCH_SIZE counts 16 B/lane reads at half: traffic = "
                                                            "WRITE + C_read + 2 * (FETCH - C_read)"})},
             "lockstep_group_alone": grp,
+            "roofline_kernel_alone": (run_kernel_alone_leg(args, gpu) if world == 1 and not args.no_extra_configs else None),
             "corr_build_gbps": tim1[0]["corr_bytes"] / (corr_ms * 1e-3) / 1e9,
             "corr_build_roofline": {"bound": "hbm", "achieved": tim1[0]["corr_bytes"] / (corr_ms * 1e-3) / 1e9,
                                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
