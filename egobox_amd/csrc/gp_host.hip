@@ -444,7 +444,7 @@ static int finish_eval_device_gls(egx_gp *gp, Workspace &w, EvalResult &out, boo
     double rho_sqr = 0.0;
     for (int b = 0; b < nblk; b++) rho_sqr += w.h_part[b];
     double slog = 0.0;
-    for (int i = 0; i < n; i++) slog += std::log10(w.h_diag[i]);
+    slog = hm::sum_log10(w.h_diag, n);
     const double sigma2n = rho_sqr / (double)n;
     out.lkh = -(double)n * (std::log10(sigma2n) + slog * 2.0 / (double)n);  // algorithm.rs:1039-1043
     out.sigma2n = sigma2n;
@@ -536,7 +536,7 @@ int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, bool keep) {
     for (int i = 0; i < n; i++) rho_sqr += rho[i] * rho[i];
     // :1039-1043
     double slog = 0.0;
-    for (int i = 0; i < n; i++) slog += std::log10(w.h_diag[i]);
+    slog = hm::sum_log10(w.h_diag, n);
     const double logdet = slog * 2.0 / (double)n;
     const double sigma2n = rho_sqr / (double)n;
     out.lkh = -(double)n * (std::log10(sigma2n) + logdet);

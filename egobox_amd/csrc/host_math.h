@@ -60,6 +60,28 @@ inline void regression_row(int mean, const double *x, int64_t d, double *f) {
             for (int64_t j = k; j < d; j++) f[c++] = x[j] * x[k];
 }
 
+// sum_i log10(d_i) for positive finite d (the log-determinant term of algorithm.rs:1039-1041) without n calls of log10:
+// the mantissas are multiplied (renormalised every 256 factors: 256 numbers in [0.5, 1) cannot underflow), the exponents added;
+// ONE logarithm at the end.  The product carries a relative error of n eps / 2, i.e. n eps / (2 ln 10) ABSOLUTE in the sum
+// (1e-12 at n = 16384 on a sum of order 1e4) -- the same order as the rounding of n separate logarithms, at a twelfth of the
+// time (the n = 16384 host half of an evaluation was 0.3 ms of log10 calls).
+inline double sum_log10(const double *d, int64_t n) {
+    double mant = 1.0;
+    int64_t ex = 0;
+    for (int64_t i0 = 0; i0 < n; i0 += 256) {
+        const int64_t i1 = (i0 + 256 < n) ? i0 + 256 : n;
+        for (int64_t i = i0; i < i1; i++) {
+            int e;
+            mant *= std::frexp(d[i], &e);
+            ex += e;
+        }
+        int e;
+        mant = std::frexp(mant, &e);
+        ex += e;
+    }
+    return std::log10(mant) + (double)ex * 0.30102999566398119521;  // log10(2)
+}
+
 // out[k] = sum_j v[j] * d f_j(x) / d x_k : RegressionModel::jacobian (mean_models.rs:50-52, 76-81, 110-128)
 // contracted with a coefficient vector v (beta for the mean gradient, B^-1 A^T for the variance gradient).
 inline void regression_jac_dot(int mean, const double *x, int64_t d, const double *v, double *out) {

@@ -36,6 +36,25 @@ int main() {
         for (int i = 0; i < n; i++) chk += xn[i * d] * xn[i * d];
         EXPECT(std::fabs(chk - (n - 1)) < 1e-12);
     }
+    // sum_log10 (mantissa product, one logarithm) against a long double sum of logarithms: Cholesky pivots from 1e-7 to 1,
+    // lengths across the 256-factor renormalisation, and pivots near the ends of the exponent range
+    {
+        std::uniform_real_distribution<double> u(-7.0, 0.0);
+        for (int64_t n : {1, 5, 255, 256, 257, 4096, 16384, 50001}) {
+            std::vector<double> dgl(n);
+            long double ref = 0.0L;
+            for (auto &e : dgl) {
+                e = std::pow(10.0, u(rng));
+                ref += log10l((long double)e);
+            }
+            const double got = hm::sum_log10(dgl.data(), n);
+            EXPECT(std::fabs(got - (double)ref) <= 4e-16 * (double)n + 1e-15 * std::fabs((double)ref));
+        }
+        const double edge[6] = {1e-300, 1e300, 3e-308, 1.5e308, 1.0, 0.5};
+        long double ref = 0.0L;
+        for (double e : edge) ref += log10l((long double)e);
+        EXPECT(std::fabs(hm::sum_log10(edge, 6) - (double)ref) <= 1e-12);
+    }
     // regression basis and its jacobian contraction vs central differences
     for (int mean = 0; mean < 3; mean++) {
         const int d = 4;
