@@ -7,7 +7,7 @@
      127.0.0.1; either way the line is only printed when the world size IS N and the RCCL communicator inside the
      library has N ranks)
 
-One "step" = one pass of the hot path over one batch of `--sweep-batch` (default 96 = three lock-step groups of four on
+One "step" = one pass of the hot path over one batch of `--sweep-batch` (default 192 = three lock-step groups of eight on
 each of 8 GPUs) candidate thetas of a theta sweep: every candidate is one fit in north_star's sense --
 correlation-matrix build (K1) + blocked FP64-MFMA Cholesky with fused forward solves (K3/K4) + GLS / reduced
 likelihood, i.e. one evaluation of the objective the reference's COBYLA multiplies
@@ -381,20 +381,20 @@ def main():
     ap.add_argument("--npoints", dest="n", type=int, default=16384)
     ap.add_argument("--dim", dest="d", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=12,
+    ap.add_argument("--in-flight", type=int, default=24,
                     help="candidates in flight per GPU (correlation-matrix workspaces of the sweep handle, 2 GiB each at "
-                         "n = 16384): 3 lock-step groups of 4 (measured 36.0 / 37.5 / 39.8 / 40.2 fits/s with 3 / 3 / 8 / 12 in "
-                         "flight and lock-step widths 1 / 3 / 4 / 4, profiles/r03_run1_*, r03_run2_*)")
-    ap.add_argument("--sweep-batch", type=int, default=96,
-                    help="candidate thetas per step, summed over ALL GPUs (fixed as N grows: strong scaling; 96 = 12 per GPU "
-                         "at N = 8, i.e. every GPU still has its three lock-step groups of four)")
+                         "n = 16384): 3 lock-step groups of 8 (measured in flight / width -> fits/s: 3 / 1 36.0, 12 / 4 40.7, "
+                         "24 / 8 41.3, 36 / 12 41.2; profiles/r03_run1_*, r03_run2_*, r03_run16_*)")
+    ap.add_argument("--sweep-batch", type=int, default=192,
+                    help="candidate thetas per step, summed over ALL GPUs (fixed as N grows: strong scaling; 192 = 24 per GPU "
+                         "at N = 8, i.e. every GPU still has its three lock-step groups of eight; BASELINE config 4 sweeps 512)")
     ap.add_argument("--kernel-alone-leg", action="store_true",
                     help="internal: the roofline launches of one fit with the look-ahead OFF (run as a child process with "
                          "EGX_LOOK_MIN set, the library reads its knobs once); prints one JSON object")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the bounded side measurements of BASELINE configs 3 / 5 and d = 64 (other_configs in the line)")
     ap.add_argument("--lockstep", type=int, default=0,
-                    help="candidates factored in lock-step by one launch sequence (0 = library default: min(in-flight, 4))")
+                    help="candidates factored in lock-step by one launch sequence (0 = library default: 8 with 24 in flight, else 4)")
     ap.add_argument("--assignment", choices=("static", "dynamic"), default="static",
                     help="candidates -> ranks: c mod N, or pulled from the node-wide counter (egx_sweep_set_assignment)")
     ap.add_argument("--collective", choices=("library", "torch"), default="library",
@@ -601,7 +601,7 @@ def main():
         # ---- ONE lock-step group alone (the unit the timed region keeps three of in flight): its whole factorisation rate.
         # (No per-launch figure for the batched launches: inside a group the rest-of-group update runs on a side stream and
         # overlaps the HIP events around the trailing update -- 47.7 TFLOP/s "per launch" beside 58.8 for the whole group.)
-        gl = max(1, min(lockstep, 4))
+        gl = max(1, min(lockstep, 8))
         grp = None
         if gl > 1:
             gq = egx.GpHandle(x, y, mean=0, corr=0, device=gpu, n_workspaces=gl)

@@ -144,7 +144,7 @@ int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int
  * workspaces) are factored by ONE launch sequence -- the candidates of a sweep have the same n, hence the same
  * schedule; the serial chain of the factorisation then costs its latency once per group and every launch has `width`
  * times the tiles.  1 = every candidate on its own stream set (round 2's pipeline); 0 = the default
- * (min(n_workspaces, 4) for large matrices, min(n_workspaces, 12) up to a padded n of 4096 where an evaluation is
+ * (4 for large matrices, 8 from 24 workspaces on; min(n_workspaces, 12) up to a padded n of 4096 where an evaluation is
  * launch-latency bound, or the EGX_LOCKSTEP environment variable); at most n_workspaces.  A candidate's result does
  * not depend on the width or on its companions (same kernels, same arithmetic: bit-identical). */
 int32_t egx_gp_set_lockstep(egx_gp *gp, int32_t width);
