@@ -51,7 +51,7 @@ def cpu_baseline(n, d, timeout_s=900):
     env = dict(os.environ)
     for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         env.pop(k, None)  # all host cores
-    cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--n", str(n), "--d", str(d)]
+    cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--n", str(n), "--d", str(d), "--blas-threads", "16,32,64,128"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout_s)
     if out.returncode != 0:
         return {"error": out.stderr[-400:]}
@@ -125,6 +125,64 @@ def cpu_baseline_reference_shaped(n_full, d):
             "sample_seconds": float(sum(ts)), "sample_status": int(r["status"])}
 
 
+def vendor_yardstick(torch, gpu, sizes=(16384, 4096)):
+    """The same-GPU external anchor (BASELINE.json publishes no number): torch.linalg.cholesky, i.e. the vendor's
+    rocSOLVER / hipSOLVER FP64 potrf behind PyTorch-ROCm, on a well-conditioned SPD matrix of the metric's size.  Run
+    AFTER the timed region, never part of the product path.  TFLOP/s = n^3/3 over the best of three calls."""
+    res = {}
+    dev = torch.device(f"cuda:{gpu}")
+    for n in sizes:
+        try:
+            gen = torch.Generator(device=dev).manual_seed(1)
+            a = torch.randn(n, 256, dtype=torch.float64, device=dev, generator=gen)
+            spd = a @ a.T
+            spd.diagonal().add_(float(n))
+            del a
+            torch.linalg.cholesky(spd)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                torch.linalg.cholesky(spd)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            del spd
+            torch.cuda.empty_cache()
+            res[f"n{n}"] = {"ms": min(ts) * 1e3, "tflops": n ** 3 / 3 / min(ts) / 1e12,
+                            "frac_of_fp64_peak": n ** 3 / 3 / min(ts) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+        except Exception as e:  # noqa: BLE001 - a side figure
+            res[f"n{n}"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    res["what"] = (f"torch.linalg.cholesky (torch {torch.__version__}: rocSOLVER / hipSOLVER potrf), float64, lower, one "
+                   f"matrix, out-of-place, best of 3; a yardstick on the same GPU, not part of the product")
+    return res
+
+
+def host_fp64_peak():
+    """cores x 16 flop/clk x clock from lscpu (two 256-bit FMA pipes per core): the denominator the CPU baseline's dpotrf
+    rate is quoted against."""
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+    except Exception:  # noqa: BLE001
+        return None
+    f = {}
+    for ln in txt.splitlines():
+        if ":" in ln:
+            k, v = ln.split(":", 1)
+            f[k.strip()] = v.strip()
+    try:
+        sockets = int(f.get("Socket(s)", "1"))
+        cps = int(f.get("Core(s) per socket", "0"))
+        mhz = float(f.get("CPU max MHz", f.get("CPU MHz", "0")).split()[0])
+        if cps <= 0 or mhz <= 0:
+            return None
+        cores = sockets * cps
+        return {"model": f.get("Model name"), "sockets": sockets, "cores": cores, "threads": int(f.get("CPU(s)", "0")),
+                "clock_mhz_max": mhz, "flop_per_clk_per_core_assumed": 16,
+                "peak_gflops": cores * 16 * mhz / 1e3}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def measured_traffic(n, d):
     """HBM/fabric bytes per launch of the update kernel from the committed PMC summary (separate --pmc passes of
     `bench.py --steps 1`), corrected as the MI355X guide prescribes: on gfx950 FETCH_SIZE tallies a 16 B/lane
@@ -152,14 +210,39 @@ def other_configs(egx, workload, gpu):
     h.finalize(th * 1.01)
     t_fit = time.perf_counter() - t0
     tm = h.timings()
-    t0 = time.perf_counter()
-    lk, g, st = h.likelihood_grad(th)
-    t_grad = time.perf_counter() - t0
+    h.likelihood_grad(th * 0.99)  # (first call: allocates the C^-T scratch)
+    t_gs = []
+    for j in range(2):
+        t0 = time.perf_counter()
+        lk, g, st = h.likelihood_grad(th * (1.0 + 0.005 * j))
+        t_gs.append(time.perf_counter() - t0)
+    t_grad = min(t_gs)
     h.close()
+    # likelihood + gradient = Cholesky n^3/3 + C^-T n^3/3 + R^-1 = C^-T C^-1 n^3/3: n^3 flop on the FP64 MFMA pipe
+    gflop = float(n) ** 3
+    grad_roof = {"bound": "mfma", "flops": gflop, "achieved": gflop / t_grad / 1e12, "peak": FP64_MFMA_PEAK_TFLOPS,
+                 "unit": "TFLOP/s", "frac": gflop / t_grad / 1e12 / FP64_MFMA_PEAK_TFLOPS, "ms": t_grad * 1e3,
+                 "how": "egx_gp_likelihood_grad, ONE candidate in flight, host wall time of the call (correlation build, "
+                        "Cholesky, host GLS, C^-T, gamma, R^-1, trace kernel, read-back) against n^3 flop"}
+    gb = None
+    try:  # the same through egx_gp_likelihood_grad_batch: 8 candidates as one lock-step group (32 GiB of M + C^-T)
+        hb = egx.GpHandle(x, y, mean=0, corr=3, device=gpu, n_workspaces=8)
+        hb.set_lockstep(8)
+        ths = np.stack([th * (1.0 + 0.004 * c) for c in range(8)])
+        hb.likelihood_grad_batch(ths)
+        t0 = time.perf_counter()
+        lkb, gbv, stb = hb.likelihood_grad_batch(ths * 1.001)
+        t_b = time.perf_counter() - t0
+        hb.close()
+        gb = {"candidates": 8, "ms_per_candidate": t_b / 8 * 1e3, "achieved": 8 * gflop / t_b / 1e12,
+              "frac": 8 * gflop / t_b / 1e12 / FP64_MFMA_PEAK_TFLOPS, "statuses_ok": int(np.sum(stb == 0))}
+    except Exception as e:  # noqa: BLE001 - a side figure
+        gb = {"error": f"{type(e).__name__}: {e}"[:200]}
     res["config3_matern52_n16384_d32"] = {
         "fixed_theta_fit_ms": t_fit * 1e3, "corr_build_ms": tm["corr_build_ms"],
         "corr_build_gbps": tm["corr_bytes"] / tm["corr_build_ms"] / 1e6, "potrf_ms": tm["potrf_ms"],
         "cholesky_tflops": tm["potrf_flops"] / tm["potrf_ms"] / 1e9, "likelihood_plus_theta_gradient_ms": t_grad * 1e3,
+        "gradient_roofline": grad_roof, "gradient_roofline_lockstep_batch_of_8": gb,
         "gradient_status": int(st), "gradient_norm": float(np.linalg.norm(g))}
     n5, d5, m5 = 8192, 16, 100000
     x5, y5 = workload.make_training_set(n5, d5, seed=7)
@@ -519,7 +602,7 @@ def main():
         probe_err = None
         try:
             sw.likelihood(cands[:world])
-            if os.environ.get("EGX_BENCH_FAIL_PROBE") == str(rank):  # test hook (tests/test_gpu_sweep.py)
+            if os.environ.get("EGX_BENCH_FAIL_PROBE") == str(rank):  # test hook (tests/test_gpu_configs.py)
                 raise RuntimeError("injected probe failure")
         except Exception as e:  # noqa: BLE001
             probe_err = f"{type(e).__name__}: {e}"[:200]
@@ -570,6 +653,29 @@ def main():
             tuned = tuned_fit_leg(egx, sw, d, world)
         except Exception as e:  # noqa: BLE001
             tuned = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # BASELINE config 4 in full: all 512 rows of the log-uniform sweep theta_sweep_candidates(512, d) (optimization.rs:49-66)
+    # through the same collective, after the timed region (most rows give R ~ I and a few are not positive definite: it is
+    # a parity / coverage figure -- tests/test_gpu_configs.py pins 33 of its rows -- never `value`)
+    config4 = None
+    if not args.no_extra_configs and (n, d) == (16384, 32):
+        try:
+            c4 = egx.theta_sweep_candidates(512, d)
+            barrier()
+            t4 = time.perf_counter()
+            if use_lib:
+                l4, s4 = sw.likelihood(c4)
+            else:
+                l4, s4 = egx.sweep_likelihood(torch_evaluate, c4, rank, world, device=None if rehearsal else tdev)
+            barrier()
+            t4 = time.perf_counter() - t4
+            okc = s4 == 0
+            config4 = {"rows": 512, "seconds": t4, "evals_per_s_all_gpus": 512 / t4, "n_gpus": world,
+                       "status_counts": {str(int(v)): int(np.sum(s4 == v)) for v in np.unique(s4)},
+                       "likelihood_checksum_ok_rows": float(np.sum(l4[okc])),
+                       "best_row": int(np.argmax(np.where(okc, l4, -np.inf))),
+                       "best_likelihood": float(np.max(np.where(okc, l4, -np.inf)))}
+        except Exception as e:  # noqa: BLE001
+            config4 = {"error": f"{type(e).__name__}: {e}"[:300]}
     sw.close()
     if use_lib and info["rccl_ranks"] != world and not rehearsal:
         sys.stderr.write(f"bench.py: the library's RCCL communicator has {info['rccl_ranks']} ranks, world is {world}\n")
@@ -602,17 +708,36 @@ def main():
         # (No per-launch figure for the batched launches: inside a group the rest-of-group update runs on a side stream and
         # overlaps the HIP events around the trailing update -- 47.7 TFLOP/s "per launch" beside 58.8 for the whole group.)
         gl = max(1, min(lockstep, 8))
-        grp = None
+        grp, roof_group = None, None
         if gl > 1:
             gq = egx.GpHandle(x, y, mean=0, corr=0, device=gpu, n_workspaces=gl)
             gq.set_lockstep(gl)
-            timg = []
-            for j in range(4):
+
+            def group_batch(j):
                 gq.likelihood_batch(np.stack([base * (1.0 + 0.01 * (j * gl + c)) for c in range(gl)]))
-                timg.append(gq.timings())
+                return gq.timings()
+            timg = [group_batch(j) for j in range(4)]
             g_potrf = float(np.mean([t["potrf_ms"] for t in timg[1:]]))
             grp = {"matrices": gl, "potrf_ms_all_matrices": g_potrf, "cholesky_tflops": gl * flops / (g_potrf * 1e-3) / 1e12,
                    "frac_of_fp64_peak": gl * flops / (g_potrf * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+            # ---- the launch the timed region issues: the trailing update of a lock-step group (grid.z = gl matrices).  In
+            # the product the look-ahead columns' update (LUr) runs BESIDE it on a side stream and overlaps the HIP events
+            # around it; for this leg LUr goes back in front of it on the main stream (egx_set_tuning "lur_side" = 0: same
+            # kernels, same arithmetic, one stream), so the events bracket the launch alone -- the next group's chain still
+            # shares the chip, as it does in the product.
+            try:
+                prev = egx.set_tuning("lur_side", 0)
+                timq = [group_batch(10 + j) for j in range(3)][1:]
+                egx.set_tuning("lur_side", prev)
+                ms8 = float(np.mean([t["potrf_syrk_ms"] for t in timq]))
+                fl8 = float(np.mean([t["syrk_flops"] for t in timq]))
+                nl8 = int(timq[0]["syrk_launches"])
+                if ms8 > 0 and nl8 > 0:
+                    roof_group = {"tflops": fl8 / (ms8 * 1e-3) / 1e12, "launches": nl8, "launch_ms_avg": ms8 / nl8,
+                                  "flops_per_launch_avg": fl8 / nl8, "share_of_potrf_flops": fl8 / (gl * flops),
+                                  "potrf_ms_all_matrices_serialised": float(np.mean([t["potrf_ms"] for t in timq]))}
+            except Exception as e:  # noqa: BLE001 - falls back to the single-matrix figure below
+                sys.stderr.write(f"bench.py: group roofline leg failed: {e}\n")
             gq.close()
         traffic, pmc = measured_traffic(n, d)
         ok = stats[args.warmup * nb:] == 0
@@ -648,7 +773,24 @@ def main():
                                     "host_gls": host_ms},
             "single_fit_in_flight_fits_per_s": 1.0 / float(np.mean(t_fit)),
             "cholesky_tflops_single_fit": tflops,
-            "roofline": {"bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "roofline": (None if roof_group is None else {
+                "bound": "mfma", "achieved": roof_group["tflops"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": roof_group["tflops"] / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "launch_shape": f"{gl} matrices per launch (grid.z): the launch the timed region issues for a lock-step group",
+                "kernel": "k_gemm_stream<LOWER> (Cholesky trailing update C -= P P^T of every matrix of the group, 128x256 tiles, "
+                          "once per group of four 256-wide panels, K = 1024; the launches with >= 512 tiles per matrix: "
+                          f"{100.0 * roof_group['share_of_potrf_flops']:.0f} % of the factorisations' n^3/3 flops)",
+                "share_of_potrf_flops": roof_group["share_of_potrf_flops"],
+                "launches_per_group": roof_group["launches"], "launch_ms_avg": roof_group["launch_ms_avg"],
+                "flops_per_launch_avg": roof_group["flops_per_launch_avg"],
+                "how": "algorithmic flops (matrices * 2*K*ncols*(ncols+1)/2 per launch) / HIP-event durations around every such "
+                       "launch on the stream it is launched on; ONE lock-step group in flight, the group's look-ahead-column "
+                       "update serialised in front of it (egx_set_tuning lur_side = 0; in the product it runs beside it), "
+                       "the next group's chain kernels sharing the chip as in the product.  Reproduce: rocprofv3 "
+                       "--kernel-trace --stats -- python tools/group_roofline.py (profiles/r04_group_roofline_kernel_stats.txt)",
+                "traffic_note": "`traffic` is per launch of ONE matrix (offline PMC passes, see roofline_single_matrix.traffic_source); "
+                                f"a group launch moves {gl} x that"}),
+            "roofline_single_matrix": {"bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic,
                          "launch_shape": "ONE matrix per launch (a lone fit; the definition of rounds 1 and 2).  The timed "
@@ -674,6 +816,7 @@ def main():
                                                            "WRITE + C_read + 2 * (FETCH - C_read)"})},
             "lockstep_group_alone": grp,
             "roofline_kernel_alone": (run_kernel_alone_leg(args, gpu) if world == 1 and not args.no_extra_configs else None),
+            "vendor_yardstick": (vendor_yardstick(torch, gpu) if world == 1 and not args.no_extra_configs else None),
             "corr_build_gbps": tim1[0]["corr_bytes"] / (corr_ms * 1e-3) / 1e9,
             "corr_build_roofline": {"bound": "hbm", "achieved": tim1[0]["corr_bytes"] / (corr_ms * 1e-3) / 1e9,
                                     "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -686,6 +829,8 @@ def main():
             "candidates_ok": int(ok.sum()), "candidates_failed": int((~ok).sum()),
             "likelihood_checksum": float(np.sum(lkhs[args.warmup * nb:][ok])),
         }
+        if out["roofline"] is None:  # (a lock-step width of one: the single-matrix launches are the timed region's)
+            out["roofline"] = out["roofline_single_matrix"]
         gp.close()
         if world == 1:
             # the boundary hands over HOST buffers: one-shot call sequences create -> fit -> read the scalars -> destroy,
@@ -719,9 +864,17 @@ def main():
             out["other_configs"] = {"config5_mixture_8_experts_sharded": moe_sharded}
         if tuned is not None:
             out.setdefault("other_configs", {})["tuned_fit_11_starts_sharded"] = tuned
+        if config4 is not None:
+            out.setdefault("other_configs", {})["config4_sweep_512"] = config4
         if not args.no_cpu_baseline and world == 1:
             torch.cuda.synchronize()
             cb = cpu_baseline(n, d)
+            hp = host_fp64_peak()
+            if hp is not None and "dpotrf_gflops" in cb:
+                cb["host_fp64_peak"] = hp
+                cb["dpotrf_frac_of_host_fp64_peak"] = cb["dpotrf_gflops"] / hp["peak_gflops"]
+                cb["note_numa"] = ("numactl is not in this image: memory placement is first-touch by the OpenMP correlation "
+                                   "build (all host threads, static schedule), i.e. spread over both sockets")
             out["cpu_baseline"] = cb
             if "value" in cb:
                 # LATENCY mode against latency mode: one fit in flight on the GPU, one fit on the CPU's best thread count

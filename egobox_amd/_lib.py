@@ -52,6 +52,7 @@ SIGNATURES = [
     ("egx_device_count", C.c_int32, []),
     ("egx_gp_config_default", None, [C.POINTER(GpConfig)]),
     ("egx_trim", C.c_int64, []),
+    ("egx_set_tuning", C.c_int32, [C.c_char_p, C.c_int32, c_int32_p]),
     ("egx_pool_stats", None, [c_int64_p, c_int64_p, c_int64_p]),
     ("egx_normalize", C.c_int32, [c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
     ("egx_regression_ncols", C.c_int64, [C.c_int32, C.c_int64]),
@@ -66,6 +67,8 @@ SIGNATURES = [
     ("egx_gp_set_lockstep", C.c_int32, [C.c_void_p, C.c_int32]),
     ("egx_gp_get_lockstep", C.c_int32, [C.c_void_p]),
     ("egx_gp_likelihood_grad", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p, c_int32_p]),
+    ("egx_gp_likelihood_grad_batch", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p,
+                                                 c_int32_p]),
     ("egx_gp_finalize", C.c_int32, [C.c_void_p, c_double_p, C.c_int64]),
     ("egx_gp_fit", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_int64, C.c_int64,
                                c_int64_p]),

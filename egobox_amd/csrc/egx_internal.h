@@ -21,6 +21,14 @@ void set_error(const std::string &msg);
         }                                                                                \
     } while (0)
 
+// hipMalloc that gives the pool of destroyed handles' resources on the current device back before it reports
+// out-of-memory (gp_host.hip): every device allocation of the library goes through it
+hipError_t dev_malloc_bytes(void **p, size_t bytes);
+template <typename T>
+inline hipError_t dev_malloc(T **p, size_t bytes) {
+    return dev_malloc_bytes(reinterpret_cast<void **>(p), bytes);
+}
+
 // ---- geometry ---------------------------------------------------------------
 constexpr int kTile = 128;      // row/col granularity of the padded correlation matrix
 constexpr int kNB = 256;        // outer Cholesky block (K of the trailing update)
@@ -77,13 +85,27 @@ int launch_gls_residual(hipStream_t s, const double *ftT, int64_t ld, const doub
                         int n_pad, double *rho, double *part);
 // zero the strict upper triangle of the leading n x n block
 int launch_zero_upper(hipStream_t s, double *M, int64_t ld, int n);
-// likelihood-gradient accumulation (new capability): for all i > j and every output k < nout
-//   out[k] += 2 Rinv[i][j] dR_k[i][j],  out[nout + k] += 2 gamma_i gamma_j dR_k[i][j]
-// hcols == 1: output k = input dimension k, dR_k = R d(log r)/d(coef_k) (nout = d; w = I: coef = theta);
-// hcols  > 1 (KPLS + Matern): output k = theta_k, dR_k = R sum_j wabs[j][k] (d log m / dt)(coef[j][k] a_j) a_j (nout = h)
-int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d, const double *coef, int hcols,
-                      const double *wabs, int nout, const double *Rinv, int64_t ld, const double *gamma,
-                      double *out /*2*nout, zeroed by the launcher*/);
+// likelihood-gradient accumulation (new capability; kernels_corr.hip K7): per candidate z of the lock-step batch and every
+// output o < nout
+//   out[z][o] = sum_{i > j} 2 R_ij (gamma_i gamma_j inv_s2 + rneg_ij) d log R_ij / d c_o
+// hcols == 1: output o = input dimension o (nout = d; w = I: coef = theta);
+// hcols  > 1 (KPLS + Matern): output o = theta_o, d log R / d theta_o = sum_j wabs[j][o] (d log m / dt)(coef[j][o] a_j) a_j
+// Deterministic (fixed reduction order): a candidate's result does not depend on the batch it runs in.
+constexpr int kGradMaxBatch = 16;
+struct GradBatch {
+    int count = 1;
+    const double *coef[kGradMaxBatch];   // d x hcols
+    const double *gamma[kGradMaxBatch];  // n_pad
+    const double *rneg[kGradMaxBatch];   // -R^-1, lower triangle, leading dimension ld
+    double inv_s2[kGradMaxBatch];        // 1 / sigma2 (normalised units)
+    double *part[kGradMaxBatch];         // grad_partial_doubles(nout) doubles of scratch
+    double *out[kGradMaxBatch];          // nout
+};
+int grad_partial_doubles(int nout);
+int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d, int hcols, const double *wabs,
+                      int nout, int64_t ld, const GradBatch &batch);
+// z (n) <- W y, W upper triangular row-major
+int launch_uptri_gemv(hipStream_t s, const double *W, int64_t ld, int n, const double *y, double *z);
 
 // ---- kernels_chol.hip -------------------------------------------------------
 // In-place blocked right-looking Cholesky of the leading n_pad x n_pad block (lower), applied to
@@ -121,13 +143,24 @@ struct PotrfBatch {
     int64_t sM = 0, sD = 0;  // doubles between consecutive matrices / their dinv blocks
     int sI = 0;              // ints between their info words
 };
+// the solves after a factorisation in lock-step: `count` factors (sM apart, tile inverses sD apart) and as many
+// right-hand-side buffers (sR apart)
+struct TrsmBatch {
+    int count = 1;
+    int64_t sM = 0, sD = 0, sR = 0;
+};
 // lk == nullptr runs everything in order on s.
 int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
                  const PotrfLookahead *lk = nullptr, GemmTrace *trace = nullptr, const PotrfBatch *batch = nullptr);
 // rows [0, m) of RT (ld) are right-hand sides: RT <- RT * C^-T  (C = lower factor in M, n_pad cols)
 // tri_rows != 0: the rows are those of the identity (solution upper triangular): zero blocks are skipped
 int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, const double *dinv,
-                     double *RT, int64_t ldr, int m, int tri_rows = 0);
+                     double *RT, int64_t ldr, int m, int tri_rows = 0, const TrsmBatch *batch = nullptr);
+// W (n_pad x n_pad, ld; `count` of them `stride` apart) <- the identity's rows, as far as the two calls below touch them
+int launch_identity_rows(hipStream_t s, double *W, int64_t ld, int n_pad, int count = 1, int64_t stride = 0);
+// C (lower tiles; n x n) <- -(W W^T), W upper triangular (C^-T): the theta-gradient's -R^-1; C is not read
+int launch_syrk_uptri_neg(hipStream_t s, double *C, int64_t ldc, const double *W, int64_t ldw, int n,
+                          const GemmBatch *batch = nullptr);
 // dinv <- inverses of the 64x64 diagonal tiles of a given lower factor (model load path)
 int launch_diag_tile_inverses(hipStream_t s, const double *M, int64_t ld, int n_pad, double *dinv);
 // Wall ((n_pad/256) x 256 x 256) <- transposed inverses of the 256x256 diagonal blocks of the factor
@@ -147,5 +180,6 @@ size_t gram_scratch_doubles(int rows, int K);
 int launch_gram_lower(hipStream_t s, const double *W, int64_t ldw, int rows, int K, double *Gneg, int64_t ldg, double *P);
 int mfma_probe(double *max_abs_err);
 int chol_init();  // one-time function attribute setup (dynamic LDS sizes)
+int set_knob(const char *name, int value);  // kernels_chol.hip tuning knobs by name; INT_MIN = unknown
 
 }  // namespace egx

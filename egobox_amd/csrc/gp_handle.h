@@ -45,7 +45,7 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        EGX_HIP_CHECK(hipMalloc(&p, sizeof(double) * n_doubles));
+        EGX_HIP_CHECK(dev_malloc(&p, sizeof(double) * n_doubles));
         cap = n_doubles;
         return EGX_SUCCESS;
     }
@@ -79,6 +79,8 @@ struct Workspace {
     double *h_diag = nullptr;  // pinned: n
     double *h_vec = nullptr;   // pinned: n_pad
     int *h_info = nullptr;     // pinned
+    // theta-gradient scratch (lazy, gp_fit.hip): the workgroups' partial sums, the reduced sums, their pinned copy
+    double *d_gpart = nullptr, *d_gout = nullptr, *h_gout = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     GemmTrace trace;
 };
@@ -138,10 +140,13 @@ struct egx_gp {
     int fit_hcols = 1;
     double *d_gamma = nullptr;  // n_pad
     double *d_fit_coef = nullptr;  // d x hcols coefficients of the fit, then x_mean (d) | x_std (d): dev_xnorm()
-    // gradient scratch (allocated on first use)
-    double *d_W = nullptr, *d_Rinv = nullptr, *d_gout = nullptr, *d_theta = nullptr;
-    // x-gradient state (lazy, per fitted factor): d_W = C^-T (shared with the theta-gradient scratch) and
+    // theta-gradient scratch (allocated on first use, gp_fit.hip): C^-T of `slab_W_count` candidates at a fixed stride of
+    // n_pad^2 doubles (lock-step), |w_star| on the device (KPLS + Matern)
+    double *slab_W = nullptr, *d_wabs = nullptr;
+    int slab_W_count = 0;
+    // x-gradient state (lazy, per fitted factor): d_W = C^-T of the FITTED factor and
     // -R^-1 F = -C^-T ft as an (n_pad x rhs_pad) matrix
+    double *d_W = nullptr;
     double *d_neg_invkf = nullptr;
     std::vector<double> h_neg_invkf;  // host copy (n x p) for the single-point path
     // device scratch of the single-point path, allocated once (a hipMalloc per call would cost more than the kernels)
@@ -179,7 +184,7 @@ int make_coef(const egx_gp *gp, const double *theta, int64_t theta_len, std::vec
 int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coef, int hcols);
 // `count` evaluations on the consecutive workspaces w0 .. w0 + count - 1, factored in lock-step on the streams of w0
 int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> *coefs, int hcols);
-int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, bool keep);
+int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, int keep);  // 0 scalars, 1 fitted state, 2 rho only
 void record_timings(egx_gp *gp, Workspace &w, double host_ms, double solve_ms);
 bool has_nan(const double *theta, int64_t len);
 int eval_one(egx_gp *gp, int widx, const double *theta, int64_t theta_len, EvalResult &res, bool keep);
@@ -195,6 +200,9 @@ struct CandidateSource {
 // results go to lkh[c] / status[c] of the candidate's own index, evaluated[c] (optional, k chars) is set for them.
 int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len, double *lkh, int32_t *status,
                           CandidateSource *src = nullptr, char *evaluated = nullptr);
+// likelihood + dL/dtheta of k candidates, pipelined over the workspaces in lock-step slots (gp_fit.hip)
+int likelihood_grad_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len, double *lkh, double *grad,
+                               int32_t *status);
 // gp_predict.hip
 int predict_impl(egx_gp *gp, const double *xq, int64_t m, double *yout, double *vout);
 int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv);

@@ -41,6 +41,9 @@ static void free_workspace(Workspace &w) {
     if (w.h_diag) hipHostFree(w.h_diag);
     if (w.h_vec) hipHostFree(w.h_vec);
     if (w.h_info) hipHostFree(w.h_info);
+    if (w.d_gpart) hipFree(w.d_gpart);
+    if (w.d_gout) hipFree(w.d_gout);
+    if (w.h_gout) hipHostFree(w.h_gout);
     for (auto &e : w.ev)
         if (e) hipEventDestroy(e);
     if (w.trace.ready)
@@ -74,11 +77,11 @@ static int alloc_workspace(egx_gp *gp, Workspace &w, int index) {
         }
     }
     const int hmax = gp->has_w ? gp->h : 1;
-    EGX_HIP_CHECK(hipMalloc(&w.d_coef, sizeof(double) * (size_t)gp->d * hmax));
-    EGX_HIP_CHECK(hipMalloc(&w.d_xs, sizeof(double) * (size_t)gp->d * gp->n_pad));
-    EGX_HIP_CHECK(hipMalloc(&w.d_diag, sizeof(double) * (size_t)gp->n_pad));
-    EGX_HIP_CHECK(hipMalloc(&w.d_vec, sizeof(double) * (size_t)gp->n_pad));
-    EGX_HIP_CHECK(hipMalloc(&w.d_rhs, sizeof(double) * (size_t)gp->n_pad));
+    EGX_HIP_CHECK(dev_malloc(&w.d_coef, sizeof(double) * (size_t)gp->d * hmax));
+    EGX_HIP_CHECK(dev_malloc(&w.d_xs, sizeof(double) * (size_t)gp->d * gp->n_pad));
+    EGX_HIP_CHECK(dev_malloc(&w.d_diag, sizeof(double) * (size_t)gp->n_pad));
+    EGX_HIP_CHECK(dev_malloc(&w.d_vec, sizeof(double) * (size_t)gp->n_pad));
+    EGX_HIP_CHECK(dev_malloc(&w.d_rhs, sizeof(double) * (size_t)gp->n_pad));
     EGX_HIP_CHECK(hipHostMalloc(&w.h_coef, sizeof(double) * (size_t)gp->d * hmax, hipHostMallocDefault));
     EGX_HIP_CHECK(hipHostMalloc(&w.h_rows, sizeof(double) * (size_t)gp->q * gp->n_pad, hipHostMallocDefault));
     EGX_HIP_CHECK(hipHostMalloc(&w.h_diag, sizeof(double) * (size_t)gp->n_pad, hipHostMallocDefault));
@@ -86,13 +89,13 @@ static int alloc_workspace(egx_gp *gp, Workspace &w, int index) {
     EGX_HIP_CHECK(hipHostMalloc(&w.h_info, sizeof(int), hipHostMallocDefault));
     if (gp->gls_device) {
         const size_t g2 = (size_t)gp->rhs_pad * gp->rhs_pad;
-        EGX_HIP_CHECK(hipMalloc(&w.d_gneg, sizeof(double) * g2));
-        EGX_HIP_CHECK(hipMalloc(&w.d_gram, sizeof(double) * g2));
-        EGX_HIP_CHECK(hipMalloc(&w.d_gdinv, sizeof(double) * dinv_doubles(gp->rhs_pad)));
-        EGX_HIP_CHECK(hipMalloc(&w.d_gramP, sizeof(double) * gram_scratch_doubles(gp->rhs_pad, gp->n_pad)));
-        EGX_HIP_CHECK(hipMalloc(&w.d_beta, sizeof(double) * (size_t)gp->rhs_pad));
-        EGX_HIP_CHECK(hipMalloc(&w.d_part, sizeof(double) * (size_t)((gp->n_pad + 255) / 256)));
-        EGX_HIP_CHECK(hipMalloc(&w.d_ginfo, sizeof(int)));
+        EGX_HIP_CHECK(dev_malloc(&w.d_gneg, sizeof(double) * g2));
+        EGX_HIP_CHECK(dev_malloc(&w.d_gram, sizeof(double) * g2));
+        EGX_HIP_CHECK(dev_malloc(&w.d_gdinv, sizeof(double) * dinv_doubles(gp->rhs_pad)));
+        EGX_HIP_CHECK(dev_malloc(&w.d_gramP, sizeof(double) * gram_scratch_doubles(gp->rhs_pad, gp->n_pad)));
+        EGX_HIP_CHECK(dev_malloc(&w.d_beta, sizeof(double) * (size_t)gp->rhs_pad));
+        EGX_HIP_CHECK(dev_malloc(&w.d_part, sizeof(double) * (size_t)((gp->n_pad + 255) / 256)));
+        EGX_HIP_CHECK(dev_malloc(&w.d_ginfo, sizeof(int)));
         EGX_HIP_CHECK(hipHostMalloc(&w.h_gram, sizeof(double) * g2, hipHostMallocDefault));
         EGX_HIP_CHECK(hipHostMalloc(&w.h_part, sizeof(double) * (size_t)((gp->n_pad + 255) / 256), hipHostMallocDefault));
         EGX_HIP_CHECK(hipHostMalloc(&w.h_beta, sizeof(double) * (size_t)gp->rhs_pad, hipHostMallocDefault));
@@ -135,9 +138,15 @@ struct PoolEntry {
 };
 static std::mutex g_pool_mu;
 static std::list<PoolEntry> g_pool;  // front = most recently returned
-static size_t g_pool_bytes = 0;
 static int64_t g_pool_hits = 0, g_pool_misses = 0;
 
+// bytes pooled on one device (the bound EGX_POOL_MAX_GB is PER DEVICE)
+static size_t pool_bytes_on(int device) {
+    size_t b = 0;
+    for (const auto &e : g_pool)
+        if (e.key.device == device) b += e.bytes;
+    return b;
+}
 static size_t pool_cap_bytes() {
     static const size_t cap = [] {
         double gb = 48.0;
@@ -154,6 +163,27 @@ static void free_entry(PoolEntry &e) {
     if (e.slab_I) (void)hipFree(e.slab_I);
     e = PoolEntry();
 }
+// everything pooled on `device` (-1: on every device) is freed; returns the bytes
+static size_t pool_trim(int device) {
+    std::list<PoolEntry> out;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        for (auto it = g_pool.begin(); it != g_pool.end();) {
+            auto next = std::next(it);
+            if (device < 0 || it->key.device == device) {
+                bytes += it->bytes;
+                out.splice(out.end(), g_pool, it);
+            }
+            it = next;
+        }
+    }
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (auto &e : out) free_entry(e);
+    if (have_cur) (void)hipSetDevice(cur);
+    return bytes;
+}
 static PoolKey pool_key(const egx_gp *gp, int nws) {
     PoolKey k;
     k.device = gp->device;
@@ -164,6 +194,23 @@ static PoolKey pool_key(const egx_gp *gp, int nws) {
     k.nws = nws;
     k.gls = gp->gls_device;
     return k;
+}
+// device bytes a handle of this shape hands to the pool: the slabs, the training-set buffers and every workspace's own
+// buffers (the lazily allocated ones -- block inverses, theta-gradient scratch -- counted when present)
+static size_t pooled_bytes(const egx_gp *gp, const std::vector<Workspace> &ws) {
+    const size_t n_pad = (size_t)gp->n_pad, d = (size_t)gp->d, hmax = gp->has_w ? (size_t)gp->h : 1;
+    size_t b = sizeof(double) * ((size_t)gp->stride_M + (size_t)gp->stride_D) * ws.size() + sizeof(int) * ws.size();
+    b += sizeof(double) * (2 * d * n_pad + (size_t)gp->q * n_pad + n_pad + d * hmax + 2 * d);
+    for (const auto &w : ws) {
+        b += sizeof(double) * (d * hmax + d * n_pad + 3 * n_pad);
+        if (w.dW) b += sizeof(double) * ((n_pad + kNB - 1) / kNB) * 65536;
+        if (w.d_gram) {
+            const size_t g = (size_t)gp->rhs_pad;
+            b += sizeof(double) * (2 * g * g + dinv_doubles((int)g) + gram_scratch_doubles((int)g, (int)n_pad) + g + (n_pad + 255) / 256);
+        }
+        if (w.d_gpart) b += sizeof(double) * ((size_t)grad_partial_doubles((int)d) + 64 + d);
+    }
+    return b;
 }
 // adopt a pooled set of resources of this shape, if there is one
 static bool pool_take(egx_gp *gp, int nws) {
@@ -179,7 +226,6 @@ static bool pool_take(egx_gp *gp, int nws) {
             gp->slab_D = it->slab_D;
             gp->slab_I = it->slab_I;
             gp->ws = std::move(it->ws);
-            g_pool_bytes -= it->bytes;
             g_pool.erase(it);
             g_pool_hits++;
             return true;
@@ -199,7 +245,7 @@ static void pool_give(egx_gp *gp) {
     e.slab_D = gp->slab_D;
     e.slab_I = gp->slab_I;
     e.ws = std::move(gp->ws);
-    e.bytes = sizeof(double) * ((size_t)gp->stride_M + (size_t)gp->stride_D) * e.ws.size();
+    e.bytes = pooled_bytes(gp, e.ws);
     gp->d_xT = gp->d_rhsT = gp->d_gamma = gp->d_fit_coef = gp->slab_M = gp->slab_D = nullptr;
     gp->slab_I = nullptr;
     gp->ws.clear();
@@ -218,14 +264,29 @@ static void pool_give(egx_gp *gp) {
     std::list<PoolEntry> evicted;
     {
         std::lock_guard<std::mutex> lock(g_pool_mu);
-        g_pool_bytes += e.bytes;
+        const int dev = e.key.device;
         g_pool.push_front(std::move(e));
-        while (g_pool_bytes > cap && g_pool.size() > 1) {
-            g_pool_bytes -= g_pool.back().bytes;
-            evicted.splice(evicted.begin(), g_pool, std::prev(g_pool.end()));
+        // least recently returned entries OF THIS DEVICE go first (the newcomer itself stays)
+        while (pool_bytes_on(dev) > cap) {
+            auto victim = g_pool.end();
+            for (auto it = std::next(g_pool.begin()); it != g_pool.end(); ++it)
+                if (it->key.device == dev) victim = it;
+            if (victim == g_pool.end()) break;
+            evicted.splice(evicted.begin(), g_pool, victim);
         }
     }
     for (auto &v : evicted) free_entry(v);
+}
+
+hipError_t dev_malloc_bytes(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+        // the library itself may hold tens of GB of destroyed handles' buffers on this device: give them back, once
+        (void)hipGetLastError();
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && pool_trim(dev) > 0) e = hipMalloc(p, bytes);
+    }
+    return e;
 }
 
 // theta (len 1 or h) -> per-dimension coefficient table (d x hcols), see kernels_corr.hip.
@@ -341,7 +402,7 @@ int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coef, int 
 // iteration and keep two decades of margin.  The Gram route is taken only when the ratio is >= 1e-7 (1e-6 estimated) and
 // the factor's diagonal ratio >= 1e-4; anything closer to the threshold goes to the host Householder + SVD route, which
 // decides exactly as for p = 1.
-static int finish_eval_device_gls(egx_gp *gp, Workspace &w, EvalResult &out, bool keep) {
+static int finish_eval_device_gls(egx_gp *gp, Workspace &w, EvalResult &out, int keep) {
     const int n = gp->n, p = gp->p, n_pad = gp->n_pad, g = gp->rhs_pad;
     if (*w.h_ginfo != 0) return 1;
     const double *L = w.h_gram;  // (g x g) row-major lower factor
@@ -450,7 +511,7 @@ static int finish_eval_device_gls(egx_gp *gp, Workspace &w, EvalResult &out, boo
     out.sigma2n = sigma2n;
     out.status = EGX_STATUS_OK;
     out.rho_on_device = true;
-    if (keep) {
+    if (keep == 1) {
         out.beta = beta;
         out.ft_qr_r.assign((size_t)p * p, 0.0);
         for (int i = 0; i < p; i++)
@@ -469,8 +530,9 @@ static int finish_eval_device_gls(egx_gp *gp, Workspace &w, EvalResult &out, boo
     return 0;
 }
 
-// Host half: algorithm.rs:1007-1043 on the downloaded ft, yt, diag(C).
-int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, bool keep) {
+// Host half: algorithm.rs:1007-1043 on the downloaded ft, yt, diag(C).  keep: 0 = the scalars only, 1 = everything the
+// fitted state needs (beta, rho, ft, its QR factor), 2 = rho only (the theta-gradient)
+int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, int keep) {
     EGX_HIP_CHECK(hipStreamSynchronize(w.eval_stream));
     const int n = gp->n, p = gp->p, n_pad = gp->n_pad;
     out = EvalResult();
@@ -542,7 +604,8 @@ int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, bool keep) {
     out.lkh = -(double)n * (std::log10(sigma2n) + logdet);
     out.sigma2n = sigma2n;
     out.status = EGX_STATUS_OK;
-    if (keep) {
+    if (keep == 2) out.rho = rho;
+    if (keep == 1) {
         out.beta = beta;
         out.rho = rho;
         out.ft_qr_r = R;
@@ -601,7 +664,7 @@ int eval_one(egx_gp *gp, int widx, const double *theta, int64_t theta_len, EvalR
     Workspace &w = gp->ws[widx];
     EGX_RC(enqueue_eval(gp, w, coef, hcols));
     auto t0 = std::chrono::steady_clock::now();
-    EGX_RC(finish_eval(gp, w, res, keep));
+    EGX_RC(finish_eval(gp, w, res, keep ? 1 : 0));
     // host_ms includes the wait for the stream; subtract GPU time below
     auto t1 = std::chrono::steady_clock::now();
     float gpu = 0;
@@ -615,7 +678,7 @@ int eval_one(egx_gp *gp, int widx, const double *theta, int64_t theta_len, EvalR
 // w.d_vec <- C^-T w.d_rhs  (block inverses are rebuilt: the factor in w.M has just changed)
 int backward_solve(egx_gp *gp, Workspace &w) {
     if (!w.dW)
-        EGX_HIP_CHECK(hipMalloc(&w.dW, sizeof(double) * (size_t)((gp->n_pad + kNB - 1) / kNB) * 65536));
+        EGX_HIP_CHECK(dev_malloc(&w.dW, sizeof(double) * (size_t)((gp->n_pad + kNB - 1) / kNB) * 65536));
     EGX_RC(launch_block_inverse(w.stream, w.M, gp->ld, gp->n_pad, w.dinv, w.dW));
     EGX_RC(launch_trsv_t(w.stream, w.M, gp->ld, gp->n_pad, w.dW, w.d_rhs, w.d_vec));
     return EGX_SUCCESS;
@@ -634,7 +697,7 @@ int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     EvalResult res;
     EGX_RC(enqueue_eval(gp, w, coef, hcols));
     auto t0 = std::chrono::steady_clock::now();
-    EGX_RC(finish_eval(gp, w, res, true));
+    EGX_RC(finish_eval(gp, w, res, 1));
     auto t1 = std::chrono::steady_clock::now();
     if (res.status == EGX_STATUS_NOT_POSITIVE_DEFINITE) {
         set_error("LinalgError: matrix is not positive definite (pivot " + std::to_string(*w.h_info) + ")");
@@ -738,7 +801,7 @@ int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t t
             if (!cand[i].empty()) {
                 for (size_t j = 0; j < cand[i].size(); j++) {
                     EvalResult res;
-                    EGX_RC(finish_eval(gp, gp->ws[w0 + (int)j], res, false));
+                    EGX_RC(finish_eval(gp, gp->ws[w0 + (int)j], res, 0));
                     lkh[cand[i][j]] = res.lkh;
                     status[cand[i][j]] = res.status;
                 }
@@ -797,22 +860,29 @@ int32_t egx_device_count(void) {
     return c;
 }
 
-int64_t egx_trim(void) {
-    std::list<PoolEntry> all;
-    size_t bytes = 0;
-    {
-        std::lock_guard<std::mutex> lock(g_pool_mu);
-        all.swap(g_pool);
-        bytes = g_pool_bytes;
-        g_pool_bytes = 0;
+int64_t egx_trim(void) { return (int64_t)pool_trim(-1); }
+
+int32_t egx_set_tuning(const char *knob, int32_t value, int32_t *previous) {
+    if (!knob) {
+        set_error("egx_set_tuning: NULL knob name");
+        return EGX_ERR_INVALID_VALUE;
     }
-    for (auto &e : all) free_entry(e);
-    return (int64_t)bytes;
+    const int old = set_knob(knob, value);
+    if (old == -2147483647 - 1) {
+        set_error(std::string("egx_set_tuning: unknown knob '") + knob + "'");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (previous) *previous = old;
+    return EGX_SUCCESS;
 }
 
 void egx_pool_stats(int64_t *cached_bytes, int64_t *hits, int64_t *misses) {
     std::lock_guard<std::mutex> lock(g_pool_mu);
-    if (cached_bytes) *cached_bytes = (int64_t)g_pool_bytes;
+    if (cached_bytes) {
+        size_t b = 0;
+        for (const auto &e : g_pool) b += e.bytes;
+        *cached_bytes = (int64_t)b;
+    }
     if (hits) *hits = g_pool_hits;
     if (misses) *misses = g_pool_misses;
 }
@@ -986,13 +1056,13 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
     gp->stride_M = (int64_t)gp->m_tot * gp->ld;
     gp->stride_D = round_up((int64_t)dinv_doubles(gp->n_pad), 64);
     if (!pool_take(gp, nws)) {  // no destroyed handle of this shape left its resources behind: allocate
-        EGX_HIPF(hipMalloc(&gp->d_xT, sizeof(double) * 2 * xT.size()));  // + dev_xs_fit()
-        EGX_HIPF(hipMalloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
-        EGX_HIPF(hipMalloc(&gp->d_gamma, sizeof(double) * gp->n_pad));
-        EGX_HIPF(hipMalloc(&gp->d_fit_coef, sizeof(double) * ((size_t)d * (gp->has_w ? gp->h : 1) + 2 * (size_t)d)));
-        EGX_HIPF(hipMalloc(&gp->slab_M, sizeof(double) * (size_t)gp->stride_M * nws));
-        EGX_HIPF(hipMalloc(&gp->slab_D, sizeof(double) * (size_t)gp->stride_D * nws));
-        EGX_HIPF(hipMalloc(&gp->slab_I, sizeof(int) * (size_t)nws));
+        EGX_HIPF(dev_malloc(&gp->d_xT, sizeof(double) * 2 * xT.size()));  // + dev_xs_fit()
+        EGX_HIPF(dev_malloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
+        EGX_HIPF(dev_malloc(&gp->d_gamma, sizeof(double) * gp->n_pad));
+        EGX_HIPF(dev_malloc(&gp->d_fit_coef, sizeof(double) * ((size_t)d * (gp->has_w ? gp->h : 1) + 2 * (size_t)d)));
+        EGX_HIPF(dev_malloc(&gp->slab_M, sizeof(double) * (size_t)gp->stride_M * nws));
+        EGX_HIPF(dev_malloc(&gp->slab_D, sizeof(double) * (size_t)gp->stride_D * nws));
+        EGX_HIPF(dev_malloc(&gp->slab_I, sizeof(int) * (size_t)nws));
         gp->ws.resize(nws);
         for (int i = 0; i < nws; i++) {
             rc = alloc_workspace(gp, gp->ws[i], i);
@@ -1026,9 +1096,8 @@ void egx_gp_destroy(egx_gp *gp) {
     if (gp->d_neg_invkf) hipFree(gp->d_neg_invkf);
     for (double *q : {gp->sp_R, gp->sp_P, gp->sp_y, gp->sp_z, gp->sp_wt, gp->sp_out, gp->sp_xq})
         if (q) hipFree(q);
-    if (gp->d_Rinv) hipFree(gp->d_Rinv);
-    if (gp->d_gout) hipFree(gp->d_gout);
-    if (gp->d_theta) hipFree(gp->d_theta);
+    if (gp->slab_W) hipFree(gp->slab_W);
+    if (gp->d_wabs) hipFree(gp->d_wabs);
     delete gp;
 }
 

@@ -194,15 +194,11 @@ static int ensure_winv(egx_gp *gp) {
     Workspace &w = gp->ws[0];
     const int n_pad = gp->n_pad;
     const size_t sq = (size_t)n_pad * n_pad;
-    if (!gp->d_W) EGX_HIP_CHECK(hipMalloc(&gp->d_W, sizeof(double) * sq));
-    if (!gp->d_neg_invkf) EGX_HIP_CHECK(hipMalloc(&gp->d_neg_invkf, sizeof(double) * (size_t)n_pad * gp->rhs_pad));
-    EGX_HIP_CHECK(hipMemsetAsync(gp->d_W, 0, sizeof(double) * sq, w.stream));
-    {
-        std::vector<double> ones(n_pad, 1.0);
-        EGX_HIP_CHECK(hipMemcpy2DAsync(gp->d_W, sizeof(double) * (n_pad + 1), ones.data(), sizeof(double),
-                                       sizeof(double), n_pad, hipMemcpyHostToDevice, w.stream));
-        EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
-    }
+    if (!gp->d_W) EGX_HIP_CHECK(dev_malloc(&gp->d_W, sizeof(double) * sq));
+    if (!gp->d_neg_invkf) EGX_HIP_CHECK(dev_malloc(&gp->d_neg_invkf, sizeof(double) * (size_t)n_pad * gp->rhs_pad));
+    // the rows of the identity, written on the device as far as the solve and the readers of W touch them (everything
+    // on and above the diagonal 128-tiles): no host round trip, no 2 GiB memset
+    EGX_RC(launch_identity_rows(w.stream, gp->d_W, n_pad, n_pad));
     EGX_RC(launch_trsm_rows(w.stream, w.M, gp->ld, n_pad, w.dinv, gp->d_W, n_pad, n_pad, 1));
     EGX_HIP_CHECK(hipMemsetAsync(gp->d_neg_invkf, 0, sizeof(double) * (size_t)n_pad * gp->rhs_pad, w.stream));
     // 0 - W [ft | yt]: the rows [ft | yt]^T sit below the factor; W upper triangular -> K range starts at the row tile
@@ -229,13 +225,13 @@ static int small_path_buffers(egx_gp *gp) {
     if (nsplit > 512) nsplit = 512;
     const int slabs = (n + 63) / 64, per = (slabs + nsplit - 1) / nsplit;
     gp->sp_nsplit = (slabs + per - 1) / per;
-    EGX_HIP_CHECK(hipMalloc(&gp->sp_R, sizeof(double) * (size_t)kTile * n_pad));
-    EGX_HIP_CHECK(hipMalloc(&gp->sp_P, sizeof(double) * (size_t)32 * n_pad));
-    EGX_HIP_CHECK(hipMalloc(&gp->sp_y, sizeof(double) * n_pad));
-    EGX_HIP_CHECK(hipMalloc(&gp->sp_z, sizeof(double) * n_pad));
-    EGX_HIP_CHECK(hipMalloc(&gp->sp_wt, sizeof(double) * n_pad));
-    EGX_HIP_CHECK(hipMalloc(&gp->sp_out, sizeof(double) * (size_t)gp->sp_nsplit * kTile * d));
-    EGX_HIP_CHECK(hipMalloc(&gp->sp_xq, sizeof(double) * (size_t)d * kTile));
+    EGX_HIP_CHECK(dev_malloc(&gp->sp_R, sizeof(double) * (size_t)kTile * n_pad));
+    EGX_HIP_CHECK(dev_malloc(&gp->sp_P, sizeof(double) * (size_t)32 * n_pad));
+    EGX_HIP_CHECK(dev_malloc(&gp->sp_y, sizeof(double) * n_pad));
+    EGX_HIP_CHECK(dev_malloc(&gp->sp_z, sizeof(double) * n_pad));
+    EGX_HIP_CHECK(dev_malloc(&gp->sp_wt, sizeof(double) * n_pad));
+    EGX_HIP_CHECK(dev_malloc(&gp->sp_out, sizeof(double) * (size_t)gp->sp_nsplit * kTile * d));
+    EGX_HIP_CHECK(dev_malloc(&gp->sp_xq, sizeof(double) * (size_t)d * kTile));
     return EGX_SUCCESS;
 }
 

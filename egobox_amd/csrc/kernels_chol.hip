@@ -322,7 +322,25 @@ __device__ __forceinline__ void stream_tile_coords(int t, int nbx, int nby, int 
     }
 }
 
-template <bool LOWER>
+// KTRI walk (R^-1 = W W^T of the theta-gradient, W = C^-T upper triangular): the K range of tile (bx, by) starts at the
+// tile's first row, so the work per tile falls with bx -- tiles are enumerated ROW by row (row bx holds by = 0 .. bx / 2),
+// the heaviest first.  Tiles before row bx: m (m + 1) for bx = 2 m, (m + 1)^2 for bx = 2 m + 1.
+__device__ __forceinline__ void stream_tile_coords_ktri(int t, int &bx, int &by) {
+    int m = (int)((sqrt(4.0 * t + 1.0) - 1.0) * 0.5);
+    while (m > 0 && m * (m + 1) > t) m--;
+    while ((m + 1) * (m + 2) <= t) m++;
+    if (t < (m + 1) * (m + 1)) {
+        bx = 2 * m;
+        by = t - m * (m + 1);
+    } else {
+        bx = 2 * m + 1;
+        by = t - (m + 1) * (m + 1);
+    }
+}
+
+// KTRI (with LOWER, square, ONE tile per workgroup): A == B == W upper triangular (row i is zero left of column i); the
+// accumulators start at ZERO and C <- -(W W^T) is written without being read (no memset of C, no read pass).
+template <bool LOWER, bool KTRI = false>
 __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, int64_t ldc, const double *__restrict__ A,
                                                         int64_t lda, const double *__restrict__ B, int64_t ldb, int K,
                                                         int nbx, int nby, int ntiles, const int *__restrict__ info,
@@ -338,8 +356,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int G = gridDim.x, nch = K / KC;
+    const int G = gridDim.x;
     const int bid = (int)blockIdx.x;
+    int nch = K / KC;
+    if (KTRI) {  // one tile per workgroup (G == ntiles): its K range starts at the tile's first row
+        int bx, by;
+        stream_tile_coords_ktri(bid, bx, by);
+        const int koff = bx * 128;
+        A += koff;
+        B += koff;
+        nch = (K - koff) / KC;
+    }
     const int my_tiles = (ntiles - bid + G - 1) / G;
     const int total = my_tiles * nch;  // chunks this workgroup streams
 
@@ -356,7 +383,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
     const double *pA_l, *pB_l;
     {
         int bx, by;
-        stream_tile_coords<LOWER>(t_l, nbx, nby, bx, by);
+        if (KTRI) stream_tile_coords_ktri(t_l, bx, by);
+        else stream_tile_coords<LOWER>(t_l, nbx, nby, bx, by);
         pA_l = A + (int64_t)bx * 128 * lda;
         pB_l = B + (int64_t)by * 256 * ldb;
     }
@@ -381,7 +409,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
             t_l += G;
             if (t_l < ntiles) {
                 int bx, by;
-                stream_tile_coords<LOWER>(t_l, nbx, nby, bx, by);
+                if (KTRI) stream_tile_coords_ktri(t_l, bx, by);
+                else stream_tile_coords<LOWER>(t_l, nbx, nby, bx, by);
                 pA_l = A + (int64_t)bx * 128 * lda;
                 pB_l = B + (int64_t)by * 256 * ldb;
             }
@@ -415,7 +444,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
     for (int i = 0; i < 4; i++) a0[i] = b0[i] = d2_t{0.0, 0.0};
     for (int t = bid; t < ntiles; t += G) {
         int bx, by;
-        stream_tile_coords<LOWER>(t, nbx, nby, bx, by);
+        if (KTRI) stream_tile_coords_ktri(t, bx, by);
+        else stream_tile_coords<LOWER>(t, nbx, nby, bx, by);
         double *Ct = C + (int64_t)(bx * 128 + wm0) * ldc + by * 256 + wn0;
         double4_t acc[4][4];
 #pragma unroll
@@ -423,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
 #pragma unroll
             for (int ni = 0; ni < 4; ni++)
 #pragma unroll
-                for (int r = 0; r < 4; r++) acc[mi][ni][r] = -Ct[(int64_t)mi * 16 * ldc + ni * 16 + coff[r]];
+                for (int r = 0; r < 4; r++) acc[mi][ni][r] = KTRI ? 0.0 : -Ct[(int64_t)mi * 16 * ldc + ni * 16 + coff[r]];
         // MID-CHUNK barrier (the survivor of five orderings, profiles/r02_run11_gemm_lab_variants_0_to_4.txt): the synchronisation for chunk g + 1 sits between the two 8-deep halves of chunk g, the
         // fragments of a half are read one half ahead, so the MFMA stream runs across the barrier and no LDS read
         // latency is exposed behind it:
@@ -1057,13 +1087,16 @@ template <int RT, bool POST = false>  // RT: 16-row tiles per workgroup: 1 (pane
                                       // (tall panels: the L fragments and the barrier serve two tiles, half the workgroups)
 __global__ __launch_bounds__(256) void k_panel_trsm16(double *__restrict__ P, int64_t ldp, const double *__restrict__ L, int64_t ldl,
                                                       const double *__restrict__ lin, int nbk, const int *__restrict__ info,
-                                                      int64_t bsM, int64_t bsL, int bsI, const double *__restrict__ tflags) {
+                                                      int64_t bsP, int64_t bsM, int64_t bsL, int bsI,
+                                                      const double *__restrict__ tflags) {
     __shared__ __attribute__((aligned(16))) double X[2][RT][16 * RB_LD];
-    {   // lock-step batch: matrix blockIdx.z
+    {   // lock-step batch: matrix blockIdx.z (bsP: between the panels' row blocks -- bsM inside a factorisation, the
+        // right-hand-side buffers' own stride in the solves after it; bsM: between the factors; bsL: between the dinv blocks)
         const int64_t z = blockIdx.z;
-        P += z * bsM;
+        P += z * bsP;
         L += z * bsM;
         lin += z * bsL;
+        if (tflags != nullptr) tflags += z * bsL;
         if (info != nullptr) info += z * bsI;
     }
     if (wg_failed_before(info)) return;  // failed pivot earlier: early exit (see k_gemm_nt_sub)
@@ -1423,8 +1456,27 @@ int chol_init() {
         set(reinterpret_cast<const void *>(&k_gemm_nt_sub<false, 128, 128, 32, 64, 512, true>), TrailShape::LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<true>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<false>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<true, true>), ST_LDS_BYTES);
     });
     return rc_once;
+}
+
+// run-time access to the knobs above (egx_set_tuning): A/B measurements inside ONE process (a gpurun call is minutes, a
+// launch sequence milliseconds) and the serialised profiling mode of bench.py's roofline leg.  Returns the previous
+// value, or INT_MIN for an unknown name.  Not to be called while evaluations are in flight.
+int set_knob(const char *name, int value) {
+    (void)chol_init();  // the environment is read first, once; a later call here wins
+    struct { const char *n; int *v; } tab[] = {{"potrf_group", &g_potrf_group}, {"stream_min", &g_stream_min_tiles},
+                                              {"stream_tpw", &g_stream_tpw},   {"gemm_small", &g_gemm_small_max},
+                                              {"look_min", &g_look_min_cols},  {"trsm_group", &g_trsm_group},
+                                              {"lur_side", &g_lur_side}};
+    for (auto &e : tab)
+        if (std::string(name) == e.n) {
+            const int old = *e.v;
+            *e.v = value;
+            return old;
+        }
+    return -2147483647 - 1;
 }
 
 // Kernel choice by the size of ONE matrix' launch (never by the batch count: a matrix is factored by the same kernels
@@ -1572,10 +1624,10 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         const double *lin = dinv + (int64_t)(k0 / 64) * 4096;
         if (below >= 4096)  // tall panels: two 16-row tiles per workgroup (+1 %, profiles/r02_run34_*)
             hipLaunchKernelGGL((k_panel_trsm16<2, false>), dim3(below / 32, 1, nz), dim3(256), 0, st, P, ld, L, ld, lin, nbk,
-                               (const int *)info, pb.sM, pb.sD, pb.sI, (const double *)nullptr);
+                               (const int *)info, pb.sM, pb.sM, pb.sD, pb.sI, (const double *)nullptr);
         else
             hipLaunchKernelGGL((k_panel_trsm16<1, false>), dim3(below / 16, 1, nz), dim3(256), 0, st, P, ld, L, ld, lin, nbk,
-                               (const int *)info, pb.sM, pb.sD, pb.sI, (const double *)nullptr);
+                               (const int *)info, pb.sM, pb.sM, pb.sD, pb.sI, (const double *)nullptr);
     };
     // C[r0.., c0..c0+N) -= P[r0.., k0..k0+K) P[c0..c0+N, k0..k0+K)^T for the M rows from r0
     auto update = [&](hipStream_t st, int r0, int c0, int Mr, int N, int k0, int K, int lower, bool *big) -> int {
@@ -1695,9 +1747,15 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
 }
 
 int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, const double *dinv, double *RT,
-                     int64_t ldr, int m, int tri_rows) {
+                     int64_t ldr, int m, int tri_rows, const TrsmBatch *batch) {
     int rc = chol_init();
     if (rc) return rc;
+    const TrsmBatch tb = batch ? *batch : TrsmBatch();
+    const unsigned nz = (unsigned)(tb.count > 0 ? tb.count : 1);
+    GemmBatch gb;  // the updates: C and A in the right-hand sides' buffers, B in the factors
+    gb.count = (int)nz;
+    gb.sC = gb.sA = tb.sR;
+    gb.sB = tb.sM;
     if (m % kTile || n_pad % kTile) {
         set_error("trsm_rows: sizes must be multiples of 128");
         return EGX_ERR_INVALID_VALUE;
@@ -1720,15 +1778,15 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
             // the same register-resident 16-row-tile solve as inside the factorisation (POST layout of the tile inverses)
             const double *tfl = dinv + (int64_t)(n_pad / 64) * 4096 + k0 / 64;
             if (m_eff >= 4096)
-                hipLaunchKernelGGL((k_panel_trsm16<2, true>), dim3(m_eff / 32), dim3(256), 0, s, RT + k0, ldr, diag, ldm, dtiles,
-                                   nbk, (const int *)nullptr, (int64_t)0, (int64_t)0, 0, tfl);
+                hipLaunchKernelGGL((k_panel_trsm16<2, true>), dim3(m_eff / 32, 1, nz), dim3(256), 0, s, RT + k0, ldr, diag, ldm,
+                                   dtiles, nbk, (const int *)nullptr, tb.sR, tb.sM, tb.sD, 0, tfl);
             else
-                hipLaunchKernelGGL((k_panel_trsm16<1, true>), dim3(m_eff / 16), dim3(256), 0, s, RT + k0, ldr, diag, ldm, dtiles,
-                                   nbk, (const int *)nullptr, (int64_t)0, (int64_t)0, 0, tfl);
+                hipLaunchKernelGGL((k_panel_trsm16<1, true>), dim3(m_eff / 16, 1, nz), dim3(256), 0, s, RT + k0, ldr, diag, ldm,
+                                   dtiles, nbk, (const int *)nullptr, tb.sR, tb.sM, tb.sD, 0, tfl);
             const int ncols = gend - (k0 + nbk);
             if (ncols > 0) {
                 rc = launch_gemm_nt_sub(s, RT + (k0 + nbk), ldr, RT + k0, ldr, M + (int64_t)(k0 + nbk) * ldm + k0, ldm,
-                                        m_eff, ncols, nbk, 0, 0);
+                                        m_eff, ncols, nbk, 0, 0, nullptr, nullptr, &gb);
                 if (rc) return rc;
             }
         }
@@ -1736,12 +1794,68 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
         if (ncols > 0) {
             const int m_eff = tri_rows ? ((gend < m) ? gend : m) : m;
             rc = launch_gemm_nt_sub(s, RT + gend, ldr, RT + g0, ldr, M + (int64_t)gend * ldm + g0, ldm, m_eff, ncols, gw, 0,
-                                    0);
+                                    0, nullptr, nullptr, &gb);
             if (rc) return rc;
         }
     }
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
+}
+
+// W <- the rows of the identity, as far as launch_trsm_rows(tri_rows) and launch_syrk_uptri_neg ever read or update
+// them: every element (i, j) with i < end of the panel group that holds column j (the upper triangle plus the lower
+// parts of the diagonal groups); the rest of the buffer is never touched.  One 128 x 128 tile per workgroup.
+__global__ __launch_bounds__(256) void k_identity_rows(double *__restrict__ W, int64_t ld, int n_pad, int gw, int64_t bsW) {
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    int gend = (bj * 128 / gw + 1) * gw;
+    if (gend > n_pad) gend = n_pad;
+    if (bi * 128 >= gend) return;
+    W += (int64_t)blockIdx.z * bsW + (int64_t)bi * 128 * ld + bj * 128;
+    const int tid = threadIdx.x, c = (tid & 63) * 2, r0 = tid >> 6;
+    for (int r = r0; r < 128; r += 4) {
+        d2_t v = d2_t{0.0, 0.0};
+        if (bi == bj) {
+            if (r == c) v[0] = 1.0;
+            if (r == c + 1) v[1] = 1.0;
+        }
+        *reinterpret_cast<d2_t *>(W + (int64_t)r * ld + c) = v;
+    }
+}
+
+int trsm_group_cols() { return (g_trsm_group > 0 ? g_trsm_group : 4) * kNB; }
+
+int launch_identity_rows(hipStream_t s, double *W, int64_t ld, int n_pad, int count, int64_t stride) {
+    int rc = chol_init();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_identity_rows, dim3(n_pad / 128, n_pad / 128, (unsigned)(count > 0 ? count : 1)), dim3(256), 0, s, W, ld,
+                       n_pad, trsm_group_cols(), stride);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+// C (lower; n x n, ldc) <- -(W W^T) for the upper triangular W = C^-T (n x n, ldw): the theta-gradient's -R^-1.
+// n % 256 == 0: the LDS-DMA stream kernel with per-tile K ranges and zero-initialised accumulators (C is not read);
+// other sizes (n_pad < 4096 only): C is zeroed and the register-staged 128 x 128 kernel subtracts.
+int launch_syrk_uptri_neg(hipStream_t s, double *C, int64_t ldc, const double *W, int64_t ldw, int n, const GemmBatch *batch) {
+    int rc = chol_init();
+    if (rc) return rc;
+    if (n % 128) {
+        set_error("syrk_uptri_neg: n must be a multiple of 128");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    const GemmBatch bt = batch ? *batch : GemmBatch();
+    const unsigned nz = (unsigned)(bt.count > 0 ? bt.count : 1);
+    if (n % 256 == 0) {
+        const int nbx = n / 128, m = nbx / 2;
+        const int nt = m * (m + 1);
+        hipLaunchKernelGGL((k_gemm_stream<true, true>), dim3((unsigned)nt, 1, nz), dim3(512), ST_LDS_BYTES, s, C, ldc, W, ldw, W,
+                           ldw, n, nbx, m, nt, (const int *)nullptr, bt);
+        EGX_HIP_CHECK(hipGetLastError());
+        return EGX_SUCCESS;
+    }
+    for (unsigned z = 0; z < nz; z++)
+        EGX_HIP_CHECK(hipMemset2DAsync(C + (int64_t)z * bt.sC, sizeof(double) * ldc, 0, sizeof(double) * n, n, s));
+    return launch_gemm_nt_sub(s, C, ldc, W, ldw, W, ldw, n, n, n, 1, 1, nullptr, nullptr, batch);
 }
 
 int launch_diag_tile_inverses(hipStream_t s, const double *M, int64_t ld, int n_pad, double *dinv) {

@@ -12,6 +12,7 @@
 // HBM traffic is the algorithmic minimum: X read once per tile row/column from L2, R written once.
 #include "egx_internal.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <mutex>
 
@@ -27,6 +28,10 @@ constexpr double k5over3 = 5.0 / 3.0;
 // by FP64 VALU issue (profiles/r03_*_pmc_corr_*), so instructions per pair are what counts.  Error <= 2 ulp; underflow
 // goes through ldexp (gradual, then 0); NaN propagates.
 __device__ __forceinline__ double exp_nonpos(double x) {
+    // exp(x) == 0 below -745.2: the clamp keeps -inf (a huge theta: the sum overflows) from turning into NaN in the
+    // reduction (fma(-inf, -c, -inf)), keeps the cast of kf defined, and lets v_ldexp flush the result to 0 as the reference's
+    // exp does.  A select, not fmax: a NaN argument must stay NaN (v_max_f64 would return the other operand).
+    x = (x < -800.0) ? -800.0 : x;
     const double kf = __builtin_rint(x * 1.4426950408889634074);
     double r = __builtin_fma(kf, -6.93147180369123816490e-01, x);
     r = __builtin_fma(kf, -1.90821492927058770002e-10, r);
@@ -638,86 +643,212 @@ __global__ __launch_bounds__(256) void k_row_reduce(const double *__restrict__ R
     }
 }
 
-// Likelihood-gradient accumulation (new capability; w = I only):
-//   out[k]     += sum_{i>j} 2 Rinv_ij dR_k,ij          (trace term)
-//   out[d + k] += sum_{i>j} 2 gamma_i gamma_j dR_k,ij  (quadratic term)
-// dR_k = R_ij * g_k(|x_ik - x_jk|): sq-exp -theta a^2 ; abs-exp -a ; Matern32 s3 a/(1+s3 t) - s3 a ;
-// Matern52 (s5 a + 10/3 theta a^2)/(1 + s5 t + 5/3 t^2) - s5 a.
+// ---------------------------------------------------------------------------------------------
+// K7: likelihood-gradient accumulation (new capability).  With Rneg = -R^-1 (lower triangle) and
+// gamma = C^-T rho, for every output o < nout
+//     out[o] = sum_{i > j} 2 R_ij (gamma_i gamma_j / sigma2 + Rneg_ij) * d log R_ij / d c_o
+//            = gamma^T dR_o gamma / sigma2 - tr(R^-1 dR_o)
+// hcols == 1 (HC1): output o = input dimension o, c_o its coefficient (w = I: theta_o; KPLS sq-exp / abs-exp: the collapsed
+// coefficient, the chain rule to theta runs on the host);  hcols > 1 (KPLS + Matern): output o = theta_o,
+//     d log R / d theta_o = sum_j |w_jo| (d log m / d t)(theta_o |w_jo| a_j) a_j.
+// d log r / d c for one dimension (a = |x_i - x_j|, t = c a):
+//     sq-exp -c a^2 ; abs-exp -a ; Matern-3/2 -3 a t / (1 + s3 t) ; Matern-5/2 -(5/3) a t (1 + s5 t) / (1 + s5 t + 5/3 t^2)
+// (the Matern forms are m'(t) / m(t) - sqrt(nu') with the constants cancelled: one reciprocal, no subtraction of nearly
+// equal terms).
+// Round 4: DETERMINISTIC (round 3 added per-tile sums into `out` with atomics, whose order varies from run to run): a
+// workgroup walks the 64 x 64 tiles t = blockIdx.x, + gridDim.x, ... of the lower triangle, keeps its DK partial sums
+// per lane in registers over all of them, reduces them once (shuffles, then the four waves in a fixed order) and writes
+// ONE partial vector; k_grad_reduce adds the workgroups' vectors in a fixed order.  A candidate's gradient is therefore
+// the same bits alone and in a lock-step batch (grid.z), whatever else runs.  Two passes per tile: (1) all d dimensions
+// -> R_ij and the pair's weight, (2) the DK outputs of this workgroup's chunk (grid.y) -> DK accumulations per pair.
+// Dimensions are staged in LDS in chunks of at most 64 (any d).  The division of round 3 (~30 FP64 instructions per pair
+// and dimension) is v_rcp_f64 + two Newton steps (m >= 1: no scaling needed).
+// ---------------------------------------------------------------------------------------------
+constexpr int kGradDC = 64;      // input dimensions staged per pass (2 x 64 x 64 doubles = 64 KB of LDS)
+constexpr int kGradMaxWG = 2048;  // workgroups (partial vectors) per candidate and output chunk
+
+__device__ __forceinline__ double rcp_ge1(double m) {  // 1 / m for m >= 1 (finite), <= 1 ulp-ish
+    double y = __builtin_amdgcn_rcp(m);
+    double e = __builtin_fma(-m, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-m, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
 template <int CORR>
-__global__ __launch_bounds__(256) void k_grad_accum(const double *__restrict__ xT, int64_t ldx, int n, int d,
-                                                    const double *__restrict__ coef, int hcols,
-                                                    const double *__restrict__ wabs, int nout,
-                                                    const double *__restrict__ Rinv, int64_t ld,
-                                                    const double *__restrict__ gamma, double *__restrict__ out) {
-    const int bi = blockIdx.x, bj = blockIdx.y;
-    if (bj > bi) return;
+__device__ __forceinline__ double dlog_dc(double c, double a) {
+    if (CORR == EGX_CORR_SQUARED_EXPONENTIAL) return -c * a * a;
+    if (CORR == EGX_CORR_ABSOLUTE_EXPONENTIAL) return -a;
+    const double t = c * a;
+    if (CORR == EGX_CORR_MATERN32) return -3.0 * a * t * rcp_ge1(__builtin_fma(kSqrt3, t, 1.0));
+    const double u = __builtin_fma(kSqrt5, t, 1.0);
+    return -k5over3 * (a * t) * u * rcp_ge1(__builtin_fma(k5over3 * t, t, u));
+}
+
+template <int CORR, bool HC1, int DK>
+__global__ __launch_bounds__(256) void k_grad_accum(const double *__restrict__ xT, int64_t ldx, int n, int d, int hcols,
+                                                    const double *__restrict__ wabs, int nout, int64_t ld, int ntiles,
+                                                    int nout_pad, GradBatch gb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *xi = sm, *xj = sm + d * 64, *red = sm + 2 * d * 64;  // red[2 * nout]
+    const int z = blockIdx.z;
+    const double *__restrict__ coef = gb.coef[z];
+    const double *__restrict__ gamma = gb.gamma[z];
+    const double *__restrict__ Rneg = gb.rneg[z];
+    const double inv_s2 = gb.inv_s2[z];
+    const int dc = d < kGradDC ? d : kGradDC;
+    double *xi = sm, *xj = sm + dc * 64;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    stage_slab(xi, xT, ldx, bi * 64, d, tid);
-    stage_slab(xj, xT, ldx, bj * 64, d, tid);
-    for (int e = tid; e < 2 * nout; e += 256) red[e] = 0.0;
-    __syncthreads();
-    double r[4][4];
-    tile_pairs<CORR>(xi, xj, coef, hcols, d, ty, tx, r);
-    double wt[4][4], wq[4][4];
+    const int o0 = blockIdx.y * DK;
+    double acc[DK];
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+    for (int oo = 0; oo < DK; oo++) acc[oo] = 0.0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while (bi * (bi + 1) / 2 > t) bi--;
+        while ((bi + 1) * (bi + 2) / 2 <= t) bi++;
+        const int bj = t - bi * (bi + 1) / 2;
+        // ---- pass 1: the correlations of the tile's 16 pairs per lane (all d dimensions, staged dc at a time)
+        PairAcc<CORR> pa[4][4];
+        for (int c0 = 0; c0 < d; c0 += dc) {
+            const int dn = (d - c0 < dc) ? (d - c0) : dc;
+            __syncthreads();  // the previous readers of the slabs are done
+            stage_slab(xi, xT + (int64_t)c0 * ldx, ldx, bi * 64, dn, tid);
+            stage_slab(xj, xT + (int64_t)c0 * ldx, ldx, bj * 64, dn, tid);
+            __syncthreads();
+            for (int k = 0; k < dn; k++) {
+                double vi[4], vj[4];
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int i = bi * 64 + ty * 4 + a, j = bj * 64 + tx * 4 + b;
-            const bool on = (i > j) && (i < n);
-            const double rv = on ? 2.0 * r[a][b] : 0.0;
-            wt[a][b] = on ? rv * Rinv[(int64_t)i * ld + j] : 0.0;
-            wq[a][b] = on ? rv * gamma[i] * gamma[j] : 0.0;
-        }
-    // d log r / d c for one scaled distance: sq-exp -c a^2 ; abs-exp -a ; Matern a (m'(t) / m(t)), t = c a
-    auto dlog = [](double c, double ad) -> double {
-        if (CORR == EGX_CORR_SQUARED_EXPONENTIAL) return -c * ad * ad;
-        if (CORR == EGX_CORR_ABSOLUTE_EXPONENTIAL) return -ad;
-        const double t = c * ad;
-        if (CORR == EGX_CORR_MATERN32) return kSqrt3 * ad / (1.0 + kSqrt3 * t) - kSqrt3 * ad;
-        return (kSqrt5 * ad + (10.0 / 3.0) * c * ad * ad) / (1.0 + kSqrt5 * t + k5over3 * t * t) - kSqrt5 * ad;
-    };
-    for (int k = 0; k < nout; k++) {
-        double st = 0.0, sq = 0.0;
-        if (hcols == 1) {
-            // output k = input dimension k, derivative with respect to the per-dimension coefficient c_k
-            const double th = coef[k];
+                for (int a = 0; a < 4; a++) vi[a] = xi[k * 64 + ty * 4 + a];
 #pragma unroll
-            for (int a = 0; a < 4; a++)
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const double g = dlog(th, fabs(xi[k * 64 + ty * 4 + a] - xj[k * 64 + tx * 4 + b]));
-                    st = __builtin_fma(wt[a][b], g, st);
-                    sq = __builtin_fma(wq[a][b], g, sq);
-                }
-        } else {
-            // KPLS + Matern: output k = theta_k, d log r / d theta_k = sum_j |w_jk| (d log m / d t)(theta_k |w_jk| a_j) a_j
-            for (int jd = 0; jd < d; jd++) {
-                const double c = coef[jd * hcols + k], wa = wabs[jd * hcols + k];
-                if (wa == 0.0) continue;
+                for (int b = 0; b < 4; b++) vj[b] = xj[k * 64 + tx * 4 + b];
+                const double *ck = coef + (int64_t)(c0 + k) * hcols;
 #pragma unroll
                 for (int a = 0; a < 4; a++)
 #pragma unroll
-                    for (int b = 0; b < 4; b++) {
-                        const double g = wa * dlog(c, fabs(xi[jd * 64 + ty * 4 + a] - xj[jd * 64 + tx * 4 + b]));
-                        st = __builtin_fma(wt[a][b], g, st);
-                        sq = __builtin_fma(wq[a][b], g, sq);
-                    }
+                    for (int b = 0; b < 4; b++) pa[a][b].add(vi[a] - vj[b], ck, hcols);
             }
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            st += __shfl_xor(st, o);
-            sq += __shfl_xor(sq, o);
+        double wp[4][4];  // 2 R_ij (gamma_i gamma_j / sigma2 - Rinv_ij) for i > j inside the matrix, else 0
+        {
+            double gi[4], gj[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) gi[a] = gamma[bi * 64 + ty * 4 + a] * inv_s2;
+#pragma unroll
+            for (int b = 0; b < 4; b++) gj[b] = gamma[bj * 64 + tx * 4 + b];
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                const int i = bi * 64 + ty * 4 + a;
+                const double *rrow = Rneg + (int64_t)i * ld + bj * 64 + tx * 4;
+                const double2 r01 = *reinterpret_cast<const double2 *>(rrow);
+                const double2 r23 = *reinterpret_cast<const double2 *>(rrow + 2);
+                const double rn[4] = {r01.x, r01.y, r23.x, r23.y};
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int j = bj * 64 + tx * 4 + b;
+                    const bool on = (i > j) && (i < n);
+                    wp[a][b] = on ? 2.0 * pa[a][b].value() * __builtin_fma(gi[a], gj[b], rn[b]) : 0.0;
+                }
+            }
         }
-        if ((tid & 63) == 0) {
-            atomicAdd(&red[k], st);
-            atomicAdd(&red[nout + k], sq);
+        // ---- pass 2: this workgroup's outputs o0 .. o0 + DK - 1
+        if (HC1) {
+            // output o <-> input dimension o.  d > dc: the chunk's dimensions are staged again, from slab row 0
+            int base = 0;
+            if (d > dc) {
+                const int dn = (nout - o0 < DK) ? (nout - o0) : DK;
+                __syncthreads();
+                stage_slab(xi, xT + (int64_t)o0 * ldx, ldx, bi * 64, dn, tid);
+                stage_slab(xj, xT + (int64_t)o0 * ldx, ldx, bj * 64, dn, tid);
+                __syncthreads();
+                base = o0;
+            }
+#pragma unroll
+            for (int oo = 0; oo < DK; oo++) {
+                const int o = o0 + oo;
+                if (o < nout) {
+                    const double c = coef[o];
+                    double vi[4], vj[4];
+#pragma unroll
+                    for (int a = 0; a < 4; a++) vi[a] = xi[(o - base) * 64 + ty * 4 + a];
+#pragma unroll
+                    for (int b = 0; b < 4; b++) vj[b] = xj[(o - base) * 64 + tx * 4 + b];
+                    double sacc = acc[oo];
+#pragma unroll
+                    for (int a = 0; a < 4; a++)
+#pragma unroll
+                        for (int b = 0; b < 4; b++) sacc = __builtin_fma(wp[a][b], dlog_dc<CORR>(c, fabs(vi[a] - vj[b])), sacc);
+                    acc[oo] = sacc;
+                }
+            }
+        } else {
+            // KPLS + Matern: output o = theta_o gets a term from every input dimension j
+            for (int c0 = 0; c0 < d; c0 += dc) {
+                const int dn = (d - c0 < dc) ? (d - c0) : dc;
+                if (d > dc) {
+                    __syncthreads();
+                    stage_slab(xi, xT + (int64_t)c0 * ldx, ldx, bi * 64, dn, tid);
+                    stage_slab(xj, xT + (int64_t)c0 * ldx, ldx, bj * 64, dn, tid);
+                    __syncthreads();
+                }
+                for (int k = 0; k < dn; k++) {
+                    double ad[4][4];
+                    {
+                        double vi[4], vj[4];
+#pragma unroll
+                        for (int a = 0; a < 4; a++) vi[a] = xi[k * 64 + ty * 4 + a];
+#pragma unroll
+                        for (int b = 0; b < 4; b++) vj[b] = xj[k * 64 + tx * 4 + b];
+#pragma unroll
+                        for (int a = 0; a < 4; a++)
+#pragma unroll
+                            for (int b = 0; b < 4; b++) ad[a][b] = fabs(vi[a] - vj[b]);
+                    }
+#pragma unroll
+                    for (int oo = 0; oo < DK; oo++) {
+                        const int o = o0 + oo;
+                        if (o < nout) {
+                            const double c = coef[(int64_t)(c0 + k) * hcols + o], wa = wabs[(int64_t)(c0 + k) * hcols + o];
+                            if (wa != 0.0) {  // (wave-uniform)
+                                double sacc = 0.0;
+#pragma unroll
+                                for (int a = 0; a < 4; a++)
+#pragma unroll
+                                    for (int b = 0; b < 4; b++) sacc = __builtin_fma(wp[a][b], dlog_dc<CORR>(c, ad[a][b]), sacc);
+                                acc[oo] = __builtin_fma(wa, sacc, acc[oo]);
+                            }
+                        }
+                    }
+                }
+            }
         }
     }
+    // ---- one reduction per workgroup: lanes of a wave (xor shuffles), then the four waves in a fixed order
     __syncthreads();
-    for (int e = tid; e < 2 * nout; e += 256) atomicAdd(&out[e], red[e]);
+    double *red = sm;  // [4][DK]
+#pragma unroll
+    for (int oo = 0; oo < DK; oo++) {
+        double v = acc[oo];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0) red[(tid >> 6) * DK + oo] = v;
+    }
+    __syncthreads();
+    if (tid < DK && o0 + tid < nout)
+        gb.part[z][(int64_t)blockIdx.x * nout_pad + o0 + tid] = ((red[tid] + red[DK + tid]) + red[2 * DK + tid]) + red[3 * DK + tid];
+}
+
+// out[z][o] = sum over the nwg partial vectors, in a fixed order: 256 lanes take every 256th, then a tree in LDS
+__global__ __launch_bounds__(256) void k_grad_reduce(int nwg, int nout, int nout_pad, GradBatch gb) {
+    __shared__ double red[256];
+    const int o = blockIdx.x, z = blockIdx.y, tid = threadIdx.x;
+    const double *part = gb.part[z];
+    double v = 0.0;
+    for (int b = tid; b < nwg; b += 256) v += part[(int64_t)b * nout_pad + o];
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) gb.out[z][o] = red[0];
 }
 
 // =============================================================================================
@@ -921,14 +1052,45 @@ int launch_row_reduce(hipStream_t s, const double *RT, int64_t ld, int m, int n,
     return EGX_SUCCESS;
 }
 
-int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d, const double *coef, int hcols,
-                      const double *wabs, int nout, const double *Rinv, int64_t ld, const double *gamma, double *out) {
-    EGX_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double) * 2 * nout, s));
-    const int nt = (n + 63) / 64;
-    dim3 grid(nt, nt);
-    const size_t lds = (size_t)(2 * d * 64 + 2 * nout) * sizeof(double);
-    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_grad_accum<C_>, grid, dim3(256), lds, s, xT, ldx, n, d, coef, hcols, wabs,
-                                               nout, Rinv, ld, gamma, out));
+int grad_partial_doubles(int nout) { return kGradMaxWG * (int)round_up(nout, 32); }
+
+// batch.count candidates (grid.z); per candidate: coef (d x hcols), gamma (n_pad), rneg (-R^-1, lower, ld), inv_s2,
+// part (grad_partial_doubles(nout) doubles of scratch), out (nout doubles)
+int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d, int hcols, const double *wabs,
+                      int nout, int64_t ld, const GradBatch &batch) {
+    if (batch.count < 1 || batch.count > kGradMaxBatch) {
+        set_error("grad_accum: batch count out of range");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    const int nt = (n + 63) / 64, ntiles = nt * (nt + 1) / 2;
+    const int nwg = ntiles < kGradMaxWG ? ntiles : kGradMaxWG;
+    const int nout_pad = (int)round_up(nout, 32);
+    const int dc = d < kGradDC ? d : kGradDC;
+    const int dk = nout <= 8 ? 8 : (nout <= 16 ? 16 : 32);
+    const size_t lds = sizeof(double) * (size_t)std::max(2 * dc * 64, 4 * dk);
+    const dim3 grid((unsigned)nwg, (unsigned)((nout + dk - 1) / dk), (unsigned)batch.count);
+#define EGX_GA(C_, HC1_, DK_)                                                                                             \
+    hipLaunchKernelGGL((k_grad_accum<C_, HC1_, DK_>), grid, dim3(256), lds, s, xT, ldx, n, d, hcols, wabs, nout, ld, ntiles, \
+                       nout_pad, batch)
+#define EGX_GA_DK(C_, HC1_)                  \
+    if (dk == 8) EGX_GA(C_, HC1_, 8);        \
+    else if (dk == 16) EGX_GA(C_, HC1_, 16); \
+    else EGX_GA(C_, HC1_, 32)
+    if (hcols == 1) {
+        EGX_DISPATCH_CORR(corr, EGX_GA_DK(C_, true));
+    } else {
+        EGX_DISPATCH_CORR(corr, EGX_GA_DK(C_, false));
+    }
+#undef EGX_GA_DK
+#undef EGX_GA
+    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)nout, (unsigned)batch.count), dim3(256), 0, s, nwg, nout, nout_pad, batch);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+// z (n) <- W y for the upper triangular W (row-major): gamma = C^-T rho through the explicit C^-T of the theta-gradient
+int launch_uptri_gemv(hipStream_t s, const double *W, int64_t ld, int n, const double *y, double *z) {
+    hipLaunchKernelGGL(k_uptri_gemv, dim3((n + 3) / 4), dim3(256), 0, s, W, ld, n, y, z);
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }

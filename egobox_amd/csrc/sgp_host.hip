@@ -40,7 +40,7 @@ struct Dev {
     int alloc(size_t n) {
         if (p) (void)hipFree(p);
         p = nullptr;
-        EGX_HIP_CHECK(hipMalloc(&p, sizeof(double) * (n ? n : 1)));
+        EGX_HIP_CHECK(dev_malloc(&p, sizeof(double) * (n ? n : 1)));
         return EGX_SUCCESS;
     }
 };
@@ -428,7 +428,7 @@ int32_t egx_sgp_create(const egx_sgp_config *cfg_in, const double *x, const doub
     SGP_TRY(g->vec.alloc(zp));
     SGP_TRY(g->tmpv.alloc(zp));
     SGP_TRY(g->wall.alloc(((zp + kNB - 1) / kNB) * 65536));
-    SGP_HIP(hipMalloc(&g->d_info, 2 * sizeof(int)));
+    SGP_HIP(dev_malloc(&g->d_info, 2 * sizeof(int)));
     SGP_HIP(hipMemcpy(g->xT.p, xT.data(), sizeof(double) * xT.size(), hipMemcpyHostToDevice));
     SGP_HIP(hipMemcpy(g->zT.p, zT.data(), sizeof(double) * zT.size(), hipMemcpyHostToDevice));
     SGP_HIP(hipMemcpy(g->y.p, yp.data(), sizeof(double) * np, hipMemcpyHostToDevice));

@@ -344,7 +344,7 @@ int32_t egx_sweep_create(const egx_gp_config *cfg_in, const double *x, const dou
     }
     {   // staging of the collective: allocated here, never inside a collective call
         const size_t one = sizeof(double) * (size_t)egx_sweep::kChunk;
-        if (hipMalloc(&sw->d_send, one) != hipSuccess || hipMalloc(&sw->d_recv, one * world) != hipSuccess ||
+        if (dev_malloc(&sw->d_send, one) != hipSuccess || dev_malloc(&sw->d_recv, one * world) != hipSuccess ||
             hipHostMalloc(&sw->h_send, one, hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc(&sw->h_recv, one * world, hipHostMallocDefault) != hipSuccess) {
             set_error("egx_sweep_create: staging buffers");
@@ -501,10 +501,13 @@ int32_t egx_sweep_likelihood(egx_sweep *sw, const double *thetas, int64_t k, int
     const auto t0 = std::chrono::steady_clock::now();
     {
         std::atomic<int64_t> *ctr = nullptr;
-        if (sw->dynamic && sw->counters) {
-            ctr = &sw->counters->next[seq % SweepCounters::kSlots];
-            if (rank == 0) sw->counters->next[(seq + SweepCounters::kSlots / 2) % SweepCounters::kSlots].store(0);
-        }
+        // The slot of call `seq` was zeroed by rank 0 half a ring earlier, when every rank had long left the slot's previous
+        // use (the all-gather of each call is a barrier).  The sequence number advances on EVERY call, so the look-ahead slot
+        // is recycled on every call too -- static ones included: a slot dirtied by a dynamic call must be clean again 64
+        // calls later whatever mode the call half a ring in between was in.
+        if (sw->counters && rank == 0)
+            sw->counters->next[(seq + SweepCounters::kSlots / 2) % SweepCounters::kSlots].store(0);
+        if (sw->dynamic && sw->counters) ctr = &sw->counters->next[seq % SweepCounters::kSlots];
         StaticSource ssrc(k, rank, world);
         DynamicSource dsrc(ctr, k);
         egx::CandidateSource *src = ctr ? static_cast<egx::CandidateSource *>(&dsrc) : &ssrc;
@@ -773,6 +776,9 @@ int32_t egx_sweep_fit(egx_sweep *sw, const double *theta0s, int64_t n_starts, co
     std::vector<int> active(h);
     for (int i = 0; i < h; i++) active[i] = i;
     std::vector<StartResult> results;
+    // one critical section on the replica from the first evaluation to the finalized model (the all-gather included: it has
+    // its own deadline), as egx_gp_fit is on a plain handle
+    std::unique_lock<std::shared_mutex> glock(gp->mu);
     int local_rc = fit_run_starts(gp, theta0s, active, theta0s, n_starts, lo, hi, bounds_len, max_eval, sw->rank, world, results);
     const std::string local_msg = local_rc ? last_error_string() : std::string();
     // payload: [status | per start: objective, evaluations, minimiser (h)], NaN objective for the starts of other ranks

@@ -217,6 +217,17 @@ class GpHandle:
                                                  C.byref(st)))
         return lk.value, g, st.value
 
+    def likelihood_grad_batch(self, thetas):
+        """(likelihoods (k), gradients (k x h), statuses (k)) of the rows of thetas: egx_gp_likelihood_grad_batch."""
+        thetas = L.as_f64(thetas, 2)
+        k = thetas.shape[0]
+        lk = np.empty(k)
+        g = np.zeros((k, self.h))
+        st = np.empty(k, dtype=np.int32)
+        L.check(self._lib.egx_gp_likelihood_grad_batch(self._h, L.dptr(thetas), k, thetas.shape[1], L.dptr(lk), L.dptr(g),
+                                                       st.ctypes.data_as(L.c_int32_p)))
+        return lk, g, st
+
     # -- fit
     def finalize(self, theta):
         theta = L.as_f64(np.atleast_1d(theta), 1)
@@ -404,6 +415,13 @@ def mfma_probe():
 def trim():
     """Free the device resources destroyed handles left in the library's pool (egx_trim); returns the bytes freed."""
     return int(L.load().egx_trim())
+
+
+def set_tuning(knob, value):
+    """egx_set_tuning: one of the factorisation's scheduling knobs by name; returns the previous value."""
+    old = C.c_int32()
+    L.check(L.load().egx_set_tuning(knob.encode(), int(value), C.byref(old)))
+    return old.value
 
 
 def pool_stats():

@@ -102,6 +102,14 @@ void egx_gp_config_default(egx_gp_config *cfg);
  * EGX_POOL_MAX_GB (environment, default 48, 0 = no pool).  egx_trim frees everything cached and returns the bytes. */
 int64_t egx_trim(void);
 void egx_pool_stats(int64_t *cached_bytes, int64_t *hits, int64_t *misses);
+/* The factorisation's scheduling knobs at run time (the EGX_* environment variables of DESIGN.md section 4, read once at
+ * start-up, by name without the prefix, lower case: "potrf_group", "stream_min", "stream_tpw", "gemm_small", "look_min",
+ * "trsm_group", "lur_side").  They move launches between streams and kernels between tile shapes, never the arithmetic
+ * inside a kernel; changing "potrf_group" / "stream_min" / "gemm_small" changes which kernel updates a block and hence
+ * the rounding.  Process-wide; not while evaluations are in flight.  *previous (optional) receives the old value.
+ * Used by bench.py's roofline leg ("lur_side" = 0: the lock-step group's launches run one after the other and have
+ * clean per-launch durations) and by A/B measurements inside one process. */
+int32_t egx_set_tuning(const char *knob, int32_t value, int32_t *previous);
 
 /* ---- host-side helpers (no device needed) -------------------------------- */
 /* utils.rs:45-54 normalize(): column mean, sample std (ddof=1), zero std -> 1. */
@@ -149,11 +157,20 @@ int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int
  * not depend on the width or on its companions (same kernels, same arithmetic: bit-identical). */
 int32_t egx_gp_set_lockstep(egx_gp *gp, int32_t width);
 int32_t egx_gp_get_lockstep(const egx_gp *gp);
-/* NEW capability (the reference has no theta-gradient, algorithm.rs:880):
- * dL/dtheta (length h); validated by finite differences of the parity-checked likelihood.
- * Runs on workspace 0 (it needs the factor, C^-T and R^-1 at this theta): a fitted model is un-fitted by the call. */
+/* NEW capability (the reference has no theta-gradient, algorithm.rs:880: the objective closure ignores `_gradient`):
+ * the reduced likelihood of algorithm.rs:988-1056 AND dL/dtheta (length h) at one theta; validated against the oracle's
+ * closed form and by finite differences of the parity-checked likelihood.  Needs the factor, C^-T (n^2 doubles of
+ * scratch per candidate in flight, allocated on first use) and R^-1 (written over the factor).  A fitted model with
+ * n_workspaces > 1 keeps workspace 0 and stays fitted; with a single workspace the call un-fits it. */
 int32_t egx_gp_likelihood_grad(egx_gp *gp, const double *theta, int64_t theta_len, double *lkh,
                                double *dlkh_dtheta /*h*/, int32_t *status);
+/* k candidates at once (thetas is k x theta_len, grads k x h row-major): the gradient counterpart of
+ * egx_gp_likelihood_batch -- the objective + gradient evaluations of a gradient-based multistart (the rayon tasks of
+ * algorithm.rs:928-945).  Candidates are pipelined over the workspaces; the candidates of a lock-step slot
+ * (egx_gp_set_lockstep, at most 16) run EVERY stage -- factorisation, C^-T, R^-1, the trace kernel -- as one launch
+ * sequence.  A candidate's (likelihood, gradient) are bit for bit what egx_gp_likelihood_grad returns for it alone. */
+int32_t egx_gp_likelihood_grad_batch(egx_gp *gp, const double *thetas, int64_t k, int64_t theta_len,
+                                     double *lkh /*k*/, double *dlkh_dtheta /*k x h*/, int32_t *status /*k*/);
 
 /* ---- fit ------------------------------------------------------------------
  * ThetaTuning::Fixed fit (algorithm.rs:869-872, 966-978; python n_start=-1,
@@ -176,9 +193,10 @@ int32_t egx_gp_fit_partial(egx_gp *gp, const double *theta_init, const int64_t *
                            const double *theta0s, int64_t n_starts, const double *lo, const double *hi,
                            int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out);
 
-/* Gradient-based variant (NEW: consumes egx_gp_likelihood_grad; same contract as egx_gp_fit otherwise):
- * projected L-BFGS on log10(theta) per start, best start wins, then finalize.  max_iter bounds the
- * iterations per start; *n_evals_out counts likelihood+gradient evaluations. */
+/* Gradient-based variant (NEW: consumes the theta-gradient; same contract as egx_gp_fit otherwise):
+ * projected L-BFGS on log10(theta) per start, ALL starts advanced in lock-step (a round's trial points are one
+ * egx_gp_likelihood_grad_batch), best start wins, then finalize.  max_iter bounds the iterations per start;
+ * *n_evals_out counts likelihood+gradient evaluations. */
 int32_t egx_gp_fit_lbfgs(egx_gp *gp, const double *theta0s, int64_t n_starts, const double *lo,
                          const double *hi, int64_t bounds_len, int64_t max_iter, int64_t *n_evals_out);
 

@@ -767,3 +767,86 @@ def test_potrf_with_stream_kernel_launches_vs_lapack(egx, n):
     assert np.all(np.triu(got, 1) == 0.0)
     idx = rng.integers(0, n, 300)
     np.testing.assert_allclose((got[idx] @ got.T)[:, idx], spd[np.ix_(idx, idx)], rtol=1e-12, atol=1e-12)
+
+
+# ------------------------------------------------------------------ round 4: the theta-gradient in lock-step batches
+@pytest.mark.parametrize("n,d,corr,nws,width", [
+    (600, 5, 0, 4, 4),      # n_pad 640: C^-T C^-1 by the register-staged kernel (n_pad % 256 != 0)
+    (1000, 7, 3, 6, 3),     # n_pad 1024: the LDS-DMA stream kernel with per-tile K ranges, two slots
+    (1000, 40, 2, 3, 2),    # two output chunks of the trace kernel (d > 32), ragged last slot
+    (4200, 6, 3, 5, 4),     # n_pad 4352: several panel groups in the solve, slots of 4 + 1
+])
+def test_theta_gradient_batch_is_bit_identical_to_single_candidates(egx, n, d, corr, nws, width):
+    """egx_gp_likelihood_grad_batch: every candidate gets, bit for bit, the likelihood and the gradient
+    egx_gp_likelihood_grad returns for it alone -- whatever the lock-step width, its companions (a NaN theta, a
+    candidate that is not positive definite) or the workspace it lands on; and twice the same call gives the same bits
+    (the trace kernel's reduction order is fixed)."""
+    x, y = _data(n, d, 21)
+    rng = np.random.default_rng(5)
+    base = egx.workload.default_theta(d) * (3.0 if corr == 0 else 1.5)
+    thetas = base * 10.0 ** rng.uniform(-0.15, 0.15, (7, d))
+    thetas[2, 0] = np.nan                      # answered at once (algorithm.rs:885-891)
+    thetas[4] = 1e-7                           # R = ones + nugget: not positive definite in floating point (if the size allows)
+    with egx.GpHandle(x, y, corr=corr, n_workspaces=1) as h1:
+        single = [h1.likelihood_grad(t) for t in thetas]
+        again = [h1.likelihood_grad(t) for t in thetas[:2]]
+    for a, b in zip(single[:2], again):
+        assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    with egx.GpHandle(x, y, corr=corr, n_workspaces=nws) as h:
+        h.set_lockstep(width)
+        lk, g, st = h.likelihood_grad_batch(thetas)
+        lk2, g2, st2 = h.likelihood_grad_batch(thetas[::-1].copy())
+    assert st[2] == 4 and lk[2] == -np.inf and np.all(g[2] == 0.0)  # EGX_STATUS_NAN_THETA
+    for c in range(7):
+        assert st[c] == single[c][2]
+        if st[c] != 0:
+            assert np.all(g[c] == 0.0)
+        else:
+            assert lk[c] == single[c][0], (c, lk[c], single[c][0])
+            assert np.array_equal(g[c], single[c][1]), (c, np.abs(g[c] - single[c][1]).max())
+            assert lk2[6 - c] == lk[c] and np.array_equal(g2[6 - c], g[c])
+    ok = [c for c in range(7) if st[c] == 0]
+    assert len(ok) >= 5 and all(np.all(np.isfinite(g[c])) and np.abs(g[c]).max() > 0 for c in ok)
+
+
+def test_theta_gradient_batch_matches_oracle_and_keeps_a_fitted_model(egx, O):
+    """The batch against the oracle's closed form (gp_oracle.likelihood_grad), on a FITTED handle: with more than one
+    workspace the fit stays in workspace 0 and predictions are unchanged afterwards."""
+    n, d = 500, 4
+    x, y = _data(n, d, 8)
+    theta0 = np.array([0.9, 1.2, 0.7, 1.5])
+    rng = np.random.default_rng(1)
+    thetas = theta0 * 10.0 ** rng.uniform(-0.2, 0.2, (5, d))
+    xq = rng.random((50, d))
+    with egx.GpHandle(x, y, corr=3, n_workspaces=3) as h:
+        h.finalize(theta0)
+        before = h.predict_valvar(xq)
+        lk, g, st = h.likelihood_grad_batch(thetas)
+        after = h.predict_valvar(xq)
+        assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    for c in range(5):
+        lk_ref, g_ref = O.likelihood_grad(x, y, thetas[c], corr="Matern52")
+        assert st[c] == 0 and lk[c] == pytest.approx(lk_ref, rel=LK_RTOL)
+        np.testing.assert_allclose(g[c], g_ref, rtol=1e-6, atol=1e-6 * np.abs(g_ref).max())
+
+
+def test_lbfgs_starts_in_lock_step_walk_their_own_trajectories(egx):
+    """egx_gp_fit_lbfgs advances all starts through one likelihood + gradient batch per round: the fitted model is the
+    one the best start reaches alone (each start sees exactly the evaluations it would see alone)."""
+    n, d = 400, 3
+    x, y = _data(n, d, 3)
+    starts = np.array([[0.3, 0.3, 0.3], [2.0, 0.5, 1.0], [0.05, 4.0, 0.7]])
+    lo, hi = [1e-3], [50.0]
+    fits = []
+    for s in range(3):
+        with egx.GpHandle(x, y, corr=0, n_workspaces=1) as h:
+            ne = h.fit_lbfgs(starts[s:s + 1], lo, hi, max_iter=30)
+            inner = h.inner()
+            fits.append((inner["likelihood"], inner["theta"].copy(), ne))
+    with egx.GpHandle(x, y, corr=0, n_workspaces=3) as h:
+        ne = h.fit_lbfgs(starts, lo, hi, max_iter=30)
+        best = int(np.argmax([f[0] for f in fits]))
+        assert ne == sum(f[2] for f in fits)
+        inner = h.inner()
+        assert inner["likelihood"] == fits[best][0]
+        assert np.array_equal(inner["theta"], fits[best][1])
