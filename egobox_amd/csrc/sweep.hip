@@ -777,7 +777,8 @@ int32_t egx_sweep_fit(egx_sweep *sw, const double *theta0s, int64_t n_starts, co
     for (int i = 0; i < h; i++) active[i] = i;
     std::vector<StartResult> results;
     // one critical section on the replica from the first evaluation to the finalized model (the all-gather included: it has
-    // its own deadline), as egx_gp_fit is on a plain handle
+    // its own deadline), as egx_gp_fit is on a plain handle.  Lock order as in egx_sweep_likelihood: the sweep, then its model.
+    std::lock_guard<std::mutex> lock(sw->mu);
     std::unique_lock<std::shared_mutex> glock(gp->mu);
     int local_rc = fit_run_starts(gp, theta0s, active, theta0s, n_starts, lo, hi, bounds_len, max_eval, sw->rank, world, results);
     const std::string local_msg = local_rc ? last_error_string() : std::string();
@@ -794,7 +795,6 @@ int32_t egx_sweep_fit(egx_sweep *sw, const double *theta0s, int64_t n_starts, co
         }
     std::vector<double> all(part.size() * (size_t)world);
     {
-        std::lock_guard<std::mutex> lock(sw->mu);
         (void)set_device(gp);
         const int coll_rc = sweep_allgather_doubles(sw, part.data(), (int64_t)part.size(), all.data());
         if (coll_rc) {
