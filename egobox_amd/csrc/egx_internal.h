@@ -94,6 +94,7 @@ int launch_zero_upper(hipStream_t s, double *M, int64_t ld, int n);
 constexpr int kGradMaxBatch = 16;
 struct GradBatch {
     int count = 1;
+    const double *xs[kGradMaxBatch];     // d x ldx: the inputs times the candidate's coefficients (prescaled form only)
     const double *coef[kGradMaxBatch];   // d x hcols
     const double *gamma[kGradMaxBatch];  // n_pad
     const double *rneg[kGradMaxBatch];   // -R^-1, lower triangle, leading dimension ld
@@ -103,7 +104,7 @@ struct GradBatch {
 };
 int grad_partial_doubles(int nout);
 int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d, int hcols, const double *wabs,
-                      int nout, int64_t ld, const GradBatch &batch);
+                      int nout, int64_t ld, const GradBatch &batch, int prescaled = 0);
 // z (n) <- W y, W upper triangular row-major
 int launch_uptri_gemv(hipStream_t s, const double *W, int64_t ld, int n, const double *y, double *z);
 
@@ -131,6 +132,19 @@ struct PotrfLookahead {
     hipStream_t s2 = nullptr, s3 = nullptr;
     hipEvent_t ev_lu = nullptr, ev_lur = nullptr, ev_panel = nullptr, ev_a = nullptr, ev_b = nullptr;
 };
+// The inverse of the factor riding along the factorisation (theta-gradient): W (n_pad x n_pad, ldw; holds the rows of the
+// identity on entry, launch_identity_rows) becomes C^-T.  As soon as a group of panels is final, the forward block
+// substitution of W's rows through THAT group -- panel solves with the 16 x 16 inverses the diagonal-block kernel left
+// behind, the in-group updates and the update of all later columns -- is enqueued on the stream `sw`, beside the
+// factorisation's own trailing update: the substitution's chip-filling GEMMs hide the factorisation's serial chain (most
+// of all in its last ~5000 columns, where the trailing matrix is small and W's rows are many), and its small launches
+// hide behind the factorisation's big ones.  Same flops as launch_trsm_rows(tri_rows) after the factorisation (n^3/3).
+struct PotrfInverse {
+    double *W = nullptr;
+    int64_t ldw = 0, sW = 0;  // sW: doubles between consecutive matrices' W (lock-step batch)
+    hipStream_t sw = nullptr;
+    hipEvent_t ev_grp = nullptr, ev_done = nullptr;
+};
 // Lock-step batches: `count` matrices of one shape, matrix z at (pointer of matrix 0) + z * stride (elements).  Every
 // kernel of the factorisation takes the batch as grid.z; a matrix gets the same arithmetic alone and in a batch.
 struct GemmBatch {
@@ -151,7 +165,8 @@ struct TrsmBatch {
 };
 // lk == nullptr runs everything in order on s.
 int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
-                 const PotrfLookahead *lk = nullptr, GemmTrace *trace = nullptr, const PotrfBatch *batch = nullptr);
+                 const PotrfLookahead *lk = nullptr, GemmTrace *trace = nullptr, const PotrfBatch *batch = nullptr,
+                 const PotrfInverse *inv = nullptr);
 // rows [0, m) of RT (ld) are right-hand sides: RT <- RT * C^-T  (C = lower factor in M, n_pad cols)
 // tri_rows != 0: the rows are those of the identity (solution upper triangular): zero blocks are skipped
 int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, const double *dinv,

@@ -169,7 +169,9 @@ namespace egx {
 // ---------------------------------------------------------------------------------------------
 // K7, host side: likelihood AND dL/dtheta of k candidates (the reference has no gradient,
 // algorithm.rs:880 ignores `_gradient`).  Per candidate, after the evaluation of the likelihood left the factor C in the
-// workspace:   W = C^-T (rows of the identity through the forward block substitution, n^3/3 flop)
+// workspace:   W = C^-T (rows of the identity through the forward block substitution, n^3/3 flop; round 4: it RIDES ALONG
+//                                          the factorisation, group of panels by group of panels on a stream of its own --
+//                                          PotrfInverse, egx_internal.h)
 //              gamma = W rho                       (one pass over W)
 //              -R^-1 = -(W W^T), lower triangle    (LDS-DMA stream kernel with per-tile K ranges, n^3/3 flop; written
 //                                                   OVER the factor: no second n^2 buffer)
@@ -206,18 +208,12 @@ static int ensure_grad_scratch(egx_gp *gp, int ws_lo, int nuse) {
 
 // the gradient stages of `count` consecutive workspaces from w0 (their factors in place, rho in d_rhs) on stream st;
 // C^-T buffers slot0 .. of slab_W
-static int enqueue_grad_run(egx_gp *gp, hipStream_t st, int w0, int count, int slot0, const double *inv_s2, int hcols) {
+// pre != 0: every candidate of the run has hcols == 1 and positive coefficients -- the trace kernel takes the prescaled form
+static int enqueue_grad_run(egx_gp *gp, hipStream_t st, int w0, int count, int slot0, const double *inv_s2, int hcols, int pre) {
     const int n = gp->n, n_pad = gp->n_pad;
     const int64_t sq = (int64_t)n_pad * n_pad;
     Workspace &lead = gp->ws[w0];
-    double *W0 = gp->slab_W + (int64_t)slot0 * sq;
-    EGX_RC(launch_identity_rows(st, W0, n_pad, n_pad, count, sq));
-    TrsmBatch tb;
-    tb.count = count;
-    tb.sM = gp->stride_M;
-    tb.sD = gp->stride_D;
-    tb.sR = sq;
-    EGX_RC(launch_trsm_rows(st, lead.M, gp->ld, n_pad, lead.dinv, W0, n_pad, n_pad, 1, &tb));
+    double *W0 = gp->slab_W + (int64_t)slot0 * sq;  // C^-T of these candidates: rode along their factorisation
     for (int j = 0; j < count; j++) {
         Workspace &w = gp->ws[w0 + j];
         EGX_RC(launch_uptri_gemv(st, W0 + (int64_t)j * sq, n_pad, n, w.d_rhs, w.d_vec));
@@ -232,6 +228,8 @@ static int enqueue_grad_run(egx_gp *gp, hipStream_t st, int w0, int count, int s
     gb.count = count;
     for (int j = 0; j < count; j++) {
         Workspace &w = gp->ws[w0 + j];
+        if (pre) EGX_RC(launch_scale_rows(st, gp->d_xT, n_pad, gp->d, w.d_coef, w.d_xs));  // (K1 may have taken its LDS-only form)
+        gb.xs[j] = w.d_xs;
         gb.coef[j] = w.d_coef;
         gb.gamma[j] = w.d_vec;
         gb.rneg[j] = w.M;
@@ -240,11 +238,12 @@ static int enqueue_grad_run(egx_gp *gp, hipStream_t st, int w0, int count, int s
         gb.out[j] = w.d_gout;
     }
     for (int j = count; j < kGradMaxBatch; j++) {
-        gb.coef[j] = gb.gamma[j] = gb.rneg[j] = nullptr;
+        gb.xs[j] = gb.coef[j] = gb.gamma[j] = gb.rneg[j] = nullptr;
         gb.inv_s2[j] = 0.0;
         gb.part[j] = gb.out[j] = nullptr;
     }
-    EGX_RC(launch_grad_accum(st, gp->corr, gp->d_xT, n_pad, n, gp->d, hcols, hcols > 1 ? gp->d_wabs : nullptr, nout, gp->ld, gb));
+    EGX_RC(launch_grad_accum(st, gp->corr, gp->d_xT, n_pad, n, gp->d, hcols, hcols > 1 ? gp->d_wabs : nullptr, nout, gp->ld, gb,
+                             pre));
     for (int j = 0; j < count; j++) {
         Workspace &w = gp->ws[w0 + j];
         EGX_HIP_CHECK(hipMemcpyAsync(w.h_gout, w.d_gout, sizeof(double) * nout, hipMemcpyDeviceToHost, st));
@@ -297,7 +296,7 @@ int likelihood_grad_batch_core(egx_gp *gp, const double *thetas, int64_t k, int6
         int phase = 0;  // 0 idle, 1 likelihood in flight, 2 gradient in flight
         std::vector<int64_t> cand;
         std::vector<std::vector<double>> coefs, thfull;
-        std::vector<char> ok;
+        std::vector<char> ok, pre;  // ok: has a gradient; pre: eligible for the prescaled trace kernel
         int hcols = 1;
     };
     std::vector<Slot> slots(nslots);
@@ -326,6 +325,7 @@ int likelihood_grad_batch_core(egx_gp *gp, const double *thetas, int64_t k, int6
                 const int cnt = (int)sl.cand.size();
                 std::vector<double> inv_s2(cnt, 0.0);
                 sl.ok.assign(cnt, 0);
+                sl.pre.assign(cnt, 0);
                 for (int j = 0; j < cnt; j++) {
                     Workspace &w = gp->ws[w0 + j];
                     EvalResult res;
@@ -336,21 +336,27 @@ int likelihood_grad_batch_core(egx_gp *gp, const double *thetas, int64_t k, int6
                     if (res.status != EGX_STATUS_OK || !(res.sigma2n > 0.0) || !std::isfinite(res.lkh)) continue;
                     sl.ok[j] = 1;
                     inv_s2[j] = 1.0 / res.sigma2n;
+                    // the prescaled form divides by the coefficient once per output: a candidate's OWN coefficients decide
+                    // (never its companions': the kernel choice must not depend on the batch)
+                    sl.pre[j] = sl.hcols == 1 ? 1 : 0;
+                    for (double cj : sl.coefs[j])
+                        if (!(cj > 0.0) || !std::isfinite(cj)) sl.pre[j] = 0;
                     if (!res.rho_on_device) {  // host GLS: rho goes back (zero padded)
                         std::memset(w.h_vec, 0, sizeof(double) * gp->n_pad);
                         std::memcpy(w.h_vec, res.rho.data(), sizeof(double) * gp->n);
                         EGX_HIP_CHECK(hipMemcpyAsync(w.d_rhs, w.h_vec, sizeof(double) * gp->n_pad, hipMemcpyHostToDevice, st));
                     }
                 }
-                // maximal runs of consecutive candidates with a gradient: each run is one lock-step launch sequence
+                // maximal runs of consecutive candidates with a gradient (and the same form of the trace kernel): each run is one
+                // lock-step launch sequence
                 for (int j = 0; j < cnt;) {
                     if (!sl.ok[j]) {
                         j++;
                         continue;
                     }
                     int e = j;
-                    while (e < cnt && sl.ok[e]) e++;
-                    EGX_RC(enqueue_grad_run(gp, st, w0 + j, e - j, i * B + j, inv_s2.data() + j, sl.hcols));
+                    while (e < cnt && sl.ok[e] && sl.pre[e] == sl.pre[j]) e++;
+                    EGX_RC(enqueue_grad_run(gp, st, w0 + j, e - j, i * B + j, inv_s2.data() + j, sl.hcols, sl.pre[j]));
                     j = e;
                 }
                 sl.phase = 2;
@@ -371,7 +377,8 @@ int likelihood_grad_batch_core(egx_gp *gp, const double *thetas, int64_t k, int6
                 sl.cand.push_back(c);
             }
             if (!sl.cand.empty()) {
-                EGX_RC(enqueue_eval_group(gp, w0, (int)sl.cand.size(), sl.coefs.data(), sl.hcols));
+                EGX_RC(enqueue_eval_group(gp, w0, (int)sl.cand.size(), sl.coefs.data(), sl.hcols,
+                                          gp->slab_W + (int64_t)(i * B) * gp->n_pad * gp->n_pad));
                 sl.phase = 1;
                 busy++;
             }

@@ -56,6 +56,9 @@ struct Workspace {
     hipStream_t eval_stream = nullptr;  // the stream the evaluation in flight was enqueued on: the workspace's own, or
                                         // the leader's when it rides in a lock-step group (finish_eval waits on it)
     PotrfLookahead lk;  // look-ahead streams + events (lk.s2 == nullptr: look-ahead off)
+    // the stream + events on which C^-T rides along a factorisation (theta-gradient; PotrfInverse, egx_internal.h)
+    hipStream_t inv_stream = nullptr;
+    hipEvent_t ev_inv_grp = nullptr, ev_inv_done = nullptr;
     // M, dinv and d_info are VIEWS into the handle's slabs (egx_gp::slab_*): consecutive workspaces sit at fixed
     // strides, which is what lets a group of them be factored in lock-step by one launch sequence
     double *M = nullptr;       // (m_tot x ld): correlation matrix / factor + appended RHS rows
@@ -183,7 +186,8 @@ int make_coef(const egx_gp *gp, const double *theta, int64_t theta_len, std::vec
               std::vector<double> *theta_full);
 int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coef, int hcols);
 // `count` evaluations on the consecutive workspaces w0 .. w0 + count - 1, factored in lock-step on the streams of w0
-int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> *coefs, int hcols);
+// W0 != nullptr: the `count` buffers W0 + j n_pad^2 receive C^-T of the candidates, riding along the factorisation
+int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> *coefs, int hcols, double *W0 = nullptr);
 int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, int keep);  // 0 scalars, 1 fitted state, 2 rho only
 void record_timings(egx_gp *gp, Workspace &w, double host_ms, double solve_ms);
 bool has_nan(const double *theta, int64_t len);

@@ -55,6 +55,9 @@ static void free_workspace(Workspace &w) {
         if (e) hipEventDestroy(e);
     if (w.lk.s2) hipStreamDestroy(w.lk.s2);
     if (w.lk.s3) hipStreamDestroy(w.lk.s3);
+    if (w.ev_inv_grp) hipEventDestroy(w.ev_inv_grp);
+    if (w.ev_inv_done) hipEventDestroy(w.ev_inv_done);
+    if (w.inv_stream) hipStreamDestroy(w.inv_stream);
     if (w.stream) hipStreamDestroy(w.stream);
     w = Workspace();
 }
@@ -65,6 +68,9 @@ static int alloc_workspace(egx_gp *gp, Workspace &w, int index) {
     w.d_info = gp->slab_I + index;
     EGX_HIP_CHECK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
     w.eval_stream = w.stream;
+    EGX_HIP_CHECK(hipStreamCreateWithFlags(&w.inv_stream, hipStreamNonBlocking));
+    EGX_HIP_CHECK(hipEventCreateWithFlags(&w.ev_inv_grp, hipEventDisableTiming));
+    EGX_HIP_CHECK(hipEventCreateWithFlags(&w.ev_inv_done, hipEventDisableTiming));
     {
         const char *la = std::getenv("EGX_LOOKAHEAD");
         if (!la || la[0] != '0') {
@@ -251,7 +257,7 @@ static void pool_give(egx_gp *gp) {
     gp->ws.clear();
     bool complete = e.slab_M && e.slab_D && e.slab_I && e.d_xT && e.d_rhsT && e.d_gamma && e.d_fit_coef && !e.ws.empty();
     for (auto &w : e.ws) {
-        complete = complete && w.stream && w.trace.ready;
+        complete = complete && w.stream && w.trace.ready && w.inv_stream && w.ev_inv_grp && w.ev_inv_done;
         w.eval_stream = w.stream;
         w.trace.used = 0;
         w.gls_enqueued = false;
@@ -336,9 +342,19 @@ int make_coef(const egx_gp *gp, const double *theta, int64_t theta_len, std::vec
 // ONE factorisation launch sequence for all of them (lock-step batch, kernels_chol.hip) with fused forward solves,
 // diagonal gather, async download of (diag C, ft^T, yt^T, info) per candidate.  All asynchronous on the streams of
 // workspace w0; every member's eval_stream is set to it.
-int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> *coefs, int hcols) {
+int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> *coefs, int hcols, double *W0) {
     Workspace &lead = gp->ws[w0];
     hipStream_t st = lead.stream;
+    PotrfInverse inv;
+    if (W0) {  // theta-gradient: C^-T rides along (identity rows first, on the rider's own stream: it is idle here)
+        inv.W = W0;
+        inv.ldw = gp->n_pad;
+        inv.sW = (int64_t)gp->n_pad * gp->n_pad;
+        inv.sw = lead.inv_stream;
+        inv.ev_grp = lead.ev_inv_grp;
+        inv.ev_done = lead.ev_inv_done;
+        EGX_RC(launch_identity_rows(inv.sw, W0, gp->n_pad, gp->n_pad, count, inv.sW));
+    }
     for (int j = 0; j < count; j++) {
         Workspace &w = gp->ws[w0 + j];
         w.eval_stream = st;
@@ -360,7 +376,7 @@ int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> 
     pb.sD = gp->stride_D;
     pb.sI = 1;
     EGX_RC(launch_potrf(st, lead.M, gp->ld, gp->n_pad, gp->m_tot, lead.dinv, lead.d_info, lead.lk.s2 ? &lead.lk : nullptr,
-                        &lead.trace, &pb));
+                        &lead.trace, &pb, W0 ? &inv : nullptr));
     EGX_HIP_CHECK(hipEventRecord(lead.ev[2], st));
     for (int j = 0; j < count; j++) {
         Workspace &w = gp->ws[w0 + j];
@@ -1089,6 +1105,7 @@ void egx_gp_destroy(egx_gp *gp) {
         if (w.stream) (void)hipStreamSynchronize(w.stream);
         if (w.lk.s2) (void)hipStreamSynchronize(w.lk.s2);
         if (w.lk.s3) (void)hipStreamSynchronize(w.lk.s3);
+        if (w.inv_stream) (void)hipStreamSynchronize(w.inv_stream);
     }
     (void)hipGetLastError();
     pool_give(gp);

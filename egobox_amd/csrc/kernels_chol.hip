@@ -1593,7 +1593,7 @@ int launch_gram_lower(hipStream_t s, const double *W, int64_t ldw, int rows, int
 // batch != nullptr: batch->count matrices in lock-step (matrix z at M + z sM, dinv + z sD, info + z sI); every launch
 // below covers all of them (grid.z), the schedule is the one a single matrix of this size gets.
 int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
-                 const PotrfLookahead *lk, GemmTrace *trace, const PotrfBatch *batch) {
+                 const PotrfLookahead *lk, GemmTrace *trace, const PotrfBatch *batch, const PotrfInverse *inv) {
     if (trace) trace->used = 0;
     int rc = chol_init();
     if (rc) return rc;
@@ -1675,7 +1675,52 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         if (pending) EGX_HIP_CHECK(hipStreamWaitEvent(st, pending, 0));
         return EGX_SUCCESS;
     };
+    // The rows of W = C^-T through the group of panels [g0, g0 + gw), which is final on `s` when this is called (PotrfInverse,
+    // egx_internal.h): on inv->sw, beside whatever the factorisation does next.  Row i of the identity is zero left of
+    // column i, so panel k0 only has the rows [0, k0 + nbk) to solve and the updates as many rows to carry.
+    GemmBatch gbw;
+    if (inv) {
+        gbw.count = (int)nz;
+        gbw.sC = gbw.sA = inv->sW;
+        gbw.sB = pb.sM;
+        gbw.sInfo = pb.sI;
+    }
+    auto inverse_group = [&](int g0, int gw) -> int {
+        if (!inv) return EGX_SUCCESS;
+        hipStream_t sw = inv->sw;
+        EGX_HIP_CHECK(hipEventRecord(inv->ev_grp, s));
+        EGX_HIP_CHECK(hipStreamWaitEvent(sw, inv->ev_grp, 0));
+        const int gend = g0 + gw;
+        for (int k0 = g0; k0 < gend; k0 += kNB) {
+            const int nbk = (gend - k0 < kNB) ? (gend - k0) : kNB;
+            const int m_eff = k0 + nbk;
+            double *P = inv->W + k0;
+            const double *L = M + (int64_t)k0 * ld + k0;
+            const double *lin = dinv + (int64_t)(k0 / 64) * 4096;
+            if (m_eff >= 4096)
+                hipLaunchKernelGGL((k_panel_trsm16<2, false>), dim3(m_eff / 32, 1, nz), dim3(256), 0, sw, P, inv->ldw, L, ld, lin, nbk,
+                                   (const int *)info, inv->sW, pb.sM, pb.sD, pb.sI, (const double *)nullptr);
+            else
+                hipLaunchKernelGGL((k_panel_trsm16<1, false>), dim3(m_eff / 16, 1, nz), dim3(256), 0, sw, P, inv->ldw, L, ld, lin, nbk,
+                                   (const int *)info, inv->sW, pb.sM, pb.sD, pb.sI, (const double *)nullptr);
+            const int ncols = gend - (k0 + nbk);
+            if (ncols > 0) {
+                int rc2 = launch_gemm_nt_sub(sw, inv->W + (k0 + nbk), inv->ldw, inv->W + k0, inv->ldw,
+                                             M + (int64_t)(k0 + nbk) * ld + k0, ld, m_eff, ncols, nbk, 0, 0, nullptr, info, &gbw);
+                if (rc2) return rc2;
+            }
+        }
+        const int ncols = n_pad - gend;
+        if (ncols > 0) {
+            int rc2 = launch_gemm_nt_sub(sw, inv->W + gend, inv->ldw, inv->W + g0, inv->ldw, M + (int64_t)gend * ld + g0, ld, gend,
+                                         ncols, gw, 0, 0, nullptr, info, &gbw);
+            if (rc2) return rc2;
+        }
+        return EGX_SUCCESS;
+    };
     rc = inner_factor(s, 0, gwidth(0), s3, nullptr);
+    if (rc) return rc;
+    rc = inverse_group(0, gwidth(0));
     if (rc) return rc;
     for (int g0 = 0; g0 < n_pad; g0 += GW) {
         const int gw = gwidth(g0);
@@ -1738,6 +1783,12 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             rc = inner_factor(s, r1, gw1, nullptr, nullptr);
             if (rc) return rc;
         }
+        rc = inverse_group(r1, gw1);  // the group that has just become final
+        if (rc) return rc;
+    }
+    if (inv) {  // W is complete; its panel solves read the 16 x 16 inverses the launch below overwrites
+        EGX_HIP_CHECK(hipEventRecord(inv->ev_done, inv->sw));
+        EGX_HIP_CHECK(hipStreamWaitEvent(s, inv->ev_done, 0));
     }
     // every stream has been joined into `s`: the 64x64 tile inverses of the complete factor(s), one launch
     hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64, 1, nz), dim3(256), 0, s, (const double *)M, ld, dinv,

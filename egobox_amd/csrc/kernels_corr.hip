@@ -684,12 +684,39 @@ __device__ __forceinline__ double dlog_dc(double c, double a) {
     return -k5over3 * (a * t) * u * rcp_ge1(__builtin_fma(k5over3 * t, t, u));
 }
 
-template <int CORR, bool HC1, int DK>
+// The same with the coefficient already inside the distance (t = c a; HC1 with every c > 0, inputs prescaled as for K1's
+// scalar-row form): d log r / d c = F(c) G(t) with G below and F = -1/c (sq-exp, abs-exp), -3/c (Matern-3/2),
+// -(5/3)/c (Matern-5/2) applied once per output when the partial sum is written.  One Newton step on v_rcp_f64 (2^-26
+// or better, squared: the last bit of a double; the gradient is asserted at 1e-6).
+__device__ __forceinline__ double rcp_ge1_fast(double m) {
+    const double y = __builtin_amdgcn_rcp(m);
+    return __builtin_fma(__builtin_fma(-m, y, 1.0), y, y);
+}
+template <int CORR>
+__device__ __forceinline__ double dlog_g_scaled(double t) {  // t >= 0
+    if (CORR == EGX_CORR_SQUARED_EXPONENTIAL) return t * t;
+    if (CORR == EGX_CORR_ABSOLUTE_EXPONENTIAL) return t;
+    const double t2 = t * t;
+    if (CORR == EGX_CORR_MATERN32) return t2 * rcp_ge1_fast(__builtin_fma(kSqrt3, t, 1.0));
+    const double u = __builtin_fma(kSqrt5, t, 1.0);
+    return (t2 * u) * rcp_ge1_fast(__builtin_fma(k5over3, t2, u));
+}
+template <int CORR>
+__device__ __forceinline__ double dlog_f_scaled(double c) {
+    if (CORR == EGX_CORR_MATERN32) return -3.0 / c;
+    if (CORR == EGX_CORR_MATERN52) return -k5over3 / c;
+    return -1.0 / c;
+}
+
+// MODE 0: hcols > 1 (KPLS + Matern);  1: hcols == 1, raw inputs;  2: hcols == 1, inputs prescaled per candidate (gb.xs)
+template <int CORR, int MODE, int DK>
 __global__ __launch_bounds__(256) void k_grad_accum(const double *__restrict__ xT, int64_t ldx, int n, int d, int hcols,
                                                     const double *__restrict__ wabs, int nout, int64_t ld, int ntiles,
                                                     int nout_pad, GradBatch gb) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int z = blockIdx.z;
+    constexpr bool HC1 = MODE != 0, PRE = MODE == 2;
+    if (PRE) xT = gb.xs[z];  // this candidate's c_k x_k (k-major like xT)
     const double *__restrict__ coef = gb.coef[z];
     const double *__restrict__ gamma = gb.gamma[z];
     const double *__restrict__ Rneg = gb.rneg[z];
@@ -724,7 +751,10 @@ __global__ __launch_bounds__(256) void k_grad_accum(const double *__restrict__ x
 #pragma unroll
                 for (int a = 0; a < 4; a++)
 #pragma unroll
-                    for (int b = 0; b < 4; b++) pa[a][b].add(vi[a] - vj[b], ck, hcols);
+                    for (int b = 0; b < 4; b++) {
+                        if (PRE) pa[a][b].add_scaled(vi[a] - vj[b]);
+                        else pa[a][b].add(vi[a] - vj[b], ck, hcols);
+                    }
             }
         }
         double wp[4][4];  // 2 R_ij (gamma_i gamma_j / sigma2 - Rinv_ij) for i > j inside the matrix, else 0
@@ -775,7 +805,10 @@ __global__ __launch_bounds__(256) void k_grad_accum(const double *__restrict__ x
 #pragma unroll
                     for (int a = 0; a < 4; a++)
 #pragma unroll
-                        for (int b = 0; b < 4; b++) sacc = __builtin_fma(wp[a][b], dlog_dc<CORR>(c, fabs(vi[a] - vj[b])), sacc);
+                        for (int b = 0; b < 4; b++) {
+                            const double ad = fabs(vi[a] - vj[b]);
+                            sacc = __builtin_fma(wp[a][b], PRE ? dlog_g_scaled<CORR>(ad) : dlog_dc<CORR>(c, ad), sacc);
+                        }
                     acc[oo] = sacc;
                 }
             }
@@ -831,8 +864,11 @@ __global__ __launch_bounds__(256) void k_grad_accum(const double *__restrict__ x
         if ((tid & 63) == 0) red[(tid >> 6) * DK + oo] = v;
     }
     __syncthreads();
-    if (tid < DK && o0 + tid < nout)
-        gb.part[z][(int64_t)blockIdx.x * nout_pad + o0 + tid] = ((red[tid] + red[DK + tid]) + red[2 * DK + tid]) + red[3 * DK + tid];
+    if (tid < DK && o0 + tid < nout) {
+        double v = ((red[tid] + red[DK + tid]) + red[2 * DK + tid]) + red[3 * DK + tid];
+        if (PRE) v *= dlog_f_scaled<CORR>(coef[o0 + tid]);
+        gb.part[z][(int64_t)blockIdx.x * nout_pad + o0 + tid] = v;
+    }
 }
 
 // out[z][o] = sum over the nwg partial vectors, in a fixed order: 256 lanes take every 256th, then a tree in LDS
@@ -1056,8 +1092,9 @@ int grad_partial_doubles(int nout) { return kGradMaxWG * (int)round_up(nout, 32)
 
 // batch.count candidates (grid.z); per candidate: coef (d x hcols), gamma (n_pad), rneg (-R^-1, lower, ld), inv_s2,
 // part (grad_partial_doubles(nout) doubles of scratch), out (nout doubles)
+// prescaled != 0 (hcols == 1, every coefficient > 0): batch.xs[z] holds candidate z's inputs times its coefficients
 int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, int n, int d, int hcols, const double *wabs,
-                      int nout, int64_t ld, const GradBatch &batch) {
+                      int nout, int64_t ld, const GradBatch &batch, int prescaled) {
     if (batch.count < 1 || batch.count > kGradMaxBatch) {
         set_error("grad_accum: batch count out of range");
         return EGX_ERR_INVALID_VALUE;
@@ -1069,17 +1106,19 @@ int launch_grad_accum(hipStream_t s, int corr, const double *xT, int64_t ldx, in
     const int dk = nout <= 8 ? 8 : (nout <= 16 ? 16 : 32);
     const size_t lds = sizeof(double) * (size_t)std::max(2 * dc * 64, 4 * dk);
     const dim3 grid((unsigned)nwg, (unsigned)((nout + dk - 1) / dk), (unsigned)batch.count);
-#define EGX_GA(C_, HC1_, DK_)                                                                                             \
-    hipLaunchKernelGGL((k_grad_accum<C_, HC1_, DK_>), grid, dim3(256), lds, s, xT, ldx, n, d, hcols, wabs, nout, ld, ntiles, \
+#define EGX_GA(C_, MODE_, DK_)                                                                                             \
+    hipLaunchKernelGGL((k_grad_accum<C_, MODE_, DK_>), grid, dim3(256), lds, s, xT, ldx, n, d, hcols, wabs, nout, ld, ntiles, \
                        nout_pad, batch)
-#define EGX_GA_DK(C_, HC1_)                  \
-    if (dk == 8) EGX_GA(C_, HC1_, 8);        \
-    else if (dk == 16) EGX_GA(C_, HC1_, 16); \
-    else EGX_GA(C_, HC1_, 32)
-    if (hcols == 1) {
-        EGX_DISPATCH_CORR(corr, EGX_GA_DK(C_, true));
+#define EGX_GA_DK(C_, MODE_)                  \
+    if (dk == 8) EGX_GA(C_, MODE_, 8);        \
+    else if (dk == 16) EGX_GA(C_, MODE_, 16); \
+    else EGX_GA(C_, MODE_, 32)
+    if (hcols == 1 && prescaled) {
+        EGX_DISPATCH_CORR(corr, EGX_GA_DK(C_, 2));
+    } else if (hcols == 1) {
+        EGX_DISPATCH_CORR(corr, EGX_GA_DK(C_, 1));
     } else {
-        EGX_DISPATCH_CORR(corr, EGX_GA_DK(C_, false));
+        EGX_DISPATCH_CORR(corr, EGX_GA_DK(C_, 0));
     }
 #undef EGX_GA_DK
 #undef EGX_GA

@@ -1173,12 +1173,16 @@ def test_device_allocation_failure_is_an_error_not_a_crash(egx):
         h.likelihood([5.0])
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info()
+    assert egx.pool_stats()["cached_bytes"] > 0  # the closed handle's resources sit in the pool
     with pytest.raises(egx.EgxError) as ei:
         egx.GpHandle(x, y)
-    assert ei.value.rc == egx._lib.ERR_HIP and "hipMalloc" in str(ei.value)
+    assert ei.value.rc == egx._lib.ERR_HIP and "out of memory" in str(ei.value)
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
-    assert abs(free0 - free1) < 64 << 20
+    assert free0 - free1 < 64 << 20  # nothing leaked ...
+    # ... and before it reported out-of-memory the library gave back what it held itself (round 3's pool kept up to 48 GB
+    # through such a failure: ADVICE r3)
+    assert egx.pool_stats()["cached_bytes"] == 0
     with egx.GpHandle(x[:300], y[:300], corr=3) as h:  # still alive
         assert h.likelihood([5.0])[1] == 0
 
