@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""A/B of run-time knobs inside ONE process (egx_set_tuning): the sweep's throughput (24 candidates in flight as three
+lock-step groups of eight, 48 candidates per measurement) and one lock-step group's per-launch trailing-update rate
+(lur_side = 0), for each setting of one knob, interleaved over several rounds.
+
+    python tools/ab_knobs.py stream_walk 0 1 [--rounds 3] [--n 16384] [--d 32]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import egobox_amd as egx  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("knob")
+ap.add_argument("values", type=int, nargs="+")
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--n", type=int, default=16384)
+ap.add_argument("--d", type=int, default=32)
+ap.add_argument("--in-flight", type=int, default=24)
+ap.add_argument("--cands", type=int, default=48)
+ap.add_argument("--no-group", action="store_true")
+a = ap.parse_args()
+x, y = egx.workload.make_training_set(a.n, a.d, 42)
+base = egx.workload.default_theta(a.d)
+rng = np.random.default_rng(3)
+h = egx.GpHandle(x, y, corr=0, n_workspaces=a.in_flight)
+cands = base * 10.0 ** rng.uniform(-0.15, 0.15, size=(a.cands, a.d))
+h.likelihood_batch(cands[: a.in_flight])
+res = {v: [] for v in a.values}
+grp = {v: [] for v in a.values}
+for r in range(a.rounds):
+    for v in a.values:
+        egx.set_tuning(a.knob, v)
+        t0 = time.perf_counter()
+        lk, st = h.likelihood_batch(cands * (1.0 + 1e-3 * r))
+        res[v].append(a.cands / (time.perf_counter() - t0))
+h.close()
+if not a.no_group:
+    g = egx.GpHandle(x, y, corr=0, n_workspaces=8)
+    g.set_lockstep(8)
+    egx.set_tuning("lur_side", 0)
+    ths = np.stack([base * (1.0 + 0.01 * c) for c in range(8)])
+    g.likelihood_batch(ths)
+    for r in range(a.rounds):
+        for v in a.values:
+            egx.set_tuning(a.knob, v)
+            g.likelihood_batch(ths * (1.0 + 1e-3 * r))
+            t = g.timings()
+            grp[v].append((t["syrk_flops"] / t["potrf_syrk_ms"] / 1e9, t["potrf_ms"]))
+    g.close()
+for v in a.values:
+    line = f"{a.knob} = {v}: sweep fits/s {' '.join(f'{q:.2f}' for q in res[v])} (mean {np.mean(res[v]):.2f})"
+    if grp[v]:
+        line += (f"; group of 8 trailing-update launches TFLOP/s {' '.join(f'{q[0]:.2f}' for q in grp[v])}, "
+                 f"group potrf ms {' '.join(f'{q[1]:.1f}' for q in grp[v])}")
+    print(line, flush=True)
