@@ -104,6 +104,11 @@ SIGNATURES = [
     ("egx_gmx_precisions_chol", C.c_int32, [c_double_p, C.c_int64, C.c_int64, c_double_p]),
     ("egx_gmx_predict_probas", C.c_int32, [C.c_int32, c_double_p, c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_double,
                                            c_double_p, C.c_int64, c_double_p]),
+    ("egx_gmx_predict_probas_derivatives", C.c_int32, [C.c_int32, c_double_p, c_double_p, c_double_p, C.c_int64, C.c_int64,
+                                                       C.c_double, c_double_p, C.c_int64, c_double_p]),
+    ("egx_moe_predict_valvar_gradients", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), c_int32_p, C.c_int64, C.c_int64,
+                                                     c_double_p, c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_int32,
+                                                     c_double_p, c_double_p]),
     ("egx_gp_last_timings", C.c_int32, [C.c_void_p, C.POINTER(Timings)]),
     ("egx_mfma_probe", C.c_int32, [c_double_p]),
     ("egx_sgp_config_default", None, [C.POINTER(SgpConfig)]),

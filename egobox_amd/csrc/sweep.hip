@@ -280,6 +280,56 @@ __global__ __launch_bounds__(64) void k_gmx_probas(const double *__restrict__ xq
     const double norm = (fabs(s) < 2.220446049250313e-16) ? 0.0 : log(s);
     for (int c = 0; c < k; c++) out[c] = exp(out[c] - norm);
 }
+
+// GaussianMixture::predict_probas_derivatives (crates/moe/src/gaussian_mixture.rs:127-170), one lane per point:
+//   u_c = w_c pdf_c(x),  v = sum_c u_c,  deriv_c = (x - mu_c) precisions_c / hf,  u'_c = -deriv_c u_c,  v' = sum_c u'_c
+//   d p_c / d x = (u'_c v - u_c v') / v^2
+// With the scaled factor P' = precisions_chol_c hf^-1/2 (what pdfs() itself uses, :253-283): z = (x - mu_c) P' gives both the
+// quadratic form |z|^2 of the pdf and deriv_c = z P'^T (precisions = P P^T, :208-217).  Pass A writes u'_c to the output and
+// accumulates v, v'; pass B finishes the output in place.  Per-lane scratch (x, z, v': d each; u: k) lives in LDS.
+__global__ __launch_bounds__(64) void k_gmx_probas_deriv(const double *__restrict__ xq, int64_t m, int d, int k,
+                                                        const double *__restrict__ means, const double *__restrict__ precs,
+                                                        const double *__restrict__ par, double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int64_t q0 = (int64_t)blockIdx.x * 64;
+    const int lane = threadIdx.x, ds = d | 1, ks = k | 1;
+    const int rows = (int)((m - q0 < 64) ? (m - q0) : 64);
+    double *xs = sm, *zs = sm + 64 * ds, *vps = zs + 64 * ds, *us = vps + 64 * ds;
+    for (int e = lane; e < rows * d; e += 64) {
+        const int i = e / d, j = e - i * d;
+        xs[i * ds + j] = xq[q0 * d + e];
+    }
+    __syncthreads();
+    if (lane >= rows) return;
+    const double *x = xs + lane * ds;
+    double *z = zs + lane * ds, *vp = vps + lane * ds, *u = us + lane * ks;
+    double *o = out + (q0 + lane) * (int64_t)k * d;
+    for (int l = 0; l < d; l++) vp[l] = 0.0;
+    double v = 0.0;
+    for (int c = 0; c < k; c++) {
+        const double *mu = means + (size_t)c * d, *P = precs + (size_t)c * d * d;
+        double q = 0.0;
+        for (int j = 0; j < d; j++) {
+            double acc = 0.0;
+            for (int i = 0; i < d; i++) acc = __builtin_fma(x[i] - mu[i], P[(size_t)i * d + j], acc);
+            z[j] = acc;
+            q = __builtin_fma(acc, acc, q);
+        }
+        const double uc = exp(par[c] - 0.5 * q);  // w_c pdf_c(x)  (:136-139: no MIN_10_EXP guard on this path)
+        u[c] = uc;
+        v += uc;
+        for (int l = 0; l < d; l++) {
+            double acc = 0.0;
+            for (int j = 0; j < d; j++) acc = __builtin_fma(z[j], P[(size_t)l * d + j], acc);
+            const double up = -acc * uc;
+            o[(int64_t)c * d + l] = up;
+            vp[l] += up;
+        }
+    }
+    const double v2 = v * v;
+    for (int c = 0; c < k; c++)
+        for (int l = 0; l < d; l++) o[(int64_t)c * d + l] = (o[(int64_t)c * d + l] * v - u[c] * vp[l]) / v2;
+}
 }  // namespace egx
 
 extern "C" {
@@ -914,6 +964,219 @@ int32_t egx_gmx_predict_probas(int32_t device, const double *weights, const doub
                        d_p.p, d_par.p, d_out.p);
     EGX_HIP_CHECK(hipGetLastError());
     EGX_HIP_CHECK(hipMemcpy(probas, d_out.p, sizeof(double) * (size_t)m * k, hipMemcpyDeviceToHost));
+    return EGX_SUCCESS;
+}
+
+int32_t egx_gmx_predict_probas_derivatives(int32_t device, const double *weights, const double *means,
+                                           const double *precisions_chol, int64_t k, int64_t d, double heaviside_factor,
+                                           const double *xq, int64_t m, double *dprobas) {
+    if (!weights || !means || !precisions_chol || k < 1 || d < 1 || m < 0 || (m > 0 && (!xq || !dprobas)) ||
+        !(heaviside_factor > 0.0)) {
+        set_error("egx_gmx_predict_probas_derivatives: bad arguments");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (m == 0) return EGX_SUCCESS;
+    const size_t lds = sizeof(double) * 64 * (size_t)(3 * (d | 1) + (k | 1));
+    if (lds > 160 * 1024) {
+        set_error("egx_gmx_predict_probas_derivatives: d / k too large for one workgroup's LDS (3 d + k <= 320)");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+        (void)hipGetLastError();
+        set_error("egx_gmx_predict_probas_derivatives: no HIP device");
+        return EGX_ERR_NO_DEVICE;
+    }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+    if (device >= ndev) {
+        set_error("egx_gmx_predict_probas_derivatives: device out of range");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    EGX_HIP_CHECK(hipSetDevice(device));
+    const double factor = std::pow(heaviside_factor, -0.5);
+    std::vector<double> precs((size_t)k * d * d), par(k);
+    const double cst = (double)d * std::log(2.0 * M_PI);
+    for (int64_t c = 0; c < k; c++) {
+        double ld = 0.0;
+        for (int64_t i = 0; i < d * d; i++) precs[(size_t)c * d * d + i] = precisions_chol[(size_t)c * d * d + i] * factor;
+        for (int64_t i = 0; i < d; i++) ld += std::log(precs[(size_t)c * d * d + i * d + i]);
+        par[c] = (-0.5 * cst + ld) + std::log(weights[c]);
+    }
+    egx::DevBuf d_x, d_mu, d_p, d_par, d_out;
+    EGX_RC(d_x.alloc((size_t)m * d));
+    EGX_RC(d_mu.alloc((size_t)k * d));
+    EGX_RC(d_p.alloc(precs.size()));
+    EGX_RC(d_par.alloc(k));
+    EGX_RC(d_out.alloc((size_t)m * k * d));
+    EGX_HIP_CHECK(hipMemcpy(d_x.p, xq, sizeof(double) * (size_t)m * d, hipMemcpyHostToDevice));
+    EGX_HIP_CHECK(hipMemcpy(d_mu.p, means, sizeof(double) * (size_t)k * d, hipMemcpyHostToDevice));
+    EGX_HIP_CHECK(hipMemcpy(d_p.p, precs.data(), sizeof(double) * precs.size(), hipMemcpyHostToDevice));
+    EGX_HIP_CHECK(hipMemcpy(d_par.p, par.data(), sizeof(double) * k, hipMemcpyHostToDevice));
+    if (lds > 64 * 1024)
+        EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&egx::k_gmx_probas_deriv),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(egx::k_gmx_probas_deriv, dim3((unsigned)((m + 63) / 64)), dim3(64), lds, 0, d_x.p, m, (int)d, (int)k,
+                       d_mu.p, d_p.p, d_par.p, d_out.p);
+    EGX_HIP_CHECK(hipGetLastError());
+    EGX_HIP_CHECK(hipMemcpy(dprobas, d_out.p, sizeof(double) * (size_t)m * k * d, hipMemcpyDeviceToHost));
+    return EGX_SUCCESS;
+}
+
+// GpMixture::predict_gradients_smooth / predict_var_gradients_smooth (crates/moe/src/algorithm.rs:691-783):
+//     d val / dx = sum_e p_e grad y_e + p'_e y_e ,   d var / dx = sum_e p_e^2 grad v_e + 2 p_e p'_e v_e
+// and predict_gradients_hard / predict_var_gradients_hard (:942-1010): the gradient of the expert of argmax_e p_e.  The
+// reference calls every expert once per ROW; here every expert gets ONE batched call per quantity on its points (all of
+// them in smooth mode, its cluster's in hard mode).  Sharded exactly like egx_moe_predict_valvar: a rank's partial
+// (m x d) sums over ITS experts -- two experts in flight, even / odd local experts into separate partial sums that are
+// added in a fixed order -- one all-gather, the sum over ranks in rank order (the same bits on every rank).
+int32_t egx_moe_predict_valvar_gradients(egx_sweep *sw, egx_gp *const *experts, const int32_t *expert_ids, int64_t n_local,
+                                         int64_t n_experts, const double *probas, const double *dprobas, const double *xq,
+                                         int64_t m, int64_t d, int32_t smooth, double *grad_val, double *grad_var) {
+    if (n_local < 0 || n_experts < 1 || m < 0 || d < 1 || (m > 0 && (!probas || !xq)) || (n_local > 0 && (!experts || !expert_ids)) ||
+        (!grad_val && !grad_var) || (smooth && n_experts > 1 && m > 0 && !dprobas)) {
+        set_error("egx_moe_predict_valvar_gradients: bad arguments (the smooth recombination of more than one expert needs dprobas)");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (!sw && n_local != n_experts) {
+        set_error("egx_moe_predict_valvar_gradients: without a sweep handle (single process) every expert must be local");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    if (m == 0) return EGX_SUCCESS;
+    const size_t md = (size_t)m * d;
+    int local_rc = EGX_SUCCESS;
+    std::string local_msg;
+    std::vector<double> part(2 * md + 1, 0.0);  // [status | grad val (m x d) | grad var (m x d)]
+    for (int64_t e = 0; e < n_local && !local_rc; e++)
+        if (!experts[e] || expert_ids[e] < 0 || expert_ids[e] >= n_experts) {
+            local_msg = "egx_moe_predict_valvar_gradients: NULL expert handle or expert id out of range";
+            local_rc = EGX_ERR_INVALID_VALUE;
+        }
+    std::vector<int32_t> cluster;
+    if (!smooth && !local_rc) {
+        cluster.resize(m);
+        for (int64_t a = 0; a < m; a++) {
+            const double *pa = probas + a * n_experts;
+            int32_t best = 0;
+            for (int32_t j = 1; j < n_experts; j++)
+                if (pa[j] > pa[best]) best = j;
+            cluster[a] = best;
+        }
+    }
+    if (!local_rc) {
+        std::mutex acc_mu;
+        // worker w takes the local experts w, w + 2, ... into its own partial sums (tv, tw)
+        auto worker = [&](int64_t first, double *tv, double *tw) {
+            std::vector<double> xs, gy, gv, ys, vs;
+            std::vector<int64_t> idx;
+            for (int64_t e = first; e < n_local; e += 2) {
+                {
+                    std::lock_guard<std::mutex> l(acc_mu);
+                    if (local_rc) return;
+                }
+                const int32_t g = expert_ids[e];
+                const double *xin = xq;
+                int64_t me = m;
+                if (!smooth) {
+                    idx.clear();
+                    for (int64_t a = 0; a < m; a++)
+                        if (cluster[a] == g) idx.push_back(a);
+                    me = (int64_t)idx.size();
+                    if (me == 0) continue;
+                    xs.resize((size_t)me * d);
+                    for (int64_t i = 0; i < me; i++) std::memcpy(&xs[(size_t)i * d], xq + idx[i] * d, sizeof(double) * d);
+                    xin = xs.data();
+                }
+                int rc = EGX_SUCCESS;
+                if (grad_val) gy.resize((size_t)me * d);
+                if (grad_var) gv.resize((size_t)me * d);
+                if (grad_val && grad_var) rc = egx_gp_predict_valvar_gradients(experts[e], xin, me, gy.data(), gv.data());
+                else if (grad_val) rc = egx_gp_predict_gradients(experts[e], xin, me, gy.data());
+                else rc = egx_gp_predict_var_gradients(experts[e], xin, me, gv.data());
+                const bool need_pp = smooth && n_experts > 1;  // the p' terms need the experts' values too
+                if (!rc && need_pp) {
+                    if (grad_val) ys.resize(me);
+                    if (grad_var) vs.resize(me);
+                    if (grad_val && grad_var) rc = egx_gp_predict_valvar(experts[e], xin, me, ys.data(), vs.data());
+                    else if (grad_val) rc = egx_gp_predict(experts[e], xin, me, ys.data());
+                    else rc = egx_gp_predict_var(experts[e], xin, me, vs.data());
+                }
+                if (rc) {
+                    std::lock_guard<std::mutex> l(acc_mu);
+                    if (!local_rc) {
+                        local_rc = rc;
+                        local_msg = last_error_string();
+                    }
+                    return;
+                }
+                if (smooth) {
+                    for (int64_t a = 0; a < m; a++) {
+                        const double p = probas[a * n_experts + g];
+                        const double *pp = need_pp ? dprobas + ((size_t)a * n_experts + g) * d : nullptr;
+                        for (int64_t j = 0; j < d; j++) {
+                            if (grad_val) tv[a * d + j] += gy[a * d + j] * p + (pp ? pp[j] * ys[a] : 0.0);
+                            if (grad_var) tw[a * d + j] += gv[a * d + j] * (p * p) + (pp ? 2.0 * p * pp[j] * vs[a] : 0.0);
+                        }
+                    }
+                } else {
+                    for (int64_t i = 0; i < me; i++) {  // disjoint rows: no sums
+                        if (grad_val) std::memcpy(tv + idx[i] * d, &gy[(size_t)i * d], sizeof(double) * d);
+                        if (grad_var) std::memcpy(tw + idx[i] * d, &gv[(size_t)i * d], sizeof(double) * d);
+                    }
+                }
+            }
+        };
+        double *pv = part.data() + 1, *pw = pv + md;
+        if (n_local > 1) {
+            std::vector<double> part2(smooth ? 2 * md : 0, 0.0);
+            // smooth: worker B accumulates into its own vectors (a fixed order of additions); hard: rows are disjoint
+            double *bv = smooth ? part2.data() : pv, *bw = smooth ? part2.data() + md : pw;
+            std::thread tb(worker, (int64_t)1, bv, bw);
+            worker(0, pv, pw);
+            tb.join();
+            if (smooth)
+                for (size_t i = 0; i < md; i++) {
+                    pv[i] += part2[i];
+                    pw[i] += part2[md + i];
+                }
+        } else {
+            worker(0, pv, pw);
+        }
+    }
+    part[0] = local_rc ? -(double)(kSweepPoison + local_rc) : 0.0;
+    const int world = sw ? sw->world : 1;
+    std::vector<double> all;
+    const double *src = part.data();
+    if (sw) {
+        std::lock_guard<std::mutex> lock(sw->mu);
+        all.resize(part.size() * (size_t)world);
+        (void)set_device(sw->gp);
+        const int coll_rc = sweep_allgather_doubles(sw, part.data(), (int64_t)part.size(), all.data());
+        if (coll_rc) {
+            if (local_rc) set_error(local_msg + " (and the collective failed: " + last_error_string() + ")");
+            return local_rc ? local_rc : coll_rc;
+        }
+        src = all.data();
+    }
+    if (local_rc) {
+        set_error(local_msg);
+        return local_rc;
+    }
+    for (int r = 0; r < world; r++)
+        if (src[(size_t)r * part.size()] != 0.0) {
+            set_error("egx_moe_predict_valvar_gradients: rank " + std::to_string(r) + " failed with egx_rc " +
+                      std::to_string((int)(-src[(size_t)r * part.size()]) - kSweepPoison));
+            return EGX_ERR_PEER;
+        }
+    for (size_t i = 0; i < md; i++) {
+        double sv = 0.0, sw2 = 0.0;
+        for (int r = 0; r < world; r++) {
+            const double *pr = src + (size_t)r * part.size() + 1;
+            sv += pr[i];
+            sw2 += pr[md + i];
+        }
+        if (grad_val) grad_val[i] = sv;
+        if (grad_var) grad_var[i] = sw2;
+    }
     return EGX_SUCCESS;
 }
 

@@ -12,7 +12,9 @@ Differences that matter on a GPU: the reference's hard recombination calls the e
 1 x nx batch (each a full n^2 triangular solve for the variance); here queries are routed once and every
 expert gets one batched call on its subset.  With several GPUs expert e lives on rank e mod G
 (BASELINE config 5) and one all-reduce of the weighted vectors replaces the fold over experts.
-The mixture algebra is k x nx x nx host arithmetic (numpy); every GP evaluation runs on the GPU.
+With GPU experts the recombinations of values, variances AND their x-gradients, the responsibilities and their
+derivatives run inside libegx_gp_hip.so (egx_moe_predict_valvar, egx_moe_predict_valvar_gradients,
+egx_gmx_predict_probas(_derivatives)); the numpy forms below serve duck-typed experts and the CPU tests.
 """
 from __future__ import annotations
 
@@ -83,6 +85,19 @@ class GaussianMixture:
                                            L.dptr(np.ascontiguousarray(self.means)),
                                            L.dptr(np.ascontiguousarray(self.precisions_chol)), k, nx,
                                            self.heaviside_factor, L.dptr(x), x.shape[0], L.dptr(out)))
+        return out
+
+    def predict_probas_derivatives_device(self, x, device=-1):
+        """d p_c / d x, (m, k, nx), from the library (egx_gmx_predict_probas_derivatives, one lane per point on the GPU)."""
+        from . import _lib as L
+        lib = L.load()
+        x = np.ascontiguousarray(np.atleast_2d(np.asarray(x, dtype=np.float64)))
+        k, nx = self.means.shape
+        out = np.empty((x.shape[0], k, nx))
+        L.check(lib.egx_gmx_predict_probas_derivatives(int(device), L.dptr(np.ascontiguousarray(self.weights)),
+                                                       L.dptr(np.ascontiguousarray(self.means)),
+                                                       L.dptr(np.ascontiguousarray(self.precisions_chol)), k, nx,
+                                                       self.heaviside_factor, L.dptr(x), x.shape[0], L.dptr(out)))
         return out
 
     def predict(self, x):
@@ -226,12 +241,43 @@ class GpMixture:
     def predict_var(self, x):
         return self.predict_valvar(x, False, True)[1]
 
+    def _predict_valvar_gradients_library(self, x, lib_handles, want_val, want_var):
+        import ctypes as C
+        from . import _lib as L
+        lib = L.load()
+        ids, hs = lib_handles
+        m, d = x.shape
+        k = len(self.experts)
+        smooth = self.recombination == "smooth"
+        dev = getattr(self.gmx, "predict_probas_device", None)
+        probas = np.ascontiguousarray(dev(x) if dev is not None else self.gmx.predict_probas(x), dtype=np.float64)
+        dprobas = None
+        if smooth and k > 1:
+            ddev = getattr(self.gmx, "predict_probas_derivatives_device", None)
+            dprobas = np.ascontiguousarray(ddev(x) if ddev is not None else self.gmx.predict_probas_derivatives(x),
+                                           dtype=np.float64)
+        harr = (C.c_void_p * max(1, len(hs)))(*[h.value if hasattr(h, "value") else h for h in hs])
+        iarr = np.asarray(ids, dtype=np.int32)
+        gy = np.empty((m, d)) if want_val else None
+        gv = np.empty((m, d)) if want_var else None
+        L.check(lib.egx_moe_predict_valvar_gradients(self.sweep._h if self.sweep is not None else None, harr,
+                                                     iarr.ctypes.data_as(L.c_int32_p), len(hs), k, L.dptr(probas),
+                                                     L.dptr(dprobas) if dprobas is not None else None, L.dptr(x), m, d,
+                                                     1 if smooth else 0, L.dptr(gy) if want_val else None,
+                                                     L.dptr(gv) if want_var else None))
+        return (gy if want_val else np.zeros((m, d))), (gv if want_var else np.zeros((m, d)))
+
     def predict_valvar_gradients(self, x, want_val=True, want_var=True):
         """crates/moe/src/algorithm.rs:691-783 (smooth), :942-1010 (hard) -> ((m, nx), (m, nx)).
         smooth:  d mean = sum_i p_i grad y_i + p'_i y_i ;  d var = sum_i p_i^2 grad v_i + 2 p_i p'_i v_i.
-        Every expert gets ONE batched call per quantity (the reference calls it once per row)."""
-        x = np.atleast_2d(np.asarray(x, dtype=np.float64))
+        Every expert gets ONE batched call per quantity (the reference calls it once per row).  With GPU experts the
+        recombination runs inside the library (egx_moe_predict_valvar_gradients, round 4); the numpy fold below serves
+        duck-typed experts (the CPU tests)."""
+        x = np.ascontiguousarray(np.atleast_2d(np.asarray(x, dtype=np.float64)))
         m, nx = x.shape
+        lib_handles = self._library_handles()
+        if lib_handles is not None and m > 0:
+            return self._predict_valvar_gradients_library(x, lib_handles, want_val, want_var)
         gy, gv = np.zeros((m, nx)), np.zeros((m, nx))
         smooth = self.recombination == "smooth"
         if smooth:

@@ -345,6 +345,24 @@ int32_t egx_gmx_precisions_chol(const double *covariances, int64_t k, int64_t d,
 int32_t egx_gmx_predict_probas(int32_t device, const double *weights, const double *means, const double *precisions_chol,
                                int64_t k, int64_t d, double heaviside_factor, const double *xq, int64_t m, double *probas);
 
+/* d p_c(x) / d x of those responsibilities: GaussianMixture::predict_probas_derivatives (gaussian_mixture.rs:127-170),
+ * dprobas is (m x k x d) row-major; on the device, one lane per point (needs 3 d + k <= 320). */
+int32_t egx_gmx_predict_probas_derivatives(int32_t device, const double *weights, const double *means,
+                                           const double *precisions_chol, int64_t k, int64_t d, double heaviside_factor,
+                                           const double *xq, int64_t m, double *dprobas /*m*k*d*/);
+/* x-gradients of the mixture's mean and variance: GpMixture::predict_gradients_smooth / predict_var_gradients_smooth
+ * (crates/moe/src/algorithm.rs:691-783:  sum_e p_e grad y_e + p'_e y_e ,  sum_e p_e^2 grad v_e + 2 p_e p'_e v_e) and
+ * predict_gradients_hard / predict_var_gradients_hard (:942-1010: the expert of argmax_e p_e) -- what EGO's infill
+ * optimiser asks of a mixture surrogate.  Arguments and sharding as egx_moe_predict_valvar (a rank passes its own
+ * experts; one all-gather of the partial (m x d) sums, added in rank order); dprobas (m x n_experts x d, from
+ * egx_gmx_predict_probas_derivatives) is read in smooth mode only and may be NULL for a single expert.  grad_val /
+ * grad_var are (m x d) row-major in original units; either may be NULL.  Every expert gets ONE batched call per
+ * quantity (the reference calls it once per row). */
+int32_t egx_moe_predict_valvar_gradients(egx_sweep *sw, egx_gp *const *experts, const int32_t *expert_ids, int64_t n_local,
+                                         int64_t n_experts, const double *probas /*m*n_experts*/,
+                                         const double *dprobas /*m*n_experts*d*/, const double *xq /*m*d*/, int64_t m,
+                                         int64_t d, int32_t smooth, double *grad_val /*m*d*/, double *grad_var /*m*d*/);
+
 /* ---- measurement ------------------------------------------------------------
  * HIP-event durations (ms) of the stages of the most recent likelihood /
  * finalize call on workspace 0, measured on the stream the kernels ran on. */

@@ -274,6 +274,24 @@ inline std::pair<std::vector<double>, std::vector<double>> moe_predict_valvar(co
     return {std::move(val), std::move(var)};
 }
 
+// GpMixture::predict_gradients / predict_var_gradients (crates/moe/src/algorithm.rs:691-783 smooth, :942-1010 hard) over
+// fitted experts of THIS process: dprobas (m x n_experts x d, GaussianMixture::predict_probas_derivatives) is read by the
+// smooth recombination only.  Returns (d val / dx, d var / dx), each (m x d) row-major.
+inline std::pair<std::vector<double>, std::vector<double>> moe_predict_valvar_gradients(
+    const std::vector<const GaussianProcess *> &experts, const double *probas, const double *dprobas, const double *xq, int64_t m,
+    int64_t d, bool smooth) {
+    std::vector<egx_gp *> hs;
+    std::vector<int32_t> ids;
+    for (size_t e = 0; e < experts.size(); e++) {
+        hs.push_back(experts[e]->handle());
+        ids.push_back((int32_t)e);
+    }
+    std::vector<double> gy((size_t)(m * d)), gv((size_t)(m * d));
+    check(egx_moe_predict_valvar_gradients(nullptr, hs.data(), ids.data(), (int64_t)hs.size(), (int64_t)hs.size(), probas, dprobas,
+                                           xq, m, d, smooth ? 1 : 0, gy.data(), gv.data()));
+    return {std::move(gy), std::move(gv)};
+}
+
 // device resources destroyed models left in the library's pool (a model of the same shape created next reuses them)
 inline int64_t trim() { return egx_trim(); }  // bytes freed
 struct PoolStats { int64_t cached_bytes = 0, hits = 0, misses = 0; };

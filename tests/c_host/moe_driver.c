@@ -102,6 +102,58 @@ int main(void) {
             ok = 0;
         }
     }
+    /* the x-gradients of both recombinations (crates/moe/src/algorithm.rs:691-783 smooth, :942-1010 hard) against the same
+     * formulas applied to the experts' own egx_gp_predict_valvar_gradients outputs; p' of the closed-form responsibilities */
+    {
+        static double gye[K][M * D], gve[K][M * D], dprobas[M * K * D], gval[M * D], gvar[M * D], gval2[M * D], gvar2[M * D];
+        for (int e = 0; e < K; e++) CHECK(egx_gp_predict_valvar_gradients(experts[e], xq, M, gye[e], gve[e]));
+        for (int a = 0; a < M; a++) {
+            /* p_e = g_e / s, g_e = exp(-2 (x0 - c_e)^2):  d p_e / d x0 = p_e (-4 (x0 - c_e) - sum_f p_f (-4 (x0 - c_f))), d / d x1 = 0 */
+            double mean_dl = 0.0;
+            for (int e = 0; e < K; e++) mean_dl += probas[a * K + e] * (-4.0 * (xq[a * D] - (e + 0.5)));
+            for (int e = 0; e < K; e++) {
+                dprobas[(a * K + e) * D] = probas[a * K + e] * (-4.0 * (xq[a * D] - (e + 0.5)) - mean_dl);
+                dprobas[(a * K + e) * D + 1] = 0.0;
+            }
+        }
+        for (int smooth = 0; smooth <= 1; smooth++) {
+            CHECK(egx_moe_predict_valvar_gradients(NULL, experts, ids, K, K, probas, dprobas, xq, M, D, smooth, gval, gvar));
+            CHECK(egx_moe_predict_valvar_gradients(sw, experts, ids, K, K, probas, dprobas, xq, M, D, smooth, gval2, gvar2));
+            double worst = 0.0, scale_y = 1e-300, scale_v = 1e-300;
+            for (int e = 0; e < K; e++)
+                for (int i = 0; i < M * D; i++) {
+                    if (fabs(gye[e][i]) > scale_y) scale_y = fabs(gye[e][i]);
+                    if (fabs(gve[e][i]) > scale_v) scale_v = fabs(gve[e][i]);
+                }
+            for (int a = 0; a < M; a++)
+                for (int j = 0; j < D; j++) {
+                    double wy = 0.0, wv = 0.0;
+                    if (smooth) {
+                        for (int e = 0; e < K; e++) {
+                            const double p = probas[a * K + e], pp = dprobas[(a * K + e) * D + j];
+                            wy += p * gye[e][a * D + j] + pp * ye[e][a];
+                            wv += p * p * gve[e][a * D + j] + 2.0 * p * pp * ve[e][a];
+                        }
+                    } else {
+                        int best = 0;
+                        for (int e = 1; e < K; e++)
+                            if (probas[a * K + e] > probas[a * K + best]) best = e;
+                        wy = gye[best][a * D + j];
+                        wv = gve[best][a * D + j];
+                    }
+                    const double ey = fabs(gval[a * D + j] - wy) / scale_y, ev = fabs(gvar[a * D + j] - wv) / scale_v;
+                    if (ey > worst) worst = ey;
+                    if (ev > worst) worst = ev;
+                    if (gval[a * D + j] != gval2[a * D + j] || gvar[a * D + j] != gvar2[a * D + j]) ok = 0;
+                }
+            if (worst > 1e-8) {
+                fprintf(stderr, "gradients, smooth %d: worst deviation from the recombination formula %.3e\n", smooth, worst);
+                ok = 0;
+            }
+        }
+        ok = ok && egx_moe_predict_valvar_gradients(NULL, experts, ids, K, K, probas, NULL, xq, M, D, 1, gval, gvar) == EGX_ERR_INVALID_VALUE;
+        CHECK(egx_moe_predict_valvar_gradients(NULL, experts, ids, K, K, probas, NULL, xq, M, D, 0, gval2, NULL));
+    }
     /* only one of the outputs; a rank that owns no expert; bad arguments */
     CHECK(egx_moe_predict_valvar(NULL, experts, ids, K, K, probas, xq, M, D, 1, val2, NULL));
     for (int a = 0; a < M; a++) ok = ok && val2[a] == val[a];
@@ -110,6 +162,7 @@ int main(void) {
     egx_sweep_destroy(sw);
     for (int e = 0; e < K; e++) egx_gp_destroy(experts[e]);
     if (!ok) return 1;
-    printf("OK moe recombination, %d experts, %d points, both recombinations, with and without a one-rank communicator\n", K, M);
+    printf("OK moe recombination (values, variances, x-gradients), %d experts, %d points, both recombinations, with and "
+           "without a one-rank communicator\n", K, M);
     return 0;
 }

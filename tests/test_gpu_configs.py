@@ -308,7 +308,9 @@ def _two_rank_worker(rank, token, q):
         gmx = GaussianMixture([0.3, 0.3, 0.4], [[0.2, 0.5], [0.5, 0.5], [0.8, 0.5]], [np.eye(2) * 0.05] * 3, 0.8)
         xq = np.random.default_rng(2).random((333, 2))
         for recomb in ("smooth", "hard"):
-            out["moe_" + recomb] = GpMixture(experts, gmx, recomb, rank=rank, world=2, sweep=sw).predict_valvar(xq)
+            mixr = GpMixture(experts, gmx, recomb, rank=rank, world=2, sweep=sw)
+            out["moe_" + recomb] = mixr.predict_valvar(xq)
+            out["moe_grad_" + recomb] = mixr.predict_valvar_gradients(xq[:100])  # egx_moe_predict_valvar_gradients, sharded
         for e in experts:
             if e is not None:
                 e.close()
@@ -390,6 +392,13 @@ def test_sweep_two_ranks_share_one_gpu_through_the_host_transport(egx):
             np.testing.assert_allclose(res[r]["moe_" + recomb][0], want[0], rtol=1e-12, atol=1e-13)
             np.testing.assert_allclose(res[r]["moe_" + recomb][1], want[1], rtol=1e-12, atol=1e-14)
         np.testing.assert_array_equal(res[0]["moe_" + recomb][0], res[1]["moe_" + recomb][0])  # the same bits on both ranks
+        wantg = GpMixture(experts, gmx, recomb).predict_valvar_gradients(xq[:100])
+        for r in range(2):
+            for q in range(2):
+                np.testing.assert_allclose(res[r]["moe_grad_" + recomb][q], wantg[q], rtol=1e-10,
+                                           atol=1e-12 * max(1.0, np.abs(wantg[q]).max()))
+        for q in range(2):
+            np.testing.assert_array_equal(res[0]["moe_grad_" + recomb][q], res[1]["moe_grad_" + recomb][q])
     for e in experts:
         e.close()
     # the sharded tuned fit IS the one-GPU tuned fit: same evaluations, same theta, same predictions, bit for bit, on both ranks
@@ -521,6 +530,31 @@ def test_gmx_responsibilities_on_the_device(k, nx, hf):
     if k > 1:
         np.testing.assert_array_equal(np.argmax(got, axis=1), go.predict(x))
     assert g.predict_probas_device(x[:0]).shape == (0, k)
+
+
+@pytest.mark.parametrize("k,nx,hf", [(1, 3, 1.0), (2, 1, 1.0), (3, 2, 0.8), (8, 16, 0.9), (5, 40, 1.0)])
+def test_gmx_responsibility_derivatives_on_the_device(k, nx, hf):
+    """egx_gmx_predict_probas_derivatives (one lane per point) against the oracle's
+    GaussianMixture::predict_probas_derivatives (crates/moe/src/gaussian_mixture.rs:127-170) and the numpy form of
+    egobox_amd.moe; the rows of every point's (k x nx) block sum to zero over the clusters (the responsibilities sum to 1)."""
+    from egobox_amd.moe import GaussianMixture
+    from oracle import moe_oracle as MO
+    rng = np.random.default_rng(7 * k + nx)
+    means = rng.standard_normal((k, nx))
+    a = rng.standard_normal((k, nx, nx))
+    covs = np.einsum("kij,klj->kil", a, a) / nx + 0.5 * np.eye(nx)
+    w = rng.random(k) + 0.2
+    w /= w.sum()
+    x = rng.standard_normal((200 + 13, nx))
+    g, go = GaussianMixture(w, means, covs, hf), MO.GaussianMixtureOracle(w, means, covs, hf)
+    got = g.predict_probas_derivatives_device(x)
+    want = go.predict_probas_derivatives(x[:40])
+    assert got.shape == (x.shape[0], k, nx)
+    scale = max(np.abs(want).max(), 1e-300)
+    np.testing.assert_allclose(got[:40], want, rtol=1e-9, atol=1e-12 * scale)
+    np.testing.assert_allclose(got, g.predict_probas_derivatives(x), rtol=1e-9, atol=1e-12 * scale)
+    np.testing.assert_allclose(got.sum(axis=1), 0.0, atol=1e-10 * scale)
+    assert g.predict_probas_derivatives_device(x[:0]).shape == (0, k, nx)
 
 
 def test_moe_c_host_drives_the_recombination(tmp_path):
