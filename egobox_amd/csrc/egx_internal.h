@@ -34,7 +34,8 @@ constexpr int kTile = 128;      // row/col granularity of the padded correlation
 constexpr int kNB = 256;        // outer Cholesky block (K of the trailing update)
 constexpr int kDiagTile = 64;   // diagonal tile factored in registers by one wave
 constexpr int kRhsPad = 128;    // rows appended below R for the fused forward solves
-constexpr int kMaxDim = 64;     // d <= 64 (north_star: "d up to 64")
+// (round 4: no cap on the input dimension d any more -- the correlation kernels stage the dimensions in chunks of 64;
+//  only the batched x-gradient kernel stops at 256, kernels_corr.hip kXgMaxDim)
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 

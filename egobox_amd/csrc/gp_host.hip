@@ -952,8 +952,8 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
         set_error("need at least 2 training points (sample standard deviation, utils.rs:48), got " + std::to_string(n));
         return EGX_ERR_INVALID_VALUE;
     }
-    if (d < 1 || d > kMaxDim) {
-        set_error("input dimension must be in [1, 64], got " + std::to_string(d));
+    if (d < 1 || d > 65535) {
+        set_error("input dimension must be at least 1, got " + std::to_string(d));
         return EGX_ERR_INVALID_VALUE;
     }
     if (cfg.corr < 0 || cfg.corr > 3 || cfg.mean < 0 || cfg.mean > 2) {
@@ -1320,7 +1320,7 @@ extern "C" {
 
 int32_t egx_corr_matrix(int32_t corr, const double *xnorm, int64_t n, int64_t d, const double *theta, double nugget,
                         double *r) {
-    if (!xnorm || !theta || !r || n < 1 || d < 1 || d > kMaxDim || corr < 0 || corr > 3) {
+    if (!xnorm || !theta || !r || n < 1 || d < 1 || corr < 0 || corr > 3) {
         set_error("egx_corr_matrix: bad arguments");
         return EGX_ERR_INVALID_VALUE;
     }
@@ -1341,7 +1341,7 @@ int32_t egx_corr_matrix(int32_t corr, const double *xnorm, int64_t n, int64_t d,
 
 int32_t egx_cross_corr(int32_t corr, const double *xq_norm, int64_t m, const double *xt_norm, int64_t n, int64_t d,
                        const double *theta, double *r) {
-    if (!xq_norm || !xt_norm || !theta || !r || n < 1 || m < 1 || d < 1 || d > kMaxDim || corr < 0 || corr > 3) {
+    if (!xq_norm || !xt_norm || !theta || !r || n < 1 || m < 1 || d < 1 || corr < 0 || corr > 3) {
         set_error("egx_cross_corr: bad arguments");
         return EGX_ERR_INVALID_VALUE;
     }

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 
 namespace egx {
 
@@ -117,13 +118,16 @@ __device__ __forceinline__ void stage_slab(double *dst, const double *__restrict
     }
 }
 
-// 4x4 micro-tile of pair accumulators from two staged slabs.
+// Input dimensions are staged in LDS in chunks of at most kCorrDC (round 4: any d; one chunk for d <= 64, where nothing
+// changes): the pair accumulators (exponent sum, Matern product) simply run on across the chunks.
+constexpr int kCorrDC = 64;
+
+// 4x4 micro-tile of pair accumulators from two staged slabs: `dn` more dimensions (coef already points at the first one)
 template <int CORR, bool PRE = false, int RI = 4>  // PRE: the slabs were staged with the coefficients applied (hcols == 1);
                                                     // RI x 4 pairs per lane (rows RI ty + a, columns 4 tx + b)
-__device__ __forceinline__ void tile_pairs(const double *xi, const double *xj, const double *__restrict__ coef,
-                                           int hcols, int d, int ty, int tx, double (&r)[RI][4]) {
-    PairAcc<CORR> acc[RI][4];
-    for (int k = 0; k < d; k++) {
+__device__ __forceinline__ void tile_pairs_acc(const double *xi, const double *xj, const double *__restrict__ coef,
+                                               int hcols, int dn, int ty, int tx, PairAcc<CORR> (&acc)[RI][4]) {
+    for (int k = 0; k < dn; k++) {
         double vi[RI], vj[4];
 #pragma unroll
         for (int a = 0; a < RI; a++) vi[a] = xi[k * 64 + ty * RI + a];
@@ -138,6 +142,12 @@ __device__ __forceinline__ void tile_pairs(const double *xi, const double *xj, c
                 else acc[a][b].add(vi[a] - vj[b], ck, hcols);
             }
     }
+}
+template <int CORR, bool PRE = false, int RI = 4>
+__device__ __forceinline__ void tile_pairs(const double *xi, const double *xj, const double *__restrict__ coef,
+                                           int hcols, int d, int ty, int tx, double (&r)[RI][4]) {
+    PairAcc<CORR> acc[RI][4];
+    tile_pairs_acc<CORR, PRE, RI>(xi, xj, coef, hcols, d, ty, tx, acc);
 #pragma unroll
     for (int a = 0; a < RI; a++)
 #pragma unroll
@@ -159,13 +169,23 @@ __global__ __launch_bounds__(1024 / RI) void k_corr_sym(const double *__restrict
     const int J = t - I * (I + 1) / 2;
     const int bi = 2 * I + (sub >> 1), bj = 2 * J + (sub & 1);
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *xi = sm, *xj = sm + d * 64;
+    const int dc = d < kCorrDC ? d : kCorrDC;
+    double *xi = sm, *xj = sm + dc * 64;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    stage_slab(xi, xT, ldx, bi * 64, d, tid, PRE ? coef : nullptr, NT);
-    stage_slab(xj, xT, ldx, bj * 64, d, tid, PRE ? coef : nullptr, NT);
-    __syncthreads();
+    PairAcc<CORR> acc[RI][4];
+    for (int c0 = 0; c0 < d; c0 += dc) {
+        const int dn = (d - c0 < dc) ? (d - c0) : dc;
+        if (c0) __syncthreads();
+        stage_slab(xi, xT + (int64_t)c0 * ldx, ldx, bi * 64, dn, tid, PRE ? coef + c0 : nullptr, NT);
+        stage_slab(xj, xT + (int64_t)c0 * ldx, ldx, bj * 64, dn, tid, PRE ? coef + c0 : nullptr, NT);
+        __syncthreads();
+        tile_pairs_acc<CORR, PRE, RI>(xi, xj, coef + (int64_t)c0 * hcols, hcols, dn, ty, tx, acc);
+    }
     double r[RI][4];
-    tile_pairs<CORR, PRE, RI>(xi, xj, coef, hcols, d, ty, tx, r);
+#pragma unroll
+    for (int a = 0; a < RI; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) r[a][b] = acc[a][b].value();
 #pragma unroll
     for (int a = 0; a < RI; a++) {
         const int i = bi * 64 + ty * RI + a;
@@ -261,15 +281,18 @@ __global__ __launch_bounds__(256) void k_normalize_queries(const double *__restr
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int q0 = blockIdx.x * 64, tid = threadIdx.x;
     const int rows = (m - q0 < 64) ? (m - q0) : 64;
-    const int ds = d | 1;  // odd row stride: the transposed reads below spread over the banks
-    for (int e = tid; e < rows * d; e += 256) {
-        const int i = e / d, k = e - i * d;
-        sm[i * ds + k] = xq[(int64_t)q0 * d + e];
+    // grid.y: chunks of kCorrDC dimensions (one for d <= 64)
+    const int c0 = blockIdx.y * kCorrDC;
+    const int dn = (d - c0 < kCorrDC) ? (d - c0) : kCorrDC;
+    const int ds = dn | 1;  // odd row stride: the transposed reads below spread over the banks
+    for (int e = tid; e < rows * dn; e += 256) {
+        const int i = e / dn, k = e - i * dn;
+        sm[i * ds + k] = xq[(int64_t)(q0 + i) * d + c0 + k];
     }
     __syncthreads();
-    for (int e = tid; e < d * 64; e += 256) {
+    for (int e = tid; e < dn * 64; e += 256) {
         const int k = e >> 6, i = e & 63;
-        xqT[(int64_t)k * ldq + q0 + i] = (i < rows) ? (sm[i * ds + k] - par[k]) / par[d + k] : 0.0;
+        xqT[(int64_t)(c0 + k) * ldq + q0 + i] = (i < rows) ? (sm[i * ds + k] - par[c0 + k]) / par[d + c0 + k] : 0.0;
     }
 }
 
@@ -279,13 +302,23 @@ __global__ __launch_bounds__(256) void k_cross_corr(const double *__restrict__ x
                                                     const double *__restrict__ coef, int hcols,
                                                     double *__restrict__ R, int64_t ld) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *xi = sm, *xj = sm + d * 64;
+    const int dc = d < kCorrDC ? d : kCorrDC;
+    double *xi = sm, *xj = sm + dc * 64;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    stage_slab(xi, xqT, ldq, blockIdx.x * 64, d, tid, PRE ? coef : nullptr);
-    stage_slab(xj, xT, ldx, blockIdx.y * 64, d, tid, PRE ? coef : nullptr);
-    __syncthreads();
+    PairAcc<CORR> acc[4][4];
+    for (int c0 = 0; c0 < d; c0 += dc) {
+        const int dn = (d - c0 < dc) ? (d - c0) : dc;
+        if (c0) __syncthreads();
+        stage_slab(xi, xqT + (int64_t)c0 * ldq, ldq, blockIdx.x * 64, dn, tid, PRE ? coef + c0 : nullptr);
+        stage_slab(xj, xT + (int64_t)c0 * ldx, ldx, blockIdx.y * 64, dn, tid, PRE ? coef + c0 : nullptr);
+        __syncthreads();
+        tile_pairs_acc<CORR, PRE>(xi, xj, coef + (int64_t)c0 * hcols, hcols, dn, ty, tx, acc);
+    }
     double r[4][4];
-    tile_pairs<CORR, PRE>(xi, xj, coef, hcols, d, ty, tx, r);
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) r[a][b] = acc[a][b].value();
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         double *p = R + (int64_t)(blockIdx.x * 64 + ty * 4 + a) * ld + blockIdx.y * 64 + tx * 4;
@@ -302,25 +335,30 @@ __global__ __launch_bounds__(256) void k_predict_mean(const double *__restrict__
                                                       const double *__restrict__ gamma,
                                                       double *__restrict__ racc, int slabs_per_split, int m_pad) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *xi = sm, *xj = sm + d * 64, *gs = sm + 2 * d * 64;
+    const int dc = d < kCorrDC ? d : kCorrDC;
+    double *xi = sm, *xj = sm + dc * 64, *gs = sm + 2 * dc * 64;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    stage_slab(xi, xqT, ldq, blockIdx.x * 64, d, tid, PRE ? coef : nullptr);
+    if (d <= dc) stage_slab(xi, xqT, ldq, blockIdx.x * 64, d, tid, PRE ? coef : nullptr);  // the queries: once
     double sum[4] = {0.0, 0.0, 0.0, 0.0};
     // grid.y splits the training range (a few queries must still fill the chip); partial sums per split
     const int j_lo = blockIdx.y * slabs_per_split * 64;
     int j_hi = j_lo + slabs_per_split * 64;
     if (j_hi > n_pad) j_hi = n_pad;
     for (int j0 = j_lo; j0 < j_hi; j0 += 64) {
-        __syncthreads();
-        stage_slab(xj, xT, ldx, j0, d, tid, PRE ? coef : nullptr);
-        if (tid < 64) gs[tid] = gamma[j0 + tid];
-        __syncthreads();
-        double r[4][4];
-        tile_pairs<CORR, PRE>(xi, xj, coef, hcols, d, ty, tx, r);
+        PairAcc<CORR> acc[4][4];
+        for (int c0 = 0; c0 < d; c0 += dc) {
+            const int dn = (d - c0 < dc) ? (d - c0) : dc;
+            __syncthreads();
+            if (d > dc) stage_slab(xi, xqT + (int64_t)c0 * ldq, ldq, blockIdx.x * 64, dn, tid, PRE ? coef + c0 : nullptr);
+            stage_slab(xj, xT + (int64_t)c0 * ldx, ldx, j0, dn, tid, PRE ? coef + c0 : nullptr);
+            if (c0 == 0 && tid < 64) gs[tid] = gamma[j0 + tid];
+            __syncthreads();
+            tile_pairs_acc<CORR, PRE>(xi, xj, coef + (int64_t)c0 * hcols, hcols, dn, ty, tx, acc);
+        }
 #pragma unroll
         for (int a = 0; a < 4; a++)
 #pragma unroll
-            for (int b = 0; b < 4; b++) sum[a] = __builtin_fma(r[a][b], gs[tx * 4 + b], sum[a]);
+            for (int b = 0; b < 4; b++) sum[a] = __builtin_fma(acc[a][b].value(), gs[tx * 4 + b], sum[a]);
     }
     // reduce over the 16 tx lanes that share the same queries (consecutive lanes of one wave)
 #pragma unroll
@@ -426,19 +464,25 @@ __device__ __forceinline__ double xgrad_factor(double diff, const double *__rest
 
 constexpr int kXgThreads = 128;
 
-template <int CORR, int DK, bool VEC>
+// XAG (64 < d <= kXgMaxDim): the lane's own query coordinates come from global memory (L1 / L2) instead of a
+// [d][kXgThreads] LDS image, which together with the d x 64 training slab would not fit any more
+constexpr int kXgMaxDim = 256;
+template <int CORR, int DK, bool VEC, bool XAG = false>
 __global__ __launch_bounds__(kXgThreads) void k_xgrad(const double *__restrict__ xqT, int64_t ldq,
                                                       const double *__restrict__ xT, int64_t ldx, int n, int d,
                                                       const double *__restrict__ coef, int hcols,
                                                       const double *__restrict__ Wt, int64_t ldw, int slabs_per_split,
                                                       double *__restrict__ out, int m_pad) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *xa = sm;                    // [d][kXgThreads]
-    double *xj = sm + d * kXgThreads;   // [d][64]
-    double *cs = xj + d * 64;           // [d * hcols]
+    double *xa = sm;                                  // [d][kXgThreads]  (not with XAG)
+    double *xj = sm + (XAG ? 0 : d * kXgThreads);     // [d][64]
+    double *cs = xj + d * 64;                         // [d * hcols]
     const int tid = threadIdx.x;
     const int a = blockIdx.x * kXgThreads + tid;
-    for (int k = 0; k < d; k++) xa[k * kXgThreads + tid] = xqT[(int64_t)k * ldq + a];
+    const double *xag = xqT + a;
+#define EGX_XA(k_) (XAG ? xag[(int64_t)(k_) * ldq] : xa[(k_) * kXgThreads + tid])
+    if (!XAG)
+        for (int k = 0; k < d; k++) xa[k * kXgThreads + tid] = xqT[(int64_t)k * ldq + a];
     for (int e = tid; e < d * hcols; e += kXgThreads) cs[e] = coef[e];
     const int j_lo = blockIdx.y * slabs_per_split * 64;
     int j_hi = j_lo + slabs_per_split * 64;
@@ -449,7 +493,7 @@ __global__ __launch_bounds__(kXgThreads) void k_xgrad(const double *__restrict__
 #pragma unroll
         for (int kk = 0; kk < DK; kk++) {
             acc[kk] = 0.0;
-            xr[kk] = (k0 + kk < d) ? xa[(k0 + kk) * kXgThreads + tid] : 0.0;
+            xr[kk] = (k0 + kk < d) ? EGX_XA(k0 + kk) : 0.0;
         }
         for (int j0 = j_lo; j0 < j_hi; j0 += 64) {
             __syncthreads();
@@ -458,7 +502,7 @@ __global__ __launch_bounds__(kXgThreads) void k_xgrad(const double *__restrict__
             const int jn = (j_hi - j0 < 64) ? (j_hi - j0) : 64;
             for (int jj = 0; jj < jn; jj++) {
                 PairAcc<CORR> pa;
-                for (int k = 0; k < d; k++) pa.add(xa[k * kXgThreads + tid] - xj[k * 64 + jj], cs + k * hcols, hcols);
+                for (int k = 0; k < d; k++) pa.add(EGX_XA(k) - xj[k * 64 + jj], cs + k * hcols, hcols);
                 const double wv = VEC ? Wt[j0 + jj] : Wt[(int64_t)(j0 + jj) * ldw + a];
                 const double rw = pa.value() * wv;
 #pragma unroll
@@ -472,6 +516,7 @@ __global__ __launch_bounds__(kXgThreads) void k_xgrad(const double *__restrict__
         for (int kk = 0; kk < DK; kk++)
             if (k0 + kk < d) o[k0 + kk] = acc[kk];
     }
+#undef EGX_XA
 }
 
 // Few-query form of the x-gradient contraction (single-point calls): the lanes run over TRAINING points instead of queries
@@ -901,13 +946,15 @@ int launch_corr_sym(hipStream_t s, int corr, const double *xT, int64_t ldx, int 
                     int hcols, double nugget, double *M, int64_t ld, int n_pad, double *xs_scratch) {
     const int nt2 = n_pad / 128;  // n_pad is a multiple of 128
     dim3 grid((unsigned)(4 * (nt2 * (nt2 + 1) / 2)));
-    const size_t lds = (size_t)2 * d * 64 * sizeof(double);
+    const int dc = d < kCorrDC ? d : kCorrDC;  // dimensions staged at a time
+    const size_t lds = (size_t)2 * dc * 64 * sizeof(double);
     static const int srow = [] {  // EGX_CORR_SROW=0: the LDS-only form (0.51 vs 0.42 ms sq-exp, 1.10 vs 0.76 at d = 64:
         const char *e = std::getenv("EGX_CORR_SROW");  // profiles/r03_run11_k1_scalar_rows_ab.txt)
         return (e && e[0] == '0') ? 0 : 1;
     }();
-    if (hcols == 1 && xs_scratch != nullptr && srow) {
-        // scalar-row form on prescaled inputs (xs_scratch: d x ldx doubles, owned by the caller's workspace)
+    if (hcols == 1 && xs_scratch != nullptr && srow && d <= kCorrDC) {
+        // scalar-row form on prescaled inputs (xs_scratch: d x ldx doubles, owned by the caller's workspace); d > 64: the
+        // LDS-only form below, which stages the dimensions in chunks
         hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((ldx + 255) / 256)), dim3(256), 0, s, xT, ldx, d, coef, xs_scratch);
         EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_corr_sym_srow<C_>), grid, dim3(256), lds / 2, s, (const double *)xs_scratch, ldx,
                                                    n, d, 1.0 + nugget, M, ld));
@@ -930,7 +977,7 @@ int launch_corr_sym(hipStream_t s, int corr, const double *xT, int64_t ldx, int 
 int launch_cross_corr(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad, const double *xT,
                       int64_t ldx, int n_pad, int d, const double *coef, int hcols, double *R, int64_t ld) {
     dim3 grid(m_pad / 64, n_pad / 64);
-    const size_t lds = (size_t)2 * d * 64 * sizeof(double);
+    const size_t lds = (size_t)2 * (d < kCorrDC ? d : kCorrDC) * 64 * sizeof(double);
     if (hcols == 1) {
         EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_cross_corr<C_, true>), grid, dim3(256), lds, s, xqT, ldq, xT, ldx, d, coef,
                                                    hcols, R, ld));
@@ -944,8 +991,9 @@ int launch_cross_corr(hipStream_t s, int corr, const double *xqT, int64_t ldq, i
 
 int launch_normalize_queries(hipStream_t s, const double *xq, int m, int d, const double *par, double *xqT, int64_t ldq,
                              int m_pad) {
-    const size_t lds = (size_t)64 * (d | 1) * sizeof(double);
-    hipLaunchKernelGGL(k_normalize_queries, dim3(m_pad / 64), dim3(256), lds, s, xq, m, d, par, xqT, ldq);
+    const size_t lds = (size_t)64 * ((d < kCorrDC ? d : kCorrDC) | 1) * sizeof(double);
+    hipLaunchKernelGGL(k_normalize_queries, dim3(m_pad / 64, (unsigned)((d + kCorrDC - 1) / kCorrDC)), dim3(256), lds, s, xq, m, d,
+                       par, xqT, ldq);
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }
@@ -959,7 +1007,7 @@ int launch_scale_rows(hipStream_t s, const double *xT, int64_t ldx, int d, const
 int launch_predict_mean(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_pad, const double *xT,
                         int64_t ldx, int n_pad, int d, const double *coef, int hcols, const double *gamma,
                         double *racc, int nsplit, const double *xs_prescaled) {
-    const size_t lds = (size_t)(2 * d * 64 + 64) * sizeof(double);
+    const size_t lds = (size_t)(2 * (d < kCorrDC ? d : kCorrDC) * 64 + 64) * sizeof(double);
     const int slabs = n_pad / 64;
     if (nsplit < 1) nsplit = 1;
     if (nsplit > slabs) nsplit = slabs;
@@ -969,7 +1017,7 @@ int launch_predict_mean(hipStream_t s, int corr, const double *xqT, int64_t ldq,
         const char *e = std::getenv("EGX_CORR_SROW");
         return (e && e[0] == '0') ? 0 : 1;
     }();
-    if (hcols == 1 && xs_prescaled != nullptr && srow) {
+    if (hcols == 1 && xs_prescaled != nullptr && srow && d <= kCorrDC) {
         const size_t lds_s = (size_t)(d * 64 + 256) * sizeof(double);
         EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_predict_mean_srow<C_>), dim3(m_pad / 64, nsplit), dim3(256), lds_s, s, xqT,
                                                    ldq, xs_prescaled, ldx, n_pad, d, coef, gamma, racc, per, m_pad));
@@ -996,21 +1044,27 @@ int launch_xgrad(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_
     if (nsplit > slabs) nsplit = slabs;
     const int per = (slabs + nsplit - 1) / nsplit;
     dim3 grid(m_pad / kXgThreads, nsplit);
-    const size_t lds = (size_t)(d * kXgThreads + d * 64 + d * hcols) * sizeof(double);
-#define EGX_XG(C_, DK_)                                                                                              \
-    if (vec) {                                                                                                       \
-        if (lds > 65536)                                                                                             \
-            EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xgrad<C_, DK_, true>),               \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
-        hipLaunchKernelGGL((k_xgrad<C_, DK_, true>), grid, dim3(kXgThreads), lds, s, xqT, ldq, xT, ldx, n, d, coef,  \
-                           hcols, Wt, ldw, per, out, m_pad);                                                         \
-    } else {                                                                                                         \
-        if (lds > 65536)                                                                                             \
-            EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xgrad<C_, DK_, false>),              \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                \
-        hipLaunchKernelGGL((k_xgrad<C_, DK_, false>), grid, dim3(kXgThreads), lds, s, xqT, ldq, xT, ldx, n, d, coef, \
-                           hcols, Wt, ldw, per, out, m_pad);                                                         \
+    // d <= 64: the lane's query coordinates in LDS; up to kXgMaxDim: from global memory (XAG), the training slab alone in LDS
+    const bool xag = d > kCorrDC;
+    if (d > kXgMaxDim) {
+        set_error("x-gradients: input dimension " + std::to_string(d) + " > " + std::to_string(kXgMaxDim) + " is not supported");
+        return EGX_ERR_UNSUPPORTED;
     }
+    const size_t lds = (size_t)((xag ? 0 : d * kXgThreads) + d * 64 + d * hcols) * sizeof(double);
+#define EGX_XG1(C_, DK_, VEC_, XAG_)                                                                                         \
+    {                                                                                                                        \
+        if (lds > 65536)                                                                                                     \
+            EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xgrad<C_, DK_, VEC_, XAG_>),                 \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+        hipLaunchKernelGGL((k_xgrad<C_, DK_, VEC_, XAG_>), grid, dim3(kXgThreads), lds, s, xqT, ldq, xT, ldx, n, d, coef,    \
+                           hcols, Wt, ldw, per, out, m_pad);                                                                 \
+    }
+#define EGX_XG(C_, DK_)                                    \
+    if (xag) {                                             \
+        if (vec) EGX_XG1(C_, 32, true, true)               \
+        else EGX_XG1(C_, 32, false, true)                  \
+    } else if (vec) EGX_XG1(C_, DK_, true, false)          \
+    else EGX_XG1(C_, DK_, false, false)
     if (d <= 8) {
         EGX_DISPATCH_CORR(corr, EGX_XG(C_, 8));
     } else if (d <= 16) {
@@ -1018,6 +1072,7 @@ int launch_xgrad(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_
     } else {
         EGX_DISPATCH_CORR(corr, EGX_XG(C_, 32));
     }
+#undef EGX_XG1
 #undef EGX_XG
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;

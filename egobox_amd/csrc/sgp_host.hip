@@ -333,8 +333,8 @@ int32_t egx_sgp_create(const egx_sgp_config *cfg_in, const double *x, const doub
     *out = nullptr;
     egx_sgp_config cfg;
     if (cfg_in) cfg = *cfg_in; else egx_sgp_config_default(&cfg);
-    if (!x || !y || !z || n < 2 || nz < 1 || nz > n || d < 1 || d > kMaxDim) {
-        set_error("egx_sgp_create: need x (n x d), y (n), z (nz x d) with 1 <= nz <= n, n >= 2, 1 <= d <= 64");
+    if (!x || !y || !z || n < 2 || nz < 1 || nz > n || d < 1) {
+        set_error("egx_sgp_create: need x (n x d), y (n), z (nz x d) with 1 <= nz <= n, n >= 2, d >= 1");
         return EGX_ERR_INVALID_VALUE;
     }
     if (cfg.corr < 0 || cfg.corr > 3 || (cfg.method != EGX_SGP_FITC && cfg.method != EGX_SGP_VFE) ||
@@ -412,7 +412,7 @@ int32_t egx_sgp_create(const egx_sgp_config *cfg_in, const double *x, const doub
     SGP_TRY(g->xT.alloc(xT.size()));
     SGP_TRY(g->zT.alloc(zT.size()));
     SGP_TRY(g->y.alloc(np));
-    SGP_TRY(g->coef.alloc(kMaxDim));
+    SGP_TRY(g->coef.alloc((size_t)d));
     SGP_TRY(g->RT.alloc(np * zp));
     SGP_TRY(g->W.alloc(ze * np));
     SGP_TRY(g->G.alloc(ze * ze));

@@ -1216,3 +1216,102 @@ def test_reference_kpls_griewank(egx):
     ytest, ytrue = gp.predict(-600.0 + 1200.0 * xtest), workload.griewank(xtest)
     assert np.linalg.norm(ytrue - ytest) / np.linalg.norm(ytrue) < 1e-2
     gp.close()
+
+
+# ------------------------------------------------------------------ round 4: input dimensions beyond 64
+# (the reference benches its kernels at dim 100, crates/gp/benches/corr.rs:11-15, and KPLS exists for d >> 64,
+#  crates/gp/src/algorithm.rs:843-855: the correlation kernels stage the dimensions in chunks of 64)
+@pytest.mark.parametrize("kind", range(4))
+@pytest.mark.parametrize("n,d", [(150, 100), (130, 200), (70, 65)])
+def test_corr_kernels_beyond_64_dimensions(egx, O, kind, n, d):
+    rng = np.random.default_rng(n + d + kind)
+    xn, _, _ = O.normalize(rng.random((n, d)))
+    theta = (0.2 + rng.random(d)) / np.sqrt(d)
+    got = egx.corr_matrix(kind, xn, theta)
+    dd, idx = O.diff_matrix(xn)
+    want = O.assemble_r(O.corr_value(KINDS[kind], dd, theta, np.eye(d)), idx, n, O.DEFAULT_NUGGET)
+    np.testing.assert_allclose(got, want, rtol=5e-13, atol=1e-300)
+    xq, _, _ = O.normalize(rng.random((97, d)))
+    gc = egx.cross_corr(kind, xq, xn, theta)
+    wc = O.corr_value(KINDS[kind], O.pairwise_differences(xq, xn), theta, np.eye(d)).reshape(97, n)
+    np.testing.assert_allclose(gc, wc, rtol=5e-13, atol=1e-300)
+
+
+@pytest.mark.parametrize("corr", range(4))
+@pytest.mark.parametrize("d", [100, 200])
+def test_fit_predict_and_gradients_beyond_64_dimensions(egx, O, corr, d):
+    """Fit at fixed theta, predict / predict_var (the LDS-only prediction kernel with chunked dimensions + the device-side
+    query normalisation over two to four chunks), the theta-gradient (its trace kernel's chunked passes and four to seven
+    output chunks) and the x-gradients (d = 100 / 200: the kernel form that reads the query from global memory) against
+    the oracle."""
+    n = 300
+    x, y = _data(n, d, seed=50 + d)
+    theta = egx.workload.default_theta(d) * (1.0 + 0.3 * np.arange(d) / (d - 1)) * (2.0 if corr == 0 else 1.0)
+    ref = _check_fit(egx, O, x, y, theta, 0, corr)
+    lk_ref, g_ref = O.likelihood_grad(x, y, theta, corr=KINDS[corr])
+    xq = x.min(0) + (x.max(0) - x.min(0)) * np.random.default_rng(3).random((40, d))
+    with egx.GpHandle(x, y, corr=corr, n_workspaces=2) as h:
+        lk, g, st = h.likelihood_grad(theta)
+        assert st == 0 and lk == pytest.approx(lk_ref, rel=LK_RTOL)
+        np.testing.assert_allclose(g, g_ref, rtol=1e-6, atol=1e-6 * np.abs(g_ref).max())
+        lkb, gb, stb = h.likelihood_grad_batch(np.stack([theta, theta * 1.01]))
+        assert lkb[0] == lk and np.array_equal(gb[0], g)
+        h.finalize(theta)
+        # x-gradients: directional central differences of the oracle-checked predictions (the oracle's own jacobians cost
+        # minutes at this d), batched form and the few-query path
+        gy, gv = h.predict_valvar_gradients(xq)
+        one = h.predict_valvar_gradients(xq[:1])
+        rng = np.random.default_rng(9)
+        span = x.max(0) - x.min(0)
+        for a in range(6):
+            v = rng.standard_normal(d) * span
+            v /= np.linalg.norm(v)
+            eps = 1e-5
+            yp, vp = h.predict_valvar(np.stack([xq[a] + eps * v, xq[a] - eps * v]))
+            fy, fv = (yp[0] - yp[1]) / (2 * eps), (vp[0] - vp[1]) / (2 * eps)
+            assert gy[a] @ v == pytest.approx(fy, rel=2e-5, abs=1e-6 * np.abs(gy).max())
+            assert gv[a] @ v == pytest.approx(fv, rel=2e-4, abs=1e-5 * np.abs(gv).max())
+        np.testing.assert_allclose(one[0], gy[:1], rtol=1e-7, atol=1e-9 * np.abs(gy).max())
+        np.testing.assert_allclose(one[1], gv[:1], rtol=1e-6, atol=1e-8 * np.abs(gv).max())
+
+
+def test_kpls_with_100_input_dimensions(egx, O):
+    """KPLS is what the reference offers for d >> 64 (algorithm.rs:843-855): d = 100 reduced to h = 3, all four kernels,
+    likelihood + predictions against the oracle, and the theta-gradient (h outputs) against finite differences."""
+    n, d, hk = 400, 100, 3
+    x, y = _data(n, d, seed=77)
+    rng = np.random.default_rng(4)
+    w = rng.standard_normal((d, hk))
+    w /= np.linalg.norm(w, axis=0)
+    theta = np.array([0.6, 0.9, 0.4])
+    xq = rng.random((50, d))
+    for corr in range(4):
+        ref = O.fit_fixed(x, y, theta, corr=KINDS[corr], w_star=w)
+        with egx.GpHandle(x, y, corr=corr, w_star=w, n_workspaces=2) as h:
+            assert h.h == hk
+            lk, st = h.likelihood(theta)
+            assert st == 0 and lk == pytest.approx(ref.likelihood, rel=LK_RTOL)
+            lkg, g, stg = h.likelihood_grad(theta)
+            assert stg == 0 and lkg == lk
+            for l in range(hk):
+                e = np.zeros(hk)
+                e[l] = 1e-5 * theta[l]
+                lks, sts = h.likelihood_batch(np.stack([theta + e, theta - e]))
+                fd = (lks[0] - lks[1]) / (2 * e[l])
+                assert g[l] == pytest.approx(fd, rel=5e-5, abs=1e-6 * np.abs(g).max())
+            h.finalize(theta)
+            yr, vr = ref.predict(xq), ref.predict_var(xq)
+            yp, vp = h.predict_valvar(xq)
+            np.testing.assert_allclose(yp, yr, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(yr).max())
+            np.testing.assert_allclose(vp, vr, rtol=PRED_RTOL, atol=1e-9 * ref.inner.sigma2 + PRED_RTOL * np.abs(vr).max())
+
+
+def test_x_gradients_beyond_256_dimensions_are_refused_not_wrong(egx):
+    n, d = 200, 300
+    x, y = _data(n, d, seed=5)
+    with egx.GpHandle(x, y, corr=0) as h:
+        h.finalize(egx.workload.default_theta(d))
+        xq = np.random.default_rng(1).random((130, d))
+        assert np.all(np.isfinite(h.predict(xq))) and np.all(h.predict_var(xq) >= 0.0)
+        with pytest.raises(egx.EgxError):
+            h.predict_gradients(xq)
