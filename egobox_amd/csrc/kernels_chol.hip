@@ -1404,6 +1404,7 @@ static int g_look_min_cols = 3072;    // EGX_LOOK_MIN: look-ahead while at least
 static int g_trsm_group = 0;          // EGX_TRSM_GROUP: panels per update in the solves after the factorisation (0 = 4)
 static int g_lur_side = 1;            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU also in lock-step batches
 static int g_stream_walk = 0;         // EGX_STREAM_WALK=1: XCD-aware 8 x 4 super-tile order of k_gemm_stream (0: column-major)
+static int g_potrf_left = 0;          // EGX_POTRF_LEFT=1: LEFT-looking at the level of the panel groups (see launch_potrf)
 
 int chol_init() {
     static std::once_flag once;
@@ -1420,6 +1421,7 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_TRSM_GROUP")) g_trsm_group = std::atoi(e);
         if (const char *e = std::getenv("EGX_LUR_SIDE")) g_lur_side = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_WALK")) g_stream_walk = std::atoi(e);
+        if (const char *e = std::getenv("EGX_POTRF_LEFT")) g_potrf_left = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -1444,7 +1446,8 @@ int set_knob(const char *name, int value) {
     struct { const char *n; int *v; } tab[] = {{"potrf_group", &g_potrf_group}, {"stream_min", &g_stream_min_tiles},
                                               {"stream_tpw", &g_stream_tpw},   {"gemm_small", &g_gemm_small_max},
                                               {"look_min", &g_look_min_cols},  {"trsm_group", &g_trsm_group},
-                                              {"lur_side", &g_lur_side},       {"stream_walk", &g_stream_walk}};
+                                              {"lur_side", &g_lur_side},       {"stream_walk", &g_stream_walk},
+                                              {"potrf_left", &g_potrf_left}};
     for (auto &e : tab)
         if (std::string(name) == e.n) {
             const int old = *e.v;
@@ -1695,6 +1698,41 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         }
         return EGX_SUCCESS;
     };
+    if (g_potrf_left) {
+        // LEFT-looking over the groups (round 4 experiment, EGX_POTRF_LEFT / egx_set_tuning "potrf_left"): the columns of
+        // group J receive ALL earlier panels' contributions in ONE update with K = g0 -- every tile of the factor is read
+        // and written once by a long K loop (what makes the theta-gradient's R^-1 launch run at 0.85 of peak), instead of
+        // once per earlier group with K = 1024.  No look-ahead: the chain of group J follows its update; lock-step batches
+        // and several groups in flight supply the parallelism a lone matrix' late, narrow updates lack.
+        for (int g0 = 0; g0 < n_pad; g0 += GW) {
+            const int gw = gwidth(g0);
+            if (g0 > 0) {
+                const bool timed = trace && trace->ready && trace->used < GemmTrace::kMax;
+                if (timed) EGX_HIP_CHECK(hipEventRecord(trace->e0[trace->used], s));
+                bool big = false;
+                rc = update(s, g0, g0, m_tot - g0, gw, 0, g0, 1, &big);
+                if (rc) return rc;
+                if (timed) {
+                    EGX_HIP_CHECK(hipEventRecord(trace->e1[trace->used], s));
+                    const double nr = (double)(n_pad - g0);
+                    trace->flops[trace->used] = (double)nz * 2.0 * g0 * (nr * gw - 0.5 * gw * (gw - 1.0));
+                    trace->used++;
+                }
+            }
+            rc = inner_factor(s, g0, gw, nullptr, nullptr);
+            if (rc) return rc;
+            rc = inverse_group(g0, gw);
+            if (rc) return rc;
+        }
+        if (inv) {
+            EGX_HIP_CHECK(hipEventRecord(inv->ev_done, inv->sw));
+            EGX_HIP_CHECK(hipStreamWaitEvent(s, inv->ev_done, 0));
+        }
+        hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64, 1, nz), dim3(256), 0, s, (const double *)M, ld, dinv,
+                           dinv + (int64_t)(n_pad / 64) * 4096, pb.sM, pb.sD);
+        EGX_HIP_CHECK(hipGetLastError());
+        return EGX_SUCCESS;
+    }
     rc = inner_factor(s, 0, gwidth(0), s3, nullptr);
     if (rc) return rc;
     rc = inverse_group(0, gwidth(0));
