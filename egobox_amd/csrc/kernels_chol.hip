@@ -1404,7 +1404,8 @@ static int g_look_min_cols = 3072;    // EGX_LOOK_MIN: look-ahead while at least
 static int g_trsm_group = 0;          // EGX_TRSM_GROUP: panels per update in the solves after the factorisation (0 = 4)
 static int g_lur_side = 1;            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU also in lock-step batches
 static int g_stream_walk = 0;         // EGX_STREAM_WALK=1: XCD-aware 8 x 4 super-tile order of k_gemm_stream (0: column-major)
-static int g_potrf_left = 0;          // EGX_POTRF_LEFT=1: LEFT-looking at the level of the panel groups (see launch_potrf)
+static int g_potrf_left = 0;          // EGX_POTRF_LEFT: left-looking group updates (launch_potrf) 0 never, 1 for handles with large n and
+                                      // a lock-step width >= 8, 2 always
 
 int chol_init() {
     static std::once_flag once;
@@ -1436,6 +1437,12 @@ int chol_init() {
         set(reinterpret_cast<const void *>(&k_gemm_stream<true, true>), ST_LDS_BYTES);
     });
     return rc_once;
+}
+
+// does a handle of this shape factor left-looking?  (per handle, never per launch: see launch_potrf)
+int potrf_left_for(int n_pad, int lockstep) {
+    (void)chol_init();
+    return g_potrf_left >= 2 || (g_potrf_left == 1 && n_pad >= 8192 && lockstep >= 8);
 }
 
 // run-time access to the knobs above (egx_set_tuning): A/B measurements inside ONE process (a gpurun call is minutes, a
@@ -1484,7 +1491,10 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         else
             wide_tiles = (int64_t)(M / 128) * (N / 256);
     }
-    if (K >= 2 * KC && wide_tiles >= g_stream_min_tiles) {
+    // (long K loops amortise a tile's prologue / epilogue and the launch: the left-looking group updates, K = all earlier
+    //  columns, stay on the stream kernel down to a handful of tiles)
+    const int64_t min_tiles = (K >= 2048) ? 8 : g_stream_min_tiles;
+    if (K >= 2 * KC && wide_tiles >= min_tiles) {
         // the launches that fill the chip on their own are the ones the roofline trace follows
         if (used_big_tile) *used_big_tile = wide_tiles >= 512;
         const int nbx = M / 128, nby = N / 256;  // LOWER: column c holds nbx - 2 c tiles (M >= N in the factorisation)
@@ -1665,10 +1675,10 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         gbw.sB = pb.sM;
         gbw.sInfo = pb.sI;
     }
-    auto inverse_group = [&](int g0, int gw) -> int {
+    auto inverse_group = [&](hipStream_t sfin, int g0, int gw) -> int {
         if (!inv) return EGX_SUCCESS;
         hipStream_t sw = inv->sw;
-        EGX_HIP_CHECK(hipEventRecord(inv->ev_grp, s));
+        EGX_HIP_CHECK(hipEventRecord(inv->ev_grp, sfin));
         EGX_HIP_CHECK(hipStreamWaitEvent(sw, inv->ev_grp, 0));
         const int gend = g0 + gw;
         for (int k0 = g0; k0 < gend; k0 += kNB) {
@@ -1698,32 +1708,55 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         }
         return EGX_SUCCESS;
     };
-    if (g_potrf_left) {
-        // LEFT-looking over the groups (round 4 experiment, EGX_POTRF_LEFT / egx_set_tuning "potrf_left"): the columns of
-        // group J receive ALL earlier panels' contributions in ONE update with K = g0 -- every tile of the factor is read
-        // and written once by a long K loop (what makes the theta-gradient's R^-1 launch run at 0.85 of peak), instead of
-        // once per earlier group with K = 1024.  No look-ahead: the chain of group J follows its update; lock-step batches
-        // and several groups in flight supply the parallelism a lone matrix' late, narrow updates lack.
-        for (int g0 = 0; g0 < n_pad; g0 += GW) {
+    if (pb.left) {
+        // LEFT-looking over the groups of panels (round 4): the columns of group J receive the contributions of ALL earlier
+        // columns in two updates -- a LONG one, K = every column before the previous group, and a SHORT one, K = the previous
+        // group (1024) -- instead of one read-modify-write pass per earlier group: a tile of the factor is read and written
+        // twice in the whole factorisation, by long K loops (what makes the theta-gradient's R^-1 launch run at 0.85 of
+        // peak; the long updates of a lock-step group of eight measured 0.82, the right-looking trailing updates 0.72).
+        // Look-ahead: the chain of group J (diagonal blocks, panel solves, in-group updates; stream s2) runs beside the
+        // long update of group J + 1 (stream s), which only needs the groups before J:
+        //     s :  ... U_long(J) | wait C(J-1) | U_short(J) | rec U(J) | U_long(J+1) | wait C(J) | U_short(J+1) ...
+        //     s2:                                            wait U(J) | chain(J) | rec C(J)
+        // A lone matrix' late long updates have few tiles with very long K loops and leave the chip underfilled: the mode is
+        // chosen per HANDLE (large n and a lock-step width of at least eight, PotrfBatch::left), never by the number of
+        // matrices in a launch, so a candidate's bits do not depend on its companions.
+        const bool la = s2 != nullptr;
+        hipStream_t sc = la ? s2 : s;  // the chain's stream
+        rc = inner_factor(s, 0, gwidth(0), s3, nullptr);
+        if (rc) return rc;
+        rc = inverse_group(s, 0, gwidth(0));
+        if (rc) return rc;
+        int gprev = 0;  // start of the previous group
+        for (int g0 = gwidth(0); g0 < n_pad; g0 += GW) {
             const int gw = gwidth(g0);
-            if (g0 > 0) {
+            if (gprev > 0) {  // U_long: columns [0, gprev), all final (C(J-2) was waited for before U_short(J-1))
                 const bool timed = trace && trace->ready && trace->used < GemmTrace::kMax;
                 if (timed) EGX_HIP_CHECK(hipEventRecord(trace->e0[trace->used], s));
-                bool big = false;
-                rc = update(s, g0, g0, m_tot - g0, gw, 0, g0, 1, &big);
+                rc = update(s, g0, g0, m_tot - g0, gw, 0, gprev, 1, nullptr);
                 if (rc) return rc;
                 if (timed) {
                     EGX_HIP_CHECK(hipEventRecord(trace->e1[trace->used], s));
                     const double nr = (double)(n_pad - g0);
-                    trace->flops[trace->used] = (double)nz * 2.0 * g0 * (nr * gw - 0.5 * gw * (gw - 1.0));
+                    trace->flops[trace->used] = (double)nz * 2.0 * gprev * (nr * gw - 0.5 * gw * (gw - 1.0));
                     trace->used++;
                 }
             }
-            rc = inner_factor(s, g0, gw, nullptr, nullptr);
+            if (la && gprev > 0) EGX_HIP_CHECK(hipStreamWaitEvent(s, lk->ev_panel, 0));  // C(J-1): the previous group is final
+            rc = update(s, g0, g0, m_tot - g0, gw, gprev, g0 - gprev, 1, nullptr);        // U_short
             if (rc) return rc;
-            rc = inverse_group(g0, gw);
+            if (la) {
+                EGX_HIP_CHECK(hipEventRecord(lk->ev_lu, s));
+                EGX_HIP_CHECK(hipStreamWaitEvent(sc, lk->ev_lu, 0));
+            }
+            rc = inner_factor(sc, g0, gw, la ? s3 : nullptr, nullptr);
             if (rc) return rc;
+            if (la) EGX_HIP_CHECK(hipEventRecord(lk->ev_panel, sc));
+            rc = inverse_group(sc, g0, gw);
+            if (rc) return rc;
+            gprev = g0;
         }
+        if (la && gprev > 0) EGX_HIP_CHECK(hipStreamWaitEvent(s, lk->ev_panel, 0));
         if (inv) {
             EGX_HIP_CHECK(hipEventRecord(inv->ev_done, inv->sw));
             EGX_HIP_CHECK(hipStreamWaitEvent(s, inv->ev_done, 0));
@@ -1735,7 +1768,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     }
     rc = inner_factor(s, 0, gwidth(0), s3, nullptr);
     if (rc) return rc;
-    rc = inverse_group(0, gwidth(0));
+    rc = inverse_group(s, 0, gwidth(0));
     if (rc) return rc;
     for (int g0 = 0; g0 < n_pad; g0 += GW) {
         const int gw = gwidth(g0);
@@ -1798,7 +1831,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             rc = inner_factor(s, r1, gw1, nullptr, nullptr);
             if (rc) return rc;
         }
-        rc = inverse_group(r1, gw1);  // the group that has just become final
+        rc = inverse_group(s, r1, gw1);  // the group that has just become final
         if (rc) return rc;
     }
     if (inv) {  // W is complete; its panel solves read the 16 x 16 inverses the launch below overwrites

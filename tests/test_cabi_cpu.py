@@ -105,7 +105,7 @@ def test_argument_validation_before_device(egx):
     with pytest.raises(egx.InvalidValueError):
         egx.GpHandle(good_x, good_y[:9])                  # ragged
     with pytest.raises(egx.InvalidValueError):
-        egx.GpHandle(np.random.rand(10, 65), good_y)      # d > 64
+        egx.GpHandle(np.zeros((10, 0)), good_y)           # d < 1 (round 4: no upper bound on d any more)
     with pytest.raises(egx.InvalidValueError):
         egx.GpHandle(good_x, good_y, corr=9)
     bad = good_x.copy()
