@@ -720,13 +720,13 @@ def main():
             g_potrf = float(np.mean([t["potrf_ms"] for t in timg[1:]]))
             grp = {"matrices": gl, "potrf_ms_all_matrices": g_potrf, "cholesky_tflops": gl * flops / (g_potrf * 1e-3) / 1e12,
                    "frac_of_fp64_peak": gl * flops / (g_potrf * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
-            # ---- the launch the timed region issues: the trailing update of a lock-step group (grid.z = gl matrices).  In
-            # the product the look-ahead columns' update (LUr) runs BESIDE it on a side stream and overlaps the HIP events
-            # around it; for this leg LUr goes back in front of it on the main stream (egx_set_tuning "lur_side" = 0: same
-            # kernels, same arithmetic, one stream), so the events bracket the launch alone -- the next group's chain still
-            # shares the chip, as it does in the product.
+            # ---- the launch the timed region issues: the dominant update of a lock-step group (grid.z = gl matrices).  A
+            # handle of this shape factors LEFT-looking over its panel groups (round 4): the long update of the next group's
+            # columns is alone on its stream, HIP events bracket it cleanly, the previous group's chain shares the chip as in
+            # the product.  (A right-looking handle -- EGX_POTRF_LEFT=0 -- runs the look-ahead columns' update beside the
+            # trailing update on a side stream; lur_side = 0 puts it back in front for this leg.)
             try:
-                prev = egx.set_tuning("lur_side", 0)
+                prev = egx.set_tuning("lur_side", 0)  # (right-looking handles only: the left-looking schedule has no LUr)
                 timq = [group_batch(10 + j) for j in range(3)][1:]
                 egx.set_tuning("lur_side", prev)
                 ms8 = float(np.mean([t["potrf_syrk_ms"] for t in timq]))
@@ -777,19 +777,22 @@ def main():
                 "bound": "mfma", "achieved": roof_group["tflops"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": roof_group["tflops"] / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
                 "launch_shape": f"{gl} matrices per launch (grid.z): the launch the timed region issues for a lock-step group",
-                "kernel": "k_gemm_stream<LOWER> (Cholesky trailing update C -= P P^T of every matrix of the group, 128x256 tiles, "
-                          "once per group of four 256-wide panels, K = 1024; the launches with >= 512 tiles per matrix: "
-                          f"{100.0 * roof_group['share_of_potrf_flops']:.0f} % of the factorisations' n^3/3 flops)",
+                "kernel": "k_gemm_stream<LOWER, TAG 1>: the LONG left-looking update of a lock-step group's next 1024 columns "
+                          "(C -= L[:, 0:g) L[cols, 0:g)^T with K = every column before the previous group, 128x256 tiles; a "
+                          "handle with n >= 8192 and a lock-step width of 8 factors left-looking over its groups of four "
+                          "256-wide panels, kernels_chol.hip launch_potrf): "
+                          f"{100.0 * roof_group['share_of_potrf_flops']:.0f} % of the factorisations' n^3/3 flops",
                 "share_of_potrf_flops": roof_group["share_of_potrf_flops"],
                 "launches_per_group": roof_group["launches"], "launch_ms_avg": roof_group["launch_ms_avg"],
                 "flops_per_launch_avg": roof_group["flops_per_launch_avg"],
-                "how": "algorithmic flops (matrices * 2*K*ncols*(ncols+1)/2 per launch) / HIP-event durations around every such "
-                       "launch on the stream it is launched on; ONE lock-step group in flight, the group's look-ahead-column "
-                       "update serialised in front of it (egx_set_tuning lur_side = 0; in the product it runs beside it), "
-                       "the next group's chain kernels sharing the chip as in the product.  Reproduce: rocprofv3 "
-                       "--kernel-trace --stats -- python tools/group_roofline.py (profiles/r04_group_roofline_kernel_stats.txt)",
-                "traffic_note": "`traffic` is per launch of ONE matrix (offline PMC passes, see roofline_single_matrix.traffic_source); "
-                                f"a group launch moves {gl} x that"}),
+                "how": "algorithmic flops (matrices * 2 * K * (rows * 1024 - 1024 * 1023 / 2) per launch) / HIP-event durations "
+                       "around every such launch on the stream it is launched on; ONE lock-step group in flight; the chain of "
+                       "the previous group (diagonal blocks, panel solves, in-group updates) shares the chip with it as in "
+                       "the product.  Reproduce: rocprofv3 --kernel-trace --stats -- python tools/group_roofline.py, row "
+                       "'left-looking long update' of tools/rocpd_stats.py (profiles/r04_group_roofline_kernel_stats.txt)",
+                "traffic_note": "`traffic` is the right-looking single-matrix launch's (offline PMC passes, see "
+                                "roofline_single_matrix.traffic_source); the left-looking launches read and write every "
+                                "tile of C once per group instead of once per earlier group"}),
             "roofline_single_matrix": {"bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic,

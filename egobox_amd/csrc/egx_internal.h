@@ -191,7 +191,8 @@ int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const d
 // info != nullptr: device flag of the enclosing factorisation; the kernel returns at once when it is non-zero
 int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
                        const double *B, int64_t ldb, int M, int N, int K, int lower, int ktri = 0,
-                       bool *used_big_tile = nullptr, const int *info = nullptr, const GemmBatch *batch = nullptr);
+                       bool *used_big_tile = nullptr, const int *info = nullptr, const GemmBatch *batch = nullptr,
+                       int tag = 0);  // tag: kernel symbol of the stream kernel (profiling only; k_gemm_stream's TAG)
 // Gneg (rows x rows, ldg; lower 64x64 tiles) <- -(W W^T) for a small output and a long contraction (split-K, partial
 // tiles in the scratch P of gram_scratch_doubles(rows, K) doubles, summed in a fixed order)
 size_t gram_scratch_doubles(int rows, int K);

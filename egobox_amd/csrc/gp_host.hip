@@ -1201,6 +1201,63 @@ int32_t egx_gp_set_lockstep(egx_gp *gp, int32_t width) {
 
 int32_t egx_gp_get_lockstep(const egx_gp *gp) { return gp ? gp->lockstep : 0; }
 
+int32_t egx_gp_shrink(egx_gp *gp, int32_t n_keep) {
+    if (!gp || n_keep < 1) {
+        set_error("egx_gp_shrink: NULL handle or n_keep < 1");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::unique_lock<std::shared_mutex> lock(gp->mu);
+    EGX_RC(set_device(gp));
+    const int nws = (int)gp->ws.size();
+    for (auto &w : gp->ws) {  // nothing of this handle may still run
+        if (w.stream) EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+        if (w.lk.s2) EGX_HIP_CHECK(hipStreamSynchronize(w.lk.s2));
+        if (w.lk.s3) EGX_HIP_CHECK(hipStreamSynchronize(w.lk.s3));
+        if (w.inv_stream) EGX_HIP_CHECK(hipStreamSynchronize(w.inv_stream));
+    }
+    if (gp->slab_W) {  // the theta-gradient's C^-T buffers are scratch between calls
+        (void)hipFree(gp->slab_W);
+        gp->slab_W = nullptr;
+        gp->slab_W_count = 0;
+    }
+    if (n_keep >= nws) return EGX_SUCCESS;
+    // the first n_keep workspaces sit at the front of the slabs: smaller slabs, one device-to-device copy each
+    double *nM = nullptr, *nD = nullptr;
+    int *nI = nullptr;
+    if (dev_malloc(&nM, sizeof(double) * (size_t)gp->stride_M * n_keep) != hipSuccess ||
+        dev_malloc(&nD, sizeof(double) * (size_t)gp->stride_D * n_keep) != hipSuccess ||
+        dev_malloc(&nI, sizeof(int) * (size_t)n_keep) != hipSuccess) {
+        (void)hipGetLastError();
+        if (nM) (void)hipFree(nM);
+        if (nD) (void)hipFree(nD);
+        if (nI) (void)hipFree(nI);
+        set_error("egx_gp_shrink: no memory for the smaller slabs (the handle is unchanged)");
+        return EGX_ERR_HIP;
+    }
+    EGX_HIP_CHECK(hipMemcpy(nM, gp->slab_M, sizeof(double) * (size_t)gp->stride_M * n_keep, hipMemcpyDeviceToDevice));
+    EGX_HIP_CHECK(hipMemcpy(nD, gp->slab_D, sizeof(double) * (size_t)gp->stride_D * n_keep, hipMemcpyDeviceToDevice));
+    EGX_HIP_CHECK(hipMemcpy(nI, gp->slab_I, sizeof(int) * (size_t)n_keep, hipMemcpyDeviceToDevice));
+    (void)hipFree(gp->slab_M);
+    (void)hipFree(gp->slab_D);
+    (void)hipFree(gp->slab_I);
+    gp->slab_M = nM;
+    gp->slab_D = nD;
+    gp->slab_I = nI;
+    for (int i = n_keep; i < nws; i++) free_workspace(gp->ws[i]);
+    gp->ws.resize((size_t)n_keep);
+    for (int i = 0; i < n_keep; i++) {
+        gp->ws[i].M = gp->slab_M + (int64_t)i * gp->stride_M;
+        gp->ws[i].dinv = gp->slab_D + (int64_t)i * gp->stride_D;
+        gp->ws[i].d_info = gp->slab_I + i;
+    }
+    {
+        std::lock_guard<std::mutex> pl(gp->pool_mu);
+        gp->ws_busy.assign((size_t)n_keep, 0);
+    }
+    gp->lockstep = default_lockstep(n_keep, gp->n_pad);
+    return EGX_SUCCESS;
+}
+
 int32_t egx_gp_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     if (!gp || !theta) {
         set_error("NULL argument");

@@ -308,7 +308,9 @@ typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
 // KTRI (with LOWER, square, ONE tile per workgroup): A == B == W upper triangular (row i is zero left of column i); the
 // accumulators start at ZERO and C <- -(W W^T) is written without being read (no memset of C, no read pass).
-template <bool LOWER, bool KTRI = false>
+// TAG: no effect on the code -- the left-looking group updates get kernel symbols of their own (1: the long update, 2: the
+// short one), so that `rocprofv3 --kernel-trace --stats` lists the launches bench.py's roofline times as their own row.
+template <bool LOWER, bool KTRI = false, int TAG = 0>
 __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, int64_t ldc, const double *__restrict__ A,
                                                         int64_t lda, const double *__restrict__ B, int64_t ldb, int K,
                                                         int nbx, int nby, int ntiles, const int *__restrict__ info,
@@ -1404,7 +1406,7 @@ static int g_look_min_cols = 3072;    // EGX_LOOK_MIN: look-ahead while at least
 static int g_trsm_group = 0;          // EGX_TRSM_GROUP: panels per update in the solves after the factorisation (0 = 4)
 static int g_lur_side = 1;            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU also in lock-step batches
 static int g_stream_walk = 0;         // EGX_STREAM_WALK=1: XCD-aware 8 x 4 super-tile order of k_gemm_stream (0: column-major)
-static int g_potrf_left = 0;          // EGX_POTRF_LEFT: left-looking group updates (launch_potrf) 0 never, 1 for handles with large n and
+static int g_potrf_left = 1;          // EGX_POTRF_LEFT: left-looking group updates (launch_potrf) 0 never, 1 for handles with large n and
                                       // a lock-step width >= 8, 2 always
 
 int chol_init() {
@@ -1435,6 +1437,8 @@ int chol_init() {
         set(reinterpret_cast<const void *>(&k_gemm_stream<true>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<false>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<true, true>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<true, false, 1>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<true, false, 2>), ST_LDS_BYTES);
     });
     return rc_once;
 }
@@ -1472,7 +1476,7 @@ int set_knob(const char *name, int value) {
 //   k_gemm_nt_sub 128x128, XCD-swizzled          the rest (the theta-gradient's R^-1 = W W^T with ktri, odd widths)
 int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, int64_t lda,
                        const double *B, int64_t ldb, int M, int N, int K, int lower, int ktri, bool *used_big_tile,
-                       const int *info, const GemmBatch *batch) {
+                       const int *info, const GemmBatch *batch, int tag) {
     if (used_big_tile) *used_big_tile = false;
     if (M <= 0 || N <= 0 || K <= 0) return EGX_SUCCESS;
     if (M % 128 || N % 128 || K % KC) {
@@ -1502,7 +1506,13 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         const int walk = (g_stream_walk != 0 && g_stream_tpw == 1) ? 1 : 0;
         if (walk) nt = stream_xcd_grid(lower != 0, nbx, nby);  // one workgroup per slot of the super-tile order
         const dim3 grid((unsigned)((nt + g_stream_tpw - 1) / g_stream_tpw), 1, nz);
-        if (lower)
+        if (lower && tag == 1)
+            hipLaunchKernelGGL((k_gemm_stream<true, false, 1>), grid, dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx,
+                               nby, nt, info, bt, walk);
+        else if (lower && tag == 2)
+            hipLaunchKernelGGL((k_gemm_stream<true, false, 2>), grid, dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx,
+                               nby, nt, info, bt, walk);
+        else if (lower)
             hipLaunchKernelGGL((k_gemm_stream<true>), grid, dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx, nby, nt,
                                info, bt, walk);
         else
@@ -1620,9 +1630,9 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
                                (const int *)info, pb.sM, pb.sM, pb.sD, pb.sI, (const double *)nullptr);
     };
     // C[r0.., c0..c0+N) -= P[r0.., k0..k0+K) P[c0..c0+N, k0..k0+K)^T for the M rows from r0
-    auto update = [&](hipStream_t st, int r0, int c0, int Mr, int N, int k0, int K, int lower, bool *big) -> int {
+    auto update = [&](hipStream_t st, int r0, int c0, int Mr, int N, int k0, int K, int lower, bool *big, int tag = 0) -> int {
         return launch_gemm_nt_sub(st, M + (int64_t)r0 * ld + c0, ld, M + (int64_t)r0 * ld + k0, ld,
-                                  M + (int64_t)c0 * ld + k0, ld, Mr, N, K, lower, 0, big, info, &gb);
+                                  M + (int64_t)c0 * ld + k0, ld, Mr, N, K, lower, 0, big, info, &gb, tag);
     };
     // groups of four panels (K = 1024 per trailing update: half the C tile traffic and tile boundaries of K = 512) pay
     // from n ~ 14000 on (measured, profiles/r02_run13_group_by_size.txt: n = 16384 -2 %, n = 12288 even, n = 8192 +5 %:
@@ -1733,7 +1743,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             if (gprev > 0) {  // U_long: columns [0, gprev), all final (C(J-2) was waited for before U_short(J-1))
                 const bool timed = trace && trace->ready && trace->used < GemmTrace::kMax;
                 if (timed) EGX_HIP_CHECK(hipEventRecord(trace->e0[trace->used], s));
-                rc = update(s, g0, g0, m_tot - g0, gw, 0, gprev, 1, nullptr);
+                rc = update(s, g0, g0, m_tot - g0, gw, 0, gprev, 1, nullptr, 1);
                 if (rc) return rc;
                 if (timed) {
                     EGX_HIP_CHECK(hipEventRecord(trace->e1[trace->used], s));
@@ -1743,7 +1753,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
                 }
             }
             if (la && gprev > 0) EGX_HIP_CHECK(hipStreamWaitEvent(s, lk->ev_panel, 0));  // C(J-1): the previous group is final
-            rc = update(s, g0, g0, m_tot - g0, gw, gprev, g0 - gprev, 1, nullptr);        // U_short
+            rc = update(s, g0, g0, m_tot - g0, gw, gprev, g0 - gprev, 1, nullptr, 2);     // U_short
             if (rc) return rc;
             if (la) {
                 EGX_HIP_CHECK(hipEventRecord(lk->ev_lu, s));

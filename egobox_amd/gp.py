@@ -194,6 +194,10 @@ class GpHandle:
         L.check(self._lib.egx_gp_set_lockstep(self._h, int(width)))
         return self._lib.egx_gp_get_lockstep(self._h)
 
+    def shrink(self, n_keep=1):
+        """egx_gp_shrink: keep the first n_keep workspaces (the fitted factor lives in workspace 0), free the rest."""
+        L.check(self._lib.egx_gp_shrink(self._h, int(n_keep)))
+
     def likelihood(self, theta):
         theta = L.as_f64(np.atleast_1d(theta), 1)
         lk, st = C.c_double(), C.c_int32()
@@ -601,6 +605,10 @@ class GpParams:
             starts_log10, _ = prepare_multistart(self._n_start, theta0[active], ab, seed=self._seed)
             n_evals = h.fit_partial(theta0, active, 10.0 ** starts_log10, [lo for lo, _ in ab],
                                     [hi for _, hi in ab], self._max_eval)
+        if nws > 1:
+            # the multistart's workspaces go back (egx_gp_shrink): the resident model keeps the factor's workspace and one
+            # more, so that likelihood evaluations on the fitted model do not un-fit it
+            h.shrink(2)
         return GaussianProcess(h, self, n_evals)
 
 

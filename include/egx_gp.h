@@ -157,6 +157,11 @@ int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int
  * not depend on the width or on its companions (same kernels, same arithmetic: bit-identical). */
 int32_t egx_gp_set_lockstep(egx_gp *gp, int32_t width);
 int32_t egx_gp_get_lockstep(const egx_gp *gp);
+/* Give back what only an optimisation needed: the handle keeps its first n_keep (>= 1) workspaces -- workspace 0 holds the
+ * fitted factor, which survives -- and frees the others together with the theta-gradient's scratch.  A tuned fit runs its
+ * multistart on up to 12 workspaces (2 GiB each at n = 16384); the fitted model that stays resident (an EGO objective, an
+ * expert of a mixture) needs one.  The lock-step width falls back to the default for the new count. */
+int32_t egx_gp_shrink(egx_gp *gp, int32_t n_keep);
 /* NEW capability (the reference has no theta-gradient, algorithm.rs:880: the objective closure ignores `_gradient`):
  * the reduced likelihood of algorithm.rs:988-1056 AND dL/dtheta (length h) at one theta; validated against the oracle's
  * closed form and by finite differences of the parity-checked likelihood.  Needs the factor, C^-T (n^2 doubles of

@@ -1318,3 +1318,37 @@ def test_x_gradients_beyond_256_dimensions_are_refused_not_wrong(egx):
         assert np.all(np.isfinite(h.predict(xq))) and np.all(h.predict_var(xq) >= 0.0)
         with pytest.raises(egx.EgxError):
             h.predict_gradients(xq)
+
+
+def test_shrink_gives_the_multistart_workspaces_back(egx):
+    """egx_gp_shrink: a handle that ran an optimisation on several workspaces keeps its fitted factor
+    (workspace 0) and frees the rest -- the device memory comes back, predictions are bit for bit unchanged, and the
+    handle keeps working (likelihood batches on what is left, a gradient that re-allocates its scratch)."""
+    import torch
+    n, d = 3000, 4
+    x, y = _data(n, d, seed=12)
+    theta = egx.workload.default_theta(d) * 2.0
+    xq = np.random.default_rng(0).random((64, d))
+    with egx.GpHandle(x, y, corr=3, n_workspaces=6) as h:
+        h.finalize(theta)
+        lk0, g0, _ = h.likelihood_grad(theta * 1.1)  # allocates the C^-T scratch
+        before = h.predict_valvar(xq)
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        h.shrink(2)
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        per_ws = 8 * 3072 * (3072 + 128)
+        assert free1 - free0 >= 4 * per_ws  # four matrices + the gradient scratch came back
+        after = h.predict_valvar(xq)
+        assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+        lks, sts = h.likelihood_batch(np.stack([theta, theta * 1.2, theta * 0.9]))
+        assert np.all(sts == 0) and np.array_equal(h.predict(xq), before[0])  # the fit survived (workspace 1 did the work)
+        lk1, g1, _ = h.likelihood_grad(theta * 1.1)
+        assert lk1 == lk0 and np.array_equal(g1, g0)
+        h.shrink(1)
+        h.shrink(5)  # more than there are: nothing to do
+        assert np.array_equal(h.predict(xq), before[0])
+    with pytest.raises(egx.InvalidValueError):
+        with egx.GpHandle(x[:100], y[:100]) as h2:
+            h2.shrink(0)

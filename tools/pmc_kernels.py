@@ -19,9 +19,10 @@ def short(nm, gx, wx):
     m = re.search(r"egx\d+(k_[a-z0-9_]+)", nm)
     base = m.group(1) if m else nm[:40]
     if base == "k_gemm_stream":
-        t = re.search(r"k_gemm_streamILb([01])ELb([01])E", nm)
+        t = re.search(r"k_gemm_streamILb([01])ELb([01])ELi(\d)E", nm)
         if t:
             base += "<lower>" if t.group(1) == "1" and t.group(2) == "0" else ("<ktri>" if t.group(2) == "1" else "<rect>")
+            base += {"1": "<left-long>", "2": "<left-short>"}.get(t.group(3), "")
         base += ">=512wg" if gx // max(1, wx) >= 512 else "<512wg"
     elif base == "k_gemm_nt_sub":
         t = re.search(r"ILb([01])ELi(\d+)ELi(\d+)", nm)

@@ -24,7 +24,7 @@ def main(path, per_fit=1):
     try:
         q2 = """select count(*), sum(d.end-d.start)/1e6, avg(d.end-d.start)/1e3, min(d.end-d.start)/1e3, max(d.end-d.start)/1e3
                 from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id
-                where s.kernel_name like '%k_gemm_streamILb1ELb0E%' and d.grid_size_x / d.workgroup_size_x >= 512
+                where s.kernel_name like '%k_gemm_streamILb1ELb0ELi0E%' and d.grid_size_x / d.workgroup_size_x >= 512
                       and d.grid_size_z <= 1"""
         c, t, a, lo, hi = list(cur.execute(q2))[0]
         if c:
@@ -36,11 +36,21 @@ def main(path, per_fit=1):
         q3 = """select d.grid_size_z, count(*), sum(d.end-d.start)/1e6, avg(d.end-d.start)/1e3, min(d.end-d.start)/1e3,
                        max(d.end-d.start)/1e3
                 from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id
-                where s.kernel_name like '%k_gemm_streamILb1ELb0E%' and d.grid_size_x / d.workgroup_size_x >= 512
+                where s.kernel_name like '%k_gemm_streamILb1ELb0ELi0E%' and d.grid_size_x / d.workgroup_size_x >= 512
                       and d.grid_size_z > 1 group by d.grid_size_z"""
         for z, c, t, a, lo, hi in cur.execute(q3):
             print(f"k_gemm_stream<LOWER>, launches of >= 512 workgroups per matrix, {z} matrices per launch")
             print(f"{'':<72} {c:>6} {t:>10.3f} {a:>10.1f} {lo:>9.1f} {hi:>10.1f} {100 * t / tot:>6.1f}")
+        # left-looking group updates (own kernel symbols, k_gemm_stream's TAG): the LONG update (K = all columns before the
+        # previous group) is what bench.py's `roofline` times in a lock-step group; the short one has K = 1024
+        for tag, what in ((1, "long update (bench.py roofline)"), (2, "short update, K = one group")):
+            qt = f"""select d.grid_size_z, count(*), sum(d.end-d.start)/1e6, avg(d.end-d.start)/1e3, min(d.end-d.start)/1e3,
+                            max(d.end-d.start)/1e3
+                     from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id
+                     where s.kernel_name like '%k_gemm_streamILb1ELb0ELi{tag}E%' group by d.grid_size_z"""
+            for z, c, t, a, lo, hi in cur.execute(qt):
+                print(f"k_gemm_stream<LOWER>, left-looking {what}, {z} matrices per launch")
+                print(f"{'':<72} {c:>6} {t:>10.3f} {a:>10.1f} {lo:>9.1f} {hi:>10.1f} {100 * t / tot:>6.1f}")
         # the theta-gradient's R^-1 = C^-T C^-1 launches (per-tile K ranges), by matrices per launch
         q4 = """select d.grid_size_z, count(*), sum(d.end-d.start)/1e6, avg(d.end-d.start)/1e3, min(d.end-d.start)/1e3,
                        max(d.end-d.start)/1e3
