@@ -1406,6 +1406,7 @@ static int g_look_min_cols = 3072;    // EGX_LOOK_MIN: look-ahead while at least
 static int g_trsm_group = 0;          // EGX_TRSM_GROUP: panels per update in the solves after the factorisation (0 = 4)
 static int g_lur_side = 1;            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU also in lock-step batches
 static int g_stream_walk = 0;         // EGX_STREAM_WALK=1: XCD-aware 8 x 4 super-tile order of k_gemm_stream (0: column-major)
+static int g_tail_merge = 1;          // EGX_TAIL_MERGE=0: without look-ahead the next group's columns and the rest are updated by two launches
 static int g_potrf_left = 1;          // EGX_POTRF_LEFT: left-looking group updates (launch_potrf) 0 never, 1 for handles with large n and
                                       // a lock-step width >= 8, 2 always
 
@@ -1425,6 +1426,7 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_LUR_SIDE")) g_lur_side = std::atoi(e);
         if (const char *e = std::getenv("EGX_STREAM_WALK")) g_stream_walk = std::atoi(e);
         if (const char *e = std::getenv("EGX_POTRF_LEFT")) g_potrf_left = std::atoi(e);
+        if (const char *e = std::getenv("EGX_TAIL_MERGE")) g_tail_merge = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -1458,7 +1460,7 @@ int set_knob(const char *name, int value) {
                                               {"stream_tpw", &g_stream_tpw},   {"gemm_small", &g_gemm_small_max},
                                               {"look_min", &g_look_min_cols},  {"trsm_group", &g_trsm_group},
                                               {"lur_side", &g_lur_side},       {"stream_walk", &g_stream_walk},
-                                              {"potrf_left", &g_potrf_left}};
+                                              {"potrf_left", &g_potrf_left},   {"tail_merge", &g_tail_merge}};
     for (auto &e : tab)
         if (std::string(name) == e.n) {
             const int old = *e.v;
@@ -1808,6 +1810,11 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             rc = inner_factor(s2, r1, gw1, s3, lk->ev_lur);
             if (rc) return rc;
             EGX_HIP_CHECK(hipEventRecord(lk->ev_panel, s2));
+        } else if (!look && g_tail_merge) {
+            // no look-ahead (small matrices, the last ~3000 columns): nothing runs beside the trailing update, so the next
+            // group's columns and the rest are ONE launch (round 4: one ramp-up and one tail instead of two)
+            rc = update(s, r1, r1, m_tot - r1, n_pad - r1, g0, gw, 1, nullptr);
+            if (rc) return rc;
         } else {
             // LU: the next group's columns only
             rc = update(s, r1, r1, m_tot - r1, gw1, g0, gw, 1, nullptr);
@@ -1822,7 +1829,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         }
         // RU: the rest of the trailing matrix
         const int r2 = r1 + gw1;
-        if (r2 < n_pad) {
+        if (r2 < n_pad && (look || !g_tail_merge)) {
             const bool timed = trace && trace->ready && trace->used < GemmTrace::kMax;
             if (timed) EGX_HIP_CHECK(hipEventRecord(trace->e0[trace->used], s));
             bool big = false;
