@@ -779,7 +779,7 @@ def main():
                 "launch_shape": f"{gl} matrices per launch (grid.z): the launch the timed region issues for a lock-step group",
                 "kernel": "k_gemm_stream<LOWER, TAG 1>: the LONG left-looking update of a lock-step group's next 1024 columns "
                           "(C -= L[:, 0:g) L[cols, 0:g)^T with K = every column before the previous group, 128x256 tiles; a "
-                          "handle with n >= 8192 and a lock-step width of 8 factors left-looking over its groups of four "
+                          "handle with n >= 14336 and a lock-step width of 8 factors left-looking over its groups of four "
                           "256-wide panels, kernels_chol.hip launch_potrf): "
                           f"{100.0 * roof_group['share_of_potrf_flops']:.0f} % of the factorisations' n^3/3 flops",
                 "share_of_potrf_flops": roof_group["share_of_potrf_flops"],

@@ -1406,9 +1406,10 @@ static int g_look_min_cols = 3072;    // EGX_LOOK_MIN: look-ahead while at least
 static int g_trsm_group = 0;          // EGX_TRSM_GROUP: panels per update in the solves after the factorisation (0 = 4)
 static int g_lur_side = 1;            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU also in lock-step batches
 static int g_stream_walk = 0;         // EGX_STREAM_WALK=1: XCD-aware 8 x 4 super-tile order of k_gemm_stream (0: column-major)
+static int g_trsm_left = 1;           // EGX_TRSM_LEFT=0: the solves after the factorisation update right-looking (one pass over all later columns per group)
 static int g_tail_merge = 1;          // EGX_TAIL_MERGE=0: without look-ahead the next group's columns and the rest are updated by two launches
-static int g_potrf_left = 1;          // EGX_POTRF_LEFT: left-looking group updates (launch_potrf) 0 never, 1 for handles with large n and
-                                      // a lock-step width >= 8, 2 always
+static int g_potrf_left = 1;          // EGX_POTRF_LEFT: left-looking group updates (launch_potrf) 0 never, 1 for handles with n_pad >= 14336
+                                      // and a lock-step width >= 8, 2 always
 
 int chol_init() {
     static std::once_flag once;
@@ -1427,6 +1428,7 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_STREAM_WALK")) g_stream_walk = std::atoi(e);
         if (const char *e = std::getenv("EGX_POTRF_LEFT")) g_potrf_left = std::atoi(e);
         if (const char *e = std::getenv("EGX_TAIL_MERGE")) g_tail_merge = std::atoi(e);
+        if (const char *e = std::getenv("EGX_TRSM_LEFT")) g_trsm_left = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -1448,7 +1450,9 @@ int chol_init() {
 // does a handle of this shape factor left-looking?  (per handle, never per launch: see launch_potrf)
 int potrf_left_for(int n_pad, int lockstep) {
     (void)chol_init();
-    return g_potrf_left >= 2 || (g_potrf_left == 1 && n_pad >= 8192 && lockstep >= 8);
+    // measured (profiles/r04_run4_*, r04_run5_ab_small_*): n = 16384 with groups of eight +2.3 % on the sweep; n = 8192 (groups
+    // of two panels, K <= 7k, <= 128 tiles per matrix and launch) -14 %; a lone matrix 2.4x slower -- hence the narrow rule
+    return g_potrf_left >= 2 || (g_potrf_left == 1 && n_pad >= 14336 && lockstep >= 8);
 }
 
 // run-time access to the knobs above (egx_set_tuning): A/B measurements inside ONE process (a gpurun call is minutes, a
@@ -1460,7 +1464,8 @@ int set_knob(const char *name, int value) {
                                               {"stream_tpw", &g_stream_tpw},   {"gemm_small", &g_gemm_small_max},
                                               {"look_min", &g_look_min_cols},  {"trsm_group", &g_trsm_group},
                                               {"lur_side", &g_lur_side},       {"stream_walk", &g_stream_walk},
-                                              {"potrf_left", &g_potrf_left},   {"tail_merge", &g_tail_merge}};
+                                              {"potrf_left", &g_potrf_left},   {"tail_merge", &g_tail_merge},
+                                              {"trsm_left", &g_trsm_left}};
     for (auto &e : tab)
         if (std::string(name) == e.n) {
             const int old = *e.v;
@@ -1731,7 +1736,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         //     s :  ... U_long(J) | wait C(J-1) | U_short(J) | rec U(J) | U_long(J+1) | wait C(J) | U_short(J+1) ...
         //     s2:                                            wait U(J) | chain(J) | rec C(J)
         // A lone matrix' late long updates have few tiles with very long K loops and leave the chip underfilled: the mode is
-        // chosen per HANDLE (large n and a lock-step width of at least eight, PotrfBatch::left), never by the number of
+        // chosen per HANDLE (n_pad >= 14336 and a lock-step width of at least eight, PotrfBatch::left), never by the number of
         // matrices in a launch, so a candidate's bits do not depend on its companions.
         const bool la = s2 != nullptr;
         hipStream_t sc = la ? s2 : s;  // the chain's stream
@@ -1881,9 +1886,18 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
     // (groups of four panels: K = 1024 per update of the remaining columns.  The factorisation pays for wide groups with
     //  a longer serial chain; here every row tile is independent, so the width is bounded by the in-group work only)
     const int GW = (g_trsm_group > 0 ? g_trsm_group : 4) * kNB;
+    // LEFT-looking over the groups (round 4, g_trsm_left; dense right-hand sides only): the columns of group J receive
+    // the contributions of ALL earlier columns in one update with K = g0 before the group's own block substitution --
+    // every tile of RT is read and written once by a long K loop instead of once per earlier group (K = 1024).  With
+    // m >= 128 rows a launch always has m / 128 x 4 tiles: none of the underfill a lone factorisation's late updates have.
+    const bool left = g_trsm_left != 0 && !tri_rows;
     for (int g0 = 0; g0 < n_pad; g0 += GW) {
         const int gw = (n_pad - g0 < GW) ? (n_pad - g0) : GW;
         const int gend = g0 + gw;
+        if (left && g0 > 0) {
+            rc = launch_gemm_nt_sub(s, RT + g0, ldr, RT, ldr, M + (int64_t)g0 * ldm, ldm, m, gw, g0, 0, 0, nullptr, nullptr, &gb);
+            if (rc) return rc;
+        }
         for (int k0 = g0; k0 < gend; k0 += kNB) {
             const int nbk = (gend - k0 < kNB) ? (gend - k0) : kNB;
             const double *diag = M + (int64_t)k0 * ldm + k0;
@@ -1907,7 +1921,7 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
             }
         }
         const int ncols = n_pad - gend;
-        if (ncols > 0) {
+        if (ncols > 0 && !left) {
             const int m_eff = tri_rows ? ((gend < m) ? gend : m) : m;
             rc = launch_gemm_nt_sub(s, RT + gend, ldr, RT + g0, ldr, M + (int64_t)gend * ldm + g0, ldm, m_eff, ncols, gw, 0,
                                     0, nullptr, nullptr, &gb);
