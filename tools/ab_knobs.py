@@ -23,12 +23,16 @@ ap.add_argument("--d", type=int, default=32)
 ap.add_argument("--in-flight", type=int, default=24)
 ap.add_argument("--cands", type=int, default=48)
 ap.add_argument("--no-group", action="store_true")
+ap.add_argument("--lockstep", type=int, default=0)
 a = ap.parse_args()
 x, y = egx.workload.make_training_set(a.n, a.d, 42)
 base = egx.workload.default_theta(a.d)
 rng = np.random.default_rng(3)
 h = egx.GpHandle(x, y, corr=0, n_workspaces=a.in_flight)
 cands = base * 10.0 ** rng.uniform(-0.15, 0.15, size=(a.cands, a.d))
+if a.lockstep:
+    h.set_lockstep(a.lockstep)
+print(f"in flight {a.in_flight}, lock-step {h.set_lockstep(a.lockstep)}, {a.cands} candidates per measurement", flush=True)
 h.likelihood_batch(cands[: a.in_flight])
 a.values = a.settings
 
