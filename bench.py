@@ -7,16 +7,16 @@
      127.0.0.1; either way the line is only printed when the world size IS N and the RCCL communicator inside the
      library has N ranks)
 
-One "step" = one pass of the hot path over one batch of `--sweep-batch` (default 192 = three lock-step groups of eight on
-each of 8 GPUs) candidate thetas of a theta sweep: every candidate is one fit in north_star's sense --
+One "step" = one pass of the hot path over one batch of `--sweep-batch` (default 192 = three lock-step groups of eight per
+step on each of 8 GPUs) candidate thetas of a theta sweep: every candidate is one fit in north_star's sense --
 correlation-matrix build (K1) + blocked FP64-MFMA Cholesky with fused forward solves (K3/K4) + GLS / reduced
 likelihood, i.e. one evaluation of the objective the reference's COBYLA multiplies
 (crates/gp/src/algorithm.rs:880-897, 988-1056).  The batch is FIXED as N grows (strong scaling): rank r evaluates
 candidates r, r + N, ... through `egx_sweep_likelihood` (include/egx_gp.h), whose RCCL all-gather of the
 (likelihood, status) pairs runs inside libegx_gp_hip.so, inside the timed region, every step -- also at N = 1
 (one-rank communicator), so the measured code path is the same at every N.  On every GPU the candidates are factored
-in LOCK-STEP groups (egx_gp_set_lockstep: one launch sequence per group of 4, grid.z = candidate), three groups in
-flight.  The training set is resident in HBM before the timed region starts.
+in LOCK-STEP groups (egx_gp_set_lockstep: one launch sequence per group of eight, grid.z = candidate; a handle of this
+size factors left-looking over its panel groups, kernels_chol.hip launch_potrf), two groups in flight.  The training set is resident in HBM before the timed region starts.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the Cholesky trailing update, FP64 MFMA
 bound), measured in a separate leg with ONE fit in flight; `cpu_baseline` is the blas-feature-shaped CPU path
@@ -464,20 +464,22 @@ def main():
     ap.add_argument("--npoints", dest="n", type=int, default=16384)
     ap.add_argument("--dim", dest="d", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=24,
+    ap.add_argument("--in-flight", type=int, default=16,
                     help="candidates in flight per GPU (correlation-matrix workspaces of the sweep handle, 2 GiB each at "
-                         "n = 16384): 3 lock-step groups of 8 (measured in flight / width -> fits/s: 3 / 1 36.0, 12 / 4 40.7, "
-                         "24 / 8 41.3, 36 / 12 41.2; profiles/r03_run1_*, r03_run2_*, r03_run16_*)")
+                         "n = 16384): 2 lock-step groups of 8, factored left-looking (round 4; in flight / width -> fits/s: "
+                         "8 / 8 40.7, 16 / 8 42.2, 24 / 8 41.9, 32 / 16 42.2; profiles/r04_run6_*.  Round 3, right-looking: "
+                         "3 / 1 36.0, 12 / 4 40.7, 24 / 8 41.3, 36 / 12 41.2)")
     ap.add_argument("--sweep-batch", type=int, default=192,
                     help="candidate thetas per step, summed over ALL GPUs (fixed as N grows: strong scaling; 192 = 24 per GPU "
-                         "at N = 8, i.e. every GPU still has its three lock-step groups of eight; BASELINE config 4 sweeps 512)")
+                         "at N = 8, i.e. three lock-step groups of eight per GPU and step, two of them in flight; BASELINE config 4 "
+                         "sweeps 512)")
     ap.add_argument("--kernel-alone-leg", action="store_true",
                     help="internal: the roofline launches of one fit with the look-ahead OFF (run as a child process with "
                          "EGX_LOOK_MIN set, the library reads its knobs once); prints one JSON object")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the bounded side measurements of BASELINE configs 3 / 5 and d = 64 (other_configs in the line)")
     ap.add_argument("--lockstep", type=int, default=0,
-                    help="candidates factored in lock-step by one launch sequence (0 = library default: 8 with 24 in flight, else 4)")
+                    help="candidates factored in lock-step by one launch sequence (0 = library default: 8 from 16 in flight on, else 4)")
     ap.add_argument("--assignment", choices=("static", "dynamic"), default="static",
                     help="candidates -> ranks: c mod N, or pulled from the node-wide counter (egx_sweep_set_assignment)")
     ap.add_argument("--collective", choices=("library", "torch"), default="library",

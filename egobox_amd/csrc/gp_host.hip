@@ -855,13 +855,14 @@ int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t t
 // =================================================================================================
 // C ABI
 // =================================================================================================
-// Lock-step width of a handle with nws workspaces (or the EGX_LOCKSTEP environment variable).  Large matrices: several
-// groups in flight matter more than their width, so a handle keeps at least three groups -- 4 wide up to 23 workspaces, 8 wide
-// from 24 on (n = 16384, one box, in flight / width -> fits/s: 12 / 4 40.7, 12 / 6 40.7, 12 / 12 40.4, 24 / 4 39.9, 24 / 6 40.8,
-// 24 / 8 41.3, 32 / 8 40.8, 36 / 12 41.2: profiles/r03_run16_in_flight_and_width.txt); up to 12 for n_pad <= 4096, where an
-// evaluation is bound by launch latency and the chain (a tuned fit's 11 COBYLA starts are then ONE launch sequence per round)
+// Lock-step width of a handle with nws workspaces (or the EGX_LOCKSTEP environment variable).  Large matrices: 8 wide from 16
+// workspaces on, else 4; up to 12 for n_pad <= 4096, where an evaluation is bound by launch latency and the chain (a tuned
+// fit's 11 COBYLA starts are then ONE launch sequence per round).  Round 3 (right-looking, n = 16384; in flight / width ->
+// fits/s): 12 / 4 40.7, 24 / 6 40.8, 24 / 8 41.3, 32 / 8 40.8, 36 / 12 41.2 -- three groups in flight were the constant.  Round 4
+// (handles of that size with width >= 8 factor left-looking, launch_potrf): 8 / 8 40.7, 16 / 8 42.2, 24 / 8 41.9, 32 / 16 42.2,
+// 36 / 12 41.2 -- TWO groups in flight (profiles/r04_run6_left_looking_in_flight_and_width.txt).
 static int default_lockstep(int nws, int n_pad) {
-    int ls = n_pad <= 4096 ? 12 : (nws >= 24 ? 8 : 4);
+    int ls = n_pad <= 4096 ? 12 : (nws >= 16 ? 8 : 4);
     if (const char *e = std::getenv("EGX_LOCKSTEP")) ls = std::atoi(e);
     return ls < 1 ? 1 : (ls > nws ? nws : ls);
 }

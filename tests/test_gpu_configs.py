@@ -912,3 +912,37 @@ def test_lbfgs_starts_in_lock_step_walk_their_own_trajectories(egx):
         inner = h.inner()
         assert inner["likelihood"] == fits[best][0]
         assert np.array_equal(inner["theta"], fits[best][1])
+
+
+def test_left_looking_handles_candidates_do_not_depend_on_their_companions(egx):
+    """Round 4: a handle with a padded n >= 14336 and a lock-step width >= 8 factors LEFT-looking over its panel groups
+    (kernels_chol.hip launch_potrf).  The schedule belongs to the handle, not to a launch: a candidate gets the same bits
+    alone (a group of one), in a full group of eight and in a ragged group, next to a NaN theta and a candidate that is not
+    positive definite; and the left-looking likelihoods are the right-looking ones to rounding (the same sums in another
+    order)."""
+    n, d = 14400, 8
+    x, y = _data(n, d, 3)
+    rng = np.random.default_rng(8)
+    thetas = egx.workload.default_theta(d) * 3.0 * 10.0 ** rng.uniform(-0.1, 0.1, (11, d))
+    thetas[2, 1] = np.nan
+    thetas[6] = 1e-4  # R ~ all ones: not positive definite (or at rounding level)
+    with egx.GpHandle(x, y, corr=0, n_workspaces=16) as h:
+        assert h.set_lockstep(0) == 8
+        lk, st = h.likelihood_batch(thetas)                       # 8 + 2 (the NaN takes no slot)
+        alone = [h.likelihood_batch(thetas[c:c + 1]) for c in range(11)]
+        lk3, st3 = h.likelihood_batch(thetas[[9, 0, 4]])          # other companions, other slots
+        prev = egx.set_tuning("potrf_left", 0)
+        try:
+            lk_r, st_r = h.likelihood_batch(thetas)               # the same handle, right-looking
+        finally:
+            egx.set_tuning("potrf_left", prev)
+    assert st[2] == 4 and st[6] in (0, 1)
+    for c in range(11):
+        assert alone[c][1][0] == st[c]
+        if st[c] == 0:
+            assert alone[c][0][0] == lk[c]
+    assert lk3[0] == lk[9] and lk3[1] == lk[0] and lk3[2] == lk[4]
+    ok = (st == 0) & (st_r == 0) & (np.arange(11) != 6)
+    assert ok.sum() == 9
+    np.testing.assert_allclose(lk[ok], lk_r[ok], rtol=1e-10)
+    assert np.any(lk[ok] != lk_r[ok])  # (it IS another order of operations: if this ever fails the knob does nothing)
