@@ -286,6 +286,31 @@ def other_configs(egx, workload, gpu):
                                              "expert_points_per_s": k * m5 / t_m,
                                              "trsm_tflops": k * float(n5) * n5 * m5 / t_m / 1e12,
                                              "checksum": float(vm.sum())}
+    # config 2 (n = 4096, d = 8, sq-exp): the serial chain's size -- one evaluation in flight, and twelve in lock-step
+    n2, d2 = 4096, 8
+    x2, y2 = workload.make_training_set(n2, d2, seed=42)
+    th2 = workload.default_theta(d2) * 3.0
+    h = egx.GpHandle(x2, y2, mean=0, corr=0, device=gpu, n_workspaces=12)
+    h.finalize(th2)
+    t0 = time.perf_counter()
+    for j in range(10):
+        h.finalize(th2 * (1.0 + 1e-3 * j))
+    t_f2 = (time.perf_counter() - t0) / 10
+    tm2 = h.timings()
+    ths2 = np.stack([th2 * (1.0 + 0.01 * c) for c in range(48)])
+    h.likelihood_batch(ths2)
+    t0 = time.perf_counter()
+    h.likelihood_batch(ths2 * 1.001)
+    t_b2 = (time.perf_counter() - t0) / 48
+    h.close()
+    res["config2_sqexp_n4096_d8"] = {
+        "fixed_theta_fit_ms_one_in_flight": t_f2 * 1e3, "fits_per_s_one_in_flight": 1.0 / t_f2, "potrf_ms": tm2["potrf_ms"],
+        "cholesky_tflops_one_in_flight": tm2["potrf_flops"] / tm2["potrf_ms"] / 1e9,
+        "frac_of_fp64_peak_one_in_flight": tm2["potrf_flops"] / tm2["potrf_ms"] / 1e9 / FP64_MFMA_PEAK_TFLOPS,
+        "likelihoods_per_s_lockstep_12": 1.0 / t_b2,
+        "frac_of_fp64_peak_lockstep_12": float(n2) ** 3 / 3 / t_b2 / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+        "note": "one in flight: the serial chain of 16 diagonal blocks (57 us each) + panel solves + updates, each a separate "
+                "launch; lock-step 12: what a round of a tuned fit's COBYLA starts is"}
     d6 = 64
     x6, y6 = workload.make_training_set(n, d6, seed=42)
     h = egx.GpHandle(x6, y6, mean=0, corr=0, device=gpu, n_workspaces=1)
