@@ -946,3 +946,41 @@ def test_left_looking_handles_candidates_do_not_depend_on_their_companions(egx):
     assert ok.sum() == 9
     np.testing.assert_allclose(lk[ok], lk_r[ok], rtol=1e-10)
     assert np.any(lk[ok] != lk_r[ok])  # (it IS another order of operations: if this ever fails the knob does nothing)
+
+
+def test_sweep_counter_slots_survive_any_mix_of_static_and_dynamic_calls(egx):
+    """the node-wide candidate counter of call s lives in slot s mod 64 and is zeroed half a ring ahead.  The
+    sequence number advances on EVERY call, so the slot must be recycled on every call too: 40 dynamic calls, 30 static
+    ones, then dynamic again used to find a dirty counter (every rank pulled nothing -> a spurious EGX_ERR_PEER)."""
+    n, d = 300, 3
+    x, y = _data(n, d, 4)
+    thetas = egx.theta_sweep_candidates(9, d, seed=2)
+    with egx.Sweep(x, y, corr=0, rank=0, world=1, id_bytes="new", n_workspaces=3) as sw:
+        want = sw.likelihood(thetas)
+        for dynamic, calls in ((True, 40), (False, 30), (True, 70), (False, 5), (True, 70)):
+            sw.set_assignment(dynamic)
+            for _ in range(calls):
+                lk, st = sw.likelihood(thetas)
+                np.testing.assert_array_equal(st, want[1])
+                np.testing.assert_array_equal(lk, want[0])
+
+
+@pytest.mark.parametrize("corr", [0, 1])
+def test_huge_theta_gives_the_identity_correlation_not_nan(egx, corr):
+    """with theta = 1e8 (1e160: the exponent's sum overflows to +inf) every off-diagonal correlation underflows to
+    0, R = (1 + nugget) I and the reference returns a perfectly good likelihood; the fast exp of the correlation kernels
+    clamps its argument instead of turning -inf into NaN."""
+    import warnings
+    from oracle import gp_oracle as O
+    x, y = _data(300, 3, seed=2)
+    for th in (1e8, 1e160):
+        theta = np.full(3, th)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = O.fit_fixed(x, y, theta, corr=["SquaredExponential", "AbsoluteExponential"][corr])
+        with egx.GpHandle(x, y, corr=corr) as h:
+            lk, st = h.likelihood(theta)
+            assert st == 0 and lk == pytest.approx(ref.likelihood, rel=LK_RTOL)
+            h.finalize(theta)
+            xq = np.random.default_rng(1).random((20, 3))
+            np.testing.assert_allclose(h.predict(xq), ref.predict(xq), rtol=PRED_RTOL, atol=1e-9)
