@@ -397,7 +397,7 @@ def kernel_alone_leg(args):
     ms = float(np.mean([t["potrf_syrk_ms"] for t in tims]))
     fl = float(np.mean([t["syrk_flops"] for t in tims]))
     nl = int(tims[0]["syrk_launches"])
-    print(json.dumps({"tflops": fl / (ms * 1e-3) / 1e12, "launch_ms_avg": ms / max(1, nl), "launches_per_fit": nl,
+    print(json.dumps({"tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0, "launch_ms_avg": ms / max(1, nl), "launches_per_fit": nl,
                       "potrf_ms": float(np.mean([t["potrf_ms"] for t in tims]))}), flush=True)
     gp.close()
     return 0
@@ -418,9 +418,10 @@ def run_kernel_alone_leg(args, gpu):
     return {"bound": "mfma", "achieved": r["tflops"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": r["tflops"] / FP64_MFMA_PEAK_TFLOPS, "launch_ms_avg": r["launch_ms_avg"],
             "launches_per_fit": r["launches_per_fit"], "potrf_ms_with_lookahead_off": r["potrf_ms"],
-            "how": "the launches of `roofline`, timed the same way in a child process with EGX_LOOK_MIN beyond n: no look-ahead, "
-                   "so the chain kernels of the next group do not share the GPU with the trailing update (and the fit as a "
-                   "whole is slower: potrf_ms_with_lookahead_off).  What the kernel does with the chip to itself"}
+            "how": "the launches of `roofline_single_matrix` (a lone right-looking fit), timed the same way in a child process with "
+                   "EGX_LOOK_MIN beyond n: no look-ahead, so the chain kernels of the next group do not share the GPU with the "
+                   "trailing update, which then covers the next group's columns too (and the fit as a whole is slower: "
+                   "potrf_ms_with_lookahead_off).  What the kernel does with the chip to itself"}
 
 
 def spawn_ranks(n_ranks):

@@ -1818,8 +1818,17 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         } else if (!look && g_tail_merge) {
             // no look-ahead (small matrices, the last ~3000 columns): nothing runs beside the trailing update, so the next
             // group's columns and the rest are ONE launch (round 4: one ramp-up and one tail instead of two)
-            rc = update(s, r1, r1, m_tot - r1, n_pad - r1, g0, gw, 1, nullptr);
+            const bool timed = trace && trace->ready && trace->used < GemmTrace::kMax;
+            if (timed) EGX_HIP_CHECK(hipEventRecord(trace->e0[trace->used], s));
+            bool big = false;
+            rc = update(s, r1, r1, m_tot - r1, n_pad - r1, g0, gw, 1, &big);
             if (rc) return rc;
+            if (timed && big) {
+                EGX_HIP_CHECK(hipEventRecord(trace->e1[trace->used], s));
+                const double nc = (double)(n_pad - r1);
+                trace->flops[trace->used] = (double)nz * 2.0 * gw * nc * (nc + 1.0) / 2.0;
+                trace->used++;
+            }
         } else {
             // LU: the next group's columns only
             rc = update(s, r1, r1, m_tot - r1, gw1, g0, gw, 1, nullptr);
