@@ -936,6 +936,15 @@ def test_left_looking_handles_candidates_do_not_depend_on_their_companions(egx):
             lk_r, st_r = h.likelihood_batch(thetas)               # the same handle, right-looking
         finally:
             egx.set_tuning("potrf_left", prev)
+        # the theta-gradient on a left-looking handle (C^-T rides along the left-looking schedule) against the same
+        # candidates on a right-looking one-workspace handle
+        lkg, gg, stg = h.likelihood_grad_batch(thetas[[0, 1, 4, 5]])
+    with egx.GpHandle(x, y, corr=0, n_workspaces=1) as h1:
+        for q, c in enumerate((0, 1, 4, 5)):
+            l1, g1, s1 = h1.likelihood_grad(thetas[c])
+            assert s1 == 0 and stg[q] == 0 and lkg[q] == lk[c]
+            assert l1 == pytest.approx(lkg[q], rel=1e-9)
+            np.testing.assert_allclose(gg[q], g1, rtol=1e-6, atol=1e-7 * np.abs(g1).max())
     assert st[2] == 4 and st[6] in (0, 1)
     for c in range(11):
         assert alone[c][1][0] == st[c]
