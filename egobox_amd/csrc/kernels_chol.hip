@@ -842,11 +842,18 @@ __device__ __forceinline__ void rb_chain_run(RbChain &ch, double *NL, double *LR
     c = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[0], b2, c, 0, 0, NEG);           \
     c = __builtin_amdgcn_mfma_f64_16x16x4f64(a23[1], b3, c, 0, 0, NEG)
 
-// (the body is a device function: k_potf2_reg runs it alone, k_potf2_update beside the tiles of an update -- round 4)
 template <int NW>  // waves: 1 chain wave + NW - 1 update waves (16 in the product; the tables also cover 8 and 12)
-__device__ __forceinline__ void potf2_reg_body(double *__restrict__ D, int64_t ld, int nbk, double *__restrict__ lin,
-                                               int *__restrict__ info, int col0, int n_valid, double *sm) {
+__global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D, int64_t ld, int nbk, double *__restrict__ lin,
+                                                          int *__restrict__ info, int col0, int n_valid, int64_t bsD,
+                                                          int64_t bsL, int bsI) {
     constexpr int NU = NW - 1, RB_NS = rb_slots(NU);
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    {   // lock-step batch: one workgroup per matrix
+        const int64_t z = blockIdx.z;
+        D += z * bsD;
+        lin += z * bsL;
+        info += z * bsI;
+    }
     // examined once the loads of the block are on their way (below).  Only diagonal-block kernels SET the flag and the
     // chain runs them one after the other, so every wave of this workgroup reads the same value.
     const int failed_before = *info;
@@ -1032,74 +1039,6 @@ __device__ __forceinline__ void potf2_reg_body(double *__restrict__ D, int64_t l
     for (int k = 1; k + 1 < nb16; k++)
         if (!strip(k)) return;
     if (wave == 1 + (nb16 - 1) % NU) store_diag(nb16 - 1);
-}
-
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 1) void k_potf2_reg(double *__restrict__ D, int64_t ld, int nbk, double *__restrict__ lin,
-                                                          int *__restrict__ info, int col0, int n_valid, int64_t bsD,
-                                                          int64_t bsL, int bsI) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int64_t z = blockIdx.z;  // lock-step batch: one workgroup per matrix
-    potf2_reg_body<NW>(D + z * bsD, ld, nbk, lin + z * bsL, info + z * bsI, col0, n_valid, sm);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Round 4: the diagonal block and the update that does not touch it in ONE launch.  Where no look-ahead runs (small
-// matrices, the last ~3000 columns) the chain is  diagonal block -> panel solve -> update -> diagonal block ...  on one
-// stream, and a cross-stream hand-off costs what it could hide (profiles/r04_run9_*).  But once the NEXT diagonal block has
-// its update (a 256 x 256 launch of its own), factoring it and updating everything else are independent: workgroup 0 of
-// this kernel is the diagonal-block factorisation (k_potf2_reg's body), the others are 128 x 128 tiles of
-//     C[r0.., c0..c0+N) -= A B^T      (lower trapezoid, the tiles of its first `skip` 128-row blocks -- the diagonal block -- left out)
-// with 1024 threads per tile (16 waves x 32 x 32).  No communication between the two roles, no spin: the overlap is the
-// dispatcher's.
-// ---------------------------------------------------------------------------------------------
-using FuseShape = GemmShape<128, 128, 32, 32, 1024>;
-constexpr int FUSE_LDS_BYTES = FuseShape::LDS_BYTES > RB_LDS_BYTES ? FuseShape::LDS_BYTES : RB_LDS_BYTES;
-
-__global__ __launch_bounds__(1024, 1) void k_potf2_update(double *__restrict__ D, int64_t ld, int nbk, double *__restrict__ lin,
-                                                         int *__restrict__ info, int col0, int n_valid, int64_t bsD, int64_t bsL,
-                                                         int bsI, double *__restrict__ C, const double *__restrict__ A,
-                                                         const double *__restrict__ B, int K, int nbx, int nby, int skip) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int64_t z = blockIdx.z;
-    if (blockIdx.x == 0) {
-        potf2_reg_body<16>(D + z * bsD, ld, nbk, lin + z * bsL, info + z * bsI, col0, n_valid, sm);
-        return;
-    }
-    C += z * bsD;
-    A += z * bsD;
-    B += z * bsD;
-    if (wg_failed_before(info + z * bsI)) return;
-    // tile blockIdx.x - 1 of the list: rows bx = skip .. nbx - 1, each with by = 0 .. min(bx, nby - 1)
-    int t = (int)blockIdx.x - 1, bx = skip;
-    for (; bx < nbx; bx++) {
-        const int cnt = (bx + 1 < nby) ? bx + 1 : nby;
-        if (t < cnt) break;
-        t -= cnt;
-    }
-    if (bx >= nbx) return;
-    const int by = t;
-    const int tid = threadIdx.x;
-    using S = FuseShape;
-    double4_t acc[S::MT][S::NT];
-#pragma unroll
-    for (int mi = 0; mi < S::MT; mi++)
-#pragma unroll
-        for (int ni = 0; ni < S::NT; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-    gemm_core<128, 128, 32, 32, 1024>(A + (int64_t)bx * 128 * ld, ld, B + (int64_t)by * 128 * ld, ld, K, acc, sm, tid);
-    const int wave = tid >> 6, lane = tid & 63;
-    const int r0 = bx * 128 + (wave / S::WAVES_N) * 32 + (lane >> 4);
-    const int c0 = by * 128 + (wave % S::WAVES_N) * 32 + (lane & 15);
-#pragma unroll
-    for (int mi = 0; mi < S::MT; mi++)
-#pragma unroll
-        for (int ni = 0; ni < S::NT; ni++) {
-            double cv[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) cv[r] = C[(int64_t)(r0 + mi * 16 + 4 * r) * ld + (c0 + ni * 16)];
-#pragma unroll
-            for (int r = 0; r < 4; r++) C[(int64_t)(r0 + mi * 16 + 4 * r) * ld + (c0 + ni * 16)] = cv[r] - acc[mi][ni][r];
-        }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1467,8 +1406,6 @@ static int g_look_min_cols = 3072;    // EGX_LOOK_MIN: look-ahead while at least
 static int g_trsm_group = 0;          // EGX_TRSM_GROUP: panels per update in the solves after the factorisation (0 = 4)
 static int g_lur_side = 1;            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU also in lock-step batches
 static int g_stream_walk = 0;         // EGX_STREAM_WALK=1: XCD-aware 8 x 4 super-tile order of k_gemm_stream (0: column-major)
-static int g_fuse_potf2 = 0;          // EGX_FUSE_POTF2=1: without look-ahead the next diagonal block is factored INSIDE the launch that
-                                      // updates everything else (k_potf2_update)
 static int g_ingroup_left = 0;        // EGX_INGROUP_LEFT=1: left-looking handles update left-looking inside a group of panels too
 static int g_trsm_left = 1;           // EGX_TRSM_LEFT=0: the solves after the factorisation update right-looking (one pass over all later columns per group)
 static int g_tail_merge = 1;          // EGX_TAIL_MERGE=0: without look-ahead the next group's columns and the rest are updated by two launches
@@ -1494,7 +1431,6 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_TAIL_MERGE")) g_tail_merge = std::atoi(e);
         if (const char *e = std::getenv("EGX_TRSM_LEFT")) g_trsm_left = std::atoi(e);
         if (const char *e = std::getenv("EGX_INGROUP_LEFT")) g_ingroup_left = std::atoi(e);
-        if (const char *e = std::getenv("EGX_FUSE_POTF2")) g_fuse_potf2 = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -1509,7 +1445,6 @@ int chol_init() {
         set(reinterpret_cast<const void *>(&k_gemm_stream<true, true>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<true, false, 1>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<true, false, 2>), ST_LDS_BYTES);
-        set(reinterpret_cast<const void *>(&k_potf2_update), FUSE_LDS_BYTES);
     });
     return rc_once;
 }
@@ -1532,8 +1467,7 @@ int set_knob(const char *name, int value) {
                                               {"look_min", &g_look_min_cols},  {"trsm_group", &g_trsm_group},
                                               {"lur_side", &g_lur_side},       {"stream_walk", &g_stream_walk},
                                               {"potrf_left", &g_potrf_left},   {"tail_merge", &g_tail_merge},
-                                              {"trsm_left", &g_trsm_left},     {"ingroup_left", &g_ingroup_left},
-                                              {"fuse_potf2", &g_fuse_potf2}};
+                                              {"trsm_left", &g_trsm_left},     {"ingroup_left", &g_ingroup_left}};
     for (auto &e : tab)
         if (std::string(name) == e.n) {
             const int old = *e.v;
@@ -1767,42 +1701,6 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         if (pending) EGX_HIP_CHECK(hipStreamWaitEvent(st, pending, 0));
         return EGX_SUCCESS;
     };
-    // {diagonal block at p0 (nbp wide)} + {C[p0.., p0..c_end) -= P[.., k0..k0+K) P^T, lower, minus that diagonal block} in ONE
-    // launch (k_potf2_update); the diagonal block must already carry this update (a 256 x 256 launch in front)
-    auto fused = [&](hipStream_t st, int p0, int nbp, int c_end, int k0, int K) -> int {
-        const int nbx = (m_tot - p0) / 128, nby = (c_end - p0) / 128, skip = nbp / 128;
-        int tiles = 0;
-        for (int bx = skip; bx < nbx; bx++) tiles += (bx + 1 < nby) ? bx + 1 : nby;
-        double *diag = M + (int64_t)p0 * ld + p0;
-        hipLaunchKernelGGL(k_potf2_update, dim3((unsigned)(1 + tiles), 1, nz), dim3(1024), FUSE_LDS_BYTES, st, diag, ld, nbp,
-                           dinv + (int64_t)(p0 / 64) * 4096, info, p0, n_pad, pb.sM, pb.sD, pb.sI, diag,
-                           (const double *)(M + (int64_t)p0 * ld + k0), (const double *)(M + (int64_t)p0 * ld + k0), K, nbx, nby,
-                           skip);
-        EGX_HIP_CHECK(hipGetLastError());
-        return EGX_SUCCESS;
-    };
-    // the panels of one group with the fused launches: panel solve, the next diagonal block's update, then
-    // {next diagonal block} + {rest of the in-group update} together.  first_done: the group's first diagonal block was
-    // factored by a fused launch already.
-    auto chain_fused = [&](hipStream_t st, int g0, int gw, bool first_done) -> int {
-        bool done = first_done;
-        for (int k0 = g0; k0 < g0 + gw; k0 += kNB) {
-            const int nbk = (g0 + gw - k0 < kNB) ? (g0 + gw - k0) : kNB;
-            if (!done) potf2(st, k0, nbk);
-            done = false;
-            trsm(st, k0, nbk);
-            const int r1 = k0 + nbk;
-            if (r1 >= g0 + gw) break;
-            const int ncols = g0 + gw - r1;
-            const int nb1 = ncols < kNB ? ncols : kNB;
-            int rc2 = update(st, r1, r1, nb1, nb1, k0, nbk, 1, nullptr);
-            if (rc2) return rc2;
-            rc2 = fused(st, r1, nb1, g0 + gw, k0, nbk);
-            if (rc2) return rc2;
-            done = true;
-        }
-        return EGX_SUCCESS;
-    };
     // The rows of W = C^-T through the group of panels [g0, g0 + gw), which is final on `s` when this is called (PotrfInverse,
     // egx_internal.h): on inv->sw, beside whatever the factorisation does next.  Row i of the identity is zero left of
     // column i, so panel k0 only has the rows [0, k0 + nbk) to solve and the updates as many rows to carry.
@@ -1904,14 +1802,13 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         EGX_HIP_CHECK(hipGetLastError());
         return EGX_SUCCESS;
     }
-    rc = g_fuse_potf2 ? chain_fused(s, 0, gwidth(0), false) : inner_factor(s, 0, gwidth(0), s3, nullptr);
+    rc = inner_factor(s, 0, gwidth(0), s3, nullptr);
     if (rc) return rc;
     rc = inverse_group(s, 0, gwidth(0));
     if (rc) return rc;
     for (int g0 = 0; g0 < n_pad; g0 += GW) {
         const int gw = gwidth(g0);
         const int r1 = g0 + gw;  // first row/col of the trailing matrix
-        bool first_fused = false;
         if (r1 >= n_pad) break;  // (right-hand-side rows below the last block were solved by its panel)
         const int gw1 = gwidth(r1);
         // the cross-stream hand-off costs ~2 x 10 us; below ~3k trailing columns RU is shorter than that (and with
@@ -1937,13 +1834,6 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             rc = inner_factor(s2, r1, gw1, s3, lk->ev_lur);
             if (rc) return rc;
             EGX_HIP_CHECK(hipEventRecord(lk->ev_panel, s2));
-        } else if (!look && g_tail_merge && g_fuse_potf2) {
-            // ... and the next group's first diagonal block is factored INSIDE that launch, once it has its own update
-            rc = update(s, r1, r1, nb1, nb1, g0, gw, 1, nullptr);
-            if (rc) return rc;
-            rc = fused(s, r1, nb1, n_pad, g0, gw);
-            if (rc) return rc;
-            first_fused = true;
         } else if (!look && g_tail_merge) {
             // no look-ahead (small matrices, the last ~3000 columns): nothing runs beside the trailing update, so the next
             // group's columns and the rest are ONE launch (round 4: one ramp-up and one tail instead of two)
@@ -1988,7 +1878,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         if (look) {
             EGX_HIP_CHECK(hipStreamWaitEvent(s, lk->ev_panel, 0));
         } else {
-            rc = g_fuse_potf2 ? chain_fused(s, r1, gw1, first_fused) : inner_factor(s, r1, gw1, nullptr, nullptr);
+            rc = inner_factor(s, r1, gw1, nullptr, nullptr);
             if (rc) return rc;
         }
         rc = inverse_group(s, r1, gw1);  // the group that has just become final
