@@ -1406,7 +1406,6 @@ static int g_look_min_cols = 3072;    // EGX_LOOK_MIN: look-ahead while at least
 static int g_trsm_group = 0;          // EGX_TRSM_GROUP: panels per update in the solves after the factorisation (0 = 4)
 static int g_lur_side = 1;            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU also in lock-step batches
 static int g_stream_walk = 0;         // EGX_STREAM_WALK=1: XCD-aware 8 x 4 super-tile order of k_gemm_stream (0: column-major)
-static int g_ingroup_left = 0;        // EGX_INGROUP_LEFT=1: left-looking handles update left-looking inside a group of panels too
 static int g_trsm_left = 1;           // EGX_TRSM_LEFT=0: the solves after the factorisation update right-looking (one pass over all later columns per group)
 static int g_tail_merge = 1;          // EGX_TAIL_MERGE=0: without look-ahead the next group's columns and the rest are updated by two launches
 static int g_potrf_left = 1;          // EGX_POTRF_LEFT: left-looking group updates (launch_potrf) 0 never, 1 for handles with n_pad >= 14336
@@ -1430,7 +1429,6 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_POTRF_LEFT")) g_potrf_left = std::atoi(e);
         if (const char *e = std::getenv("EGX_TAIL_MERGE")) g_tail_merge = std::atoi(e);
         if (const char *e = std::getenv("EGX_TRSM_LEFT")) g_trsm_left = std::atoi(e);
-        if (const char *e = std::getenv("EGX_INGROUP_LEFT")) g_ingroup_left = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -1467,7 +1465,7 @@ int set_knob(const char *name, int value) {
                                               {"look_min", &g_look_min_cols},  {"trsm_group", &g_trsm_group},
                                               {"lur_side", &g_lur_side},       {"stream_walk", &g_stream_walk},
                                               {"potrf_left", &g_potrf_left},   {"tail_merge", &g_tail_merge},
-                                              {"trsm_left", &g_trsm_left},     {"ingroup_left", &g_ingroup_left}};
+                                              {"trsm_left", &g_trsm_left}};
     for (auto &e : tab)
         if (std::string(name) == e.n) {
             const int old = *e.v;
@@ -1653,23 +1651,6 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     // that brought this group's columns up to date)
     auto inner_factor = [&](hipStream_t st, int g0, int gw, hipStream_t side, hipEvent_t first_wait) -> int {
         hipEvent_t pending = first_wait;
-        if (pb.left && g_ingroup_left) {
-            // left-looking INSIDE the group too (round 4, left-looking handles): panel p's 256 columns receive the group's
-            // earlier panels in ONE update with K = 256 p right before its diagonal block is factored, instead of one
-            // K = 256 update of all remaining group columns per panel: the same flops, each tile read and written once.
-            // No diagonal-first split: in a lock-step group the chain hides behind the next group's long update anyway.
-            if (pending) EGX_HIP_CHECK(hipStreamWaitEvent(st, pending, 0));
-            for (int k0 = g0; k0 < g0 + gw; k0 += kNB) {
-                const int nbk = (g0 + gw - k0 < kNB) ? (g0 + gw - k0) : kNB;
-                if (k0 > g0) {
-                    int rc2 = update(st, k0, k0, m_tot - k0, nbk, g0, k0 - g0, 1, nullptr);
-                    if (rc2) return rc2;
-                }
-                potf2(st, k0, nbk);
-                trsm(st, k0, nbk);
-            }
-            return EGX_SUCCESS;
-        }
         for (int k0 = g0; k0 < g0 + gw; k0 += kNB) {
             const int nbk = (g0 + gw - k0 < kNB) ? (g0 + gw - k0) : kNB;
             potf2(st, k0, nbk);
