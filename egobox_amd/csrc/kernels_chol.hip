@@ -304,7 +304,7 @@ constexpr int ST_LDS_BYTES = ST_NSTAGE * ST_STAGE * 8;
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 
-#include "tile_walks.h"  // tile index -> (bx, by): column-major, XCD super-tiles, the KTRI row walk
+#include "tile_walks.h"  // tile index -> (bx, by): column-major, the KTRI row walk
 
 // KTRI (with LOWER, square, ONE tile per workgroup): A == B == W upper triangular (row i is zero left of column i); the
 // accumulators start at ZERO and C <- -(W W^T) is written without being read (no memset of C, no read pass).
@@ -314,7 +314,7 @@ template <bool LOWER, bool KTRI = false, int TAG = 0>
 __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, int64_t ldc, const double *__restrict__ A,
                                                         int64_t lda, const double *__restrict__ B, int64_t ldb, int K,
                                                         int nbx, int nby, int ntiles, const int *__restrict__ info,
-                                                        GemmBatch bt, int walk) {
+                                                        GemmBatch bt) {
     {   // lock-step batch: matrix blockIdx.z
         const int64_t z = blockIdx.z;
         C += z * bt.sC;
@@ -328,9 +328,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x;
     const int bid = (int)blockIdx.x;
-    // walk != 0 (never with KTRI; one tile per workgroup: ntiles == G): the XCD-aware super-tile order
-    int xbx = 0, xby = 0;
-    if (!KTRI && walk != 0 && !stream_tile_coords_xcd<LOWER>(bid, nbx, nby, xbx, xby)) return;
     int nch = K / KC;
     if (KTRI) {  // one tile per workgroup (G == ntiles): its K range starts at the tile's first row
         int bx, by;
@@ -357,7 +354,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
     {
         int bx, by;
         if (KTRI) stream_tile_coords_ktri(t_l, bx, by);
-        else if (walk != 0) bx = xbx, by = xby;
         else stream_tile_coords<LOWER>(t_l, nbx, nby, bx, by);
         pA_l = A + (int64_t)bx * 128 * lda;
         pB_l = B + (int64_t)by * 256 * ldb;
@@ -419,7 +415,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
     for (int t = bid; t < ntiles; t += G) {
         int bx, by;
         if (KTRI) stream_tile_coords_ktri(t, bx, by);
-        else if (walk != 0) bx = xbx, by = xby;
         else stream_tile_coords<LOWER>(t, nbx, nby, bx, by);
         double *Ct = C + (int64_t)(bx * 128 + wm0) * ldc + by * 256 + wn0;
         double4_t acc[4][4];
@@ -1405,7 +1400,6 @@ static int g_gemm_small_max = 1024;   // EGX_GEMM_SMALL: below this many 128x128
 static int g_look_min_cols = 3072;    // EGX_LOOK_MIN: look-ahead while at least this many columns trail the next group
 static int g_trsm_group = 0;          // EGX_TRSM_GROUP: panels per update in the solves after the factorisation (0 = 4)
 static int g_lur_side = 1;            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU also in lock-step batches
-static int g_stream_walk = 0;         // EGX_STREAM_WALK=1: XCD-aware 8 x 4 super-tile order of k_gemm_stream (0: column-major)
 static int g_trsm_left = 1;           // EGX_TRSM_LEFT=0: the solves after the factorisation update right-looking (one pass over all later columns per group)
 static int g_tail_merge = 1;          // EGX_TAIL_MERGE=0: without look-ahead the next group's columns and the rest are updated by two launches
 static int g_potrf_left = 1;          // EGX_POTRF_LEFT: left-looking group updates (launch_potrf) 0 never, 1 for handles with n_pad >= 14336
@@ -1425,7 +1419,6 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_LOOK_MIN")) g_look_min_cols = std::atoi(e);
         if (const char *e = std::getenv("EGX_TRSM_GROUP")) g_trsm_group = std::atoi(e);
         if (const char *e = std::getenv("EGX_LUR_SIDE")) g_lur_side = std::atoi(e);
-        if (const char *e = std::getenv("EGX_STREAM_WALK")) g_stream_walk = std::atoi(e);
         if (const char *e = std::getenv("EGX_POTRF_LEFT")) g_potrf_left = std::atoi(e);
         if (const char *e = std::getenv("EGX_TAIL_MERGE")) g_tail_merge = std::atoi(e);
         if (const char *e = std::getenv("EGX_TRSM_LEFT")) g_trsm_left = std::atoi(e);
@@ -1463,7 +1456,7 @@ int set_knob(const char *name, int value) {
     struct { const char *n; int *v; } tab[] = {{"potrf_group", &g_potrf_group}, {"stream_min", &g_stream_min_tiles},
                                               {"stream_tpw", &g_stream_tpw},   {"gemm_small", &g_gemm_small_max},
                                               {"look_min", &g_look_min_cols},  {"trsm_group", &g_trsm_group},
-                                              {"lur_side", &g_lur_side},       {"stream_walk", &g_stream_walk},
+                                              {"lur_side", &g_lur_side},
                                               {"potrf_left", &g_potrf_left},   {"tail_merge", &g_tail_merge},
                                               {"trsm_left", &g_trsm_left}};
     for (auto &e : tab)
@@ -1509,22 +1502,20 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
         // the launches that fill the chip on their own are the ones the roofline trace follows
         if (used_big_tile) *used_big_tile = wide_tiles >= 512;
         const int nbx = M / 128, nby = N / 256;  // LOWER: column c holds nbx - 2 c tiles (M >= N in the factorisation)
-        int nt = (int)wide_tiles;
-        const int walk = (g_stream_walk != 0 && g_stream_tpw == 1) ? 1 : 0;
-        if (walk) nt = stream_xcd_grid(lower != 0, nbx, nby);  // one workgroup per slot of the super-tile order
+        const int nt = (int)wide_tiles;
         const dim3 grid((unsigned)((nt + g_stream_tpw - 1) / g_stream_tpw), 1, nz);
         if (lower && tag == 1)
             hipLaunchKernelGGL((k_gemm_stream<true, false, 1>), grid, dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx,
-                               nby, nt, info, bt, walk);
+                               nby, nt, info, bt);
         else if (lower && tag == 2)
             hipLaunchKernelGGL((k_gemm_stream<true, false, 2>), grid, dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx,
-                               nby, nt, info, bt, walk);
+                               nby, nt, info, bt);
         else if (lower)
             hipLaunchKernelGGL((k_gemm_stream<true>), grid, dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx, nby, nt,
-                               info, bt, walk);
+                               info, bt);
         else
             hipLaunchKernelGGL((k_gemm_stream<false>), grid, dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx, nby, nt,
-                               info, bt, walk);
+                               info, bt);
         EGX_HIP_CHECK(hipGetLastError());
         return EGX_SUCCESS;
     }
@@ -1988,7 +1979,7 @@ int launch_syrk_uptri_neg(hipStream_t s, double *C, int64_t ldc, const double *W
         const int nbx = n / 128, m = nbx / 2;
         const int nt = m * (m + 1);
         hipLaunchKernelGGL((k_gemm_stream<true, true>), dim3((unsigned)nt, 1, nz), dim3(512), ST_LDS_BYTES, s, C, ldc, W, ldw, W,
-                           ldw, n, nbx, m, nt, (const int *)nullptr, bt, 0);
+                           ldw, n, nbx, m, nt, (const int *)nullptr, bt);
         EGX_HIP_CHECK(hipGetLastError());
         return EGX_SUCCESS;
     }

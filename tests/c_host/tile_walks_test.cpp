@@ -19,7 +19,7 @@ static int fails = 0;
 template <bool LOWER>
 static void check_rect(int nbx, int nby) {
     // the region: LOWER -> tiles (bx, by) with bx >= 2 by (the 128 x 256 tiles that touch the lower triangle)
-    std::map<std::pair<int, int>, int> want, col, xcd;
+    std::map<std::pair<int, int>, int> want, col;
     for (int by = 0; by < nby; by++)
         for (int bx = 0; bx < nbx; bx++)
             if (!LOWER || bx >= 2 * by) want[{bx, by}] = 0;
@@ -29,20 +29,12 @@ static void check_rect(int nbx, int nby) {
         stream_tile_coords<LOWER>(t, nbx, nby, bx, by);
         col[{bx, by}]++;
     }
-    const int g = stream_xcd_grid(LOWER, nbx, nby);
-    CHECK(g % 256 == 0 && g >= nt, "xcd grid %d for %d tiles (nbx %d nby %d)", g, nt, nbx, nby);
-    for (int t = 0; t < g; t++) {
-        int bx = -1, by = -1;
-        if (stream_tile_coords_xcd<LOWER>(t, nbx, nby, bx, by)) xcd[{bx, by}]++;
-    }
     for (auto &kv : want) {
         CHECK(col[kv.first] == 1, "column walk: tile (%d, %d) visited %d times (nbx %d nby %d lower %d)", kv.first.first,
               kv.first.second, col[kv.first], nbx, nby, (int)LOWER);
-        CHECK(xcd[kv.first] == 1, "xcd walk: tile (%d, %d) visited %d times (nbx %d nby %d lower %d)", kv.first.first,
-              kv.first.second, xcd[kv.first], nbx, nby, (int)LOWER);
     }
-    CHECK(col.size() == want.size() && xcd.size() == want.size(), "a walk left its region (nbx %d nby %d lower %d): %zu / %zu / %zu",
-          nbx, nby, (int)LOWER, col.size(), xcd.size(), want.size());
+    CHECK(col.size() == want.size(), "the column walk left its region (nbx %d nby %d lower %d): %zu / %zu", nbx, nby, (int)LOWER,
+          col.size(), want.size());
 }
 
 static void check_ktri(int nbx) {  // square, nbx even: rows bx hold by = 0 .. bx / 2, heaviest (smallest bx) first

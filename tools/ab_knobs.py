@@ -3,7 +3,7 @@
 lock-step groups of eight, 48 candidates per measurement) and one lock-step group's per-launch trailing-update rate
 (lur_side = 0), for each setting of one knob, interleaved over several rounds.
 
-    python tools/ab_knobs.py "stream_walk=0" "stream_walk=1" [--rounds 3] [--n 16384] [--d 32]
+    python tools/ab_knobs.py "potrf_left=0" "potrf_left=1" [--rounds 3] [--n 16384] [--d 32]
     python tools/ab_knobs.py "potrf_left=0,stream_min=128" "potrf_left=1,stream_min=8"     (several knobs per setting)"""
 import argparse
 import os

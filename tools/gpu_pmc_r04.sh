@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-4 PMC passes (counters only beside --kernel-trace; every counter group in its own run):
-#   update kernel of a lone n = 16384 fit, column-major walk and XCD super-tile walk (EGX_STREAM_WALK=1)
+#   update kernel of a lone n = 16384 fit, column-major walk and -- while that code existed (commit 54a9160 .. its removal) -- the XCD
+#   super-tile walk (EGX_STREAM_WALK=1; today the variable does nothing)
 #       FETCH_SIZE | WRITE_SIZE + L2 hits / misses | MFMA busy     -> gpurun_out/r04_pmc_update_kernel[_walk1].json
 #   the theta-gradient (tools/one_grad.py, config 3)                -> gpurun_out/r04_pmc_theta_gradient_pass<i>.json
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
