@@ -154,6 +154,26 @@ class GaussianProcess {
         check(egx_gp_likelihood_batch(h_.get(), thetas, k, theta_len, lk.data(), st.data()));
         return {std::move(lk), std::move(st)};
     }
+    // the same with dL/dtheta (new: the reference's objective has no gradient, algorithm.rs:880): likelihoods (k), gradients
+    // (k x h row-major), statuses (k); every stage in lock-step over a slot's candidates, bit for bit the single call
+    struct LikelihoodGrad {
+        std::vector<double> likelihood, gradient;
+        std::vector<int32_t> status;
+    };
+    LikelihoodGrad likelihood_grad_batch(const double *thetas, int64_t k, int64_t theta_len) {
+        int64_t h = 0;
+        check(egx_gp_dims(h_.get(), nullptr, nullptr, nullptr, &h));
+        LikelihoodGrad out;
+        out.likelihood.resize((size_t)k);
+        out.gradient.assign((size_t)(k * h), 0.0);
+        out.status.resize((size_t)k);
+        check(egx_gp_likelihood_grad_batch(h_.get(), thetas, k, theta_len, out.likelihood.data(), out.gradient.data(),
+                                           out.status.data()));
+        return out;
+    }
+    // a tuned model ran its multistart on several workspaces; the resident model needs one (plus one for likelihood
+    // evaluations that must not un-fit it)
+    void shrink(int32_t n_keep = 1) { check(egx_gp_shrink(h_.get(), n_keep)); }
     int32_t set_lockstep(int32_t width) {  // candidates per launch sequence (0 = the library's choice); returns the width in force
         check(egx_gp_set_lockstep(h_.get(), width));
         return egx_gp_get_lockstep(h_.get());

@@ -123,12 +123,41 @@ static void test_round3_mirror() {
     auto l4 = a.likelihood_batch(thetas, 4, 2);
     for (int c = 0; c < 4; c++) EXPECT(l1.second[c] == l4.second[c] && l1.first[c] == l4.first[c]);
     EXPECT(l1.second[0] == EGX_STATUS_OK && std::fabs(l1.first[0] - a.likelihood()) <= 1e-12 * std::fabs(a.likelihood()));
+    // likelihoods + theta-gradients of the same candidates: the likelihoods are the batch's, the gradient of candidate 0 agrees
+    // with a central difference of the likelihood, and a second call returns the same bits (fixed reduction order)
+    auto g1 = a.likelihood_grad_batch(thetas, 4, 2);
+    auto g2 = a.likelihood_grad_batch(thetas, 4, 2);
+    for (int c = 0; c < 4; c++) {
+        EXPECT(g1.status[c] == l1.second[c]);
+        if (g1.status[c] == EGX_STATUS_OK) EXPECT(g1.likelihood[c] == l1.first[c] && g1.likelihood[c] == g2.likelihood[c]);
+        for (int l = 0; l < 2; l++) EXPECT(g1.gradient[2 * c + l] == g2.gradient[2 * c + l]);
+    }
+    {
+        const double e = 1e-6, pm[4] = {0.3 + e, 0.12, 0.3 - e, 0.12};
+        auto lpm = a.likelihood_batch(pm, 2, 2);
+        const double fd = (lpm.first[0] - lpm.first[1]) / (2 * e);
+        EXPECT(std::fabs(g1.gradient[0] - fd) <= 1e-4 * (1.0 + std::fabs(fd)));
+    }
+    a.shrink(2);
+    auto l2 = a.likelihood_batch(thetas, 4, 2);  // on the workspaces that are left
+    for (int c = 0; c < 4; c++) EXPECT(l2.second[c] == l1.second[c] && (l2.second[c] != EGX_STATUS_OK || l2.first[c] == l1.first[c]));
     auto td = a.training_data(12);
     for (int i = 0; i < 24; i++) EXPECT(td.first[i] == xt[i]);
     for (int i = 0; i < 12; i++) EXPECT(td.second[i] == yt[i]);
     // mixture of the two experts
     const double probas[6] = {0.7, 0.3, 0.2, 0.8, 0.5, 0.5};
     auto ya = a.predict_valvar(xq, 3), yb = b.predict_valvar(xq, 3);
+    {   // x-gradients of the hard mixture = the routed experts' own gradients
+        auto hg = moe_predict_valvar_gradients({&a, &b}, probas, nullptr, xq, 3, 2, false);
+        auto ga = a.predict_valvar_gradients(xq, 3), gb = b.predict_valvar_gradients(xq, 3);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 2; j++) {
+                const bool first = probas[2 * i] >= probas[2 * i + 1];
+                const double wy = (first ? ga.first : gb.first)[2 * i + j], wv = (first ? ga.second : gb.second)[2 * i + j];
+                EXPECT(std::fabs(hg.first[2 * i + j] - wy) <= 1e-10 * (1.0 + std::fabs(wy)));   // (a routed subset is another batch)
+                EXPECT(std::fabs(hg.second[2 * i + j] - wv) <= 1e-10 * (1.0 + std::fabs(wv)));
+            }
+    }
     auto smooth = moe_predict_valvar({&a, &b}, probas, xq, 3, 2, true);
     auto hard = moe_predict_valvar({&a, &b}, probas, xq, 3, 2, false);
     for (int i = 0; i < 3; i++) {
