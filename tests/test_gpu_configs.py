@@ -993,3 +993,34 @@ def test_huge_theta_gives_the_identity_correlation_not_nan(egx, corr):
             h.finalize(theta)
             xq = np.random.default_rng(1).random((20, 3))
             np.testing.assert_allclose(h.predict(xq), ref.predict(xq), rtol=PRED_RTOL, atol=1e-9)
+
+
+def test_theta_gradient_batch_edge_cases(egx):
+    """Small and degenerate calls of egx_gp_likelihood_grad_batch: no candidate, one point more than the trend needs, a
+    one-dimensional input, a broadcast theta (theta_len = 1), more candidates than workspaces, every kernel."""
+    from oracle import gp_oracle as O
+    rng = np.random.default_rng(0)
+    x = rng.random((37, 2))
+    y = np.sin(3 * x[:, 0]) + x[:, 1]
+    for corr in range(4):
+        with egx.GpHandle(x, y, corr=corr, n_workspaces=3) as h:
+            lk, g, st = h.likelihood_grad_batch(np.zeros((0, 2)))
+            assert lk.shape == (0,) and g.shape == (0, 2) and st.shape == (0,)
+            thetas = 0.5 + rng.random((7, 2))
+            lk, g, st = h.likelihood_grad_batch(thetas)
+            assert np.all(st == 0)
+            for c in (0, 6):
+                lr, gr = O.likelihood_grad(x, y, thetas[c], corr=["SquaredExponential", "AbsoluteExponential", "Matern32", "Matern52"][corr])
+                assert lk[c] == pytest.approx(lr, rel=LK_RTOL)
+                np.testing.assert_allclose(g[c], gr, rtol=1e-6, atol=1e-7 * np.abs(gr).max())
+            # broadcast: theta_len = 1 stands for (t, t); the gradient has h = 2 entries and is the full gradient at (t, t)
+            lb, gb, sb = h.likelihood_grad_batch(np.array([[0.8], [1.1]]))
+            lf, gf, sf = h.likelihood_grad_batch(np.array([[0.8, 0.8], [1.1, 1.1]]))
+            assert np.array_equal(lb, lf) and np.array_equal(gb, gf) and gb.shape == (2, 2)
+    x1 = np.linspace(0.0, 1.0, 9).reshape(-1, 1)
+    y1 = np.cos(4 * x1[:, 0])
+    with egx.GpHandle(x1, y1, corr=0) as h:
+        lk, g, st = h.likelihood_grad(np.array([2.0]))
+        e = 1e-6
+        fd = (h.likelihood([2.0 + e])[0] - h.likelihood([2.0 - e])[0]) / (2 * e)
+        assert st == 0 and g[0] == pytest.approx(fd, rel=1e-5, abs=1e-7)
