@@ -713,19 +713,26 @@ def main():
         # ---- roofline leg (not part of `value`): ONE fit in flight on its own handle, so the HIP-event duration of
         # every update-kernel launch on its stream is not overlapped by another candidate's kernels
         gp = egx.GpHandle(x, y, mean=0, corr=0, device=gpu, n_workspaces=1)
-        tim1 = []
-        t_fit = []
-        for j in range(4):
+        t_fit, tim0 = [], []
+        for j in range(4):  # the product's schedule: what a lone fit costs
             tf0 = time.perf_counter()
             gp.finalize(base * (1.0 + 0.01 * j))
             t_fit.append(time.perf_counter() - tf0)
+            tim0.append(gp.timings())
+        t_fit, tim0 = t_fit[1:], tim0[1:]
+        # ... and the same fits with the look-ahead columns' update back IN FRONT of the trailing update on the main stream
+        # (in the product it runs beside it on a side stream and overlaps the HIP events around it): clean per-launch durations
+        prev_side = egx.set_tuning("lur_side", 0)
+        tim1 = []
+        for j in range(3):
+            gp.finalize(base * (1.0 + 0.01 * (4 + j)))
             tim1.append(gp.timings())
-        tim1, t_fit = tim1[1:], t_fit[1:]
+        egx.set_tuning("lur_side", prev_side)
         fits = args.steps * nb
-        potrf_ms = float(np.mean([t["potrf_ms"] for t in tim1]))
-        corr_ms = float(np.mean([t["corr_build_ms"] for t in tim1]))
-        solve_ms = float(np.mean([t["solve_ms"] for t in tim1]))
-        host_ms = float(np.mean([t["host_ms"] for t in tim1]))
+        potrf_ms = float(np.mean([t["potrf_ms"] for t in tim0]))
+        corr_ms = float(np.mean([t["corr_build_ms"] for t in tim0]))
+        solve_ms = float(np.mean([t["solve_ms"] for t in tim0]))
+        host_ms = float(np.mean([t["host_ms"] for t in tim0]))
         flops = tim1[0]["potrf_flops"]
         tflops = flops / (potrf_ms * 1e-3) / 1e12
         syrk_ms = float(np.mean([t["potrf_syrk_ms"] for t in tim1]))
@@ -824,9 +831,10 @@ def main():
             "roofline_single_matrix": {"bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic,
-                         "launch_shape": "ONE matrix per launch (a lone fit; the definition of rounds 1 and 2).  The timed "
-                                         "region launches the kernel for a lock-step group of matrices at once; a group's "
-                                         "whole factorisation rate is in lockstep_group_alone",
+                         "launch_shape": "ONE matrix per launch (a lone right-looking fit; the definition of rounds 1 to 3), with the "
+                                         "look-ahead columns' update serialised in front of it for this leg (lur_side = 0; the "
+                                         "product runs it beside the trailing update).  The timed region launches left-looking "
+                                         "updates for lock-step groups of eight: `roofline`",
                          "kernel": "k_gemm_stream<LOWER> (Cholesky trailing update C -= P P^T, 128x256 tiles, once per group "
                                    "of four 256-wide panels, K = 1024, at this size; the launches with >= 512 tiles: "
                                    f"{100.0 * syrk_flops / flops:.0f} % of the factorisation's n^3/3 flops)",

@@ -1793,12 +1793,13 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             if (rc) return rc;
             EGX_HIP_CHECK(hipEventRecord(lk->ev_lu, s));
             EGX_HIP_CHECK(hipStreamWaitEvent(s2, lk->ev_lu, 0));
-            // LUr writes the next group's columns, RU the columns right of them, both only READ this group's panel.  In a
-            // lock-step batch LUr goes to the (high-priority) side stream, so that RU fills the CUs LUr's last, partly filled
-            // round of tiles leaves idle (+0.8 % on the sweep, profiles/r03_run4_lur_side_ab.txt).  A lone matrix keeps LUr in
-            // front of RU on `s`: its RU launches are the ones the roofline times per launch, and they would share the chip
-            // with LUr.  Streams only: the arithmetic of a matrix is the same either way.
-            hipStream_t slu = (nz > 1 && g_lur_side) ? s3 : s;
+            // LUr writes the next group's columns, RU the columns right of them, both only READ this group's panel: LUr goes
+            // to the (high-priority) side stream, so that RU fills the CUs LUr's last, partly filled round of tiles leaves idle
+            // (+0.8 % on the sweep, +1 % on a lone fit: profiles/r03_run4_lur_side_ab.txt, r03_run8_*).  Round 3 kept a lone
+            // matrix' LUr in front of RU because the driver line's roofline timed those RU launches one by one; since round 4
+            // that leg switches the side stream off for itself (egx_set_tuning "lur_side" = 0).  Streams only: the arithmetic
+            // of a matrix is the same either way.
+            hipStream_t slu = g_lur_side ? s3 : s;
             if (slu != s) EGX_HIP_CHECK(hipStreamWaitEvent(slu, lk->ev_lu, 0));
             rc = update(slu, r1 + nb1, r1, m_tot - r1 - nb1, gw1, g0, gw, 0, nullptr);
             if (rc) return rc;
