@@ -1797,9 +1797,10 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             // to the (high-priority) side stream, so that RU fills the CUs LUr's last, partly filled round of tiles leaves idle
             // (+0.8 % on the sweep, +1 % on a lone fit: profiles/r03_run4_lur_side_ab.txt, r03_run8_*).  Round 3 kept a lone
             // matrix' LUr in front of RU because the driver line's roofline timed those RU launches one by one; since round 4
-            // that leg switches the side stream off for itself (egx_set_tuning "lur_side" = 0).  Streams only: the arithmetic
-            // of a matrix is the same either way.
-            hipStream_t slu = g_lur_side ? s3 : s;
+            // that leg switches the side stream off for itself (egx_set_tuning "lur_side" = 0).  From n_pad 14336 on only
+            // (n = 16384 lone: 31.5 -> 30.9 ms; n = 8192: one fit 6.24 -> 6.44 ms, twelve in lock-step 260 -> 258 fits/s:
+            // profiles/r04_run11_lur_side_lone_ab.txt).  Streams only: the arithmetic of a matrix is the same either way.
+            hipStream_t slu = (g_lur_side && n_pad >= 14336) ? s3 : s;
             if (slu != s) EGX_HIP_CHECK(hipStreamWaitEvent(slu, lk->ev_lu, 0));
             rc = update(slu, r1 + nb1, r1, m_tot - r1 - nb1, gw1, g0, gw, 0, nullptr);
             if (rc) return rc;
