@@ -90,29 +90,48 @@ def main():
         n, d = 16384, 32
         x, y = workload.make_training_set(n, d, 42)
         th = workload.default_theta(d)
-        h = egx.GpHandle(x, y, corr=3, n_workspaces=2)
-        thetas = np.stack([th * (1 + 0.01 * i) for i in range(4)])
-        t = timeit(lambda: h.likelihood_batch(thetas), 2) / 4
+        # one evaluation in flight (stage times), sixteen in flight as two lock-step groups of eight (throughput), and the
+        # likelihood + theta-gradient alone and in a lock-step batch of eight
+        h = egx.GpHandle(x, y, corr=3, n_workspaces=1)
+        h.finalize(th)
+        t1 = timeit(lambda: h.finalize(th * 1.01), 3)
         tm = h.timings()
+        h.likelihood_grad(th)
         t0 = time.perf_counter()
-        lk, g, st = h.likelihood_grad(th)
+        lk, g, st = h.likelihood_grad(th * 1.001)
         tg = time.perf_counter() - t0
-        emit({"config": 3, "n": n, "d": d, "corr": "Matern52", "likelihood_evals_per_s_2_workspaces": 1 / t,
+        h.close()
+        h = egx.GpHandle(x, y, corr=3, n_workspaces=16)
+        thetas = np.stack([th * (1 + 0.003 * i) for i in range(48)])
+        h.likelihood_batch(thetas[:16])
+        t = timeit(lambda: h.likelihood_batch(thetas), 1) / len(thetas)
+        h.close()
+        h = egx.GpHandle(x, y, corr=3, n_workspaces=8)
+        h.set_lockstep(8)
+        h.likelihood_grad_batch(thetas[:8])
+        t0 = time.perf_counter()
+        lkb, gb, stb = h.likelihood_grad_batch(thetas[8:16])
+        tgb = (time.perf_counter() - t0) / 8
+        h.close()
+        emit({"config": 3, "n": n, "d": d, "corr": "Matern52", "fixed_theta_fit_ms_one_in_flight": t1 * 1e3,
+              "likelihood_evals_per_s_16_in_flight": 1 / t,
               "corr_build_ms": tm["corr_build_ms"], "corr_build_gbps": tm["corr_bytes"] / tm["corr_build_ms"] / 1e6,
               "potrf_ms": tm["potrf_ms"], "cholesky_tflops": tm["potrf_flops"] / tm["potrf_ms"] / 1e9,
-              "likelihood_plus_gradient_s": tg, "grad_status": int(st), "grad_norm": float(np.linalg.norm(g)),
-              "likelihood": lk})
-        h.close()
+              "likelihood_plus_gradient_s": tg, "likelihood_plus_gradient_frac_of_fp64_peak": float(n) ** 3 / tg / 78.6e12,
+              "likelihood_plus_gradient_s_per_candidate_lockstep_8": tgb,
+              "likelihood_plus_gradient_frac_of_fp64_peak_lockstep_8": float(n) ** 3 / tgb / 78.6e12,
+              "grad_status": int(st), "grad_norm": float(np.linalg.norm(g)), "likelihood": lk})
 
     # ---------------- config 4
     if args.only in (0, 4):
         n, d = 16384, 32
         x, y = workload.make_training_set(n, d, 42)
-        k = 16 if args.quick else 64
+        k = 32 if args.quick else 512
         thetas = egx.theta_sweep_candidates(512, d)[:k]
-        # through the boundary's multi-GPU entry point (egx_sweep_*, one-rank RCCL communicator on this box)
-        h = egx.Sweep(x, y, rank=0, world=1, id_bytes="new")
-        h.likelihood(thetas[:2])
+        # through the boundary's multi-GPU entry point (egx_sweep_*, one-rank RCCL communicator on this box), in the
+        # product's shape: 16 candidates in flight as two lock-step groups of eight (left-looking)
+        h = egx.Sweep(x, y, rank=0, world=1, id_bytes="new", n_workspaces=16)
+        h.likelihood(thetas[:16])
         t0 = time.perf_counter()
         lk, st = h.likelihood(thetas)
         t = time.perf_counter() - t0
