@@ -606,11 +606,11 @@ class GpParams:
             n_evals = h.fit_partial(theta0, active, 10.0 ** starts_log10, [lo for lo, _ in ab],
                                     [hi for _, hi in ab], self._max_eval)
         n_pad = -(-x.shape[0] // 128) * 128
-        if nws > 2 and (nws - 2) * 8 * n_pad * (n_pad + 128) >= (1 << 30):
-            # the multistart's workspaces go back (egx_gp_shrink) when they hold a GiB or more: the resident model keeps the
+        if nws > 2 and (nws - 2) * 8 * n_pad * (n_pad + 128) >= (4 << 30):
+            # the multistart's workspaces go back (egx_gp_shrink) when they hold 4 GiB or more: the resident model keeps the
             # factor's workspace and one more, so that likelihood evaluations on the fitted model do not un-fit it.  (Below
-            # that it is not worth it: tearing down a workspace's streams and ~400 events costs ~20 ms, a tuned fit at
-            # n = 1024 takes 45 ms in all.)
+            # that it is not worth it: tearing down a workspace's streams and ~400 events costs ~20 ms -- 0.18 s for nine of
+            # them, against 0.41 s for a whole tuned fit at n = 4096 and 45 ms at n = 1024.)
             h.shrink(2)
         return GaussianProcess(h, self, n_evals)
 
