@@ -218,52 +218,32 @@ static int enqueue_grad_run(egx_gp *gp, hipStream_t st, int w0, int count, int s
         Workspace &w = gp->ws[w0 + j];
         EGX_RC(launch_uptri_gemv(st, W0 + (int64_t)j * sq, n_pad, n, w.d_rhs, w.d_vec));
     }
+    GemmBatch gbm;
+    gbm.count = count;
+    gbm.sC = gp->stride_M;
+    gbm.sA = gbm.sB = sq;
+    EGX_RC(launch_syrk_uptri_neg(st, lead.M, gp->ld, W0, n_pad, n_pad, &gbm));
     const int nout = (hcols == 1) ? gp->d : gp->h;
-    // R^-1 (FP64 MFMA) and the trace kernel (FP64 VALU) of DIFFERENT candidates can share the chip: a run of several
-    // candidates goes in two halves -- the trace kernel of the first half runs on the (by now idle) rider stream beside the
-    // R^-1 launch of the second.  Per candidate the kernels, their inputs and their order are the same as for a run of one.
-    const int half = count >= 2 ? count / 2 : count;
-    auto syrk = [&](int j0, int cnt) -> int {
-        GemmBatch gbm;
-        gbm.count = cnt;
-        gbm.sC = gp->stride_M;
-        gbm.sA = gbm.sB = sq;
-        return launch_syrk_uptri_neg(st, gp->ws[w0 + j0].M, gp->ld, W0 + (int64_t)j0 * sq, n_pad, n_pad, &gbm);
-    };
-    auto accum = [&](hipStream_t sa, int j0, int cnt) -> int {
-        GradBatch gb;
-        gb.count = cnt;
-        for (int j = 0; j < kGradMaxBatch; j++) {
-            gb.xs[j] = gb.coef[j] = gb.gamma[j] = gb.rneg[j] = nullptr;
-            gb.inv_s2[j] = 0.0;
-            gb.part[j] = gb.out[j] = nullptr;
-        }
-        for (int j = 0; j < cnt; j++) {
-            Workspace &w = gp->ws[w0 + j0 + j];
-            if (pre) EGX_RC(launch_scale_rows(sa, gp->d_xT, n_pad, gp->d, w.d_coef, w.d_xs));  // (K1 may have taken its LDS-only form)
-            gb.xs[j] = w.d_xs;
-            gb.coef[j] = w.d_coef;
-            gb.gamma[j] = w.d_vec;
-            gb.rneg[j] = w.M;
-            gb.inv_s2[j] = inv_s2[j0 + j];
-            gb.part[j] = w.d_gpart;
-            gb.out[j] = w.d_gout;
-        }
-        return launch_grad_accum(sa, gp->corr, gp->d_xT, n_pad, n, gp->d, hcols, hcols > 1 ? gp->d_wabs : nullptr, nout, gp->ld, gb,
-                                 pre);
-    };
-    EGX_RC(syrk(0, half));
-    if (half < count) {
-        EGX_HIP_CHECK(hipEventRecord(lead.ev_inv_grp, st));
-        EGX_HIP_CHECK(hipStreamWaitEvent(lead.inv_stream, lead.ev_inv_grp, 0));
-        EGX_RC(accum(lead.inv_stream, 0, half));
-        EGX_HIP_CHECK(hipEventRecord(lead.ev_inv_done, lead.inv_stream));
-        EGX_RC(syrk(half, count - half));
-        EGX_RC(accum(st, half, count - half));
-        EGX_HIP_CHECK(hipStreamWaitEvent(st, lead.ev_inv_done, 0));
-    } else {
-        EGX_RC(accum(st, 0, half));
+    GradBatch gb;
+    gb.count = count;
+    for (int j = 0; j < count; j++) {
+        Workspace &w = gp->ws[w0 + j];
+        if (pre) EGX_RC(launch_scale_rows(st, gp->d_xT, n_pad, gp->d, w.d_coef, w.d_xs));  // (K1 may have taken its LDS-only form)
+        gb.xs[j] = w.d_xs;
+        gb.coef[j] = w.d_coef;
+        gb.gamma[j] = w.d_vec;
+        gb.rneg[j] = w.M;
+        gb.inv_s2[j] = inv_s2[j];
+        gb.part[j] = w.d_gpart;
+        gb.out[j] = w.d_gout;
     }
+    for (int j = count; j < kGradMaxBatch; j++) {
+        gb.xs[j] = gb.coef[j] = gb.gamma[j] = gb.rneg[j] = nullptr;
+        gb.inv_s2[j] = 0.0;
+        gb.part[j] = gb.out[j] = nullptr;
+    }
+    EGX_RC(launch_grad_accum(st, gp->corr, gp->d_xT, n_pad, n, gp->d, hcols, hcols > 1 ? gp->d_wabs : nullptr, nout, gp->ld, gb,
+                             pre));
     for (int j = 0; j < count; j++) {
         Workspace &w = gp->ws[w0 + j];
         EGX_HIP_CHECK(hipMemcpyAsync(w.h_gout, w.d_gout, sizeof(double) * nout, hipMemcpyDeviceToHost, st));
