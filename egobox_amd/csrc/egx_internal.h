@@ -158,8 +158,10 @@ struct PotrfBatch {
     int64_t sM = 0, sD = 0;  // doubles between consecutive matrices / their dinv blocks
     int sI = 0;              // ints between their info words
     int left = 0;            // left-looking group updates (launch_potrf); chosen per handle: potrf_left_for()
+    int w_left = 0;          // ... and the C^-T rider's (PotrfInverse) left-looking update: w_left_for()
 };
 int potrf_left_for(int n_pad, int lockstep);
+int w_left_for(int n_pad, int lockstep);
 // the solves after a factorisation in lock-step: `count` factors (sM apart, tile inverses sD apart) and as many
 // right-hand-side buffers (sR apart)
 struct TrsmBatch {

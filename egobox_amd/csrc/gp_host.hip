@@ -376,6 +376,7 @@ int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> 
     pb.sD = gp->stride_D;
     pb.sI = 1;
     pb.left = potrf_left_for(gp->n_pad, gp->lockstep);
+    pb.w_left = w_left_for(gp->n_pad, gp->lockstep);
     EGX_RC(launch_potrf(st, lead.M, gp->ld, gp->n_pad, gp->m_tot, lead.dinv, lead.d_info, lead.lk.s2 ? &lead.lk : nullptr,
                         &lead.trace, &pb, W0 ? &inv : nullptr));
     EGX_HIP_CHECK(hipEventRecord(lead.ev[2], st));

@@ -315,8 +315,17 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
                                                         int64_t lda, const double *__restrict__ B, int64_t ldb, int K,
                                                         int nbx, int nby, int ntiles, const int *__restrict__ info,
                                                         GemmBatch bt) {
+    int G = gridDim.x, bid = (int)blockIdx.x;
     {   // lock-step batch: matrix blockIdx.z
-        const int64_t z = blockIdx.z;
+        int64_t z = blockIdx.z;
+        if (KTRI && !LOWER) {
+            // the rectangle's tiles differ in their K ranges by two orders of magnitude: the matrices of a batch are
+            // INTERLEAVED in the dispatch order (grid.x = tiles x matrices), so the heavy tiles of every matrix start first
+            const int nzc = bt.count > 0 ? bt.count : 1;
+            z = bid % nzc;
+            bid = bid / nzc;
+            G = ntiles;
+        }
         C += z * bt.sC;
         A += z * bt.sA;
         B += z * bt.sB;
@@ -326,12 +335,15 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int G = gridDim.x;
-    const int bid = (int)blockIdx.x;
+    auto tile_of = [&](int t, int &bx, int &by) {  // tile index -> (bx, by)
+        if (KTRI && LOWER) stream_tile_coords_ktri(t, bx, by);
+        else if (KTRI) stream_tile_coords_ktri_rect(t, nby, bx, by);
+        else stream_tile_coords<LOWER>(t, nbx, nby, bx, by);
+    };
     int nch = K / KC;
     if (KTRI) {  // one tile per workgroup (G == ntiles): its K range starts at the tile's first row
         int bx, by;
-        stream_tile_coords_ktri(bid, bx, by);
+        tile_of(bid, bx, by);
         const int koff = bx * 128;
         A += koff;
         B += koff;
@@ -353,8 +365,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
     const double *pA_l, *pB_l;
     {
         int bx, by;
-        if (KTRI) stream_tile_coords_ktri(t_l, bx, by);
-        else stream_tile_coords<LOWER>(t_l, nbx, nby, bx, by);
+        tile_of(t_l, bx, by);
         pA_l = A + (int64_t)bx * 128 * lda;
         pB_l = B + (int64_t)by * 256 * ldb;
     }
@@ -379,8 +390,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
             t_l += G;
             if (t_l < ntiles) {
                 int bx, by;
-                if (KTRI) stream_tile_coords_ktri(t_l, bx, by);
-                else stream_tile_coords<LOWER>(t_l, nbx, nby, bx, by);
+                tile_of(t_l, bx, by);
                 pA_l = A + (int64_t)bx * 128 * lda;
                 pB_l = B + (int64_t)by * 256 * ldb;
             }
@@ -414,8 +424,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
     for (int i = 0; i < 4; i++) a0[i] = b0[i] = d2_t{0.0, 0.0};
     for (int t = bid; t < ntiles; t += G) {
         int bx, by;
-        if (KTRI) stream_tile_coords_ktri(t, bx, by);
-        else stream_tile_coords<LOWER>(t, nbx, nby, bx, by);
+        tile_of(t, bx, by);
         double *Ct = C + (int64_t)(bx * 128 + wm0) * ldc + by * 256 + wn0;
         double4_t acc[4][4];
 #pragma unroll
@@ -1402,6 +1411,7 @@ static int g_trsm_group = 0;          // EGX_TRSM_GROUP: panels per update in th
 static int g_lur_side = 1;            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU also in lock-step batches
 static int g_trsm_left = 1;           // EGX_TRSM_LEFT=0: the solves after the factorisation update right-looking (one pass over all later columns per group)
 static int g_tail_merge = 1;          // EGX_TAIL_MERGE=0: without look-ahead the next group's columns and the rest are updated by two launches
+static int g_w_left = 1;              // EGX_W_LEFT: left-looking update of the C^-T rider 0 never, 1 per handle (w_left_for), 2 always
 static int g_potrf_left = 1;          // EGX_POTRF_LEFT: left-looking group updates (launch_potrf) 0 never, 1 for handles with n_pad >= 14336
                                       // and a lock-step width >= 8, 2 always
 
@@ -1422,6 +1432,7 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_POTRF_LEFT")) g_potrf_left = std::atoi(e);
         if (const char *e = std::getenv("EGX_TAIL_MERGE")) g_tail_merge = std::atoi(e);
         if (const char *e = std::getenv("EGX_TRSM_LEFT")) g_trsm_left = std::atoi(e);
+        if (const char *e = std::getenv("EGX_W_LEFT")) g_w_left = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -1434,6 +1445,7 @@ int chol_init() {
         set(reinterpret_cast<const void *>(&k_gemm_stream<true>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<false>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<true, true>), ST_LDS_BYTES);
+        set(reinterpret_cast<const void *>(&k_gemm_stream<false, true>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<true, false, 1>), ST_LDS_BYTES);
         set(reinterpret_cast<const void *>(&k_gemm_stream<true, false, 2>), ST_LDS_BYTES);
     });
@@ -1448,6 +1460,18 @@ int potrf_left_for(int n_pad, int lockstep) {
     return g_potrf_left >= 2 || (g_potrf_left == 1 && n_pad >= 14336 && lockstep >= 8);
 }
 
+// does the C^-T rider (the theta-gradient's W, PotrfInverse) of a handle of this shape update left-looking?  Per handle like
+// potrf_left_for.  Measured (profiles/r04_run12_w_left_ab.txt; likelihood + gradient, ms per candidate, right- -> left-looking):
+//   n = 16384   lock-step 8: 74.4 -> 71.9    lock-step 4: 75.8 -> 73.4    one workspace: 78.1 -> 78.4
+//   n = 8192    lock-step 12: 10.4 -> 9.9    ONE candidate: 12.6 -> 21.7   (n = 4096: 1.79 -> 1.69, 3.4 -> 5.5)
+// a lone matrix' launch has few tiles with K ranges from 128 to all earlier columns, and the next group's solves wait for
+// the longest: from n_pad 14336 on (where one candidate on such a handle neither gains nor loses) and lock-step widths >= 4.
+// At these sizes both forms add the same products in the same order: the same bits (checked by the A/B).
+int w_left_for(int n_pad, int lockstep) {
+    (void)chol_init();
+    return n_pad % 256 == 0 && (g_w_left >= 2 || (g_w_left == 1 && n_pad >= 14336 && lockstep >= 4));
+}
+
 // run-time access to the knobs above (egx_set_tuning): A/B measurements inside ONE process (a gpurun call is minutes, a
 // launch sequence milliseconds) and the serialised profiling mode of bench.py's roofline leg.  Returns the previous
 // value, or INT_MIN for an unknown name.  Not to be called while evaluations are in flight.
@@ -1458,7 +1482,7 @@ int set_knob(const char *name, int value) {
                                               {"look_min", &g_look_min_cols},  {"trsm_group", &g_trsm_group},
                                               {"lur_side", &g_lur_side},
                                               {"potrf_left", &g_potrf_left},   {"tail_merge", &g_tail_merge},
-                                              {"trsm_left", &g_trsm_left}};
+                                              {"trsm_left", &g_trsm_left},     {"w_left", &g_w_left}};
     for (auto &e : tab)
         if (std::string(name) == e.n) {
             const int old = *e.v;
@@ -1683,6 +1707,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         gbw.sB = pb.sM;
         gbw.sInfo = pb.sI;
     }
+    const bool w_left = pb.w_left != 0 && n_pad % 256 == 0;  // one decision for the whole factorisation (GW % 256 == 0)
     auto inverse_group = [&](hipStream_t sfin, int g0, int gw) -> int {
         if (!inv) return EGX_SUCCESS;
         hipStream_t sw = inv->sw;
@@ -1709,7 +1734,20 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             }
         }
         const int ncols = n_pad - gend;
-        if (ncols > 0) {
+        if (ncols > 0 && w_left) {
+            // left-looking rider (round 4; w_left_for): the NEXT group's columns of W receive all earlier columns at once,
+            //     W[0:gend, next) = -W[0:gend, 0:gend) L[next, 0:gend)^T      (rows below gend: the identity, untouched)
+            // by one launch of the stream kernel with per-tile K ranges (row i of W is zero left of column i) and
+            // zero-initialised accumulators: a tile of W is written once by a long K loop, then read and written once by
+            // its group's own solves -- instead of one read-modify-write pass (K = 1024) per earlier group.  It only reads
+            // rows of the factor that are final with THIS group, so it is issued here, ahead of the next group's chain.
+            const int gwn = gwidth(gend);
+            const int nbx = gend / 128, nby = gwn / 256, nt = nbx * nby;
+            hipLaunchKernelGGL((k_gemm_stream<false, true>), dim3((unsigned)nt * nz, 1, 1), dim3(512), ST_LDS_BYTES, sw, inv->W + gend,
+                               inv->ldw, (const double *)inv->W, inv->ldw, (const double *)(M + (int64_t)gend * ld), ld, gend, nbx,
+                               nby, nt, (const int *)info, gbw);
+            EGX_HIP_CHECK(hipGetLastError());
+        } else if (ncols > 0) {
             int rc2 = launch_gemm_nt_sub(sw, inv->W + gend, inv->ldw, inv->W + g0, inv->ldw, M + (int64_t)gend * ld + g0, ld, gend,
                                          ncols, gw, 0, 0, nullptr, info, &gbw);
             if (rc2) return rc2;

@@ -47,3 +47,10 @@ EGX_HD void stream_tile_coords_ktri(int t, int &bx, int &by) {
     }
 }
 
+// KTRI walk of a RECTANGLE (the left-looking update of the C^-T rider, launch_potrf: columns of one group of panels, all
+// rows above the group): again the K range of tile (bx, by) starts at the tile's first row -- row by row from the top, the
+// heaviest first, nby tiles per row.
+EGX_HD void stream_tile_coords_ktri_rect(int t, int nby, int &bx, int &by) {
+    bx = t / nby;
+    by = t - bx * nby;
+}

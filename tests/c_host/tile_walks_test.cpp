@@ -52,6 +52,20 @@ static void check_ktri(int nbx) {  // square, nbx even: rows bx hold by = 0 .. b
     CHECK((int)seen.size() == nt, "ktri walk: %zu distinct tiles of %d (nbx %d)", seen.size(), nt, nbx);
 }
 
+static void check_ktri_rect(int nbx, int nby) {  // all nbx x nby tiles, row by row from the top (the longest K ranges first)
+    std::map<std::pair<int, int>, int> seen;
+    int last_bx = 0;
+    for (int t = 0; t < nbx * nby; t++) {
+        int bx = -1, by = -1;
+        stream_tile_coords_ktri_rect(t, nby, bx, by);
+        CHECK(bx >= last_bx, "ktri rectangle walk not row by row at t = %d", t);
+        last_bx = bx;
+        CHECK(bx >= 0 && bx < nbx && by >= 0 && by < nby, "ktri rectangle walk: tile (%d, %d) outside (%d x %d)", bx, by, nbx, nby);
+        seen[{bx, by}]++;
+    }
+    CHECK((int)seen.size() == nbx * nby, "ktri rectangle walk: %zu distinct tiles of %d", seen.size(), nbx * nby);
+}
+
 int main() {
     for (int nby = 1; nby <= 70; nby++) {
         check_rect<true>(2 * nby, nby);           // the trailing matrix of a factorisation
@@ -61,6 +75,8 @@ int main() {
     }
     for (int nbx = 1; nbx <= 130; nbx += 3)
         for (int nby = 1; nby <= 64; nby += 5) check_rect<false>(nbx, nby);
+    for (int nbx = 1; nbx <= 128; nbx += 7)
+        for (int nby = 1; nby <= 4; nby++) check_ktri_rect(nbx, nby);  // the C^-T rider's left-looking update: nby = 4
     if (fails) std::printf("%d failures\n", fails);
     else std::printf("tile walks ok\n");
     return fails ? 1 : 0;
