@@ -1411,6 +1411,7 @@ static int g_trsm_group = 0;          // EGX_TRSM_GROUP: panels per update in th
 static int g_lur_side = 1;            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU also in lock-step batches
 static int g_trsm_left = 1;           // EGX_TRSM_LEFT=0: the solves after the factorisation update right-looking (one pass over all later columns per group)
 static int g_tail_merge = 1;          // EGX_TAIL_MERGE=0: without look-ahead the next group's columns and the rest are updated by two launches
+static int g_lur_side_min = 6144;     // EGX_LUR_SIDE_MIN: ... only while at least this many columns trail the look-ahead group
 static int g_w_left = 1;              // EGX_W_LEFT: left-looking update of the C^-T rider 0 never, 1 per handle (w_left_for), 2 always
 static int g_potrf_left = 1;          // EGX_POTRF_LEFT: left-looking group updates (launch_potrf) 0 never, 1 for handles with n_pad >= 14336
                                       // and a lock-step width >= 8, 2 always
@@ -1433,6 +1434,7 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_TAIL_MERGE")) g_tail_merge = std::atoi(e);
         if (const char *e = std::getenv("EGX_TRSM_LEFT")) g_trsm_left = std::atoi(e);
         if (const char *e = std::getenv("EGX_W_LEFT")) g_w_left = std::atoi(e);
+        if (const char *e = std::getenv("EGX_LUR_SIDE_MIN")) g_lur_side_min = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -1482,7 +1484,8 @@ int set_knob(const char *name, int value) {
                                               {"look_min", &g_look_min_cols},  {"trsm_group", &g_trsm_group},
                                               {"lur_side", &g_lur_side},
                                               {"potrf_left", &g_potrf_left},   {"tail_merge", &g_tail_merge},
-                                              {"trsm_left", &g_trsm_left},     {"w_left", &g_w_left}};
+                                              {"trsm_left", &g_trsm_left},     {"w_left", &g_w_left},
+                                              {"lur_side_min", &g_lur_side_min}};
     for (auto &e : tab)
         if (std::string(name) == e.n) {
             const int old = *e.v;
@@ -1837,8 +1840,10 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             // matrix' LUr in front of RU because the driver line's roofline timed those RU launches one by one; since round 4
             // that leg switches the side stream off for itself (egx_set_tuning "lur_side" = 0).  From n_pad 14336 on only
             // (n = 16384 lone: 31.5 -> 30.9 ms; n = 8192: one fit 6.24 -> 6.44 ms, twelve in lock-step 260 -> 258 fits/s:
-            // profiles/r04_run11_lur_side_lone_ab.txt).  Streams only: the arithmetic of a matrix is the same either way.
-            hipStream_t slu = (g_lur_side && n_pad >= 14336) ? s3 : s;
+            // profiles/r04_run11_lur_side_lone_ab.txt).  In the last ~6000 columns the chain is what a factorisation waits for and
+            // its first panel solve waits for LUr: there LUr runs ALONE in front of RU (250 us instead of 520-770 beside it;
+            // n = 16384 lone: 29.85 -> 29.6 ms, profiles/r04_run14_*).  Streams only: the arithmetic is the same either way.
+            hipStream_t slu = (g_lur_side && n_pad >= 14336 && n_pad - r1 - gw1 >= g_lur_side_min) ? s3 : s;
             if (slu != s) EGX_HIP_CHECK(hipStreamWaitEvent(slu, lk->ev_lu, 0));
             rc = update(slu, r1 + nb1, r1, m_tot - r1 - nb1, gw1, g0, gw, 0, nullptr);
             if (rc) return rc;
