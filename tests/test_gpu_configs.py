@@ -939,12 +939,24 @@ def test_left_looking_handles_candidates_do_not_depend_on_their_companions(egx):
         # the theta-gradient on a left-looking handle (C^-T rides along the left-looking schedule) against the same
         # candidates on a right-looking one-workspace handle
         lkg, gg, stg = h.likelihood_grad_batch(thetas[[0, 1, 4, 5]])
+    singles = []
     with egx.GpHandle(x, y, corr=0, n_workspaces=1) as h1:
         for q, c in enumerate((0, 1, 4, 5)):
             l1, g1, s1 = h1.likelihood_grad(thetas[c])
+            singles.append((l1, g1))
             assert s1 == 0 and stg[q] == 0 and lkg[q] == lk[c]
             assert l1 == pytest.approx(lkg[q], rel=1e-9)
             np.testing.assert_allclose(gg[q], g1, rtol=1e-6, atol=1e-7 * np.abs(g1).max())
+    # a lock-step width of four: right-looking factorisation (the same likelihood bits as the one-workspace handle), but the
+    # C^-T rider updates LEFT-looking (w_left_for): the same products as the right-looking rider, in the same order where every
+    # group is 1024 columns wide (n = 16384: identical bits, profiles/r04_run12_*); here the last group is 256 wide and its
+    # right-looking update is another kernel's -- equal to rounding
+    with egx.GpHandle(x, y, corr=0, n_workspaces=4) as h4:
+        assert h4.set_lockstep(0) == 4
+        lk4, g4, st4 = h4.likelihood_grad_batch(thetas[[0, 1, 4, 5]])
+        for q in range(4):
+            assert st4[q] == 0 and lk4[q] == singles[q][0]
+            np.testing.assert_allclose(g4[q], singles[q][1], rtol=1e-9)
     assert st[2] == 4 and st[6] in (0, 1)
     for c in range(11):
         assert alone[c][1][0] == st[c]
