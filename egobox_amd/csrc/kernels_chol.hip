@@ -1468,7 +1468,8 @@ int potrf_left_for(int n_pad, int lockstep) {
 //   n = 8192    lock-step 12: 10.4 -> 9.9    ONE candidate: 12.6 -> 21.7   (n = 4096: 1.79 -> 1.69, 3.4 -> 5.5)
 // a lone matrix' launch has few tiles with K ranges from 128 to all earlier columns, and the next group's solves wait for
 // the longest: from n_pad 14336 on (where one candidate on such a handle neither gains nor loses) and lock-step widths >= 4.
-// At these sizes both forms add the same products in the same order: the same bits (checked by the A/B).
+// Both forms add the same products in the same order wherever every group is 1024 columns wide: the same bits at n = 16384
+// (checked by the A/B); a narrower last group's right-looking update is another kernel's (3e-12 at n = 14400).
 int w_left_for(int n_pad, int lockstep) {
     (void)chol_init();
     return n_pad % 256 == 0 && (g_w_left >= 2 || (g_w_left == 1 && n_pad >= 14336 && lockstep >= 4));
