@@ -104,9 +104,9 @@ int64_t egx_trim(void);
 void egx_pool_stats(int64_t *cached_bytes, int64_t *hits, int64_t *misses);
 /* The factorisation's scheduling knobs at run time (the EGX_* environment variables of DESIGN.md section 4, read once at
  * start-up, by name without the prefix, lower case: "potrf_group", "stream_min", "stream_tpw", "gemm_small", "look_min",
- * "trsm_group", "lur_side").  They move launches between streams and kernels between tile shapes, never the arithmetic
- * inside a kernel; changing "potrf_group" / "stream_min" / "gemm_small" changes which kernel updates a block and hence
- * the rounding.  Process-wide; not while evaluations are in flight.  *previous (optional) receives the old value.
+ * "trsm_group", "lur_side", "lur_side_min", "potrf_left", "tail_merge", "trsm_left", "w_left").  They move launches between streams and kernels between tile shapes, never the arithmetic
+ * inside a kernel; changing "potrf_group" / "stream_min" / "gemm_small" / "potrf_left" / "trsm_left" / "tail_merge" changes
+ * which kernel updates a block, or in which order the updates are summed, and hence the rounding.  Process-wide; not while evaluations are in flight.  *previous (optional) receives the old value.
  * Used by bench.py's roofline leg ("lur_side" = 0: the lock-step group's launches run one after the other and have
  * clean per-launch durations) and by A/B measurements inside one process. */
 int32_t egx_set_tuning(const char *knob, int32_t value, int32_t *previous);
