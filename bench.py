@@ -788,6 +788,12 @@ def main():
                 sys.stderr.write(f"bench.py: group roofline leg failed: {e}\n")
             gq.close()
         traffic, pmc = measured_traffic(n, d)
+        # the same counters for the launch `roofline` describes (8 matrices, left-looking long update): committed summary
+        ll_pmc = None
+        ll_path = os.path.join(ROOT, "profiles", "r04_pmc_lockstep_group_left_looking_summary.json")
+        if (n, d) == (16384, 32) and os.path.exists(ll_path):
+            with open(ll_path) as f:
+                ll_pmc = json.load(f)
         ok = stats[args.warmup * nb:] == 0
         out = {
             "metric": "gp_fixed_theta_fits_per_sec", "value": fits / elapsed, "unit": "fits/s",
@@ -823,7 +829,9 @@ def main():
             "cholesky_tflops_single_fit": tflops,
             "roofline": (None if roof_group is None else {
                 "bound": "mfma", "achieved": roof_group["tflops"], "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": roof_group["tflops"] / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                "frac": roof_group["tflops"] / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": (ll_pmc["corrected_traffic_bytes_per_launch"] if ll_pmc and gl == 8 else None),
+                "traffic_algorithmic_bytes": (ll_pmc["algorithmic_bytes_per_launch"] if ll_pmc and gl == 8 else None),
                 "launch_shape": f"{gl} matrices per launch (grid.z): the launch the timed region issues for a lock-step group",
                 "kernel": "k_gemm_stream<LOWER, TAG 1>: the LONG left-looking update of a lock-step group's next 1024 columns "
                           "(C -= L[:, 0:g) L[cols, 0:g)^T with K = every column before the previous group, 128x256 tiles; a "
@@ -838,9 +846,17 @@ def main():
                        "the previous group (diagonal blocks, panel solves, in-group updates) shares the chip with it as in "
                        "the product.  Reproduce: rocprofv3 --kernel-trace --stats -- python tools/group_roofline.py, row "
                        "'left-looking long update' of tools/rocpd_stats.py (profiles/r04_group_roofline_kernel_stats.txt)",
-                "traffic_note": "`traffic` is the right-looking single-matrix launch's (offline PMC passes, see "
-                                "roofline_single_matrix.traffic_source); the left-looking launches read and write every "
-                                "tile of C once per group instead of once per earlier group"}),
+                "traffic_source": (None if not ll_pmc else {
+                    "file": "profiles/r04_pmc_lockstep_group_left_looking_summary.json (from ..._pass1-3.json: separate "
+                            "rocprofv3 --pmc passes of tools/group_roofline.py, offline)",
+                    "fetch_size_bytes_per_launch_raw": ll_pmc["fetch_bytes_per_launch"],
+                    "write_size_bytes_per_launch_raw": ll_pmc["write_bytes_per_launch"],
+                    "correction": ll_pmc["correction"], "l2_hit_rate": ll_pmc["l2_hit_rate"],
+                    "mfma_busy_frac": ll_pmc["mfma_busy_frac"],
+                    "note": "3.8x the algorithmic bytes: each 128-row block of the factor is fetched by the four column tiles "
+                            "that use it on four different XCDs; 13.9 GB in 11 ms = 1.3 TB/s of fabric traffic (mostly "
+                            "Infinity-Cache hits), far from the bound -- and both walks that share those rows inside one XCD's "
+                            "L2 were slower (profiles/r04_run2_stream_walk_*, r04_run18_*)"})}),
             "roofline_single_matrix": {"bound": "mfma", "achieved": syrk_tflops, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": syrk_tflops / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": traffic,
