@@ -159,6 +159,8 @@ struct PotrfBatch {
     int sI = 0;              // ints between their info words
     int left = 0;            // left-looking group updates (launch_potrf); chosen per handle: potrf_left_for()
     int w_left = 0;          // ... and the C^-T rider's (PotrfInverse) left-looking update: w_left_for()
+    int *sync = nullptr;     // hand-off words of the pipelined chain kernel (kernels_pipe.hip): pipe_sync_ints() ints per matrix,
+    int64_t sS = 0;          // sS ints apart; nullptr: the chain runs as separate launches (k_potf2_reg, k_panel_trsm16, updates)
 };
 int potrf_left_for(int n_pad, int lockstep);
 int w_left_for(int n_pad, int lockstep);
@@ -200,6 +202,20 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
 size_t gram_scratch_doubles(int rows, int K);
 int launch_gram_lower(hipStream_t s, const double *W, int64_t ldw, int rows, int K, double *Gneg, int64_t ldg, double *P);
 int mfma_probe(double *max_abs_err);
+
+// ---- kernels_pipe.hip -------------------------------------------------------
+// The serial chain of a GROUP of panels -- diagonal blocks, panel solves, the updates of the group's own later columns -- as
+// ONE persistent launch with device-side hand-offs (k_potrf_pipe): the group [g0, g0 + gw) of `pb.count` matrices in lock-step,
+// whose columns have received every update of the earlier groups.  `pb.sync` = pipe_sync_ints(n_pad, m_tot) ints per matrix,
+// ZEROED once per factorisation (launch_potrf does it) -- all hand-off words count upwards over the launches of one
+// factorisation.  After the factorisation word 0 of the FIRST matrix' block is non-zero iff a bounded wait inside a launch
+// ran out (EGX_PIPE_TIMEOUT_MS): the factors are then unusable and the caller reports EGX_ERR_HIP.
+size_t pipe_sync_ints(int n_pad, int m_tot);
+int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
+                      const PotrfBatch &pb, int g0, int gw);
+int pipe_enabled();    // EGX_PIPE (default on)
+int pipe_whole_max();  // EGX_PIPE_WHOLE: padded size up to which a factorisation is ONE chain launch
+int pipe_set_knob(const char *name, int value);  // "pipe", "pipe_wgs", "pipe_rt", "pipe_timeout_ms", "pipe_stall" (tests); INT_MIN = unknown
 int chol_init();  // one-time function attribute setup (dynamic LDS sizes)
 int set_knob(const char *name, int value);  // kernels_chol.hip tuning knobs by name; INT_MIN = unknown
 

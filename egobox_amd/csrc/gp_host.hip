@@ -886,7 +886,8 @@ int32_t egx_set_tuning(const char *knob, int32_t value, int32_t *previous) {
         set_error("egx_set_tuning: NULL knob name");
         return EGX_ERR_INVALID_VALUE;
     }
-    const int old = set_knob(knob, value);
+    int old = set_knob(knob, value);
+    if (old == -2147483647 - 1) old = pipe_set_knob(knob, value);  // the chain kernel's knobs (kernels_pipe.hip)
     if (old == -2147483647 - 1) {
         set_error(std::string("egx_set_tuning: unknown knob '") + knob + "'");
         return EGX_ERR_INVALID_VALUE;

@@ -1,0 +1,671 @@
+// The serial chain of a group of Cholesky panels as ONE persistent launch with device-side hand-offs (gfx950 / MI355X).
+//
+// What it replaces: launch_potrf's chain -- per 256-column panel a diagonal-block launch (k_potf2_reg, one workgroup,
+// ~57 us), a panel solve launch (k_panel_trsm16, ~20 us) and one or two update launches of the group's own later columns --
+// i.e. the panel step of LAPACK dpotrf / linfa-linalg `cholesky()` behind crates/gp/src/algorithm.rs:1004, which is what a
+// LONE factorisation waits for (n = 4096: 16 x (57 + 20 + 15..80) us of launches in a row for 0.3 ms worth of flops).
+// Here the panel solve consumes the diagonal block STRIP BY STRIP while it is being factored, the update of the next
+// panel's columns starts row chunk by row chunk as the solve finishes them, and the next diagonal block starts as soon as
+// its own ten tiles are up to date: no launch boundary, no cross-stream event on the chain.
+//
+// ROLES.  Every workgroup has 1024 threads and takes a TICKET (one device-scope atomicAdd) when it starts:
+//   ticket z < nz          DIAG role for matrix z of the lock-step batch: walks the group's diagonal blocks with
+//                          rb_factor_block<16, PIPE> (potf2_blocks.h), publishing every finished 16-column strip
+//   later tickets          workers: ticket -> (task, matrix) from a task list in an order in which every task depends on
+//                          EARLIER tasks only; a worker that finishes takes the next ticket
+//     TRSM(p, rows)        64 * RT rows of the panel below diagonal block p: the register-resident 16-row-tile solve of
+//                          k_panel_trsm16, driven by the strips as they are published (two workgroup barriers per strip,
+//                          the fragments of the next strip prefetched whenever that strip is already there)
+//     FINE(p, i, j)        64 x 64 tile of block column p + 1 (the NEXT panel: on the chain) -= P_p P_p^T, K = 256 split over
+//                          the four wave quadruples of the workgroup, partial tiles summed through LDS in a fixed order
+//     COARSE(p, I, J)      128 x 128 tile of the group's columns beyond the next panel -= P_p P_p^T, K = 256
+// Because tickets are taken in order by workgroups that are RESIDENT, every task's producers are finished, running, or
+// held by a resident workgroup that only waits for still earlier tasks: no dispatch-order or placement assumption, no
+// deadlock.  Every wait is bounded (EGX_PIPE_TIMEOUT_MS): a waiter whose time runs out raises the launch's abort word
+// and returns, everybody else sees the word in its own wait or at its next ticket, the launch drains and the host reports
+// EGX_ERR_HIP (tests/test_gpu_pipe.py forces this path).
+//
+// HAND-OFFS (MI355X guide, "agent-scope release/acquire"; all words zeroed once per factorisation, counting upwards):
+//   strips[z]            DIAG -> TRSM: 16-column strips published (absolute); payload = the strip's column of the factor,
+//                        its diagonal tile, the tile's inverse + refinement flag: write-through (sc1) stores, drained by
+//                        every storing wave in front of a workgroup barrier, then one relaxed agent-scope flag store;
+//                        the consumer reads them with agent-scope loads (they bypass its L1)
+//   rowT[P][c]           TRSM -> FINE / COARSE: the 64-row chunk c of panel P is solved (sc1 stores + drain + flag)
+//   fcnt[Q][c]           FINE -> TRSM / DIAG: fine tiles of block column Q, row chunk c, that are up to date
+//   cver[I][J]           COARSE -> COARSE / FINE: updates of this launch applied to the 128 x 128 tile (I, J)
+// A task first waits (ONE lane polls, relaxed loads + s_sleep), then ONE agent-scope acquire drops the stale lines of its
+// CU's L1, a workgroup barrier, then plain loads.
+//
+// ARITHMETIC.  DIAG and TRSM do exactly what k_potf2_reg / k_panel_trsm16 do (same instructions on the same values: a
+// group of ONE panel gives the same bits as the separate launches, tools/pipe_check.hip); FINE / COARSE add their K = 256
+// products in an order of their own (fixed: a matrix gets the same bits alone and in a lock-step batch, on any grid size).
+#include "egx_internal.h"
+#include "mfma_gemm_core.h"
+#include "potf2_blocks.h"
+
+#include <climits>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
+namespace egx {
+
+enum { PT_TRSM = 0, PT_FINE = 1, PT_COARSE = 2, PT_DIAG = 3 };
+struct PipeTask {
+    int type, p, a, b;  // TRSM: a = first 64-row chunk (absolute); FINE: a = row chunk, b = column tile 0..3; COARSE: a = I, b = J (128-tiles, absolute)
+};
+
+// sync words of one matrix (ints): [0] abort (the launch's: matrix 0's), [1] strips published, [2] scratch (stalled strips of
+// the timeout test), [8 + P] ticket of the launch whose group starts at panel P (matrix 0's), then rowT, fcnt, cver
+constexpr int kPipeHdr = 8;
+struct PipeLayout {
+    int NP, NC, NJ;  // panels, 64-row chunks, 128-column tiles
+    int off_rowT, off_fcnt, off_cver, total;
+};
+static PipeLayout pipe_layout(int n_pad, int m_tot) {
+    PipeLayout l;
+    l.NP = (n_pad + 255) / 256;
+    l.NC = m_tot / 64;
+    l.NJ = n_pad / 128;
+    l.off_rowT = kPipeHdr + l.NP;
+    l.off_fcnt = l.off_rowT + l.NP * l.NC;
+    l.off_cver = l.off_fcnt + (l.NP + 1) * l.NC;
+    l.total = l.off_cver + (m_tot / 128) * l.NJ;
+    l.total = (l.total + 63) / 64 * 64;
+    return l;
+}
+size_t pipe_sync_ints(int n_pad, int m_tot) { return (size_t)pipe_layout(n_pad, m_tot).total; }
+
+struct PipeArgs {
+    double *M;
+    int64_t ld;
+    int n_pad, m_tot;
+    double *dinv;
+    int *info;
+    int *sync;
+    int64_t sM, sD, sS;
+    int sI, nz;
+    int g0, np;
+    const PipeTask *tasks;
+    int ntasks;
+    int NC, NJ, off_rowT, off_fcnt, off_cver;
+    int rt;             // 64-row chunks per TRSM task (1 or 2)
+    int stall;          // test hook: 1 + the strip (absolute) from which the DIAG role publishes into the scratch word
+    long long timeout;  // wall_clock64 ticks (100 MHz)
+};
+
+// The roles are separate (non-inlined) functions -- each gets a register allocation of its own under the kernel's 128-VGPR
+// budget (inlined into one body the diagonal role alone filled it and everything spilled) -- that read the launch arguments
+// from the kernel-argument segment (scalar loads, nothing held live across a role) and get the LDS base as an LDS pointer.
+typedef const __attribute__((address_space(4))) PipeArgs *pipe_kargs_t;
+typedef __attribute__((address_space(3))) double *pipe_lds_t;
+__device__ __forceinline__ PipeArgs pipe_kargs() {
+    pipe_kargs_t k = (pipe_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    PipeArgs a;
+    a.M = k->M, a.ld = k->ld, a.n_pad = k->n_pad, a.m_tot = k->m_tot, a.dinv = k->dinv, a.info = k->info, a.sync = k->sync;
+    a.sM = k->sM, a.sD = k->sD, a.sS = k->sS, a.sI = k->sI, a.nz = k->nz, a.g0 = k->g0, a.np = k->np, a.tasks = k->tasks;
+    a.ntasks = k->ntasks, a.NC = k->NC, a.NJ = k->NJ, a.off_rowT = k->off_rowT, a.off_fcnt = k->off_fcnt, a.off_cver = k->off_cver;
+    a.rt = k->rt, a.stall = k->stall, a.timeout = k->timeout;
+    return a;
+}
+
+constexpr int kFineStage2 = 2 * GemmShape<64, 64, 32, 32, 256>::STAGE;  // doubles of LDS per K quarter of a FINE task
+constexpr int kPipeLdsDoubles = 4 * kFineStage2;                         // 147 456 B: the largest role's
+constexpr int kPipeLdsBytes = kPipeLdsDoubles * 8 + 64;                  // + the control words
+static_assert(kPipeLdsDoubles * 8 >= RB_LDS_BYTES && kPipeLdsDoubles >= 2 * GemmShape<128, 128, 32, 32, 1024>::STAGE,
+              "LDS of the other roles");
+
+// ONE lane waits until *flag >= need.  0: there; 1: this matrix lost a pivot (nothing left to compute for it); 2: the launch
+// is aborted (somebody's wait ran out, maybe this one's)
+__device__ __forceinline__ int pipe_wait_ge(const int *flag, int need, int *abortp, const int *infop, long long limit) {
+    if (load_flag(flag) >= need) return 0;
+    const long long t0 = wall_clock64();
+    for (unsigned spins = 1;; spins++) {
+        __builtin_amdgcn_s_sleep(2);
+        if (load_flag(flag) >= need) return 0;
+        if ((spins & 7) == 0) {
+            if (load_flag(abortp) != 0) return 2;
+            if (load_flag(infop) != 0) return 1;
+            if (wall_clock64() - t0 > limit) {
+                store_flag(abortp, 1);
+                return 2;
+            }
+        }
+    }
+}
+
+// the outcome of thread 0's waits, for the whole workgroup (two barriers; on success thread 0 has executed the agent-scope
+// acquire that lets the workgroup read, with plain loads, what the producers it waited for have published)
+template <typename F>
+__device__ __forceinline__ int pipe_wg_wait(int *s_ctl, F &&waits) {
+    if (threadIdx.x == 0) {
+        const int r = waits();
+        if (r == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_ctl[0] = r;
+    }
+    __syncthreads();
+    const int r = s_ctl[0];
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DIAG: the diagonal blocks of the group, one after the other
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ int pipe_role_diag(pipe_lds_t sm3, int z, int p) {
+    const PipeArgs a = pipe_kargs();
+    double *sm = (double *)sm3;
+    int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
+    const int k0 = a.g0 + 256 * p, P = k0 >> 8;
+    const int nbk = (a.n_pad - k0 < 256) ? (a.n_pad - k0) : 256;
+    int *info = a.info + (int64_t)z * a.sI;
+    int *S = a.sync + (int64_t)z * a.sS;
+    {   // the block's fine tiles (i, j <= i) have received the previous panel (first block of a launch: nothing to wait for)
+        const int r = pipe_wg_wait(s_ctl, [&]() {
+            int rr = load_flag(info) != 0 ? 1 : 0;
+            const int *fc = S + a.off_fcnt + P * a.NC + (k0 >> 6);
+            for (int i = 0; i < nbk / 64 && rr == 0 && p > 0; i++) rr = pipe_wait_ge(fc + i, i + 1, a.sync, info, a.timeout);
+            return rr;
+        });
+        if (r) return r;
+    }
+    RbPublish pub;
+    pub.base = k0 >> 4;
+    pub.strips = S + 1;
+    if (a.stall && pub.base + (nbk >> 4) >= a.stall) pub.strips = S + 2;  // (test hook: this block's strips are never seen)
+    (void)rb_factor_block<16, true>(a.M + (int64_t)z * a.sM + (int64_t)k0 * a.ld + k0, a.ld, nbk,
+                                    a.dinv + (int64_t)z * a.sD + (int64_t)(k0 / 64) * 4096, info, k0, a.n_pad, sm, pub);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TRSM: 64 RT rows of the panel below diagonal block p.  Wave w: row-tile group w / 4 (RT tiles of 16 rows), strips
+// C = w % 4 (mod 4) of those tiles as FP64-MFMA accumulators (k_panel_trsm16's layout and arithmetic).  What a strip
+// needs from the DIAG role -- its column of the factor below and including the diagonal tile, the tile's inverse and
+// refinement flag -- is STAGED through LDS by the whole workgroup (one agent-scope 32-byte piece per thread; two buffers:
+// strip k + 1 is fetched, whenever it is already published, while strip k is being applied).
+// ---------------------------------------------------------------------------------------------
+constexpr int kTrsmXDoubles = 2 * 4 * 2 * 16 * RB_LD;  // X_k of 4 row-tile groups x (up to) 2 tiles, two buffers
+constexpr int kTrsmLBuf = 256 * RB_LD + 16 * RB_LD + 8;  // strip column (row r of the block at r * RB_LD), Linv_k, flag
+static_assert(kTrsmXDoubles + 2 * kTrsmLBuf <= kFineStage2 * 4, "LDS of the TRSM role");
+
+template <int RT>
+__device__ __noinline__ int pipe_role_trsm(pipe_lds_t sm3, int z, int p, int c0) {
+    const PipeArgs a = pipe_kargs();
+    double *sm = (double *)sm3;
+    int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
+    const int k0 = a.g0 + 256 * p, P = k0 >> 8, base = k0 >> 4;
+    const int nbk = (a.n_pad - k0 < 256) ? (a.n_pad - k0) : 256, nb16 = nbk >> 4;
+    double *Mz = a.M + (int64_t)z * a.sM;
+    const double *lin = a.dinv + (int64_t)z * a.sD + (int64_t)(k0 / 64) * 4096;
+    const int *info = a.info + (int64_t)z * a.sI;
+    int *S = a.sync + (int64_t)z * a.sS;
+    const int tid = threadIdx.x, lane = tid & 63, frow = lane & 15, fk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, sw = wave & 3;
+    const int prow = ((frow & 3) << 2) | (frow >> 2);  // pi(frow), see rb_factor_block
+    // the rows' columns of this panel have received the previous panel (fine tiles), and strip 0 is there
+    if (tid == 0) {
+        int r = load_flag(info) != 0 ? 1 : 0;
+        if (p > 0)
+            for (int c = 0; c < RT && r == 0; c++)
+                r = pipe_wait_ge(S + a.off_fcnt + P * a.NC + c0 + c, nbk / 64, a.sync, info, a.timeout);
+        if (r == 0) r = pipe_wait_ge(S + 1, base + 1, a.sync, info, a.timeout);
+        if (r == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        s_ctl[0] = r;
+        s_ctl[1] = load_flag(S + 1);
+    }
+    __syncthreads();
+    {
+        const int r = s_ctl[0];
+        if (r) {
+            __syncthreads();
+            return r;
+        }
+    }
+    int avail = s_ctl[1];  // strips published when thread 0 last looked (>= base + 1)
+    double *Pw = Mz + (int64_t)(64 * c0 + grp * RT * 16 + frow) * a.ld + k0 + 4 * fk;  // + 16 r ld + 16 C: row tile r, strip C
+    double acc[RT][16];  // row tile r, slot t <-> strip C = 4 t + sw
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int C = 4 * t + sw, Cc = C < nb16 ? C : 0;
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            const double *src = Pw + (int64_t)(16 * r) * a.ld + 16 * Cc;
+            const d2_t v0 = *reinterpret_cast<const d2_t *>(src), v1 = *reinterpret_cast<const d2_t *>(src + 2);
+            acc[r][4 * t] = v0[0];
+            acc[r][4 * t + 1] = v0[1];
+            acc[r][4 * t + 2] = v1[0];
+            acc[r][4 * t + 3] = v1[1];
+        }
+    }
+    double *Xs = sm, *Ls = sm + kTrsmXDoubles;
+    // staging of strip k: thread -> row tid / 4 of the diagonal block, doubles [4 (tid % 4), + 4) of the strip's 16 columns
+    // (rows above the strip's diagonal tile are not needed); threads 0..63 also carry the tile's inverse, thread 64 the flag
+    const int srow = tid >> 2, spart = (tid & 3) * 4;
+    const double *Lcol = Mz + (int64_t)(k0 + srow) * a.ld + k0 + spart;  // + 16 k
+    d2_t sv0, sv1, si0, si1;
+    double sflag = 0.0;
+    auto stage_load = [&](int k) {
+        if (srow >= 16 * k && srow < nbk) {
+            sv0 = load_d2_sc1(Lcol + 16 * k);
+            sv1 = load_d2_sc1(Lcol + 16 * k + 2);
+        }
+        const double *lk = lin + (int64_t)(k >> 2) * 4096 + (k & 3) * 256;
+        if (tid < 64) {
+            si0 = load_d2_sc1(lk + tid * 4);
+            si1 = load_d2_sc1(lk + tid * 4 + 2);
+        }
+        if (tid == 64) sflag = load_sc1(lin + (int64_t)(k >> 2) * 4096 + 1024 + (k & 3));
+    };
+    auto stage_store = [&](int k) {
+        double *Lb = Ls + (k & 1) * kTrsmLBuf;
+        if (srow >= 16 * k && srow < nbk) {
+            *reinterpret_cast<d2_t *>(Lb + srow * RB_LD + spart) = sv0;
+            *reinterpret_cast<d2_t *>(Lb + srow * RB_LD + spart + 2) = sv1;
+        }
+        if (tid < 64) {
+            double *li = Lb + 256 * RB_LD + (tid >> 2) * RB_LD + (tid & 3) * 4;
+            *reinterpret_cast<d2_t *>(li) = si0;
+            *reinterpret_cast<d2_t *>(li + 2) = si1;
+        }
+        if (tid == 64) Lb[256 * RB_LD + 16 * RB_LD] = sflag;
+    };
+    auto xbuf = [&](int k, int r) { return Xs + ((size_t)((k & 1) * 4 + grp) * 2 + r) * (16 * RB_LD); };
+    // solve strip k (slot k / 4 of the waves with sw == k % 4): X_k = T_k Linv_k^T (+ one refinement step) -> LDS, global
+    auto solve = [&](int k) {
+        const int t = k >> 2;
+        const double *Lb = Ls + (k & 1) * kTrsmLBuf;
+        const double *li = Lb + 256 * RB_LD + prow * RB_LD + 4 * fk;
+        const d2_t n01 = *reinterpret_cast<const d2_t *>(li), n23 = *reinterpret_cast<const d2_t *>(li + 2);
+        const bool refine = Lb[256 * RB_LD + 16 * RB_LD] != 0.0;
+        d2_t l01 = d2_t{0.0, 0.0}, l23 = d2_t{0.0, 0.0};
+        if (refine) {  // rows pi(frow) of the raw diagonal tile, zero right of the diagonal
+            const double *lr = Lb + (16 * k + prow) * RB_LD + 4 * fk;
+            const d2_t r01 = *reinterpret_cast<const d2_t *>(lr), r23 = *reinterpret_cast<const d2_t *>(lr + 2);
+            l01 = d2_t{(4 * fk <= prow) ? r01[0] : 0.0, (4 * fk + 1 <= prow) ? r01[1] : 0.0};
+            l23 = d2_t{(4 * fk + 2 <= prow) ? r23[0] : 0.0, (4 * fk + 3 <= prow) ? r23[1] : 0.0};
+        }
+#pragma unroll
+        for (int r = 0; r < RT; r++) {
+            double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
+            RB_MFMA4(x, 0, n01, n23, acc[r][4 * t], acc[r][4 * t + 1], acc[r][4 * t + 2], acc[r][4 * t + 3]);
+            if (refine) {
+                double4_t rs = double4_t{acc[r][4 * t], acc[r][4 * t + 1], acc[r][4 * t + 2], acc[r][4 * t + 3]};
+                RB_MFMA4(rs, 1, l01, l23, x[0], x[1], x[2], x[3]);
+                RB_MFMA4(x, 0, n01, n23, rs[0], rs[1], rs[2], rs[3]);
+            }
+            double *xs = xbuf(k, r) + frow * RB_LD + 4 * fk;
+            *reinterpret_cast<d2_t *>(xs) = d2_t{x[0], x[1]};
+            *reinterpret_cast<d2_t *>(xs + 2) = d2_t{x[2], x[3]};
+            double *dst = Pw + (int64_t)(16 * r) * a.ld + 16 * k;
+            store_d2_sc1(dst, d2_t{x[0], x[1]});
+            store_d2_sc1(dst + 2, d2_t{x[2], x[3]});
+        }
+    };
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();  // strip 0 is staged
+    bool have = false;  // strip k + 1's pieces are in this thread's registers
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < nb16) {
+            have = (k + 1 < nb16) && (avail >= base + k + 2);
+            if (have) stage_load(k + 1);
+            if (sw == (k & 3)) solve(k);
+            __syncthreads();  // X_k is in LDS
+            {
+                const double *Lb = Ls + (k & 1) * kTrsmLBuf;
+                d2_t b01[RT], b23[RT];
+#pragma unroll
+                for (int r = 0; r < RT; r++) {
+                    const double *xs = xbuf(k, r) + frow * RB_LD + 4 * fk;
+                    b01[r] = *reinterpret_cast<const d2_t *>(xs);
+                    b23[r] = *reinterpret_cast<const d2_t *>(xs + 2);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int C = 4 * t + sw;
+                    if (C > k && C < nb16) {  // T_C -= X_k L(C, k)^T
+                        const double *lf = Lb + (16 * C + prow) * RB_LD + 4 * fk;
+                        const d2_t a01 = *reinterpret_cast<const d2_t *>(lf), a23 = *reinterpret_cast<const d2_t *>(lf + 2);
+#pragma unroll
+                        for (int r = 0; r < RT; r++) {
+                            double4_t c4 = double4_t{acc[r][4 * t], acc[r][4 * t + 1], acc[r][4 * t + 2], acc[r][4 * t + 3]};
+                            RB_MFMA4(c4, 1, a01, a23, b01[r][0], b01[r][1], b23[r][0], b23[r][1]);
+                            acc[r][4 * t] = c4[0];
+                            acc[r][4 * t + 1] = c4[1];
+                            acc[r][4 * t + 2] = c4[2];
+                            acc[r][4 * t + 3] = c4[3];
+                        }
+                    }
+                }
+            }
+            if (k + 1 < nb16) {
+                if (!have) {  // strip k + 1 was not there yet: thread 0 waits for it, then everybody fetches
+                    if (tid == 0) {
+                        const int r = pipe_wait_ge(S + 1, base + k + 2, a.sync, info, a.timeout);
+                        s_ctl[1] = r ? -r : load_flag(S + 1);
+                    }
+                    __syncthreads();
+                    avail = s_ctl[1];
+                    if (avail < 0) return -avail;
+                    stage_load(k + 1);
+                } else if (tid == 0) {
+                    s_ctl[1] = load_flag(S + 1);  // (a fresh look for the next strip's prefetch decision)
+                }
+                stage_store(k + 1);
+                __syncthreads();  // strip k + 1 is staged (and s_ctl[1] is everybody's)
+                avail = s_ctl[1];
+            }
+        }
+    }
+    drain_stores();
+    __syncthreads();
+    if (tid == 0)
+        for (int c = 0; c < RT; c++) store_flag(S + a.off_rowT + P * a.NC + c0 + c, 1);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FINE: C (64 x 64 at rows 64 c_row, columns k0 + 256 + 64 j) -= A B^T over panel p's 256 columns.  Wave quadruple q
+// contracts k in [64 q, 64 q + 64) through its own LDS staging area; quadruple 0 adds the partial tiles in the order
+// 0, 1, 2, 3 and subtracts.
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ int pipe_role_fine(pipe_lds_t sm3, int z, int p, int c_row, int j) {
+    const PipeArgs a = pipe_kargs();
+    double *sm = (double *)sm3;
+    int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
+    const int k0 = a.g0 + 256 * p, P = k0 >> 8;
+    const int R0 = 64 * c_row, C0 = k0 + 256 + 64 * j, c_col = C0 >> 6;
+    double *Mz = a.M + (int64_t)z * a.sM;
+    const int *info = a.info + (int64_t)z * a.sI;
+    int *S = a.sync + (int64_t)z * a.sS;
+    const int r = pipe_wg_wait(s_ctl, [&]() {
+        int rr = load_flag(info) != 0 ? 1 : 0;
+        if (rr == 0) rr = pipe_wait_ge(S + a.off_rowT + P * a.NC + c_row, 1, a.sync, info, a.timeout);
+        if (rr == 0) rr = pipe_wait_ge(S + a.off_rowT + P * a.NC + c_col, 1, a.sync, info, a.timeout);
+        if (rr == 0 && p > 0) rr = pipe_wait_ge(S + a.off_cver + (R0 >> 7) * a.NJ + (C0 >> 7), p, a.sync, info, a.timeout);
+        return rr;
+    });
+    if (r) return r;
+    const int tid = threadIdx.x, q = tid >> 8, tl = tid & 255, lane = tid & 63, lw = tl >> 6;
+    double4_t acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm_core<64, 64, 32, 32, 256>(Mz + (int64_t)R0 * a.ld + k0 + 64 * q, a.ld, Mz + (int64_t)C0 * a.ld + k0 + 64 * q, a.ld, 64, acc,
+                                   sm + q * kFineStage2, tl);
+    // (gemm_core ends behind a workgroup barrier: the staging areas are free)
+    const int rl = (lw >> 1) * 32 + (lane >> 4), cl = (lw & 1) * 32 + (lane & 15);  // + 16 mi + 4 r, + 16 ni
+    if (q > 0) {
+        double *part = sm + (q - 1) * 4096;
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) part[(rl + 16 * mi + 4 * rr) * 64 + cl + 16 * ni] = acc[mi][ni][rr];
+    }
+    __syncthreads();
+    if (q == 0) {
+        double *Ct = Mz + (int64_t)(R0 + rl) * a.ld + C0 + cl;
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const int e = (rl + 16 * mi + 4 * rr) * 64 + cl + 16 * ni;
+                    const double sum = ((acc[mi][ni][rr] + sm[e]) + sm[4096 + e]) + sm[8192 + e];
+                    double *cp = Ct + (int64_t)(16 * mi + 4 * rr) * a.ld + 16 * ni;
+                    __hip_atomic_store(cp, *cp - sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+    }
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(S + a.off_fcnt + (P + 1) * a.NC + c_row, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// COARSE: C (128 x 128 tile (I, J), absolute) -= A B^T over panel p's 256 columns; sixteen waves x 32 x 32
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ int pipe_role_coarse(pipe_lds_t sm3, int z, int p, int I, int J) {
+    const PipeArgs a = pipe_kargs();
+    double *sm = (double *)sm3;
+    int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
+    const int k0 = a.g0 + 256 * p, P = k0 >> 8;
+    const int R0 = 128 * I, C0 = 128 * J;
+    double *Mz = a.M + (int64_t)z * a.sM;
+    const int *info = a.info + (int64_t)z * a.sI;
+    int *S = a.sync + (int64_t)z * a.sS;
+    int *ver = S + a.off_cver + I * a.NJ + J;
+    const int r = pipe_wg_wait(s_ctl, [&]() {
+        int rr = load_flag(info) != 0 ? 1 : 0;
+        const int *rowT = S + a.off_rowT + P * a.NC;
+        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I, 1, a.sync, info, a.timeout);
+        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I + 1, 1, a.sync, info, a.timeout);
+        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * J, 1, a.sync, info, a.timeout);
+        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * J + 1, 1, a.sync, info, a.timeout);
+        if (rr == 0 && p > 0) rr = pipe_wait_ge(ver, p, a.sync, info, a.timeout);
+        return rr;
+    });
+    if (r) return r;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double4_t acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
+    gemm_core<128, 128, 32, 32, 1024>(Mz + (int64_t)R0 * a.ld + k0, a.ld, Mz + (int64_t)C0 * a.ld + k0, a.ld, 256, acc, sm, tid);
+    double *Ct = Mz + (int64_t)(R0 + (wave >> 2) * 32 + (lane >> 4)) * a.ld + C0 + (wave & 3) * 32 + (lane & 15);
+    double cv[2][2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) cv[mi][ni][rr] = Ct[(int64_t)(16 * mi + 4 * rr) * a.ld + 16 * ni];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++)
+                __hip_atomic_store(Ct + (int64_t)(16 * mi + 4 * rr) * a.ld + 16 * ni, cv[mi][ni][rr] - acc[mi][ni][rr], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) store_flag(ver, p + 1);
+    return 0;
+}
+
+__global__ __launch_bounds__(1024) void k_potrf_pipe(PipeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
+    int *ticket = a.sync + kPipeHdr + (a.g0 >> 8);
+    auto next_ticket = [&]() {
+        if (threadIdx.x == 0) s_ctl[2] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int t = s_ctl[2];
+        __syncthreads();
+        return t;
+    };
+    const int total = a.ntasks * a.nz;
+    for (;;) {
+        const int t = next_ticket();
+        if (t >= total) return;
+        const int z = t % a.nz;
+        const PipeTask task = a.tasks[t / a.nz];
+        int r;
+        if (task.type == PT_DIAG) r = pipe_role_diag((pipe_lds_t)sm, z, task.p);
+        else if (task.type == PT_TRSM) r = (a.rt == 2) ? pipe_role_trsm<2>((pipe_lds_t)sm, z, task.p, task.a) : pipe_role_trsm<1>((pipe_lds_t)sm, z, task.p, task.a);
+        else if (task.type == PT_FINE) r = pipe_role_fine((pipe_lds_t)sm, z, task.p, task.a, task.b);
+        else r = pipe_role_coarse((pipe_lds_t)sm, z, task.p, task.a, task.b);
+        if (r == 2) return;  // aborted: the launch drains
+    }
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static int g_pipe = 1;              // EGX_PIPE=0: launch_potrf keeps the chain as separate launches
+static int g_pipe_wgs = 0;          // EGX_PIPE_WGS: workgroups of a chain launch (0: one per compute unit)
+static int g_pipe_rt = 0;           // EGX_PIPE_RT: 64-row chunks per TRSM task (0: by panel height)
+static int g_pipe_timeout_ms = 2000;  // EGX_PIPE_TIMEOUT_MS: bound of every wait inside the launch
+static int g_pipe_la = 1;            // EGX_PIPE_LA: how many panels ahead of their column's factorisation the coarse updates are queued
+static int g_pipe_whole = 0;         // EGX_PIPE_WHOLE: padded size up to which the WHOLE factorisation is one chain launch
+static int g_pipe_stall = 0;        // test hook (egx_set_tuning "pipe_stall"): see PipeArgs::stall
+
+static void pipe_init() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (const char *e = std::getenv("EGX_PIPE")) g_pipe = std::atoi(e);
+        if (const char *e = std::getenv("EGX_PIPE_WGS")) g_pipe_wgs = std::atoi(e);
+        if (const char *e = std::getenv("EGX_PIPE_RT")) g_pipe_rt = std::atoi(e);
+        if (const char *e = std::getenv("EGX_PIPE_WHOLE")) g_pipe_whole = std::atoi(e);
+        if (const char *e = std::getenv("EGX_PIPE_LA")) g_pipe_la = std::atoi(e) >= 0 ? std::atoi(e) : 0;
+        if (const char *e = std::getenv("EGX_PIPE_TIMEOUT_MS")) g_pipe_timeout_ms = std::atoi(e) > 0 ? std::atoi(e) : 1;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_pipe), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kPipeLdsBytes);
+    });
+}
+
+int pipe_set_knob(const char *name, int value) {
+    pipe_init();
+    struct { const char *n; int *v; } tab[] = {{"pipe", &g_pipe}, {"pipe_wgs", &g_pipe_wgs}, {"pipe_rt", &g_pipe_rt}, {"pipe_la", &g_pipe_la}, {"pipe_whole", &g_pipe_whole},
+                                              {"pipe_timeout_ms", &g_pipe_timeout_ms}, {"pipe_stall", &g_pipe_stall}};
+    for (auto &e : tab)
+        if (std::string(name) == e.n) {
+            const int old = *e.v;
+            *e.v = value;
+            return old;
+        }
+    return INT_MIN;
+}
+int pipe_enabled() {
+    pipe_init();
+    return g_pipe;
+}
+int pipe_whole_max() {
+    pipe_init();
+    return g_pipe_whole;
+}
+
+// The task list of the group [g0, g0 + 256 np), in STAGES.  Stage s: the FINE tiles of X(s - 1 -> s) (panel s - 1 into block
+// column s: what DIAG(s) and TRSM(s) wait for -- the diagonal block's tiles first, then row chunk by row chunk), DIAG(s), the
+// TRSM tasks of panel s (rows of the next diagonal block first), then the COARSE tiles of the updates X(p -> q), q >= p + 2,
+// with max(p + 1, q - la) == s in the order of their panels.  la = 0 queues
+// every update just in time (left-looking order), a large la right behind its panel (right-looking order); in every such
+// order a task depends on EARLIER entries only (X(p -> q) follows TRSM(p) and X(p - 1 -> q)), which is what makes the
+// ticket scheme of the kernel deadlock free.
+static std::vector<PipeTask> pipe_tasks(int n_pad, int m_tot, int g0, int np, int rt, int la) {
+    std::vector<PipeTask> v;
+    auto width = [&](int p) { const int k0 = g0 + 256 * p; return (n_pad - k0 < 256) ? (n_pad - k0) : 256; };
+    for (int s = 0; s < np; s++) {
+        auto coarse = [&](bool own_column) {  // COARSE: X(p -> q), q >= p + 2, of this stage
+            for (int p = 0; p + 1 < np; p++)
+                for (int q = p + 2; q < np; q++) {
+                    const int stage = (p + 1 > q - la) ? p + 1 : q - la;
+                    if (stage != s || (q == s) != own_column) continue;
+                    const int cq = g0 + 256 * q;
+                    for (int J = cq / 128; J < (cq + width(q)) / 128; J++)
+                        for (int I = J; I < m_tot / 128; I++) v.push_back({PT_COARSE, p, I, J});
+                }
+        };
+        coarse(true);  // (la == 0 only: block column s itself still has coarse updates to receive, ahead of its fine ones)
+        if (s > 0) {   // FINE: panel s - 1 into block column s
+            const int c0 = (g0 + 256 * s) / 64;
+            for (int c = c0; c < m_tot / 64; c++)
+                for (int j = 0; j < width(s) / 64; j++)
+                    if (c - c0 >= j) v.push_back({PT_FINE, s - 1, c, j});  // (tiles above the diagonal block's diagonal: none)
+        }
+        v.push_back({PT_DIAG, s, 0, 0});
+        const int r0 = g0 + 256 * s + width(s);
+        for (int c = r0 / 64; c + rt <= m_tot / 64; c += rt) v.push_back({PT_TRSM, s, c, 0});
+        coarse(false);  // (behind the chain's own tasks: nothing of this stage waits for them)
+    }
+    return v;
+}
+
+struct PipePlan {
+    PipeTask *d_tasks = nullptr;
+    int ntasks = 0;
+};
+static std::mutex g_plan_mu;
+static std::map<std::tuple<int, int, int, int, int, int, int>, PipePlan> g_plans;
+
+int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
+                      const PotrfBatch &pb, int g0, int gw) {
+    pipe_init();
+    if (!pb.sync || g0 % 256 || gw <= 0 || (m_tot - n_pad) % 128 || n_pad % 128) {
+        set_error("potrf_pipe: needs sync words, a group that starts on a panel boundary and padded sizes");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    const int np = (gw + 255) / 256;
+    int dev = 0;
+    EGX_HIP_CHECK(hipGetDevice(&dev));
+    // tall panels: two row chunks per solve task (the fragments and the barriers serve two tiles per wave quadruple)
+    const int rt = g_pipe_rt ? (g_pipe_rt >= 2 ? 2 : 1) : ((m_tot - g0) >= 8192 ? 2 : 1);
+    PipePlan plan;
+    {
+        std::lock_guard<std::mutex> lock(g_plan_mu);
+        const auto key = std::make_tuple(dev, n_pad, m_tot, g0, np, rt, g_pipe_la);
+        auto it = g_plans.find(key);
+        if (it == g_plans.end()) {
+            const std::vector<PipeTask> tasks = pipe_tasks(n_pad, m_tot, g0, np, rt, g_pipe_la);
+            PipePlan pl;
+            pl.ntasks = (int)tasks.size();
+            if (pl.ntasks > 0) {
+                EGX_HIP_CHECK(dev_malloc(&pl.d_tasks, sizeof(PipeTask) * tasks.size()));
+                EGX_HIP_CHECK(hipMemcpy(pl.d_tasks, tasks.data(), sizeof(PipeTask) * tasks.size(), hipMemcpyHostToDevice));
+            }
+            it = g_plans.emplace(key, pl).first;
+        }
+        plan = it->second;
+    }
+    const PipeLayout l = pipe_layout(n_pad, m_tot);
+    PipeArgs a;
+    a.M = M;
+    a.ld = ld;
+    a.n_pad = n_pad;
+    a.m_tot = m_tot;
+    a.dinv = dinv;
+    a.info = info;
+    a.sync = pb.sync;
+    a.sM = pb.sM;
+    a.sD = pb.sD;
+    a.sS = pb.sS;
+    a.sI = pb.sI;
+    a.nz = pb.count > 0 ? pb.count : 1;
+    a.g0 = g0;
+    a.np = np;
+    a.tasks = plan.d_tasks;
+    a.ntasks = plan.ntasks;
+    a.NC = l.NC;
+    a.NJ = l.NJ;
+    a.off_rowT = l.off_rowT;
+    a.off_fcnt = l.off_fcnt;
+    a.off_cver = l.off_cver;
+    a.rt = rt;
+    a.stall = g_pipe_stall;
+    a.timeout = (long long)g_pipe_timeout_ms * 100000ll;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        hipDeviceProp_t prop;
+        EGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long long want = (long long)a.nz * plan.ntasks;
+    long long wgs = g_pipe_wgs > 0 ? g_pipe_wgs : n_cu;
+    if (wgs > want) wgs = want;
+    hipLaunchKernelGGL(k_potrf_pipe, dim3((unsigned)wgs), dim3(1024), kPipeLdsBytes, s, a);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+}  // namespace egx

@@ -1,0 +1,389 @@
+// Checker + timer of the pipelined chain kernel (egobox_amd/csrc/kernels_pipe.hip) against the separate-launch chain
+// (k_potf2_reg + k_panel_trsm16 + update launches) of launch_potrf, on kernel matrices built on the device:
+//   bits      groups of ONE panel (potrf_group = 1): the chain launch holds a diagonal block and its panel solve only -- the
+//             same arithmetic as the separate launches, so the factors must agree BIT FOR BIT (this checks every hand-off)
+//   groups    the default groups, and the whole factorisation as ONE launch (pipe_whole), queue look-ahead 0 / 1 / 2 / 99:
+//             factor vs the separate launches (relative) and residual max |L L^T - A| / max |A|
+//   batch     lock-step batches: every matrix gets the bits it gets alone
+//   pivot     a matrix that loses a pivot: same `info` as the separate launches, and the launch ends
+//   timeout   strips never published (pipe_stall): the launch drains within the bound and raises its abort word
+//   time      median milliseconds of launch_potrf, separate launches vs chain launches
+// usage: pipe_check [max_n]   (run under `timeout`: a bug here may spin until the in-kernel bound)
+#include "../egobox_amd/csrc/kernels_chol.hip"
+#include "../egobox_amd/csrc/kernels_pipe.hip"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace egx {
+void set_error(const std::string &m) { fprintf(stderr, "egx error: %s\n", m.c_str()); }
+hipError_t dev_malloc_bytes(void **p, size_t bytes) { return hipMalloc(p, bytes); }
+}  // namespace egx
+using namespace egx;
+
+#define CK(x)                                                                          \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            exit(2);                                                                   \
+        }                                                                              \
+    } while (0)
+
+__device__ __forceinline__ double hash01(unsigned a, unsigned b) {
+    unsigned h = a * 2654435761u ^ (b + 0x9e3779b9u) * 40503u;
+    h ^= h >> 15, h *= 2246822519u, h ^= h >> 13, h *= 3266489917u, h ^= h >> 16;
+    return (h >> 8) * (1.0 / 16777216.0);
+}
+// rows [0, n): squared-exponential kernel matrix of n points in 3-D (+ nugget), identity padding up to n_pad; rows
+// [n_pad, m_tot): right-hand sides
+__global__ void k_build(double *M, int64_t ld, int n, int n_pad, int m_tot, double scale, double nugget, unsigned seed) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= n_pad || i >= m_tot) return;
+    double v;
+    if (i >= n_pad) v = (j < n) ? hash01(i + seed, j) - 0.5 : 0.0;
+    else if (i >= n || j >= n) v = (i == j) ? 1.0 : 0.0;
+    else {
+        double s = 0.0;
+        for (int d = 0; d < 3; d++) {
+            const double a = hash01(i * 3 + d, seed), b = hash01(j * 3 + d, seed);
+            s += (a - b) * (a - b);
+        }
+        v = exp(-scale * s) + (i == j ? nugget : 0.0);
+    }
+    M[(int64_t)i * ld + j] = v;
+}
+// max |(L L^T)_ij - A_ij| over the lower triangle of the leading n x n block (A rebuilt on the fly), per-thread atomicMax on bits
+__global__ void k_resid(const double *L, int64_t ld, int n, double scale, double nugget, unsigned seed, unsigned long long *out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j > i || i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k <= j; k++) s += L[(int64_t)i * ld + k] * L[(int64_t)j * ld + k];
+    double a = 0.0;
+    for (int d = 0; d < 3; d++) {
+        const double x = hash01(i * 3 + d, seed), y = hash01(j * 3 + d, seed);
+        a += (x - y) * (x - y);
+    }
+    a = exp(-scale * a) + (i == j ? nugget : 0.0);
+    const double e = fabs(s - a);
+    atomicMax(out, (unsigned long long)__double_as_longlong(e));
+}
+
+struct Problem {
+    int n, n_pad, m_tot, nz;
+    int64_t ld;
+    size_t mat, dinv_n, sync_n;
+    double *M = nullptr, *dinv = nullptr;
+    int *info = nullptr, *sync = nullptr;
+    PotrfLookahead lk;
+    void create(int n_, int nz_, bool lookahead) {
+        n = n_, nz = nz_;
+        n_pad = (int)round_up(n, n >= 4096 ? 256 : 128);
+        m_tot = n_pad + 128;
+        ld = n_pad;
+        mat = (size_t)m_tot * ld;
+        dinv_n = (dinv_doubles(n_pad) + 63) / 64 * 64;
+        sync_n = pipe_sync_ints(n_pad, m_tot);
+        CK(hipMalloc(&M, sizeof(double) * mat * nz));
+        CK(hipMalloc(&dinv, sizeof(double) * dinv_n * nz));
+        CK(hipMalloc(&info, sizeof(int) * nz));
+        CK(hipMalloc(&sync, sizeof(int) * sync_n * nz));
+        if (lookahead) {
+            int lo, hi;
+            CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            CK(hipStreamCreateWithPriority(&lk.s2, hipStreamNonBlocking, hi));
+            CK(hipStreamCreateWithPriority(&lk.s3, hipStreamNonBlocking, hi));
+            for (hipEvent_t *e : {&lk.ev_lu, &lk.ev_lur, &lk.ev_panel, &lk.ev_a, &lk.ev_b}) CK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        }
+    }
+    void destroy() {
+        hipFree(M), hipFree(dinv), hipFree(info), hipFree(sync);
+        if (lk.s2) {
+            hipStreamDestroy(lk.s2), hipStreamDestroy(lk.s3);
+            for (hipEvent_t e : {lk.ev_lu, lk.ev_lur, lk.ev_panel, lk.ev_a, lk.ev_b}) hipEventDestroy(e);
+        }
+    }
+    void build(hipStream_t s, double scale, double nugget, unsigned seed0) {
+        for (int z = 0; z < nz; z++)
+            hipLaunchKernelGGL(k_build, dim3((n_pad + 255) / 256, m_tot), dim3(256), 0, s, M + z * mat, ld, n, n_pad, m_tot, scale, nugget,
+                               seed0 + 17u * z);
+        CK(hipMemsetAsync(info, 0, sizeof(int) * nz, s));
+    }
+    int factor(hipStream_t s, bool pipe) {
+        PotrfBatch pb;
+        pb.count = nz;
+        pb.sM = (int64_t)mat;
+        pb.sD = (int64_t)dinv_n;
+        pb.sI = 1;
+        pb.sync = pipe ? sync : nullptr;
+        pb.sS = (int64_t)sync_n;
+        return launch_potrf(s, M, ld, n_pad, m_tot, dinv, info, lk.s2 ? &lk : nullptr, nullptr, &pb, nullptr);
+    }
+    std::vector<double> download(int z) {
+        std::vector<double> h(mat);
+        CK(hipMemcpy(h.data(), M + z * mat, sizeof(double) * mat, hipMemcpyDeviceToHost));
+        return h;
+    }
+    int abort_word() {
+        int v = 0;
+        CK(hipMemcpy(&v, sync, sizeof(int), hipMemcpyDeviceToHost));
+        return v;
+    }
+    std::vector<int> infos() {
+        std::vector<int> v(nz);
+        CK(hipMemcpy(v.data(), info, sizeof(int) * nz, hipMemcpyDeviceToHost));
+        return v;
+    }
+};
+
+// lower triangle (by 128-tiles, as the factorisation defines it) + right-hand-side rows: max relative difference, and
+// whether all those doubles are the same bits
+static void compare(const Problem &P, const std::vector<double> &a, const std::vector<double> &b, double &rel, bool &same) {
+    double num = 0.0, den = 0.0;
+    same = true;
+    for (int i = 0; i < P.m_tot; i++) {
+        const int jmax = (i < P.n_pad) ? std::min(P.n_pad, (i / 128 + 1) * 128) : P.n_pad;
+        for (int j = 0; j < jmax; j++) {
+            if (i < P.n_pad && j > i && (j / 64) == (i / 64) && (j / 16) > (i / 16)) continue;  // (zeroed by both)
+            if (i < P.n_pad && j > i) continue;
+            const double x = a[(size_t)i * P.ld + j], y = b[(size_t)i * P.ld + j];
+            if (std::memcmp(&x, &y, 8) != 0) same = false;
+            num = std::max(num, std::fabs(x - y));
+            den = std::max(den, std::fabs(x));
+        }
+    }
+    rel = den > 0 ? num / den : num;
+}
+
+static double residual(Problem &P, int z, double scale, double nugget, unsigned seed) {
+    unsigned long long *d;
+    CK(hipMalloc(&d, 8));
+    CK(hipMemset(d, 0, 8));
+    hipLaunchKernelGGL(k_resid, dim3((P.n + 255) / 256, P.n), dim3(256), 0, 0, P.M + z * P.mat, P.ld, P.n, scale, nugget, seed + 17u * z, d);
+    unsigned long long h;
+    CK(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost));
+    hipFree(d);
+    double e;
+    std::memcpy(&e, &h, 8);
+    return e;
+}
+
+static int g_fail = 0;
+static void verdict(bool ok, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    printf("%s ", ok ? "PASS" : "FAIL");
+    vprintf(fmt, ap);
+    printf("\n");
+    va_end(ap);
+    fflush(stdout);
+    if (!ok) g_fail++;
+}
+
+static double time_factor(Problem &P, bool pipe, double scale, double nugget, int reps) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    std::vector<float> ms;
+    for (int r = 0; r < reps + 1; r++) {
+        P.build(0, scale, nugget, 1000);
+        CK(hipEventRecord(e0, 0));
+        if (P.factor(0, pipe)) exit(3);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float t;
+        CK(hipEventElapsedTime(&t, e0, e1));
+        if (r) ms.push_back(t);
+    }
+    hipEventDestroy(e0), hipEventDestroy(e1);
+    std::sort(ms.begin(), ms.end());
+    return ms[ms.size() / 2];
+}
+
+int main(int argc, char **argv) {
+    const int max_n = argc > 1 ? atoi(argv[1]) : 8192;
+    const double scale = 6.0, nugget = 1e-8;  // cond ~ 1e8..1e10: the refinement step of the solves is exercised
+    if (chol_init()) return 1;
+    pipe_set_knob("pipe_timeout_ms", 500);
+    // ---------------------------------------------------------------- bits: one panel per chain launch
+    set_knob("potrf_group", 1);
+    for (int n : {200, 512, 1000, 2048}) {
+        for (int nz : {1, 3}) {
+            Problem P;
+            P.create(n, nz, false);
+            P.build(0, scale, nugget, 7);
+            if (P.factor(0, false)) return 3;
+            CK(hipDeviceSynchronize());
+            std::vector<std::vector<double>> ref;
+            for (int z = 0; z < nz; z++) ref.push_back(P.download(z));
+            P.build(0, scale, nugget, 7);
+            if (P.factor(0, true)) return 3;
+            CK(hipDeviceSynchronize());
+            bool all_same = true;
+            double worst = 0.0;
+            for (int z = 0; z < nz; z++) {
+                double rel;
+                bool same;
+                compare(P, ref[z], P.download(z), rel, same);
+                all_same = all_same && same;
+                worst = std::max(worst, rel);
+            }
+            verdict(all_same && P.abort_word() == 0, "bits    n=%d nz=%d one panel per launch: %s (max rel diff %.2e), abort word %d", n, nz,
+                    all_same ? "bit-identical" : "DIFFERENT", worst, P.abort_word());
+            P.destroy();
+        }
+    }
+    set_knob("potrf_group", 0);
+    // ---------------------------------------------------------------- groups / whole factorisation
+    for (int n : {1000, 2048, 4096}) {
+        if (n > max_n) continue;
+        Problem P;
+        P.create(n, 1, false);
+        P.build(0, scale, nugget, 11);
+        if (P.factor(0, false)) return 3;
+        CK(hipDeviceSynchronize());
+        const std::vector<double> ref = P.download(0);
+        const double res_ref = residual(P, 0, scale, nugget, 11);
+        struct Mode { int whole, la; };
+        for (Mode m : {Mode{0, 1}, Mode{1 << 30, 0}, Mode{1 << 30, 1}, Mode{1 << 30, 2}, Mode{1 << 30, 99}}) {
+            pipe_set_knob("pipe_whole", m.whole);
+            pipe_set_knob("pipe_la", m.la);
+            P.build(0, scale, nugget, 11);
+            if (P.factor(0, true)) return 3;
+            CK(hipDeviceSynchronize());
+            double rel;
+            bool same;
+            compare(P, ref, P.download(0), rel, same);
+            const double res = residual(P, 0, scale, nugget, 11);
+            verdict(rel < 1e-6 && res < 50 * std::max(res_ref, 1e-15) && P.abort_word() == 0 && P.infos()[0] == 0,
+                    "groups  n=%d %s la=%d: vs separate launches %.2e, residual %.2e (separate launches %.2e), info %d abort %d", n,
+                    m.whole ? "WHOLE" : "per-group", m.la, rel, res, res_ref, P.infos()[0], P.abort_word());
+        }
+        pipe_set_knob("pipe_whole", 0);
+        pipe_set_knob("pipe_la", 1);
+        P.destroy();
+    }
+    // ---------------------------------------------------------------- lock-step batches: the bits a matrix gets alone
+    for (int whole : {0, 1 << 30}) {
+        pipe_set_knob("pipe_whole", whole);
+        const int n = 1500, nz = 4;
+        Problem B, S;
+        B.create(n, nz, false);
+        S.create(n, 1, false);
+        B.build(0, scale, nugget, 23);
+        if (B.factor(0, true)) return 3;
+        CK(hipDeviceSynchronize());
+        bool ok = true;
+        for (int z = 0; z < nz; z++) {
+            S.build(0, scale, nugget, 23 + 17u * z);
+            if (S.factor(0, true)) return 3;
+            CK(hipDeviceSynchronize());
+            double rel;
+            bool same;
+            compare(S, S.download(0), B.download(z), rel, same);
+            ok = ok && same;
+        }
+        verdict(ok && B.abort_word() == 0, "batch   n=%d nz=%d %s: every matrix %s its lone factor", n, nz, whole ? "WHOLE" : "per-group",
+                ok ? "bit-identical to" : "DIFFERENT from");
+        // smaller grids: the same bits on 3 and on 17 workgroups
+        bool ok2 = true;
+        const std::vector<double> full = B.download(1);
+        for (int wgs : {3, 17}) {
+            pipe_set_knob("pipe_wgs", wgs);
+            B.build(0, scale, nugget, 23);
+            if (B.factor(0, true)) return 3;
+            CK(hipDeviceSynchronize());
+            double rel;
+            bool same;
+            compare(B, full, B.download(1), rel, same);
+            ok2 = ok2 && same && B.abort_word() == 0;
+        }
+        pipe_set_knob("pipe_wgs", 0);
+        verdict(ok2, "grid    n=%d nz=%d %s: the same bits on 3, 17 and all workgroups", n, nz, whole ? "WHOLE" : "per-group");
+        B.destroy(), S.destroy();
+    }
+    pipe_set_knob("pipe_whole", 0);
+    // ---------------------------------------------------------------- a lost pivot
+    for (int whole : {0, 1 << 30}) {
+        pipe_set_knob("pipe_whole", whole);
+        Problem P;
+        P.create(1200, 2, false);
+        int infos[2][2];
+        for (int pipe = 0; pipe < 2; pipe++) {
+            P.build(0, scale, nugget, 31);
+            const double bad = -3.0;  // matrix 1 loses pivot 701 (1-based), matrix 0 stays fine
+            CK(hipMemcpy(P.M + P.mat + (size_t)700 * P.ld + 700, &bad, 8, hipMemcpyHostToDevice));
+            if (P.factor(0, pipe != 0)) return 3;
+            CK(hipDeviceSynchronize());
+            infos[pipe][0] = P.infos()[0], infos[pipe][1] = P.infos()[1];
+        }
+        verdict(infos[0][0] == 0 && infos[0][1] == 701 && infos[1][0] == 0 && infos[1][1] == 701 && P.abort_word() == 0,
+                "pivot   %s: info separate launches (%d, %d), chain launches (%d, %d), abort %d", whole ? "WHOLE" : "per-group", infos[0][0],
+                infos[0][1], infos[1][0], infos[1][1], P.abort_word());
+        P.destroy();
+    }
+    pipe_set_knob("pipe_whole", 0);
+    // ---------------------------------------------------------------- strips that are never published
+    {
+        Problem P;
+        P.create(1024, 1, false);
+        pipe_set_knob("pipe_timeout_ms", 20);
+        pipe_set_knob("pipe_stall", 1);
+        P.build(0, scale, nugget, 5);
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, 0));
+        if (P.factor(0, true)) return 3;
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        verdict(P.abort_word() != 0 && ms < 2000.0f, "timeout strips never published: abort word %d, the factorisation's launches drained in %.1f ms (bound 20 ms per wait)",
+                P.abort_word(), ms);
+        pipe_set_knob("pipe_stall", 0);
+        pipe_set_knob("pipe_timeout_ms", 500);
+        // ... and the next factorisation on the same words is fine again
+        P.build(0, scale, nugget, 5);
+        if (P.factor(0, true)) return 3;
+        CK(hipDeviceSynchronize());
+        verdict(P.abort_word() == 0 && P.infos()[0] == 0, "timeout the next factorisation is clean: abort %d info %d", P.abort_word(), P.infos()[0]);
+        P.destroy();
+    }
+    // ---------------------------------------------------------------- timings
+    printf("\n# median ms of launch_potrf (one matrix unless nz is given); flops = n_pad^3 / 3\n");
+    for (int n : {1024, 2048, 4096, 8192, 16384}) {
+        if (n > max_n) continue;
+        for (int nz : {1, 8}) {
+            if (nz > 1 && n != 4096 && n != 8192) continue;
+            Problem P;
+            P.create(n, nz, n >= 8192);
+            const double fl = nz * (double)P.n_pad * P.n_pad * P.n_pad / 3.0;
+            const int reps = n >= 8192 ? 3 : 7;
+            const double t_sep = time_factor(P, false, scale, nugget, reps);
+            pipe_set_knob("pipe_whole", 0);
+            const double t_grp = time_factor(P, true, scale, nugget, reps);
+            printf("time    n=%5d nz=%d separate %8.3f ms (%5.1f TFLOP/s) | chain per group %8.3f ms (%5.1f)", n, nz, t_sep, fl / t_sep * 1e-9,
+                   t_grp, fl / t_grp * 1e-9);
+            if (n <= 8192) {
+                for (int la : {0, 1, 2, 4}) {
+                    pipe_set_knob("pipe_whole", 1 << 30);
+                    pipe_set_knob("pipe_la", la);
+                    const double t = time_factor(P, true, scale, nugget, reps);
+                    printf(" | whole la=%d %8.3f ms (%5.1f)", la, t, fl / t * 1e-9);
+                }
+                pipe_set_knob("pipe_whole", 0);
+                pipe_set_knob("pipe_la", 1);
+            }
+            printf(" abort %d\n", P.abort_word());
+            fflush(stdout);
+            P.destroy();
+        }
+    }
+    printf("\n%s (%d failed)\n", g_fail ? "SOME CHECKS FAILED" : "ALL CHECKS PASSED", g_fail);
+    return g_fail ? 1 : 0;
+}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Tile -> (update wave, slot) table of the 16-wave register-resident diagonal-block kernel (rb_rc15 in
-egobox_amd/csrc/kernels_chol.hip).  135 tiles of 16x16 (lower triangle of a 256x256 block without tile (0,0)), 15 update
+egobox_amd/csrc/potf2_blocks.h).  135 tiles of 16x16 (lower triangle of a 256x256 block without tile (0,0)), 15 update
 waves x 9 slots.  Constraints: the pair {(r, r-1), (r, r)} on one wave in consecutive slots; update waves 3, 7, 11 (they
 share the chain wave's SIMD) own tiles of columns 0..4 only, at most two per column; everything else dealt column-major to
 the least loaded wave, different waves within a column where possible.  Prints the per-strip maxima (TRSM tiles, trailing
