@@ -213,6 +213,7 @@ int mfma_probe(double *max_abs_err);
 size_t pipe_sync_ints(int n_pad, int m_tot);
 int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
                       const PotrfBatch &pb, int g0, int gw);
+void pipe_set_trace(long long *device_buf);  // profiling: 8 words per ticket of the next chain launches (nullptr: off)
 int pipe_enabled();    // EGX_PIPE (default on)
 int pipe_whole_max();  // EGX_PIPE_WHOLE: padded size up to which a factorisation is ONE chain launch
 int pipe_set_knob(const char *name, int value);  // "pipe", "pipe_wgs", "pipe_rt", "pipe_timeout_ms", "pipe_stall" (tests); INT_MIN = unknown

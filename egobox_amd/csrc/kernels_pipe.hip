@@ -94,20 +94,33 @@ struct PipeArgs {
     int rt;             // 64-row chunks per TRSM task (1 or 2)
     int stall;          // test hook: 1 + the strip (absolute) from which the DIAG role publishes into the scratch word
     long long timeout;  // wall_clock64 ticks (100 MHz)
+    long long *trace;   // profiling (tools/pipe_check): 8 words per ticket -- task, times taken / ready / done (100 MHz), XCD
 };
 
 // The roles are separate (non-inlined) functions -- each gets a register allocation of its own under the kernel's 128-VGPR
 // budget (inlined into one body the diagonal role alone filled it and everything spilled) -- that read the launch arguments
-// from the kernel-argument segment (scalar loads, nothing held live across a role) and get the LDS base as an LDS pointer.
+// from the kernel-argument segment (scalar loads through the pointer the kernel hands them) and get the LDS base as an LDS pointer.
 typedef const __attribute__((address_space(4))) PipeArgs *pipe_kargs_t;
 typedef __attribute__((address_space(3))) double *pipe_lds_t;
-__device__ __forceinline__ PipeArgs pipe_kargs() {
-    pipe_kargs_t k = (pipe_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
-    PipeArgs a;
+// Function arguments arrive in VECTOR registers: whatever is computed from them counts as divergent and lives in vector
+// registers too (the diagonal role lost ~20 of its 128 that way and kept two accumulator tiles in scratch).  The roles'
+// arguments are wave-uniform by construction, so they are moved to scalar registers on entry.
+__device__ __forceinline__ int pipe_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T *pipe_uniform(T *p) {
+    const unsigned long long u = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ PipeArgs pipe_kargs(pipe_kargs_t kv) {  // (kv: the kernel's own kernarg pointer -- inside a
+    PipeArgs a;                                                   //  called function the intrinsic yields a null pointer)
+    const unsigned long long u = (unsigned long long)kv;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    pipe_kargs_t k = (pipe_kargs_t)(((unsigned long long)hi << 32) | lo);
     a.M = k->M, a.ld = k->ld, a.n_pad = k->n_pad, a.m_tot = k->m_tot, a.dinv = k->dinv, a.info = k->info, a.sync = k->sync;
     a.sM = k->sM, a.sD = k->sD, a.sS = k->sS, a.sI = k->sI, a.nz = k->nz, a.g0 = k->g0, a.np = k->np, a.tasks = k->tasks;
     a.ntasks = k->ntasks, a.NC = k->NC, a.NJ = k->NJ, a.off_rowT = k->off_rowT, a.off_fcnt = k->off_fcnt, a.off_cver = k->off_cver;
-    a.rt = k->rt, a.stall = k->stall, a.timeout = k->timeout;
+    a.rt = k->rt, a.stall = k->stall, a.timeout = k->timeout, a.trace = k->trace;
     return a;
 }
 
@@ -152,35 +165,6 @@ __device__ __forceinline__ int pipe_wg_wait(int *s_ctl, F &&waits) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// DIAG: the diagonal blocks of the group, one after the other
-// ---------------------------------------------------------------------------------------------
-__device__ __noinline__ int pipe_role_diag(pipe_lds_t sm3, int z, int p) {
-    const PipeArgs a = pipe_kargs();
-    double *sm = (double *)sm3;
-    int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
-    const int k0 = a.g0 + 256 * p, P = k0 >> 8;
-    const int nbk = (a.n_pad - k0 < 256) ? (a.n_pad - k0) : 256;
-    int *info = a.info + (int64_t)z * a.sI;
-    int *S = a.sync + (int64_t)z * a.sS;
-    {   // the block's fine tiles (i, j <= i) have received the previous panel (first block of a launch: nothing to wait for)
-        const int r = pipe_wg_wait(s_ctl, [&]() {
-            int rr = load_flag(info) != 0 ? 1 : 0;
-            const int *fc = S + a.off_fcnt + P * a.NC + (k0 >> 6);
-            for (int i = 0; i < nbk / 64 && rr == 0 && p > 0; i++) rr = pipe_wait_ge(fc + i, i + 1, a.sync, info, a.timeout);
-            return rr;
-        });
-        if (r) return r;
-    }
-    RbPublish pub;
-    pub.base = k0 >> 4;
-    pub.strips = S + 1;
-    if (a.stall && pub.base + (nbk >> 4) >= a.stall) pub.strips = S + 2;  // (test hook: this block's strips are never seen)
-    (void)rb_factor_block<16, true>(a.M + (int64_t)z * a.sM + (int64_t)k0 * a.ld + k0, a.ld, nbk,
-                                    a.dinv + (int64_t)z * a.sD + (int64_t)(k0 / 64) * 4096, info, k0, a.n_pad, sm, pub);
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------
 // TRSM: 64 RT rows of the panel below diagonal block p.  Wave w: row-tile group w / 4 (RT tiles of 16 rows), strips
 // C = w % 4 (mod 4) of those tiles as FP64-MFMA accumulators (k_panel_trsm16's layout and arithmetic).  What a strip
 // needs from the DIAG role -- its column of the factor below and including the diagonal tile, the tile's inverse and
@@ -192,9 +176,15 @@ constexpr int kTrsmLBuf = 256 * RB_LD + 16 * RB_LD + 8;  // strip column (row r 
 static_assert(kTrsmXDoubles + 2 * kTrsmLBuf <= kFineStage2 * 4, "LDS of the TRSM role");
 
 template <int RT>
-__device__ __noinline__ int pipe_role_trsm(pipe_lds_t sm3, int z, int p, int c0) {
-    const PipeArgs a = pipe_kargs();
-    double *sm = (double *)sm3;
+__device__ __noinline__ int pipe_role_trsm(pipe_kargs_t ka, pipe_lds_t sm3, long long *tr, int z, int p, int c0) {
+    const PipeArgs a = pipe_kargs(ka);
+    z = pipe_uniform(z), p = pipe_uniform(p), c0 = pipe_uniform(c0);
+#ifdef EGX_PIPE_TRACE
+    tr = pipe_uniform(tr);
+#else
+    tr = nullptr;
+#endif
+    double *sm = (double *)(pipe_lds_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)sm3);
     int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
     const int k0 = a.g0 + 256 * p, P = k0 >> 8, base = k0 >> 4;
     const int nbk = (a.n_pad - k0 < 256) ? (a.n_pad - k0) : 256, nb16 = nbk >> 4;
@@ -226,6 +216,7 @@ __device__ __noinline__ int pipe_role_trsm(pipe_lds_t sm3, int z, int p, int c0)
         }
     }
     int avail = s_ctl[1];  // strips published when thread 0 last looked (>= base + 1)
+    if (tr && threadIdx.x == 0) tr[3] = wall_clock64();
     double *Pw = Mz + (int64_t)(64 * c0 + grp * RT * 16 + frow) * a.ld + k0 + 4 * fk;  // + 16 r ld + 16 C: row tile r, strip C
     double acc[RT][16];  // row tile r, slot t <-> strip C = 4 t + sw
 #pragma unroll
@@ -374,9 +365,15 @@ __device__ __noinline__ int pipe_role_trsm(pipe_lds_t sm3, int z, int p, int c0)
 // contracts k in [64 q, 64 q + 64) through its own LDS staging area; quadruple 0 adds the partial tiles in the order
 // 0, 1, 2, 3 and subtracts.
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ int pipe_role_fine(pipe_lds_t sm3, int z, int p, int c_row, int j) {
-    const PipeArgs a = pipe_kargs();
-    double *sm = (double *)sm3;
+__device__ __noinline__ int pipe_role_fine(pipe_kargs_t ka, pipe_lds_t sm3, long long *tr, int z, int p, int c_row, int j) {
+    const PipeArgs a = pipe_kargs(ka);
+    z = pipe_uniform(z), p = pipe_uniform(p), c_row = pipe_uniform(c_row), j = pipe_uniform(j);
+#ifdef EGX_PIPE_TRACE
+    tr = pipe_uniform(tr);
+#else
+    tr = nullptr;
+#endif
+    double *sm = (double *)(pipe_lds_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)sm3);
     int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
     const int k0 = a.g0 + 256 * p, P = k0 >> 8;
     const int R0 = 64 * c_row, C0 = k0 + 256 + 64 * j, c_col = C0 >> 6;
@@ -391,6 +388,7 @@ __device__ __noinline__ int pipe_role_fine(pipe_lds_t sm3, int z, int p, int c_r
         return rr;
     });
     if (r) return r;
+    if (tr && threadIdx.x == 0) tr[3] = wall_clock64();
     const int tid = threadIdx.x, q = tid >> 8, tl = tid & 255, lane = tid & 63, lw = tl >> 6;
     double4_t acc[2][2];
 #pragma unroll
@@ -434,9 +432,15 @@ __device__ __noinline__ int pipe_role_fine(pipe_lds_t sm3, int z, int p, int c_r
 // ---------------------------------------------------------------------------------------------
 // COARSE: C (128 x 128 tile (I, J), absolute) -= A B^T over panel p's 256 columns; sixteen waves x 32 x 32
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ int pipe_role_coarse(pipe_lds_t sm3, int z, int p, int I, int J) {
-    const PipeArgs a = pipe_kargs();
-    double *sm = (double *)sm3;
+__device__ __noinline__ int pipe_role_coarse(pipe_kargs_t ka, pipe_lds_t sm3, long long *tr, int z, int p, int I, int J) {
+    const PipeArgs a = pipe_kargs(ka);
+    z = pipe_uniform(z), p = pipe_uniform(p), I = pipe_uniform(I), J = pipe_uniform(J);
+#ifdef EGX_PIPE_TRACE
+    tr = pipe_uniform(tr);
+#else
+    tr = nullptr;
+#endif
+    double *sm = (double *)(pipe_lds_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)sm3);
     int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
     const int k0 = a.g0 + 256 * p, P = k0 >> 8;
     const int R0 = 128 * I, C0 = 128 * J;
@@ -455,6 +459,7 @@ __device__ __noinline__ int pipe_role_coarse(pipe_lds_t sm3, int z, int p, int I
         return rr;
     });
     if (r) return r;
+    if (tr && threadIdx.x == 0) tr[3] = wall_clock64();
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     double4_t acc[2][2];
 #pragma unroll
@@ -484,30 +489,89 @@ __device__ __noinline__ int pipe_role_coarse(pipe_lds_t sm3, int z, int p, int I
     return 0;
 }
 
-__global__ __launch_bounds__(1024) void k_potrf_pipe(PipeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+// the workers: ticket -> (task, matrix), until the list is exhausted or the launch is aborted
+__device__ __noinline__ void pipe_worker_loop(pipe_kargs_t ka, pipe_lds_t sm3) {
+    const PipeArgs a = pipe_kargs(ka);
+    double *sm = (double *)(pipe_lds_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)sm3);
     int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
     int *ticket = a.sync + kPipeHdr + (a.g0 >> 8);
-    auto next_ticket = [&]() {
+    const int total = a.ntasks * a.nz;
+    for (;;) {
         if (threadIdx.x == 0) s_ctl[2] = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const int t = s_ctl[2];
         __syncthreads();
-        return t;
-    };
-    const int total = a.ntasks * a.nz;
-    for (;;) {
-        const int t = next_ticket();
         if (t >= total) return;
         const int z = t % a.nz;
         const PipeTask task = a.tasks[t / a.nz];
+#ifdef EGX_PIPE_TRACE
+        long long *tr = a.trace ? a.trace + 8 * (int64_t)t : nullptr;
+#else
+        long long *tr = nullptr;  // (task timelines: tools/pipe_check builds with -DEGX_PIPE_TRACE)
+#endif
+        if (tr && threadIdx.x == 0) {
+            tr[0] = task.type | (task.p << 8) | (z << 16);
+            tr[1] = (unsigned)task.a | ((long long)task.b << 32);
+            tr[2] = wall_clock64();
+            tr[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((long long)blockIdx.x << 8);  // XCC_ID, workgroup
+        }
         int r;
-        if (task.type == PT_DIAG) r = pipe_role_diag((pipe_lds_t)sm, z, task.p);
-        else if (task.type == PT_TRSM) r = (a.rt == 2) ? pipe_role_trsm<2>((pipe_lds_t)sm, z, task.p, task.a) : pipe_role_trsm<1>((pipe_lds_t)sm, z, task.p, task.a);
-        else if (task.type == PT_FINE) r = pipe_role_fine((pipe_lds_t)sm, z, task.p, task.a, task.b);
-        else r = pipe_role_coarse((pipe_lds_t)sm, z, task.p, task.a, task.b);
+        if (task.type == PT_TRSM) r = (a.rt == 2) ? pipe_role_trsm<2>(ka, (pipe_lds_t)sm, tr, z, task.p, task.a) : pipe_role_trsm<1>(ka, (pipe_lds_t)sm, tr, z, task.p, task.a);
+        else if (task.type == PT_FINE) r = pipe_role_fine(ka, (pipe_lds_t)sm, tr, z, task.p, task.a, task.b);
+        else r = pipe_role_coarse(ka, (pipe_lds_t)sm, tr, z, task.p, task.a, task.b);
+        if (tr && threadIdx.x == 0) tr[4] = wall_clock64();
         if (r == 2) return;  // aborted: the launch drains
     }
+}
+
+// Workgroup b < np * nz is a DIAG workgroup: diagonal block b / nz of matrix b % nz, INLINE in the kernel body -- in kernel
+// context the register-resident block fits its 128 vector registers without a spill (as a called function it kept an
+// accumulator tile in scratch memory and ran at 90 us per block instead of 60) -- and a worker afterwards.  All of them are
+// resident from the start (the grid never exceeds one workgroup per compute unit) and wait for their block's fine tiles.
+__global__ __launch_bounds__(1024) void k_potrf_pipe(PipeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    if ((int)blockIdx.x < a.np * a.nz) {
+        const int z = (int)blockIdx.x % a.nz, p = (int)blockIdx.x / a.nz;
+        int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
+        const int k0 = a.g0 + 256 * p, P = k0 >> 8;
+        const int nbk = (a.n_pad - k0 < 256) ? (a.n_pad - k0) : 256;
+        int *info = a.info + (int64_t)z * a.sI;
+        int *S = a.sync + (int64_t)z * a.sS;
+#ifdef EGX_PIPE_TRACE
+        long long *tr = a.trace ? a.trace + 8 * (int64_t)(a.ntasks * a.nz + (int)blockIdx.x) : nullptr;
+        if (tr && threadIdx.x == 0) {
+            tr[0] = PT_DIAG | (p << 8) | (z << 16);
+            tr[1] = 0;
+            tr[2] = wall_clock64();
+            tr[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((long long)blockIdx.x << 8);
+        }
+#endif
+        // the block's fine tiles (i, j <= i) have received the previous panel (first block of a launch: nothing to wait for)
+        const int r = pipe_wg_wait(s_ctl, [&]() {
+            int rr = load_flag(info) != 0 ? 1 : 0;
+            const int *fc = S + a.off_fcnt + P * a.NC + (k0 >> 6);
+            for (int i = 0; i < nbk / 64 && rr == 0 && p > 0; i++) rr = pipe_wait_ge(fc + i, i + 1, a.sync, info, a.timeout);
+            return rr;
+        });
+        if (r == 2) return;
+        if (r == 0) {
+            RbPublish pub;
+            pub.base = k0 >> 4;
+            pub.strips = S + 1;
+            if (a.stall && pub.base + (nbk >> 4) >= a.stall) pub.strips = S + 2;  // (test hook: this block's strips are never seen)
+#ifdef EGX_PIPE_TRACE
+            pub.trace = tr;
+            if (tr && threadIdx.x == 0) tr[3] = wall_clock64();
+#endif
+            (void)rb_factor_block<16, true>(a.M + (int64_t)z * a.sM + (int64_t)k0 * a.ld + k0, a.ld, nbk,
+                                            a.dinv + (int64_t)z * a.sD + (int64_t)(k0 / 64) * 4096, info, k0, a.n_pad, sm, pub);
+#ifdef EGX_PIPE_TRACE
+            if (tr && threadIdx.x == 0) tr[4] = wall_clock64();
+#endif
+        }
+        __syncthreads();  // (the waves of a block that lost a pivot leave rb_factor_block at different points)
+    }
+    pipe_worker_loop((pipe_kargs_t)__builtin_amdgcn_kernarg_segment_ptr(), (pipe_lds_t)sm);
 }
 
 // =============================================================================================
@@ -519,6 +583,7 @@ static int g_pipe_rt = 0;           // EGX_PIPE_RT: 64-row chunks per TRSM task 
 static int g_pipe_timeout_ms = 2000;  // EGX_PIPE_TIMEOUT_MS: bound of every wait inside the launch
 static int g_pipe_la = 1;            // EGX_PIPE_LA: how many panels ahead of their column's factorisation the coarse updates are queued
 static int g_pipe_whole = 0;         // EGX_PIPE_WHOLE: padded size up to which the WHOLE factorisation is one chain launch
+static long long *g_pipe_trace = nullptr;  // profiling buffer of the NEXT launches (pipe_set_trace; tools/pipe_check)
 static int g_pipe_stall = 0;        // test hook (egx_set_tuning "pipe_stall"): see PipeArgs::stall
 
 static void pipe_init() {
@@ -547,6 +612,7 @@ int pipe_set_knob(const char *name, int value) {
         }
     return INT_MIN;
 }
+void pipe_set_trace(long long *buf) { g_pipe_trace = buf; }
 int pipe_enabled() {
     pipe_init();
     return g_pipe;
@@ -584,7 +650,6 @@ static std::vector<PipeTask> pipe_tasks(int n_pad, int m_tot, int g0, int np, in
                 for (int j = 0; j < width(s) / 64; j++)
                     if (c - c0 >= j) v.push_back({PT_FINE, s - 1, c, j});  // (tiles above the diagonal block's diagonal: none)
         }
-        v.push_back({PT_DIAG, s, 0, 0});
         const int r0 = g0 + 256 * s + width(s);
         for (int c = r0 / 64; c + rt <= m_tot / 64; c += rt) v.push_back({PT_TRSM, s, c, 0});
         coarse(false);  // (behind the chain's own tasks: nothing of this stage waits for them)
@@ -654,15 +719,24 @@ int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot
     a.rt = rt;
     a.stall = g_pipe_stall;
     a.timeout = (long long)g_pipe_timeout_ms * 100000ll;
+    a.trace = g_pipe_trace;
     static int n_cu = 0;
     if (n_cu == 0) {
         hipDeviceProp_t prop;
         EGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    const long long want = (long long)a.nz * plan.ntasks;
+    // the DIAG workgroups (one per diagonal block and matrix, resident from the start) + workers, never more than one
+    // workgroup per compute unit: every workgroup of the grid is resident, whatever the dispatch order
+    const long long n_diag = (long long)a.nz * np, want = n_diag + (long long)a.nz * plan.ntasks;
     long long wgs = g_pipe_wgs > 0 ? g_pipe_wgs : n_cu;
+    if (wgs > n_cu) wgs = n_cu;
     if (wgs > want) wgs = want;
+    if (wgs < n_diag + 1) wgs = n_diag + 1;
+    if (n_diag + 1 > n_cu) {
+        set_error("potrf_pipe: more diagonal blocks in one chain launch than compute units");
+        return EGX_ERR_INVALID_VALUE;
+    }
     hipLaunchKernelGGL(k_potrf_pipe, dim3((unsigned)wgs), dim3(1024), kPipeLdsBytes, s, a);
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;

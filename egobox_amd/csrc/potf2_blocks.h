@@ -18,9 +18,10 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 // (relaxed, agent scope).  Consumers poll that one word relaxed and read the payload with agent-scope (sc1) loads, or
 // after one agent-scope acquire with plain loads.
 __device__ __forceinline__ void store_d2_sc1(double *p, d2_t v) {
-    // (inline asm is invisible to the hazard recogniser: the wait state a >64-bit store needs before its data registers
-    //  may be overwritten is part of the statement)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" : : "v"(p), "v"(v) : "memory");
+    // (inline asm is invisible to the hazard recogniser: the TWO wait states gfx940+ needs between a store of more than 64
+    //  bits and a VALU write of its data registers are part of the statement -- with one, a v_and that followed the asm
+    //  replaced the low word of a stored double in lanes 0..15)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 template <bool SC1>
 __device__ __forceinline__ void store_d2(double *p, d2_t v) {
@@ -335,6 +336,9 @@ __device__ __forceinline__ void rb_chain_run(RbChain &ch, double *NL, double *LR
 struct RbPublish {
     int *strips = nullptr;
     int base = 0;
+#ifdef EGX_PIPE_TRACE
+    long long *trace = nullptr;  // (profiling builds: [6] / [7] receive the times of the first / last publication)
+#endif
 };
 
 // The factorisation of ONE nbk x nbk diagonal block (nbk a multiple of 16 up to 256) by the calling workgroup of NW waves
@@ -475,13 +479,6 @@ __device__ __forceinline__ bool rb_factor_block(double *__restrict__ D, int64_t 
             // pivot).  One step of iterative refinement, X += (A - X L^T) Linv^T, restores eps |A| as long as
             // eps cond(L)^2 < 1; it is skipped for well-conditioned diagonal tiles (the chain wave's estimate, flag[1]).
             const bool refine = flag[1] != 0;
-            d2_t l01 = d2_t{0.0, 0.0}, l23 = d2_t{0.0, 0.0};
-            if (refine) {  // A' operand of X L^T: rows pi(frow) of the raw factor, zero right of the diagonal
-                const d2_t r01 = *reinterpret_cast<const d2_t *>(LR + pr * RB_LD + f4);
-                const d2_t r23 = *reinterpret_cast<const d2_t *>(LR + pr * RB_LD + f4 + 2);
-                l01 = d2_t{(f4 <= pr) ? r01[0] : 0.0, (f4 + 1 <= pr) ? r01[1] : 0.0};
-                l23 = d2_t{(f4 + 2 <= pr) ? r23[0] : 0.0, (f4 + 3 <= pr) ? r23[1] : 0.0};
-            }
 #pragma unroll
             for (int s = 0; s < RB_NS; s++) {
                 if (m_trsm & (1u << s)) {
@@ -489,6 +486,12 @@ __device__ __forceinline__ bool rb_factor_block(double *__restrict__ D, int64_t 
                     double4_t x = double4_t{0.0, 0.0, 0.0, 0.0};
                     RB_MFMA4(x, 0, n01, n23, acc[4 * s], acc[4 * s + 1], acc[4 * s + 2], acc[4 * s + 3]);
                     if (refine) {
+                        // A' operand of X L^T: rows pi(frow) of the raw factor, zero right of the diagonal (read per tile:
+                        // held across the slots it costs eight registers the pipelined form of this block does not have)
+                        const d2_t r01 = *reinterpret_cast<const d2_t *>(LR + pr * RB_LD + f4);
+                        const d2_t r23 = *reinterpret_cast<const d2_t *>(LR + pr * RB_LD + f4 + 2);
+                        const d2_t l01 = d2_t{(f4 <= pr) ? r01[0] : 0.0, (f4 + 1 <= pr) ? r01[1] : 0.0};
+                        const d2_t l23 = d2_t{(f4 + 2 <= pr) ? r23[0] : 0.0, (f4 + 3 <= pr) ? r23[1] : 0.0};
                         double4_t r = double4_t{acc[4 * s], acc[4 * s + 1], acc[4 * s + 2], acc[4 * s + 3]};  // A
                         RB_MFMA4(r, 1, l01, l23, x[0], x[1], x[2], x[3]);                                      // A - X L^T
                         RB_MFMA4(x, 0, n01, n23, r[0], r[1], r[2], r[3]);                                      // X + (A - X L^T) Linv^T
@@ -496,9 +499,19 @@ __device__ __forceinline__ bool rb_factor_block(double *__restrict__ D, int64_t 
                     double *px = P + (R * 16 + fr) * RB_LD + f4;
                     *reinterpret_cast<d2_t *>(px) = d2_t{x[0], x[1]};
                     *reinterpret_cast<d2_t *>(px + 2) = d2_t{x[2], x[3]};
-                    double *dst = D + (int64_t)(R * 16 + fr) * ld + k * 16 + f4;
-                    store_d2<PIPE>(dst, d2_t{x[0], x[1]});
-                    store_d2<PIPE>(dst + 2, d2_t{x[2], x[3]});
+#ifdef RB_DBG_PHASEA
+                    {
+                        double *dst = D + (int64_t)(R * 16 + fr) * ld + k * 16 + f4;
+                        store_d2<PIPE>(dst, d2_t{x[0], x[1]});
+                        store_d2<PIPE>(dst + 2, d2_t{x[2], x[3]});
+                    }
+#else
+                    if constexpr (!PIPE) {  // (PIPE: the strip's column goes to global memory from the LDS panel, in phase B)
+                        double *dst = D + (int64_t)(R * 16 + fr) * ld + k * 16 + f4;
+                        *reinterpret_cast<d2_t *>(dst) = d2_t{x[0], x[1]};
+                        *reinterpret_cast<d2_t *>(dst + 2) = d2_t{x[2], x[3]};
+                    }
+#endif
                     if (s + 1 < RB_NS && (m_pair & (1u << s))) {  // slot s + 1 is tile (k+1, k+1): T -= X X^T, A' = own LDS rows
                         const double *pa = P + (R * 16 + pr) * RB_LD + f4;
                         const d2_t a01 = *reinterpret_cast<const d2_t *>(pa), a23 = *reinterpret_cast<const d2_t *>(pa + 2);
@@ -513,6 +526,19 @@ __device__ __forceinline__ bool rb_factor_block(double *__restrict__ D, int64_t 
         }
         __syncthreads();
         // ---- phase B: all other tiles right of column k, while wave 0 factors tile (k+1, k+1)
+#ifndef RB_DBG_PHASEA
+        if constexpr (PIPE) {
+            // PIPE: update wave w first sends row tile w of the strip's column (X_w, in the LDS panel since phase A) to global
+            // memory, write-through: the stores leave the TRSM phase (they cost it address registers it does not have, and
+            // issue slots on the chain's critical path) for the phase in which the update waves wait for the chain anyway
+            if (wave > k && wave < nb16) {
+                const double *px = P + (wave * 16 + fr) * RB_LD + f4;
+                double *dst = D + (int64_t)(wave * 16 + fr) * ld + k * 16 + f4;
+                store_d2_sc1(dst, *reinterpret_cast<const d2_t *>(px));
+                store_d2_sc1(dst + 2, *reinterpret_cast<const d2_t *>(px + 2));
+            }
+        }
+#endif
 #pragma unroll
         for (int s = 0; s < RB_NS; s++) {
             if (m_upd & (1u << s)) {
@@ -532,7 +558,12 @@ __device__ __forceinline__ bool rb_factor_block(double *__restrict__ D, int64_t 
         if (PIPE) drain_stores();  // strip k's column, diagonal tile and inverse: issued a phase ago
         __syncthreads();
         if (*flag) return false;
-        if (PIPE && wave == 1 && lane == 0) store_flag(pub.strips, pub.base + k + 1);
+        if (PIPE && wave == 1 && lane == 0) {
+            store_flag(pub.strips, pub.base + k + 1);
+#ifdef EGX_PIPE_TRACE
+            if (pub.trace && k == 0) pub.trace[6] = wall_clock64();
+#endif
+        }
         m_trsm = n_trsm;
         m_pair = n_pair;
         m_upd = n_upd;
@@ -545,7 +576,12 @@ __device__ __forceinline__ bool rb_factor_block(double *__restrict__ D, int64_t 
     if (PIPE) {
         drain_stores();
         __syncthreads();
-        if (wave == 1 && lane == 0) store_flag(pub.strips, pub.base + nb16);
+        if (wave == 1 && lane == 0) {
+            store_flag(pub.strips, pub.base + nb16);
+#ifdef EGX_PIPE_TRACE
+            if (pub.trace) pub.trace[7] = wall_clock64();
+#endif
+        }
     }
     return true;
 }
