@@ -66,6 +66,7 @@ SIGNATURES = [
     ("egx_gp_likelihood_batch", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_int32_p]),
     ("egx_gp_set_lockstep", C.c_int32, [C.c_void_p, C.c_int32]),
     ("egx_gp_get_lockstep", C.c_int32, [C.c_void_p]),
+    ("egx_gp_get_schedule", C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]),
     ("egx_gp_shrink", C.c_int32, [C.c_void_p, C.c_int32]),
     ("egx_gp_likelihood_grad", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p, c_int32_p]),
     ("egx_gp_likelihood_grad_batch", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p,

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "../../include/egx_gp.h"
+#include "schedule.h"
 
 namespace egx {
 
@@ -161,9 +162,15 @@ struct PotrfBatch {
     int w_left = 0;          // ... and the C^-T rider's (PotrfInverse) left-looking update: w_left_for()
     int *sync = nullptr;     // hand-off words of the pipelined chain kernel (kernels_pipe.hip): pipe_sync_ints() ints per matrix,
     int64_t sS = 0;          // sS ints apart; nullptr: the chain runs as separate launches (k_potf2_reg, k_panel_trsm16, updates)
+    int pipe = 0;            // ... the chain of every group of panels is one chain launch (schedule.h: per handle)
+    int whole = 0;           // ... the WHOLE factorisation is one chain launch (every update inside it)
+    int tail = 0;            // ... right-looking: the last `tail` columns are one chain launch
 };
 int potrf_left_for(int n_pad, int lockstep);
 int w_left_for(int n_pad, int lockstep);
+// the schedule of a handle's factorisations, decided once per handle shape: schedule.h (table, rationale, host test)
+PotrfSchedule schedule_for(int n_pad, int lockstep, int n_workspaces);
+int potrf_group_panels(int n_pad);
 // the solves after a factorisation in lock-step: `count` factors (sM apart, tile inverses sD apart) and as many
 // right-hand-side buffers (sR apart)
 struct TrsmBatch {
@@ -211,11 +218,17 @@ int mfma_probe(double *max_abs_err);
 // factorisation.  After the factorisation word 0 of the FIRST matrix' block is non-zero iff a bounded wait inside a launch
 // ran out (EGX_PIPE_TIMEOUT_MS): the factors are then unusable and the caller reports EGX_ERR_HIP.
 size_t pipe_sync_ints(int n_pad, int m_tot);
+// ext_need != 0: the solves of the group's first panel wait, on the device, until pipe_signal(.., ext_need) has run (the rest
+// of the group's columns is being updated by a launch beside this one); shared_chip: other launches of the factorisation run
+// beside this one (look-ahead): the grid leaves them compute units.
 int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
-                      const PotrfBatch &pb, int g0, int gw);
+                      const PotrfBatch &pb, int g0, int gw, int ext_need = 0, int shared_chip = 0);
+int pipe_signal(hipStream_t s, const PotrfBatch &pb, int value);
 void pipe_set_trace(long long *device_buf);  // profiling: 8 words per ticket of the next chain launches (nullptr: off)
 int pipe_enabled();    // EGX_PIPE (default on)
-int pipe_whole_max();  // EGX_PIPE_WHOLE: padded size up to which a factorisation is ONE chain launch
+int pipe_group_max();  // EGX_PIPE_MAX: padded size up to which the chain of every panel group is a chain launch (schedule.h)
+int pipe_tail_cols();  // EGX_PIPE_TAIL (default 0)
+int pipe_whole_max();  // EGX_PIPE_WHOLE: padded size up to which a handle may factor as ONE chain launch (schedule.h)
 int pipe_set_knob(const char *name, int value);  // "pipe", "pipe_wgs", "pipe_rt", "pipe_timeout_ms", "pipe_stall" (tests); INT_MIN = unknown
 int chol_init();  // one-time function attribute setup (dynamic LDS sizes)
 int set_knob(const char *name, int value);  // kernels_chol.hip tuning knobs by name; INT_MIN = unknown

@@ -70,6 +70,7 @@ struct Workspace {
     double *d_vec = nullptr;   // n_pad (gamma)
     double *d_rhs = nullptr;   // n_pad (rho, destroyed by the back-substitution)
     int *d_info = nullptr;
+    const int *sync_lead = nullptr;  // hand-off words of the lead of the lock-step group this evaluation ran in (diagnostics)
     // device-side GLS (p > 1 trend columns): Gram matrix of [ft | yt] and its factor, all (rhs_pad x rhs_pad)
     double *d_gneg = nullptr, *d_gram = nullptr, *d_gdinv = nullptr, *d_gramP = nullptr, *d_beta = nullptr,
            *d_part = nullptr;
@@ -81,7 +82,7 @@ struct Workspace {
     double *h_rows = nullptr;  // pinned: q x n_pad solved RHS rows (ft^T, yt^T)
     double *h_diag = nullptr;  // pinned: n
     double *h_vec = nullptr;   // pinned: n_pad
-    int *h_info = nullptr;     // pinned
+    int *h_info = nullptr;     // pinned: [0] the factorisation's info, [1..8] the abort word + diagnostics of its chain launches
     // theta-gradient scratch (lazy, gp_fit.hip): the workgroups' partial sums, the reduced sums, their pinned copy
     double *d_gpart = nullptr, *d_gout = nullptr, *h_gout = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -124,9 +125,11 @@ struct egx_gp {
     std::vector<egx::Workspace> ws;
     // one allocation each for all workspaces' matrices, tile inverses and failure flags (strides in elements)
     double *slab_M = nullptr, *slab_D = nullptr;
-    int *slab_I = nullptr;
-    int64_t stride_M = 0, stride_D = 0;
+    int *slab_I = nullptr;  // one failure flag per workspace, then (from sync_off on) stride_S hand-off words per workspace
+                            // for the pipelined chain kernel (kernels_pipe.hip; zeroed by every factorisation)
+    int64_t stride_M = 0, stride_D = 0, stride_S = 0, sync_off = 0;
     int lockstep = 1;  // candidates of a likelihood batch factored in lock-step (consecutive workspaces), <= ws.size()
+    egx::PotrfSchedule sched;  // how this handle factors: decided at create / egx_gp_set_lockstep (schedule_for), kept by shrink
     // exclusive for everything that touches the fitted state or all workspaces; SHARED for egx_gp_likelihood, whose
     // concurrent callers (the reference's rayon multistart closures, algorithm.rs:928-945) each take a workspace
     // from the pool below
@@ -175,6 +178,9 @@ int fit_reduce_finalize(egx_gp *gp, const double *theta_base, const std::vector<
 // x_mean (d) | x_std (d) on the device, behind the coefficients of the fit in the same allocation
 // the training inputs times the coefficients of the fit (d x n_pad, k-major; valid when fit_hcols == 1), behind d_xT in
 // the same allocation: what the scalar-row prediction kernel reads (kernels_corr.hip k_predict_mean_srow)
+// ints of slab_I for `nws` workspaces, and workspace i's hand-off words in it
+inline size_t slab_I_ints(const egx_gp *gp, int nws) { return (size_t)egx::round_up(nws, 64) + (size_t)gp->stride_S * (size_t)nws; }
+inline int *dev_sync(const egx_gp *gp, int i) { return gp->slab_I + gp->sync_off + (int64_t)i * gp->stride_S; }
 inline double *dev_xs_fit(const egx_gp *gp) { return gp->d_xT + (size_t)gp->d * gp->n_pad; }
 inline double *dev_xnorm(const egx_gp *gp) { return gp->d_fit_coef + (size_t)gp->d * (gp->has_w ? gp->h : 1); }
 

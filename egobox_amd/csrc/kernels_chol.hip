@@ -874,26 +874,25 @@ int chol_init() {
     return rc_once;
 }
 
-// does a handle of this shape factor left-looking?  (per handle, never per launch: see launch_potrf)
-int potrf_left_for(int n_pad, int lockstep) {
+static ScheduleKnobs schedule_knobs() {
     (void)chol_init();
-    // measured (profiles/r04_run4_*, r04_run5_ab_small_*): n = 16384 with groups of eight +2.3 % on the sweep; n = 8192 (groups
-    // of two panels, K <= 7k, <= 128 tiles per matrix and launch) -14 %; a lone matrix 2.4x slower -- hence the narrow rule
-    return g_potrf_left >= 2 || (g_potrf_left == 1 && n_pad >= 14336 && lockstep >= 8);
+    ScheduleKnobs k;
+    k.potrf_left = g_potrf_left;
+    k.w_left = g_w_left;
+    k.pipe = pipe_enabled();
+    k.pipe_max = pipe_group_max();
+    k.pipe_whole = pipe_whole_max();
+    k.pipe_tail = pipe_tail_cols();
+    k.potrf_group = g_potrf_group;
+    return k;
 }
-
-// does the C^-T rider (the theta-gradient's W, PotrfInverse) of a handle of this shape update left-looking?  Per handle like
-// potrf_left_for.  Measured (profiles/r04_run12_w_left_ab.txt; likelihood + gradient, ms per candidate, right- -> left-looking):
-//   n = 16384   lock-step 8: 74.4 -> 71.9    lock-step 4: 75.8 -> 73.4    one workspace: 78.1 -> 78.4
-//   n = 8192    lock-step 12: 10.4 -> 9.9    ONE candidate: 12.6 -> 21.7   (n = 4096: 1.79 -> 1.69, 3.4 -> 5.5)
-// a lone matrix' launch has few tiles with K ranges from 128 to all earlier columns, and the next group's solves wait for
-// the longest: from n_pad 14336 on (where one candidate on such a handle neither gains nor loses) and lock-step widths >= 4.
-// Both forms add the same products in the same order wherever every group is 1024 columns wide: the same bits at n = 16384
-// (checked by the A/B); a narrower last group's right-looking update is another kernel's (3e-12 at n = 14400).
-int w_left_for(int n_pad, int lockstep) {
-    (void)chol_init();
-    return n_pad % 256 == 0 && (g_w_left >= 2 || (g_w_left == 1 && n_pad >= 14336 && lockstep >= 4));
+int potrf_group_panels(int n_pad) { return schedule_table(n_pad, 1, 1, schedule_knobs()).group_panels; }
+// the one place where a handle's schedule is decided: schedule.h
+PotrfSchedule schedule_for(int n_pad, int lockstep, int n_workspaces) {
+    return schedule_table(n_pad, lockstep, n_workspaces, schedule_knobs());
 }
+int potrf_left_for(int n_pad, int lockstep) { return schedule_for(n_pad, lockstep, 1).left; }
+int w_left_for(int n_pad, int lockstep) { return schedule_for(n_pad, lockstep, 1).w_left; }
 
 // run-time access to the knobs above (egx_set_tuning): A/B measurements inside ONE process (a gpurun call is minutes, a
 // launch sequence milliseconds) and the serialised profiling mode of bench.py's roofline leg.  Returns the previous
@@ -1085,9 +1084,11 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     // the chain of a group gets longer while its trailing update shrinks)
     // the serial chain as ONE persistent launch per group of panels (kernels_pipe.hip) when the caller provides the hand-off
     // words; up to `pipe_whole_max()` columns the whole factorisation is one such launch (every update inside it)
-    const bool pipe = pb.sync != nullptr && pipe_enabled() != 0;
-    if (pipe) EGX_HIP_CHECK(hipMemsetAsync(pb.sync, 0, sizeof(int) * (nz > 1 ? (size_t)pb.sS * nz : pipe_sync_ints(n_pad, m_tot)), s));
-    if (pipe && !inv && n_pad <= pipe_whole_max()) {
+    const bool have_sync = pb.sync != nullptr && pipe_enabled() != 0;
+    const bool pipe = have_sync && pb.pipe;  // (chain launches per group; pb.tail: for the last columns only)
+    if (have_sync) EGX_HIP_CHECK(hipMemsetAsync(pb.sync, 0, sizeof(int) * (nz > 1 ? (size_t)pb.sS * nz : pipe_sync_ints(n_pad, m_tot)), s));
+    // (decided per HANDLE, never by the number of matrices in a launch: a matrix gets the same bits in any batch)
+    if (pipe && !inv && pb.whole) {
         rc = launch_potrf_pipe(s, M, ld, n_pad, m_tot, dinv, info, pb, 0, n_pad);
         if (rc) return rc;
         hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64, 1, nz), dim3(256), 0, s, (const double *)M, ld, dinv,
@@ -1095,15 +1096,19 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         EGX_HIP_CHECK(hipGetLastError());
         return EGX_SUCCESS;
     }
-    const int GW = (g_potrf_group ? g_potrf_group : (n_pad >= 14336 ? 4 : 2)) * kNB;
+    const int GW = potrf_group_panels(n_pad) * kNB;
     auto gwidth = [&](int g0) { return (n_pad - g0 < GW) ? (n_pad - g0) : GW; };
     // panels of one group on stream `st`; `side` != nullptr splits every in-group update into the next diagonal block
     // (on st) and the rest (on side); `first_wait` is waited for before the FIRST panel solve (the rest of the update
     // that brought this group's columns up to date)
     auto inner_factor = [&](hipStream_t st, int g0, int gw, hipStream_t side, hipEvent_t first_wait) -> int {
         if (pipe) {  // one launch: diagonal blocks, panel solves and in-group updates hand over to each other on the device
-            if (first_wait) EGX_HIP_CHECK(hipStreamWaitEvent(st, first_wait, 0));
-            return launch_potrf_pipe(st, M, ld, n_pad, m_tot, dinv, info, pb, g0, gw);
+            // (first_wait -- the rest of the update that brought this group's columns up to date, on another stream -- is
+            //  waited for ON THE DEVICE by the first panel's solve tasks: pipe_signal behind that update)
+            const int rc2 = launch_potrf_pipe(st, M, ld, n_pad, m_tot, dinv, info, pb, g0, gw, first_wait ? g0 / kNB + 1 : 0, st != s);
+            // (... and by the stream behind the launch: a matrix that lost a pivot skips its tasks without waiting for anything)
+            if (rc2 == EGX_SUCCESS && first_wait) EGX_HIP_CHECK(hipStreamWaitEvent(st, first_wait, 0));
+            return rc2;
         }
         hipEvent_t pending = first_wait;
         for (int k0 = g0; k0 < g0 + gw; k0 += kNB) {
@@ -1260,6 +1265,15 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         const int gw = gwidth(g0);
         const int r1 = g0 + gw;  // first row/col of the trailing matrix
         if (r1 >= n_pad) break;  // (right-hand-side rows below the last block were solved by its panel)
+        if (have_sync && !inv && pb.tail > 0 && n_pad - r1 <= pb.tail) {
+            // TAIL (schedule.h): one update brings the whole trailing matrix up to date, one chain launch factors it -- where
+            // the trailing updates are too short to hide the chain, the chain should at least not be cut into launches
+            rc = update(s, r1, r1, m_tot - r1, n_pad - r1, g0, gw, 1, nullptr);
+            if (rc) return rc;
+            rc = launch_potrf_pipe(s, M, ld, n_pad, m_tot, dinv, info, pb, r1, n_pad - r1);
+            if (rc) return rc;
+            break;
+        }
         const int gw1 = gwidth(r1);
         // the cross-stream hand-off costs ~2 x 10 us; below ~3k trailing columns RU is shorter than that (and with
         // several fits in flight the extra hand-offs cost more than they hide: profiles/r02_run23_tail_lookahead_ab.txt)
@@ -1285,6 +1299,10 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             rc = update(slu, r1 + nb1, r1, m_tot - r1 - nb1, gw1, g0, gw, 0, nullptr);
             if (rc) return rc;
             EGX_HIP_CHECK(hipEventRecord(lk->ev_lur, slu));
+            if (pipe) {
+                rc = pipe_signal(slu, pb, r1 / kNB + 1);
+                if (rc) return rc;
+            }
             rc = inner_factor(s2, r1, gw1, s3, lk->ev_lur);
             if (rc) return rc;
             EGX_HIP_CHECK(hipEventRecord(lk->ev_panel, s2));

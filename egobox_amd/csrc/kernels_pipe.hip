@@ -58,7 +58,8 @@ struct PipeTask {
 };
 
 // sync words of one matrix (ints): [0] abort (the launch's: matrix 0's), [1] strips published, [2] scratch (stalled strips of
-// the timeout test), [8 + P] ticket of the launch whose group starts at panel P (matrix 0's), then rowT, fcnt, cver
+// the timeout test), [4..7] diagnostics of the first wait that ran out, [8 + P] task ticket and [8 + NP + P] start ticket of the
+// launch whose group starts at panel P (matrix 0's), then rowT, fcnt, cver
 constexpr int kPipeHdr = 8;
 struct PipeLayout {
     int NP, NC, NJ;  // panels, 64-row chunks, 128-column tiles
@@ -69,7 +70,7 @@ static PipeLayout pipe_layout(int n_pad, int m_tot) {
     l.NP = (n_pad + 255) / 256;
     l.NC = m_tot / 64;
     l.NJ = n_pad / 128;
-    l.off_rowT = kPipeHdr + l.NP;
+    l.off_rowT = kPipeHdr + 2 * l.NP;  // (behind the launches' task tickets and start tickets)
     l.off_fcnt = l.off_rowT + l.NP * l.NC;
     l.off_cver = l.off_fcnt + (l.NP + 1) * l.NC;
     l.total = l.off_cver + (m_tot / 128) * l.NJ;
@@ -90,8 +91,10 @@ struct PipeArgs {
     int g0, np;
     const PipeTask *tasks;
     int ntasks;
-    int NC, NJ, off_rowT, off_fcnt, off_cver;
+    int NP, NC, NJ, off_rowT, off_fcnt, off_cver;
     int rt;             // 64-row chunks per TRSM task (1 or 2)
+    int ext_need;       // != 0: the solve tasks of the launch's FIRST panel wait until word 3 (matrix 0's) reaches this value: the
+                        // rest of the group's columns has been updated by a launch that runs beside this one (pipe_signal)
     int stall;          // test hook: 1 + the strip (absolute) from which the DIAG role publishes into the scratch word
     long long timeout;  // wall_clock64 ticks (100 MHz)
     long long *trace;   // profiling (tools/pipe_check): 8 words per ticket -- task, times taken / ready / done (100 MHz), XCD
@@ -119,8 +122,8 @@ __device__ __forceinline__ PipeArgs pipe_kargs(pipe_kargs_t kv) {  // (kv: the k
     pipe_kargs_t k = (pipe_kargs_t)(((unsigned long long)hi << 32) | lo);
     a.M = k->M, a.ld = k->ld, a.n_pad = k->n_pad, a.m_tot = k->m_tot, a.dinv = k->dinv, a.info = k->info, a.sync = k->sync;
     a.sM = k->sM, a.sD = k->sD, a.sS = k->sS, a.sI = k->sI, a.nz = k->nz, a.g0 = k->g0, a.np = k->np, a.tasks = k->tasks;
-    a.ntasks = k->ntasks, a.NC = k->NC, a.NJ = k->NJ, a.off_rowT = k->off_rowT, a.off_fcnt = k->off_fcnt, a.off_cver = k->off_cver;
-    a.rt = k->rt, a.stall = k->stall, a.timeout = k->timeout, a.trace = k->trace;
+    a.ntasks = k->ntasks, a.NP = k->NP, a.NC = k->NC, a.NJ = k->NJ, a.off_rowT = k->off_rowT, a.off_fcnt = k->off_fcnt, a.off_cver = k->off_cver;
+    a.rt = k->rt, a.ext_need = k->ext_need, a.stall = k->stall, a.timeout = k->timeout, a.trace = k->trace;
     return a;
 }
 
@@ -132,7 +135,8 @@ static_assert(kPipeLdsDoubles * 8 >= RB_LDS_BYTES && kPipeLdsDoubles >= 2 * Gemm
 
 // ONE lane waits until *flag >= need.  0: there; 1: this matrix lost a pivot (nothing left to compute for it); 2: the launch
 // is aborted (somebody's wait ran out, maybe this one's)
-__device__ __forceinline__ int pipe_wait_ge(const int *flag, int need, int *abortp, const int *infop, long long limit) {
+__device__ __forceinline__ int pipe_wait_ge(const int *flag, int need, int *abortp, const int *infop, long long limit,
+                                            int who = 0) {
     if (load_flag(flag) >= need) return 0;
     const long long t0 = wall_clock64();
     for (unsigned spins = 1;; spins++) {
@@ -142,7 +146,13 @@ __device__ __forceinline__ int pipe_wait_ge(const int *flag, int need, int *abor
             if (load_flag(abortp) != 0) return 2;
             if (load_flag(infop) != 0) return 1;
             if (wall_clock64() - t0 > limit) {
-                store_flag(abortp, 1);
+                // (diagnostics behind the abort word: who gave up, on which word, what it wanted and what it saw)
+                if (__hip_atomic_fetch_add(abortp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                    store_flag(abortp + 4, who);
+                    store_flag(abortp + 5, (int)(flag - abortp));
+                    store_flag(abortp + 6, need);
+                    store_flag(abortp + 7, load_flag(flag));
+                }
                 return 2;
             }
         }
@@ -199,10 +209,11 @@ __device__ __noinline__ int pipe_role_trsm(pipe_kargs_t ka, pipe_lds_t sm3, long
     // the rows' columns of this panel have received the previous panel (fine tiles), and strip 0 is there
     if (tid == 0) {
         int r = load_flag(info) != 0 ? 1 : 0;
+        if (p == 0 && a.ext_need && r == 0) r = pipe_wait_ge(a.sync + 3, a.ext_need, a.sync, info, a.timeout, (9 << 28) | (c0 & 0xfffff));
         if (p > 0)
             for (int c = 0; c < RT && r == 0; c++)
-                r = pipe_wait_ge(S + a.off_fcnt + P * a.NC + c0 + c, nbk / 64, a.sync, info, a.timeout);
-        if (r == 0) r = pipe_wait_ge(S + 1, base + 1, a.sync, info, a.timeout);
+                r = pipe_wait_ge(S + a.off_fcnt + P * a.NC + c0 + c, nbk / 64, a.sync, info, a.timeout, (1 << 28) | ((p) << 20) | ((c0) & 0xfffff));
+        if (r == 0) r = pipe_wait_ge(S + 1, base + 1, a.sync, info, a.timeout, (2 << 28) | ((p) << 20) | ((c0) & 0xfffff));
         if (r == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         s_ctl[0] = r;
         s_ctl[1] = load_flag(S + 1);
@@ -337,7 +348,7 @@ __device__ __noinline__ int pipe_role_trsm(pipe_kargs_t ka, pipe_lds_t sm3, long
             if (k + 1 < nb16) {
                 if (!have) {  // strip k + 1 was not there yet: thread 0 waits for it, then everybody fetches
                     if (tid == 0) {
-                        const int r = pipe_wait_ge(S + 1, base + k + 2, a.sync, info, a.timeout);
+                        const int r = pipe_wait_ge(S + 1, base + k + 2, a.sync, info, a.timeout, (3 << 28) | ((p) << 20) | ((c0) & 0xfffff));
                         s_ctl[1] = r ? -r : load_flag(S + 1);
                     }
                     __syncthreads();
@@ -382,9 +393,9 @@ __device__ __noinline__ int pipe_role_fine(pipe_kargs_t ka, pipe_lds_t sm3, long
     int *S = a.sync + (int64_t)z * a.sS;
     const int r = pipe_wg_wait(s_ctl, [&]() {
         int rr = load_flag(info) != 0 ? 1 : 0;
-        if (rr == 0) rr = pipe_wait_ge(S + a.off_rowT + P * a.NC + c_row, 1, a.sync, info, a.timeout);
-        if (rr == 0) rr = pipe_wait_ge(S + a.off_rowT + P * a.NC + c_col, 1, a.sync, info, a.timeout);
-        if (rr == 0 && p > 0) rr = pipe_wait_ge(S + a.off_cver + (R0 >> 7) * a.NJ + (C0 >> 7), p, a.sync, info, a.timeout);
+        if (rr == 0) rr = pipe_wait_ge(S + a.off_rowT + P * a.NC + c_row, 1, a.sync, info, a.timeout, (4 << 28) | ((p) << 20) | ((c_row) & 0xfffff));
+        if (rr == 0) rr = pipe_wait_ge(S + a.off_rowT + P * a.NC + c_col, 1, a.sync, info, a.timeout, (5 << 28) | ((p) << 20) | ((c_row) & 0xfffff));
+        if (rr == 0 && p > 0) rr = pipe_wait_ge(S + a.off_cver + (R0 >> 7) * a.NJ + (C0 >> 7), p, a.sync, info, a.timeout, (6 << 28) | ((p) << 20) | ((c_row) & 0xfffff));
         return rr;
     });
     if (r) return r;
@@ -451,11 +462,11 @@ __device__ __noinline__ int pipe_role_coarse(pipe_kargs_t ka, pipe_lds_t sm3, lo
     const int r = pipe_wg_wait(s_ctl, [&]() {
         int rr = load_flag(info) != 0 ? 1 : 0;
         const int *rowT = S + a.off_rowT + P * a.NC;
-        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I, 1, a.sync, info, a.timeout);
-        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I + 1, 1, a.sync, info, a.timeout);
-        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * J, 1, a.sync, info, a.timeout);
-        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * J + 1, 1, a.sync, info, a.timeout);
-        if (rr == 0 && p > 0) rr = pipe_wait_ge(ver, p, a.sync, info, a.timeout);
+        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I, 1, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
+        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I + 1, 1, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
+        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * J, 1, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
+        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * J + 1, 1, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
+        if (rr == 0 && p > 0) rr = pipe_wait_ge(ver, p, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
         return rr;
     });
     if (r) return r;
@@ -524,21 +535,27 @@ __device__ __noinline__ void pipe_worker_loop(pipe_kargs_t ka, pipe_lds_t sm3) {
     }
 }
 
-// Workgroup b < np * nz is a DIAG workgroup: diagonal block b / nz of matrix b % nz, INLINE in the kernel body -- in kernel
-// context the register-resident block fits its 128 vector registers without a spill (as a called function it kept an
-// accumulator tile in scratch memory and ran at 90 us per block instead of 60) -- and a worker afterwards.  All of them are
-// resident from the start (the grid never exceeds one workgroup per compute unit) and wait for their block's fine tiles.
+// The first np * nz workgroups TO START (a start ticket, not the block index: with several chain launches in flight a block's
+// compute-unit slot may free up long after its neighbours', and workers spinning on a diagonal block that is still queued
+// behind them would never let it in) are the DIAG workgroups: start ticket t factors diagonal block t / nz of matrix t % nz,
+// INLINE in the kernel body -- in kernel context the register-resident block fits its 128 vector registers without a spill
+// (as a called function it ran at 75-95 us per block instead of 60-68) -- and is a worker afterwards.  They are resident
+// before any worker holds a task, and wait for their block's fine tiles.
 __global__ __launch_bounds__(1024) void k_potrf_pipe(PipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    if ((int)blockIdx.x < a.np * a.nz) {
-        const int z = (int)blockIdx.x % a.nz, p = (int)blockIdx.x / a.nz;
-        int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
+    int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
+    if (threadIdx.x == 0)
+        s_ctl[3] = __hip_atomic_fetch_add(a.sync + kPipeHdr + a.NP + (a.g0 >> 8), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int start = s_ctl[3];
+    if (start < a.np * a.nz) {
+        const int z = start % a.nz, p = start / a.nz;
         const int k0 = a.g0 + 256 * p, P = k0 >> 8;
         const int nbk = (a.n_pad - k0 < 256) ? (a.n_pad - k0) : 256;
         int *info = a.info + (int64_t)z * a.sI;
         int *S = a.sync + (int64_t)z * a.sS;
 #ifdef EGX_PIPE_TRACE
-        long long *tr = a.trace ? a.trace + 8 * (int64_t)(a.ntasks * a.nz + (int)blockIdx.x) : nullptr;
+        long long *tr = a.trace ? a.trace + 8 * (int64_t)(a.ntasks * a.nz + start) : nullptr;
         if (tr && threadIdx.x == 0) {
             tr[0] = PT_DIAG | (p << 8) | (z << 16);
             tr[1] = 0;
@@ -550,7 +567,7 @@ __global__ __launch_bounds__(1024) void k_potrf_pipe(PipeArgs a) {
         const int r = pipe_wg_wait(s_ctl, [&]() {
             int rr = load_flag(info) != 0 ? 1 : 0;
             const int *fc = S + a.off_fcnt + P * a.NC + (k0 >> 6);
-            for (int i = 0; i < nbk / 64 && rr == 0 && p > 0; i++) rr = pipe_wait_ge(fc + i, i + 1, a.sync, info, a.timeout);
+            for (int i = 0; i < nbk / 64 && rr == 0 && p > 0; i++) rr = pipe_wait_ge(fc + i, i + 1, a.sync, info, a.timeout, (8 << 28) | ((p) << 20) | ((z) & 0xfffff));
             return rr;
         });
         if (r == 2) return;
@@ -579,10 +596,13 @@ __global__ __launch_bounds__(1024) void k_potrf_pipe(PipeArgs a) {
 // =============================================================================================
 static int g_pipe = 1;              // EGX_PIPE=0: launch_potrf keeps the chain as separate launches
 static int g_pipe_wgs = 0;          // EGX_PIPE_WGS: workgroups of a chain launch (0: one per compute unit)
+static int g_pipe_shared_wgs = 96;   // EGX_PIPE_SHARED_WGS: workgroups of a chain launch that runs beside other launches of its factorisation
 static int g_pipe_rt = 0;           // EGX_PIPE_RT: 64-row chunks per TRSM task (0: by panel height)
 static int g_pipe_timeout_ms = 2000;  // EGX_PIPE_TIMEOUT_MS: bound of every wait inside the launch
-static int g_pipe_la = 1;            // EGX_PIPE_LA: how many panels ahead of their column's factorisation the coarse updates are queued
-static int g_pipe_whole = 0;         // EGX_PIPE_WHOLE: padded size up to which the WHOLE factorisation is one chain launch
+static int g_pipe_la = 4;            // EGX_PIPE_LA: how many panels ahead of their column's factorisation the coarse updates are queued
+static int g_pipe_max = 4096;           // EGX_PIPE_MAX: padded size up to which launch_potrf uses chain launches per group of panels
+static int g_pipe_tail = 0;             // EGX_PIPE_TAIL: see schedule.h (measured, not adopted)
+static int g_pipe_whole = 4096;         // EGX_PIPE_WHOLE: padded size up to which the WHOLE factorisation is one chain launch
 static long long *g_pipe_trace = nullptr;  // profiling buffer of the NEXT launches (pipe_set_trace; tools/pipe_check)
 static int g_pipe_stall = 0;        // test hook (egx_set_tuning "pipe_stall"): see PipeArgs::stall
 
@@ -592,7 +612,10 @@ static void pipe_init() {
         if (const char *e = std::getenv("EGX_PIPE")) g_pipe = std::atoi(e);
         if (const char *e = std::getenv("EGX_PIPE_WGS")) g_pipe_wgs = std::atoi(e);
         if (const char *e = std::getenv("EGX_PIPE_RT")) g_pipe_rt = std::atoi(e);
+        if (const char *e = std::getenv("EGX_PIPE_SHARED_WGS")) g_pipe_shared_wgs = std::atoi(e) > 0 ? std::atoi(e) : 1;
         if (const char *e = std::getenv("EGX_PIPE_WHOLE")) g_pipe_whole = std::atoi(e);
+        if (const char *e = std::getenv("EGX_PIPE_TAIL")) g_pipe_tail = std::atoi(e);
+        if (const char *e = std::getenv("EGX_PIPE_MAX")) g_pipe_max = std::atoi(e);
         if (const char *e = std::getenv("EGX_PIPE_LA")) g_pipe_la = std::atoi(e) >= 0 ? std::atoi(e) : 0;
         if (const char *e = std::getenv("EGX_PIPE_TIMEOUT_MS")) g_pipe_timeout_ms = std::atoi(e) > 0 ? std::atoi(e) : 1;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_pipe), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -602,7 +625,7 @@ static void pipe_init() {
 
 int pipe_set_knob(const char *name, int value) {
     pipe_init();
-    struct { const char *n; int *v; } tab[] = {{"pipe", &g_pipe}, {"pipe_wgs", &g_pipe_wgs}, {"pipe_rt", &g_pipe_rt}, {"pipe_la", &g_pipe_la}, {"pipe_whole", &g_pipe_whole},
+    struct { const char *n; int *v; } tab[] = {{"pipe", &g_pipe}, {"pipe_wgs", &g_pipe_wgs}, {"pipe_rt", &g_pipe_rt}, {"pipe_shared_wgs", &g_pipe_shared_wgs}, {"pipe_la", &g_pipe_la}, {"pipe_whole", &g_pipe_whole}, {"pipe_tail", &g_pipe_tail}, {"pipe_max", &g_pipe_max},
                                               {"pipe_timeout_ms", &g_pipe_timeout_ms}, {"pipe_stall", &g_pipe_stall}};
     for (auto &e : tab)
         if (std::string(name) == e.n) {
@@ -616,6 +639,14 @@ void pipe_set_trace(long long *buf) { g_pipe_trace = buf; }
 int pipe_enabled() {
     pipe_init();
     return g_pipe;
+}
+int pipe_group_max() {
+    pipe_init();
+    return g_pipe_max;
+}
+int pipe_tail_cols() {
+    pipe_init();
+    return g_pipe_tail;
 }
 int pipe_whole_max() {
     pipe_init();
@@ -664,8 +695,16 @@ struct PipePlan {
 static std::mutex g_plan_mu;
 static std::map<std::tuple<int, int, int, int, int, int, int>, PipePlan> g_plans;
 
+// word 3 of the batch's hand-off words <- value, in stream order (a one-thread kernel behind the launch it reports on)
+__global__ void k_pipe_signal(int *word, int value) { store_flag(word, value); }
+int pipe_signal(hipStream_t s, const PotrfBatch &pb, int value) {
+    hipLaunchKernelGGL(k_pipe_signal, dim3(1), dim3(1), 0, s, pb.sync + 3, value);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
 int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
-                      const PotrfBatch &pb, int g0, int gw) {
+                      const PotrfBatch &pb, int g0, int gw, int ext_need, int shared_chip) {
     pipe_init();
     if (!pb.sync || g0 % 256 || gw <= 0 || (m_tot - n_pad) % 128 || n_pad % 128) {
         set_error("potrf_pipe: needs sync words, a group that starts on a panel boundary and padded sizes");
@@ -711,12 +750,14 @@ int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot
     a.np = np;
     a.tasks = plan.d_tasks;
     a.ntasks = plan.ntasks;
+    a.NP = l.NP;
     a.NC = l.NC;
     a.NJ = l.NJ;
     a.off_rowT = l.off_rowT;
     a.off_fcnt = l.off_fcnt;
     a.off_cver = l.off_cver;
     a.rt = rt;
+    a.ext_need = ext_need;
     a.stall = g_pipe_stall;
     a.timeout = (long long)g_pipe_timeout_ms * 100000ll;
     a.trace = g_pipe_trace;
@@ -729,7 +770,9 @@ int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot
     // the DIAG workgroups (one per diagonal block and matrix, resident from the start) + workers, never more than one
     // workgroup per compute unit: every workgroup of the grid is resident, whatever the dispatch order
     const long long n_diag = (long long)a.nz * np, want = n_diag + (long long)a.nz * plan.ntasks;
-    long long wgs = g_pipe_wgs > 0 ? g_pipe_wgs : n_cu;
+    // (a chain launch that runs BESIDE the launches it waits for or shares the chip with -- look-ahead -- must leave them
+    //  compute units: its workgroups fill one each and would otherwise spin on a launch that cannot start)
+    long long wgs = g_pipe_wgs > 0 ? g_pipe_wgs : (shared_chip ? (g_pipe_shared_wgs < n_cu ? g_pipe_shared_wgs : n_cu) : n_cu);
     if (wgs > n_cu) wgs = n_cu;
     if (wgs > want) wgs = want;
     if (wgs < n_diag + 1) wgs = n_diag + 1;

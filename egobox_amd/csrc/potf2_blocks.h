@@ -492,9 +492,12 @@ __device__ __forceinline__ bool rb_factor_block(double *__restrict__ D, int64_t 
                         const d2_t r23 = *reinterpret_cast<const d2_t *>(LR + pr * RB_LD + f4 + 2);
                         const d2_t l01 = d2_t{(f4 <= pr) ? r01[0] : 0.0, (f4 + 1 <= pr) ? r01[1] : 0.0};
                         const d2_t l23 = d2_t{(f4 + 2 <= pr) ? r23[0] : 0.0, (f4 + 3 <= pr) ? r23[1] : 0.0};
+                        // (the residual is formed IN the tile's own registers: the tile is dead once it has become X, and a copy
+                        //  would cost eight registers at the point where the block has none to spare)
                         double4_t r = double4_t{acc[4 * s], acc[4 * s + 1], acc[4 * s + 2], acc[4 * s + 3]};  // A
                         RB_MFMA4(r, 1, l01, l23, x[0], x[1], x[2], x[3]);                                      // A - X L^T
-                        RB_MFMA4(x, 0, n01, n23, r[0], r[1], r[2], r[3]);                                      // X + (A - X L^T) Linv^T
+                        acc[4 * s] = r[0], acc[4 * s + 1] = r[1], acc[4 * s + 2] = r[2], acc[4 * s + 3] = r[3];
+                        RB_MFMA4(x, 0, n01, n23, acc[4 * s], acc[4 * s + 1], acc[4 * s + 2], acc[4 * s + 3]);  // X + (A - X L^T) Linv^T
                     }
                     double *px = P + (R * 16 + fr) * RB_LD + f4;
                     *reinterpret_cast<d2_t *>(px) = d2_t{x[0], x[1]};
@@ -517,6 +520,7 @@ __device__ __forceinline__ bool rb_factor_block(double *__restrict__ D, int64_t 
                         const d2_t a01 = *reinterpret_cast<const d2_t *>(pa), a23 = *reinterpret_cast<const d2_t *>(pa + 2);
                         double4_t c4 = double4_t{acc[4 * s + 4], acc[4 * s + 5], acc[4 * s + 6], acc[4 * s + 7]};
                         RB_MFMA4(c4, 1, a01, a23, x[0], x[1], x[2], x[3]);
+                        acc[4 * s + 4] = c4[0], acc[4 * s + 5] = c4[1], acc[4 * s + 6] = c4[2], acc[4 * s + 7] = c4[3];  // (in place: dead after the hand-off)
                         double *dg = Dg + fr * RB_LD + f4;
                         *reinterpret_cast<d2_t *>(dg) = d2_t{c4[0], c4[1]};
                         *reinterpret_cast<d2_t *>(dg + 2) = d2_t{c4[2], c4[3]};

@@ -194,6 +194,13 @@ class GpHandle:
         L.check(self._lib.egx_gp_set_lockstep(self._h, int(width)))
         return self._lib.egx_gp_get_lockstep(self._h)
 
+    def schedule(self):
+        """egx_gp_get_schedule: how this handle factors (decided per handle, so all its evaluations agree bit for bit)."""
+        out = (C.c_int32 * 6)()
+        L.check(self._lib.egx_gp_get_schedule(self._h, out, 6))
+        keys = ("left_looking", "left_looking_rider", "pipelined_chain", "whole_factorisation_launch", "panels_per_group", "lockstep")
+        return dict(zip(keys, [int(v) for v in out]))
+
     def shrink(self, n_keep=1):
         """egx_gp_shrink: keep the first n_keep workspaces (the fitted factor lives in workspace 0), free the rest."""
         L.check(self._lib.egx_gp_shrink(self._h, int(n_keep)))

@@ -162,10 +162,19 @@ int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int
  * evaluations of a handle -- and of its replicas on other ranks -- agree bit for bit. */
 int32_t egx_gp_set_lockstep(egx_gp *gp, int32_t width);
 int32_t egx_gp_get_lockstep(const egx_gp *gp);
+/* Which schedule the handle's factorisations follow -- decided when the handle is created or its lock-step width is set,
+ * from its padded size, lock-step width and number of workspaces, kept by egx_gp_shrink -- so that a caller can tell two
+ * handles that will not give the same bits apart (a sweep on a 16-workspace handle and a re-evaluation of its winner on a
+ * 1-workspace handle at n = 16384 differ by 1e-10 relative).  out[0..5] = { left-looking group updates, left-looking
+ * C^-T rider, pipelined chain launches (the chain of a panel group -- diagonal blocks, panel solves, in-group updates: the
+ * panel step of `cholesky()`, crates/gp/src/algorithm.rs:1004 -- as one persistent launch), whole factorisation as one such
+ * launch, panels per group, lock-step width [, columns at the end of the matrix factored by one chain launch] }; out_len >= 6. */
+int32_t egx_gp_get_schedule(const egx_gp *gp, int32_t *out, int32_t out_len);
 /* Give back what only an optimisation needed: the handle keeps its first n_keep (>= 1) workspaces -- workspace 0 holds the
  * fitted factor, which survives -- and frees the others together with the theta-gradient's scratch.  A tuned fit runs its
  * multistart on up to 12 workspaces (2 GiB each at n = 16384); the fitted model that stays resident (an EGO objective, an
- * expert of a mixture) needs one.  The lock-step width falls back to the default for the new count. */
+ * expert of a mixture) needs one.  The schedule of the handle (egx_gp_get_schedule) does not change -- the model keeps giving
+ * the bits it gave before --; the lock-step width is capped by the workspaces that are left. */
 int32_t egx_gp_shrink(egx_gp *gp, int32_t n_keep);
 /* NEW capability (the reference has no theta-gradient, algorithm.rs:880: the objective closure ignores `_gradient`):
  * the reduced likelihood of algorithm.rs:988-1056 AND dL/dtheta (length h) at one theta; validated against the oracle's

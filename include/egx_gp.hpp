@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <array>
 #include <vector>
 
 #include "egx_gp.h"
@@ -174,6 +175,12 @@ class GaussianProcess {
     // a tuned model ran its multistart on several workspaces; the resident model needs one (plus one for likelihood
     // evaluations that must not un-fit it)
     void shrink(int32_t n_keep = 1) { check(egx_gp_shrink(h_.get(), n_keep)); }
+    // { left-looking, left-looking rider, pipelined chain launches, whole-factorisation launch, panels per group, lock-step width }
+    std::array<int32_t, 6> schedule() const {
+        std::array<int32_t, 6> s{};
+        check(egx_gp_get_schedule(h_.get(), s.data(), 6));
+        return s;
+    }
     int32_t set_lockstep(int32_t width) {  // candidates per launch sequence (0 = the library's choice); returns the width in force
         check(egx_gp_set_lockstep(h_.get(), width));
         return egx_gp_get_lockstep(h_.get());

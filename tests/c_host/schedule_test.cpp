@@ -1,0 +1,74 @@
+// Host check of the schedule table (egobox_amd/csrc/schedule.h): the documented rows, the knobs' meaning, and that nothing
+// but (padded size, lock-step width, workspaces) enters.  Built and run by tests/test_tile_tables_cpu.py (g++, no GPU).
+#include <cstdio>
+
+#include "../../egobox_amd/csrc/schedule.h"
+
+static int fails = 0;
+static void expect(int n_pad, int lockstep, int nws, const egx::ScheduleKnobs &k, int left, int w_left, int pipe, int whole, int gp,
+                   int tail = 0) {
+    const egx::PotrfSchedule s = egx::schedule_table(n_pad, lockstep, nws, k);
+    if (s.left != left || s.w_left != w_left || s.pipe != pipe || s.whole != whole || s.group_panels != gp || s.tail != tail) {
+        std::printf("n_pad %d lockstep %d workspaces %d: got {%d %d %d %d %d tail %d}, table says {%d %d %d %d %d tail %d}\n", n_pad, lockstep,
+                    nws, s.left, s.w_left, s.pipe, s.whole, s.group_panels, s.tail, left, w_left, pipe, whole, gp, tail);
+        fails++;
+    }
+}
+
+int main() {
+    const egx::ScheduleKnobs d;  // the defaults
+    // the table's rows
+    expect(4096, 1, 1, d, 0, 0, 1, 1, 2);     // a lone fit at config 2's size: one launch
+    expect(4096, 2, 2, d, 0, 0, 1, 1, 2);     // 2 x 16 panels = 32 diagonal blocks: still one launch
+    expect(4096, 12, 12, d, 0, 0, 1, 0, 2);   // a tuned fit's twelve starts: chain launches per group
+    expect(2176, 6, 6, d, 0, 0, 1, 0, 2);     // 6 x 9 > 32
+    expect(1024, 8, 8, d, 0, 0, 1, 1, 2);     // 8 x 4 = 32
+    expect(4352, 1, 1, d, 0, 0, 0, 0, 2);        // beyond 4096 columns: separate launches
+    expect(8192, 2, 2, d, 0, 0, 0, 0, 2);
+    expect(8192, 12, 12, d, 0, 0, 0, 0, 2);
+    expect(14336, 1, 1, d, 0, 0, 0, 0, 4);
+    expect(16384, 1, 1, d, 0, 0, 0, 0, 4);       // a lone fit at the metric's size
+    expect(16384, 4, 4, d, 0, 1, 0, 0, 4);
+    expect(16384, 7, 16, d, 0, 1, 0, 0, 4);
+    expect(16384, 8, 16, d, 1, 1, 0, 0, 4);
+    expect(16384, 8, 8, d, 1, 1, 0, 0, 4);
+    expect(14400, 8, 8, d, 1, 0, 0, 0, 4);       // (the rider's left-looking form needs 256-column panels throughout)
+    // the width enters through the lock-step thresholds only, the workspaces through the whole-launch bound only
+    for (int n_pad = 128; n_pad <= 20480; n_pad += 128)
+        for (int w = 1; w <= 16; w++)
+            for (int nws = w; nws <= 24; nws += 5) {
+                const egx::PotrfSchedule a = egx::schedule_table(n_pad, w, nws, d), b = egx::schedule_table(n_pad, w, nws + 100, d);
+                if (a.left != b.left || a.w_left != b.w_left || a.group_panels != b.group_panels || a.pipe != b.pipe) fails++;
+                const egx::PotrfSchedule c = egx::schedule_table(n_pad, w + 100, nws, d);
+                if (a.whole != c.whole || a.group_panels != c.group_panels) fails++;
+                if (a.whole && !(n_pad <= 4096 && nws * ((n_pad + 255) / 256) <= 32)) fails++;
+                if (a.tail && (a.pipe || a.whole || a.left || n_pad <= 4096 || nws > 2)) fails++;
+                if (a.pipe != (n_pad <= 4096)) fails++;
+                if (a.left && !a.w_left && n_pad % 256 == 0) fails++;  // left-looking handles' riders are left-looking too
+            }
+    // the knobs
+    egx::ScheduleKnobs k = d;
+    k.pipe = 0;
+    expect(4096, 1, 1, k, 0, 0, 0, 0, 2);
+    k = d, k.pipe_whole = 0;
+    expect(4096, 1, 1, k, 0, 0, 1, 0, 2);
+    k = d, k.pipe_max = 1 << 30;
+    expect(8192, 1, 1, k, 0, 0, 1, 0, 2);
+    k = d, k.pipe_tail = 4096;                   // (the tail launch: measured, off by default)
+    expect(16384, 1, 1, k, 0, 0, 0, 0, 4, 4096);
+    expect(16384, 3, 3, k, 0, 0, 0, 0, 4, 0);
+    expect(16384, 8, 8, k, 1, 1, 0, 0, 4, 0);
+    expect(4096, 1, 1, k, 0, 0, 1, 1, 2, 0);
+    k = d, k.potrf_left = 0, k.w_left = 0;
+    expect(16384, 8, 16, k, 0, 0, 0, 0, 4);
+    k = d, k.potrf_left = 2, k.w_left = 2;
+    expect(2048, 1, 1, k, 1, 1, 1, 1, 2);
+    k = d, k.potrf_group = 3;
+    expect(16384, 8, 16, k, 1, 1, 0, 0, 3);
+    if (fails) {
+        std::printf("%d schedule checks failed\n", fails);
+        return 1;
+    }
+    std::printf("schedule table ok\n");
+    return 0;
+}

@@ -74,6 +74,8 @@ __global__ void k_resid(const double *L, int64_t ld, int n, double scale, double
     atomicMax(out, (unsigned long long)__double_as_longlong(e));
 }
 
+static int g_tail = 0;        // PotrfBatch::tail: the last g_tail columns as one chain launch (separate launches before)
+static bool g_whole = false;  // PotrfBatch::whole of the next factorisations (the library decides it per handle)
 struct Problem {
     int n, n_pad, m_tot, nz;
     int64_t ld;
@@ -122,6 +124,9 @@ struct Problem {
         pb.sI = 1;
         pb.sync = pipe ? sync : nullptr;
         pb.sS = (int64_t)sync_n;
+        pb.pipe = (pipe && !g_tail) ? 1 : 0;
+        pb.whole = (g_whole && !g_tail) ? 1 : 0;
+        pb.tail = g_tail;
         return launch_potrf(s, M, ld, n_pad, m_tot, dinv, info, lk.s2 ? &lk : nullptr, nullptr, &pb, nullptr);
     }
     std::vector<double> download(int z) {
@@ -250,7 +255,7 @@ static int diag_alone_main() {
 static int trace_main(int n, int whole, int la, int nz) {
     const double scale = 6.0, nugget = 1e-8;
     pipe_set_knob("pipe_timeout_ms", 500);
-    pipe_set_knob("pipe_whole", whole ? 1 << 30 : 0);
+    g_whole = (whole ? 1 << 30 : 0) != 0;
     pipe_set_knob("pipe_la", la);
     Problem P;
     P.create(n, nz, n >= 8192);
@@ -355,7 +360,7 @@ int main(int argc, char **argv) {
         const double res_ref = residual(P, 0, scale, nugget, 11);
         struct Mode { int whole, la; };
         for (Mode m : {Mode{0, 1}, Mode{1 << 30, 0}, Mode{1 << 30, 1}, Mode{1 << 30, 2}, Mode{1 << 30, 99}}) {
-            pipe_set_knob("pipe_whole", m.whole);
+            g_whole = (m.whole) != 0;
             pipe_set_knob("pipe_la", m.la);
             P.build(0, scale, nugget, 11);
             if (P.factor(0, true)) return 3;
@@ -368,13 +373,34 @@ int main(int argc, char **argv) {
                     "groups  n=%d %s la=%d: vs separate launches %.2e, residual %.2e (separate launches %.2e), info %d abort %d", n,
                     m.whole ? "WHOLE" : "per-group", m.la, rel, res, res_ref, P.infos()[0], P.abort_word());
         }
-        pipe_set_knob("pipe_whole", 0);
+        g_whole = (0) != 0;
         pipe_set_knob("pipe_la", 1);
+        P.destroy();
+    }
+    // ---------------------------------------------------------------- tail: the last columns of a larger matrix as one chain launch
+    for (int n : {5000, 8192}) {
+        if (n > max_n) continue;
+        Problem P;
+        P.create(n, 1, true);
+        P.build(0, scale, nugget, 13);
+        if (P.factor(0, false)) return 3;
+        CK(hipDeviceSynchronize());
+        const std::vector<double> ref = P.download(0);
+        g_tail = 4096;
+        P.build(0, scale, nugget, 13);
+        if (P.factor(0, true)) return 3;
+        CK(hipDeviceSynchronize());
+        g_tail = 0;
+        double rel;
+        bool same;
+        compare(P, ref, P.download(0), rel, same);
+        verdict(rel < 2e-5 && P.abort_word() == 0 && P.infos()[0] == 0, "tail    n=%d, last 4096 columns as one chain launch: vs separate launches %.2e, info %d abort %d", n, rel,
+                P.infos()[0], P.abort_word());
         P.destroy();
     }
     // ---------------------------------------------------------------- lock-step batches: the bits a matrix gets alone
     for (int whole : {0, 1 << 30}) {
-        pipe_set_knob("pipe_whole", whole);
+        g_whole = (whole) != 0;
         const int n = 1500, nz = 4;
         Problem B, S;
         B.create(n, nz, false);
@@ -411,10 +437,10 @@ int main(int argc, char **argv) {
         verdict(ok2, "grid    n=%d nz=%d %s: the same bits on 3, 17 and all workgroups", n, nz, whole ? "WHOLE" : "per-group");
         B.destroy(), S.destroy();
     }
-    pipe_set_knob("pipe_whole", 0);
+    g_whole = (0) != 0;
     // ---------------------------------------------------------------- a lost pivot
     for (int whole : {0, 1 << 30}) {
-        pipe_set_knob("pipe_whole", whole);
+        g_whole = (whole) != 0;
         Problem P;
         P.create(1200, 2, false);
         int infos[2][2];
@@ -431,7 +457,7 @@ int main(int argc, char **argv) {
                 infos[0][1], infos[1][0], infos[1][1], P.abort_word());
         P.destroy();
     }
-    pipe_set_knob("pipe_whole", 0);
+    g_whole = (0) != 0;
     // ---------------------------------------------------------------- strips that are never published
     {
         Problem P;
@@ -470,18 +496,24 @@ int main(int argc, char **argv) {
             const double fl = nz * (double)P.n_pad * P.n_pad * P.n_pad / 3.0;
             const int reps = n >= 8192 ? 3 : 7;
             const double t_sep = time_factor(P, false, scale, nugget, reps);
-            pipe_set_knob("pipe_whole", 0);
+            g_whole = (0) != 0;
             const double t_grp = time_factor(P, true, scale, nugget, reps);
             printf("time    n=%5d nz=%d separate %8.3f ms (%5.1f TFLOP/s) | chain per group %8.3f ms (%5.1f)", n, nz, t_sep, fl / t_sep * 1e-9,
                    t_grp, fl / t_grp * 1e-9);
-            if (n <= 8192) {
+            if (n > 4096 && nz == 1) {
+                g_tail = 4096;
+                const double t = time_factor(P, true, scale, nugget, reps);
+                g_tail = 0;
+                printf(" | tail 4096 %8.3f ms (%5.1f)", t, fl / t * 1e-9);
+            }
+            if (n <= 4096) {
                 for (int la : {0, 1, 2, 4}) {
-                    pipe_set_knob("pipe_whole", 1 << 30);
+                    g_whole = (1 << 30) != 0;
                     pipe_set_knob("pipe_la", la);
                     const double t = time_factor(P, true, scale, nugget, reps);
                     printf(" | whole la=%d %8.3f ms (%5.1f)", la, t, fl / t * 1e-9);
                 }
-                pipe_set_knob("pipe_whole", 0);
+                g_whole = (0) != 0;
                 pipe_set_knob("pipe_la", 1);
             }
             printf(" abort %d\n", P.abort_word());
