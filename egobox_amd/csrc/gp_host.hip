@@ -408,8 +408,13 @@ int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> 
         }
         EGX_HIP_CHECK(hipMemcpyAsync(w.h_info, w.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
         // word 0 of the LEAD's hand-off words: non-zero iff a bounded wait inside a chain launch of this group ran out
-        EGX_HIP_CHECK(hipMemcpyAsync(w.h_info + 1, dev_sync(gp, w0), 8 * sizeof(int), hipMemcpyDeviceToHost, st));
-        w.sync_lead = dev_sync(gp, w0);
+        if (pb.sync) {
+            EGX_HIP_CHECK(hipMemcpyAsync(w.h_info + 1, pb.sync, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+            w.sync_lead = pb.sync;
+        } else {  // (a handle whose schedule has no chain launches never touches its hand-off words)
+            w.h_info[1] = 0;
+            w.sync_lead = nullptr;
+        }
     }
     EGX_HIP_CHECK(hipEventRecord(lead.ev[3], st));
     return EGX_SUCCESS;
@@ -1483,9 +1488,26 @@ int32_t egx_potrf(double *a, int64_t n, int32_t *info) {
     EGX_RC(d_info.alloc(1));
     EGX_HIP_CHECK(hipMemset(d_info.p, 0, sizeof(double)));
     EGX_HIP_CHECK(hipMemcpy(d_M.p, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
-    EGX_RC(launch_potrf(0, d_M.p, n_pad, n_pad, n_pad, d_dinv.p, reinterpret_cast<int *>(d_info.p)));
+    // the schedule a one-workspace handle of this size gets (schedule.h): up to 4096 columns one chain launch
+    const PotrfSchedule sch = schedule_for(n_pad, 1, 1);
+    DevBuf d_sync;  // (ints in double-sized slots)
+    PotrfBatch pb;
+    pb.left = sch.left, pb.pipe = sch.pipe, pb.whole = sch.whole, pb.tail = sch.tail;
+    if (sch.pipe || sch.tail) {
+        EGX_RC(d_sync.alloc((pipe_sync_ints(n_pad, n_pad) + 1) / 2));
+        pb.sync = reinterpret_cast<int *>(d_sync.p);
+    }
+    EGX_RC(launch_potrf(0, d_M.p, n_pad, n_pad, n_pad, d_dinv.p, reinterpret_cast<int *>(d_info.p), nullptr, nullptr, &pb));
     EGX_HIP_CHECK(hipMemcpy(hp.data(), d_M.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost));
     EGX_HIP_CHECK(hipMemcpy(info, d_info.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (pb.sync) {
+        int aborted = 0;
+        EGX_HIP_CHECK(hipMemcpy(&aborted, pb.sync, sizeof(int), hipMemcpyDeviceToHost));
+        if (aborted) {
+            set_error("egx_potrf: a wait inside the pipelined chain kernel exceeded EGX_PIPE_TIMEOUT_MS");
+            return EGX_ERR_HIP;
+        }
+    }
     for (int64_t i = 0; i < n; i++)
         for (int64_t j = 0; j < n; j++) a[i * n + j] = (j <= i) ? hp[(size_t)i * n_pad + j] : 0.0;
     return EGX_SUCCESS;

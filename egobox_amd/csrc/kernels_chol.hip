@@ -1087,15 +1087,6 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     const bool have_sync = pb.sync != nullptr && pipe_enabled() != 0;
     const bool pipe = have_sync && pb.pipe;  // (chain launches per group; pb.tail: for the last columns only)
     if (have_sync) EGX_HIP_CHECK(hipMemsetAsync(pb.sync, 0, sizeof(int) * (nz > 1 ? (size_t)pb.sS * nz : pipe_sync_ints(n_pad, m_tot)), s));
-    // (decided per HANDLE, never by the number of matrices in a launch: a matrix gets the same bits in any batch)
-    if (pipe && !inv && pb.whole) {
-        rc = launch_potrf_pipe(s, M, ld, n_pad, m_tot, dinv, info, pb, 0, n_pad);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64, 1, nz), dim3(256), 0, s, (const double *)M, ld, dinv,
-                           dinv + (int64_t)(n_pad / 64) * 4096, pb.sM, pb.sD);
-        EGX_HIP_CHECK(hipGetLastError());
-        return EGX_SUCCESS;
-    }
     const int GW = potrf_group_panels(n_pad) * kNB;
     auto gwidth = [&](int g0) { return (n_pad - g0 < GW) ? (n_pad - g0) : GW; };
     // panels of one group on stream `st`; `side` != nullptr splits every in-group update into the next diagonal block
@@ -1199,6 +1190,24 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         }
         return EGX_SUCCESS;
     };
+    // (decided per HANDLE, never by the number of matrices in a launch: a matrix gets the same bits in any batch -- and with or
+    //  without the theta-gradient's rider: its substitution then follows the launch group by group instead of riding along)
+    if (pipe && pb.whole) {
+        rc = launch_potrf_pipe(s, M, ld, n_pad, m_tot, dinv, info, pb, 0, n_pad);
+        if (rc) return rc;
+        if (inv) {
+            for (int g0 = 0; g0 < n_pad; g0 += GW) {
+                rc = inverse_group(s, g0, gwidth(g0));
+                if (rc) return rc;
+            }
+            EGX_HIP_CHECK(hipEventRecord(inv->ev_done, inv->sw));
+            EGX_HIP_CHECK(hipStreamWaitEvent(s, inv->ev_done, 0));
+        }
+        hipLaunchKernelGGL(k_diag_tile_inverses, dim3(n_pad / 64, 1, nz), dim3(256), 0, s, (const double *)M, ld, dinv,
+                           dinv + (int64_t)(n_pad / 64) * 4096, pb.sM, pb.sD);
+        EGX_HIP_CHECK(hipGetLastError());
+        return EGX_SUCCESS;
+    }
     if (pb.left) {
         // LEFT-looking over the groups of panels (round 4): the columns of group J receive the contributions of ALL earlier
         // columns in two updates -- a LONG one, K = every column before the previous group, and a SHORT one, K = the previous

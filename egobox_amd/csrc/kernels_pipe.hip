@@ -161,11 +161,12 @@ __device__ __forceinline__ int pipe_wait_ge(const int *flag, int need, int *abor
 
 // the outcome of thread 0's waits, for the whole workgroup (two barriers; on success thread 0 has executed the agent-scope
 // acquire that lets the workgroup read, with plain loads, what the producers it waited for have published)
-template <typename F>
+// (ACQUIRE = false: the caller reads what it waited for with agent-scope loads only)
+template <bool ACQUIRE = true, typename F>
 __device__ __forceinline__ int pipe_wg_wait(int *s_ctl, F &&waits) {
     if (threadIdx.x == 0) {
         const int r = waits();
-        if (r == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (ACQUIRE && r == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         s_ctl[0] = r;
     }
     __syncthreads();
@@ -391,7 +392,7 @@ __device__ __noinline__ int pipe_role_fine(pipe_kargs_t ka, pipe_lds_t sm3, long
     double *Mz = a.M + (int64_t)z * a.sM;
     const int *info = a.info + (int64_t)z * a.sI;
     int *S = a.sync + (int64_t)z * a.sS;
-    const int r = pipe_wg_wait(s_ctl, [&]() {
+    const int r = pipe_wg_wait<false>(s_ctl, [&]() {  // (operands and the C tile are read with agent-scope loads: no fence)
         int rr = load_flag(info) != 0 ? 1 : 0;
         if (rr == 0) rr = pipe_wait_ge(S + a.off_rowT + P * a.NC + c_row, 1, a.sync, info, a.timeout, (4 << 28) | ((p) << 20) | ((c_row) & 0xfffff));
         if (rr == 0) rr = pipe_wait_ge(S + a.off_rowT + P * a.NC + c_col, 1, a.sync, info, a.timeout, (5 << 28) | ((p) << 20) | ((c_row) & 0xfffff));
@@ -406,7 +407,7 @@ __device__ __noinline__ int pipe_role_fine(pipe_kargs_t ka, pipe_lds_t sm3, long
     for (int mi = 0; mi < 2; mi++)
 #pragma unroll
         for (int ni = 0; ni < 2; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-    gemm_core<64, 64, 32, 32, 256>(Mz + (int64_t)R0 * a.ld + k0 + 64 * q, a.ld, Mz + (int64_t)C0 * a.ld + k0 + 64 * q, a.ld, 64, acc,
+    gemm_core<64, 64, 32, 32, 256, true>(Mz + (int64_t)R0 * a.ld + k0 + 64 * q, a.ld, Mz + (int64_t)C0 * a.ld + k0 + 64 * q, a.ld, 64, acc,
                                    sm + q * kFineStage2, tl);
     // (gemm_core ends behind a workgroup barrier: the staging areas are free)
     const int rl = (lw >> 1) * 32 + (lane >> 4), cl = (lw & 1) * 32 + (lane & 15);  // + 16 mi + 4 r, + 16 ni
@@ -431,7 +432,7 @@ __device__ __noinline__ int pipe_role_fine(pipe_kargs_t ka, pipe_lds_t sm3, long
                     const int e = (rl + 16 * mi + 4 * rr) * 64 + cl + 16 * ni;
                     const double sum = ((acc[mi][ni][rr] + sm[e]) + sm[4096 + e]) + sm[8192 + e];
                     double *cp = Ct + (int64_t)(16 * mi + 4 * rr) * a.ld + 16 * ni;
-                    __hip_atomic_store(cp, *cp - sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(cp, load_sc1(cp) - sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
     }
     drain_stores();
@@ -527,7 +528,7 @@ __device__ __noinline__ void pipe_worker_loop(pipe_kargs_t ka, pipe_lds_t sm3) {
             tr[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((long long)blockIdx.x << 8);  // XCC_ID, workgroup
         }
         int r;
-        if (task.type == PT_TRSM) r = (a.rt == 2) ? pipe_role_trsm<2>(ka, (pipe_lds_t)sm, tr, z, task.p, task.a) : pipe_role_trsm<1>(ka, (pipe_lds_t)sm, tr, z, task.p, task.a);
+        if (task.type == PT_TRSM) r = pipe_role_trsm<1>(ka, (pipe_lds_t)sm, tr, z, task.p, task.a);
         else if (task.type == PT_FINE) r = pipe_role_fine(ka, (pipe_lds_t)sm, tr, z, task.p, task.a, task.b);
         else r = pipe_role_coarse(ka, (pipe_lds_t)sm, tr, z, task.p, task.a, task.b);
         if (tr && threadIdx.x == 0) tr[4] = wall_clock64();
@@ -597,9 +598,8 @@ __global__ __launch_bounds__(1024) void k_potrf_pipe(PipeArgs a) {
 static int g_pipe = 1;              // EGX_PIPE=0: launch_potrf keeps the chain as separate launches
 static int g_pipe_wgs = 0;          // EGX_PIPE_WGS: workgroups of a chain launch (0: one per compute unit)
 static int g_pipe_shared_wgs = 96;   // EGX_PIPE_SHARED_WGS: workgroups of a chain launch that runs beside other launches of its factorisation
-static int g_pipe_rt = 0;           // EGX_PIPE_RT: 64-row chunks per TRSM task (0: by panel height)
 static int g_pipe_timeout_ms = 2000;  // EGX_PIPE_TIMEOUT_MS: bound of every wait inside the launch
-static int g_pipe_la = 4;            // EGX_PIPE_LA: how many panels ahead of their column's factorisation the coarse updates are queued
+static int g_pipe_la = 16;           // EGX_PIPE_LA: how many panels ahead of their column's factorisation the coarse updates are queued
 static int g_pipe_max = 4096;           // EGX_PIPE_MAX: padded size up to which launch_potrf uses chain launches per group of panels
 static int g_pipe_tail = 0;             // EGX_PIPE_TAIL: see schedule.h (measured, not adopted)
 static int g_pipe_whole = 4096;         // EGX_PIPE_WHOLE: padded size up to which the WHOLE factorisation is one chain launch
@@ -611,7 +611,6 @@ static void pipe_init() {
     std::call_once(once, [] {
         if (const char *e = std::getenv("EGX_PIPE")) g_pipe = std::atoi(e);
         if (const char *e = std::getenv("EGX_PIPE_WGS")) g_pipe_wgs = std::atoi(e);
-        if (const char *e = std::getenv("EGX_PIPE_RT")) g_pipe_rt = std::atoi(e);
         if (const char *e = std::getenv("EGX_PIPE_SHARED_WGS")) g_pipe_shared_wgs = std::atoi(e) > 0 ? std::atoi(e) : 1;
         if (const char *e = std::getenv("EGX_PIPE_WHOLE")) g_pipe_whole = std::atoi(e);
         if (const char *e = std::getenv("EGX_PIPE_TAIL")) g_pipe_tail = std::atoi(e);
@@ -625,7 +624,7 @@ static void pipe_init() {
 
 int pipe_set_knob(const char *name, int value) {
     pipe_init();
-    struct { const char *n; int *v; } tab[] = {{"pipe", &g_pipe}, {"pipe_wgs", &g_pipe_wgs}, {"pipe_rt", &g_pipe_rt}, {"pipe_shared_wgs", &g_pipe_shared_wgs}, {"pipe_la", &g_pipe_la}, {"pipe_whole", &g_pipe_whole}, {"pipe_tail", &g_pipe_tail}, {"pipe_max", &g_pipe_max},
+    struct { const char *n; int *v; } tab[] = {{"pipe", &g_pipe}, {"pipe_wgs", &g_pipe_wgs},  {"pipe_shared_wgs", &g_pipe_shared_wgs}, {"pipe_la", &g_pipe_la}, {"pipe_whole", &g_pipe_whole}, {"pipe_tail", &g_pipe_tail}, {"pipe_max", &g_pipe_max},
                                               {"pipe_timeout_ms", &g_pipe_timeout_ms}, {"pipe_stall", &g_pipe_stall}};
     for (auto &e : tab)
         if (std::string(name) == e.n) {
@@ -713,8 +712,9 @@ int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot
     const int np = (gw + 255) / 256;
     int dev = 0;
     EGX_HIP_CHECK(hipGetDevice(&dev));
-    // tall panels: two row chunks per solve task (the fragments and the barriers serve two tiles per wave quadruple)
-    const int rt = g_pipe_rt ? (g_pipe_rt >= 2 ? 2 : 1) : ((m_tot - g0) >= 8192 ? 2 : 1);
+    // (64 rows per solve task; the two-chunk form -- the fragments and the barriers serve two tiles per wave quadruple --
+    //  spilled registers and was only meant for panels taller than the sizes chain launches are used for: removed)
+    const int rt = 1;
     PipePlan plan;
     {
         std::lock_guard<std::mutex> lock(g_plan_mu);

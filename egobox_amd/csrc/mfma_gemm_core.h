@@ -18,11 +18,16 @@ constexpr int LDS_LD = 18;  // doubles per staged tile row (16 + 2 pad): conflic
 // Global -> register staging of one K chunk of a tile.  `g` is the wave-uniform tile base (+ k0): the
 // per-thread part of the address is a 32-bit element offset so the loads use the SGPR-base + VGPR-offset form
 // (64-bit per-thread addresses cost 2 VGPRs per load and pushed the 128-VGPR trailing-update kernel into scratch).
-template <int ROWS, int NT>
+// SC1: agent-scope loads (they bypass the L1 of the compute unit): operands another workgroup of the SAME launch has just
+// published (kernels_pipe.hip) need no acquire fence in front of them
+template <int ROWS, int NT, bool SC1 = false>
 __device__ __forceinline__ void tile_load_regs(const double *__restrict__ g, const unsigned (&off)[ROWS * 8 / NT],
                                                d2_t (&r)[ROWS * 8 / NT]) {
 #pragma unroll
-    for (int i = 0; i < ROWS * 8 / NT; i++) r[i] = *reinterpret_cast<const d2_t *>(g + off[i]);
+    for (int i = 0; i < ROWS * 8 / NT; i++) {
+        if constexpr (SC1) r[i] = load_d2_sc1(g + off[i]);
+        else r[i] = *reinterpret_cast<const d2_t *>(g + off[i]);
+    }
 }
 template <int ROWS, int NT>
 __device__ __forceinline__ void tile_offsets(int64_t ld, unsigned (&off)[ROWS * 8 / NT], int tid) {
@@ -57,7 +62,7 @@ struct GemmShape {
     static_assert((BM * 8) % NTHREADS == 0 && (BN * 8) % NTHREADS == 0, "tile rows per load pass");
 };
 
-template <int BM, int BN, int WM, int WN, int NTHREADS = 256>
+template <int BM, int BN, int WM, int WN, int NTHREADS = 256, bool SC1 = false>
 __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t lda,
                                           const double *__restrict__ B, int64_t ldb, int K,
                                           double4_t (&acc)[WM / 16][WN / 16], double *smem, int tid) {
@@ -72,8 +77,8 @@ __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t 
     unsigned oa[BM * 8 / NTHREADS], ob[BN * 8 / NTHREADS];
     tile_offsets<BM, NTHREADS>(lda, oa, tid);
     tile_offsets<BN, NTHREADS>(ldb, ob, tid);
-    tile_load_regs<BM, NTHREADS>(A, oa, ra);
-    tile_load_regs<BN, NTHREADS>(B, ob, rb);
+    tile_load_regs<BM, NTHREADS, SC1>(A, oa, ra);
+    tile_load_regs<BN, NTHREADS, SC1>(B, ob, rb);
     tile_store_lds<BM, NTHREADS>(smem, ra, tid);
     tile_store_lds<BN, NTHREADS>(smem + S::A_TILE, rb, tid);
     __syncthreads();
@@ -82,8 +87,8 @@ __device__ __forceinline__ void gemm_core(const double *__restrict__ A, int64_t 
         double *Bs = As + S::A_TILE;
         const bool more = (c + 1 < nchunks);
         if (more) {
-            tile_load_regs<BM, NTHREADS>(A + (c + 1) * KC, oa, ra);
-            tile_load_regs<BN, NTHREADS>(B + (c + 1) * KC, ob, rb);
+            tile_load_regs<BM, NTHREADS, SC1>(A + (c + 1) * KC, oa, ra);
+            tile_load_regs<BN, NTHREADS, SC1>(B + (c + 1) * KC, ob, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < KC / 4; kk++) {

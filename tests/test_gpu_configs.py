@@ -933,9 +933,16 @@ def test_left_looking_handles_candidates_do_not_depend_on_their_companions(egx):
         lk3, st3 = h.likelihood_batch(thetas[[9, 0, 4]])          # other companions, other slots
         prev = egx.set_tuning("potrf_left", 0)
         try:
+            # (round 5: a handle's schedule is decided when it is created or its lock-step width is set, schedule.h:
+            #  setting the width again re-decides it under the changed knob)
+            assert h.schedule()["left_looking"] == 1
+            h.set_lockstep(0)
+            assert h.schedule()["left_looking"] == 0
             lk_r, st_r = h.likelihood_batch(thetas)               # the same handle, right-looking
         finally:
             egx.set_tuning("potrf_left", prev)
+            h.set_lockstep(0)
+        assert h.schedule()["left_looking"] == 1
         # the theta-gradient on a left-looking handle (C^-T rides along the left-looking schedule) against the same
         # candidates on a right-looking one-workspace handle
         lkg, gg, stg = h.likelihood_grad_batch(thetas[[0, 1, 4, 5]])

@@ -383,7 +383,6 @@ def test_one_shot_fits_are_warm_fits_and_the_pool_is_bounded(egx):
     n, d = 4096, 8
     theta = egx.workload.default_theta(d) * 4.0
     egx.trim()
-    free0 = torch.cuda.mem_get_info()[0]
     x0, y0 = _data(n, d, seed=100)
     with egx.GpHandle(x0, y0) as h:           # resident handle: the yardstick
         h.finalize(theta)
@@ -392,6 +391,13 @@ def test_one_shot_fits_are_warm_fits_and_the_pool_is_bounded(egx):
             h.finalize(theta)
         resident = (time.perf_counter() - t0) / 5
         ref_lk = h.fitted_scalars()[0]
+    # The baseline is taken with the pool EMPTY but after this shape's first use: what the HIP runtime allocates once per
+    # hardware queue -- code objects, and since round 5 the scratch buffer in which the chain kernel's called roles save
+    # registers (168 bytes x 64 lanes x every wave slot of the chip, ~90 MB per queue) -- is not the pool's to return.
+    egx.trim()
+    free0 = torch.cuda.mem_get_info()[0]
+    with egx.GpHandle(x0, y0) as h:           # (leaves its resources in the pool for the cycles below)
+        h.finalize(theta)
     stats0 = egx.pool_stats()
     assert stats0["cached_bytes"] > 0
     cycle, used = [], []

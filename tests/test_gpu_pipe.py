@@ -1,0 +1,140 @@
+"""The pipelined chain kernel (csrc/kernels_pipe.hip: the serial chain of a group of Cholesky panels -- diagonal blocks,
+panel solves, in-group updates: the panel step of `cholesky()`, crates/gp/src/algorithm.rs:1004 -- as ONE persistent launch
+with device-side hand-offs) through the C ABI: against the separate-launch chain and LAPACK, the schedule a handle reports,
+a lost pivot, and the bounded waits (a hand-off that never arrives is an ERROR within the bound, not a hang)."""
+import time
+
+import numpy as np
+import pytest
+import scipy.linalg as sl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def egx():
+    import egobox_amd
+    return egobox_amd
+
+
+def _data(n, d, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(size=(n, d))
+    y = np.sin(3 * x[:, 0]) + x[:, 1:].sum(axis=1) ** 2 + 0.1 * rng.standard_normal(n)
+    return x, y
+
+
+@pytest.fixture()
+def knobs(egx):
+    """egx_set_tuning settings of one test, restored afterwards"""
+    saved = {}
+
+    def setk(name, value):
+        old = egx.set_tuning(name, value)
+        saved.setdefault(name, old)
+        return old
+    yield setk
+    for k, v in saved.items():
+        egx.set_tuning(k, v)
+
+
+@pytest.mark.parametrize("n", [300, 1000, 2100, 4096])
+def test_chain_launches_agree_with_separate_launches_and_lapack(egx, knobs, n):
+    """egx_potrf on a kernel matrix: one chain launch for the whole factorisation (the default up to 4096 columns), chain
+    launches per group of panels (pipe_whole = 0), separate launches (pipe = 0): the same factor to rounding, LAPACK's
+    residual."""
+    rng = np.random.default_rng(n)
+    pts = rng.uniform(size=(n, 3))
+    d2 = ((pts[:, None, :] - pts[None, :, :]) ** 2).sum(-1)
+    a = np.exp(-6.0 * d2) + 1e-8 * np.eye(n)
+    want = sl.cholesky(a, lower=True)
+    res_lapack = np.abs(want @ want.T - a).max()
+    facs = {}
+    for name, settings in (("whole", {"pipe": 1, "pipe_whole": 4096}), ("groups", {"pipe": 1, "pipe_whole": 0}), ("separate", {"pipe": 0})):
+        for k, v in settings.items():
+            knobs(k, v)
+        got, info = egx.potrf(a)
+        assert info == 0
+        assert np.abs(got @ got.T - a).max() <= 10 * max(res_lapack, 1e-15), name
+        facs[name] = got
+    scale = np.abs(want).max()
+    assert np.abs(facs["whole"] - facs["separate"]).max() <= 2e-5 * scale     # (cond ~ 1e8: the factors agree to 1e-7)
+    assert np.abs(facs["groups"] - facs["separate"]).max() <= 2e-5 * scale
+    if n <= 256:
+        np.testing.assert_array_equal(facs["groups"], facs["separate"])      # one panel: the same arithmetic, the same bits
+
+
+@pytest.mark.parametrize("n,bad", [(700, 0), (700, 255), (700, 256), (700, 300), (700, 699), (2000, 1500)])
+def test_info_is_lapacks_under_chain_launches(egx, knobs, n, bad):
+    rng = np.random.default_rng(n + bad)
+    g = rng.standard_normal((n, n))
+    a = g @ g.T / n + 0.1 * np.eye(n)
+    a[bad, bad] = -1.0
+    _, info_lapack = sl.lapack.dpotrf(a, lower=1)
+    for whole in (4096, 0):
+        knobs("pipe", 1)
+        knobs("pipe_whole", whole)
+        _, info = egx.potrf(a)
+        assert info == info_lapack == bad + 1
+
+
+def test_schedule_is_reported_and_survives_shrink(egx):
+    """egx_gp_get_schedule: a small one-workspace handle factors as ONE chain launch, a handle with many workspaces per group,
+    a large one by separate launches; egx_gp_shrink does not change what the handle was created with."""
+    x, y = _data(900, 4, 1)
+    with egx.GpHandle(x, y, n_workspaces=1) as h:
+        s = h.schedule()
+        assert s["pipelined_chain"] == 1 and s["whole_factorisation_launch"] == 1 and s["left_looking"] == 0
+    with egx.GpHandle(x, y, n_workspaces=12) as h:      # 12 x 4 panels > 32 diagonal blocks
+        s = h.schedule()
+        assert s["pipelined_chain"] == 1 and s["whole_factorisation_launch"] == 0
+        th = np.full(4, 0.3)
+        lk0, st0 = h.likelihood(th)
+        h.finalize(th)
+        h.shrink(1)
+        assert h.schedule() == {**s, "lockstep": 1}      # the width is capped, the schedule stays
+        lk1, st1 = h.likelihood(th)
+        assert st0 == st1 == 0 and lk0 == lk1           # ... and so do the bits
+    x, y = _data(4200, 4, 2)
+    with egx.GpHandle(x, y, n_workspaces=1) as h:
+        s = h.schedule()
+        assert s["pipelined_chain"] == 0 and s["whole_factorisation_launch"] == 0
+
+
+def test_likelihood_does_not_depend_on_the_chain_form_beyond_rounding(egx, knobs):
+    x, y = egx.workload.make_training_set(1500, 8, 42)     # (the benchmark's well-conditioned family: the 1e-8 bar applies)
+    th = egx.workload.default_theta(8) * 3.0
+    vals = []
+    for settings in ({"pipe": 1, "pipe_whole": 4096}, {"pipe": 1, "pipe_whole": 0}, {"pipe": 0}):
+        for k, v in settings.items():
+            knobs(k, v)
+        with egx.GpHandle(x, y) as h:
+            lk, st = h.likelihood(th)
+            assert st == 0
+            vals.append(lk)
+    assert abs(vals[0] - vals[2]) <= 1e-10 * abs(vals[2]) and abs(vals[1] - vals[2]) <= 1e-10 * abs(vals[2])
+
+
+def test_a_hand_off_that_never_arrives_is_an_error_within_the_bound_not_a_hang(egx, knobs):
+    """pipe_stall lets the diagonal role publish its strips into a scratch word: every consumer's bounded wait runs out, the
+    launch drains, the evaluation reports EGX_ERR_HIP -- and the next one, with the hook off, is fine on the same handle."""
+    x, y = _data(1000, 4, 4)
+    th = np.full(4, 0.3)
+    with egx.GpHandle(x, y) as h:
+        good, st = h.likelihood(th)
+        assert st == 0
+        knobs("pipe_timeout_ms", 25)
+        knobs("pipe_stall", 1)
+        t0 = time.perf_counter()
+        with pytest.raises(egx.EgxError, match="pipelined chain kernel"):
+            h.likelihood(th)
+        assert time.perf_counter() - t0 < 5.0
+        knobs("pipe_stall", 0)
+        knobs("pipe_timeout_ms", 2000)
+        again, st = h.likelihood(th)
+        assert st == 0 and again == good
+    a = np.eye(600) + 0.01
+    knobs("pipe_timeout_ms", 25)
+    knobs("pipe_stall", 1)
+    with pytest.raises(egx.EgxError, match="pipelined chain kernel"):
+        egx.potrf(a)

@@ -252,11 +252,26 @@ static int diag_alone_main() {
 }
 
 // one traced factorisation: every task of its chain launches with the times it was taken / became ready / finished
+static void env_knobs() {
+    if (const char *e = getenv("PIPE_KNOBS")) {
+        std::string s(e);
+        size_t i = 0;
+        while (i < s.size()) {
+            size_t j = s.find(',', i);
+            if (j == std::string::npos) j = s.size();
+            const std::string kv = s.substr(i, j - i);
+            const size_t q = kv.find('=');
+            if (q != std::string::npos) pipe_set_knob(kv.substr(0, q).c_str(), atoi(kv.substr(q + 1).c_str()));
+            i = j + 1;
+        }
+    }
+}
 static int trace_main(int n, int whole, int la, int nz) {
     const double scale = 6.0, nugget = 1e-8;
     pipe_set_knob("pipe_timeout_ms", 500);
     g_whole = (whole ? 1 << 30 : 0) != 0;
     pipe_set_knob("pipe_la", la);
+    env_knobs();
     Problem P;
     P.create(n, nz, n >= 8192);
     const size_t cap = 1 << 20;  // tickets
