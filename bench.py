@@ -196,6 +196,47 @@ def measured_traffic(n, d):
     return write + c_read + 2.0 * max(0.0, fetch - c_read), p
 
 
+def size_ladder(egx, workload, gpu):
+    """The Cholesky of ONE fixed-theta fit across sizes, driver-visible: n in {2048, 4096, 8192, 16384} x {one evaluation in
+    flight on a one-workspace handle, a lock-step batch on a handle with as many workspaces}: milliseconds per
+    factorisation, TFLOP/s for n^3 / 3 flop, fraction of the FP64 peak, and the schedule the handle reports
+    (egx_gp_get_schedule).  Squared exponential, the metric's data family.  ~10 s."""
+    out = {}
+    for n, d, width in ((2048, 8, 12), (4096, 8, 12), (8192, 16, 12), (16384, 32, 8)):
+        x, y = workload.make_training_set(n, d, seed=42)
+        th = workload.default_theta(d) * (3.0 if d <= 8 else 1.0)
+        flop = float(n) ** 3 / 3.0
+        h = egx.GpHandle(x, y, mean=0, corr=0, device=gpu, n_workspaces=1)
+        h.finalize(th)
+        reps = 10 if n <= 4096 else 3
+        t0 = time.perf_counter()
+        pm = []
+        for j in range(reps):
+            h.finalize(th * (1.0 + 1e-3 * j))
+            pm.append(h.timings()["potrf_ms"])
+        t_fit = (time.perf_counter() - t0) / reps
+        sched = h.schedule()
+        h.close()
+        one = {"fit_ms": t_fit * 1e3, "potrf_ms": float(np.median(pm)), "potrf_tflops": flop / float(np.median(pm)) / 1e9,
+               "potrf_frac_of_fp64_peak": flop / float(np.median(pm)) / 1e9 / FP64_MFMA_PEAK_TFLOPS, "schedule": sched}
+        h = egx.GpHandle(x, y, mean=0, corr=0, device=gpu, n_workspaces=width)
+        h.set_lockstep(width)
+        ths = np.stack([th * (1.0 + 0.004 * c) for c in range(2 * width)])
+        h.likelihood_batch(ths[:width])
+        t0 = time.perf_counter()
+        lk, st = h.likelihood_batch(ths * 1.001)
+        t_b = (time.perf_counter() - t0) / (2 * width)
+        schedb = h.schedule()
+        h.close()
+        out[f"n{n}_d{d}"] = {
+            "one_in_flight": one,
+            f"lockstep_{width}": {"evaluation_ms_per_candidate": t_b * 1e3, "likelihoods_per_s": 1.0 / t_b,
+                                   "tflops_for_n3_over_3": flop / t_b / 1e12,
+                                   "frac_of_fp64_peak": flop / t_b / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                                   "statuses_ok": int(np.sum(st == 0)), "schedule": schedb}}
+    return out
+
+
 def other_configs(egx, workload, gpu):
     """Bounded side measurements in the SAME driver-run line (never `value`): BASELINE config 3 (Matern-5/2 likelihood
     and likelihood + theta-gradient at n = 16384, d = 32), config 5 (one expert n = 8192, d = 16: predict / predict_var on
@@ -280,11 +321,40 @@ def other_configs(egx, workload, gpu):
     from egobox_amd.moe import GaussianMixture, GpMixture
     k = 8
     rng = np.random.default_rng(5)
-    experts = []
-    for e in range(k):
-        xe, ye = workload.make_training_set(n5, d5, seed=7 + e)
-        experts.append(egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr())
-                       .theta_tuning(egx.ThetaTuning.Fixed(workload.default_theta(d5))).fit(xe, ye))
+    # the experts are fitted the way egobox-moe's expert loop fits them (crates/moe/src/algorithm.rs:167-177: one fixed-theta
+    # `fit` per cluster) -- one after the other first (a model per call), then in LOCK-STEP (GpParams.fit_group:
+    # egx_gp_create_group + egx_gp_finalize_multi, one launch sequence for the eight factorisations)
+    sets5 = [workload.make_training_set(n5, d5, seed=7 + e) for e in range(k)]
+    params5 = (egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr())
+               .theta_tuning(egx.ThetaTuning.Fixed(workload.default_theta(d5))))
+    lone = [params5.fit(*s) for s in sets5[:2]]          # (warm: pool, code objects)
+    for e in lone:
+        e.close()
+    t0 = time.perf_counter()
+    lone = [params5.fit(*s) for s in sets5]
+    t_lone = time.perf_counter() - t0
+    lone_lk = [e.likelihood() for e in lone]
+    for e in lone:
+        e.close()
+    xs5, ys5 = np.stack([s[0] for s in sets5]), np.stack([s[1] for s in sets5])
+    for e in params5.fit_group(xs5, ys5):                # (warm)
+        e.close()
+    t0 = time.perf_counter()
+    experts = params5.fit_group(xs5, ys5)
+    t_group = time.perf_counter() - t0
+    hs5 = [e.handle for e in experts]
+    th5 = np.tile(workload.default_theta(d5), (k, 1))
+    t0 = time.perf_counter()
+    egx.finalize_multi(hs5, th5)                          # the factorisations alone (models resident: no create, no upload)
+    t_multi = time.perf_counter() - t0
+    flop5 = k * float(n5) ** 3 / 3.0
+    res["config5_expert_fits_8"] = {
+        "experts": k, "n": n5, "d": d5,
+        "create_and_fit_one_after_the_other_ms": t_lone * 1e3, "create_and_fit_in_lock_step_ms": t_group * 1e3,
+        "refit_in_lock_step_ms": t_multi * 1e3, "refit_tflops_for_n3_over_3": flop5 / t_multi / 1e12,
+        "refit_frac_of_fp64_peak": flop5 / t_multi / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+        "bit_identical_to_lone_fits": bool(all(e.likelihood() == l for e, l in zip(experts, lone_lk))),
+        "note": "egx_gp_create_group + egx_gp_finalize_multi: eight models of one shape, one launch sequence"}
     w = rng.random(k) + 0.5
     w /= w.sum()
     gmx = GaussianMixture(w, rng.random((k, d5)), np.array([np.eye(d5) * 0.3] * k), 0.9)
@@ -299,17 +369,23 @@ def other_configs(egx, workload, gpu):
                                              "expert_points_per_s": k * m5 / t_m,
                                              "trsm_tflops": k * float(n5) * n5 * m5 / t_m / 1e12,
                                              "checksum": float(vm.sum())}
-    # config 2 (n = 4096, d = 8, sq-exp): the serial chain's size -- one evaluation in flight, and twelve in lock-step
+    # config 2 (n = 4096, d = 8, sq-exp): the serial chain's size -- one evaluation in flight on a one-workspace handle (the
+    # reference's `fit` at fixed theta: the whole factorisation is ONE chain launch, kernels_pipe.hip), and twelve in
+    # lock-step on a twelve-workspace handle (a round of a tuned fit's COBYLA starts: chain launches per group of panels)
     n2, d2 = 4096, 8
     x2, y2 = workload.make_training_set(n2, d2, seed=42)
     th2 = workload.default_theta(d2) * 3.0
-    h = egx.GpHandle(x2, y2, mean=0, corr=0, device=gpu, n_workspaces=12)
+    h = egx.GpHandle(x2, y2, mean=0, corr=0, device=gpu, n_workspaces=1)
+    sched_one = h.schedule()
     h.finalize(th2)
     t0 = time.perf_counter()
     for j in range(10):
         h.finalize(th2 * (1.0 + 1e-3 * j))
     t_f2 = (time.perf_counter() - t0) / 10
     tm2 = h.timings()
+    h.close()
+    h = egx.GpHandle(x2, y2, mean=0, corr=0, device=gpu, n_workspaces=12)
+    sched_12 = h.schedule()
     ths2 = np.stack([th2 * (1.0 + 0.01 * c) for c in range(48)])
     h.likelihood_batch(ths2)
     t0 = time.perf_counter()
@@ -320,10 +396,14 @@ def other_configs(egx, workload, gpu):
         "fixed_theta_fit_ms_one_in_flight": t_f2 * 1e3, "fits_per_s_one_in_flight": 1.0 / t_f2, "potrf_ms": tm2["potrf_ms"],
         "cholesky_tflops_one_in_flight": tm2["potrf_flops"] / tm2["potrf_ms"] / 1e9,
         "frac_of_fp64_peak_one_in_flight": tm2["potrf_flops"] / tm2["potrf_ms"] / 1e9 / FP64_MFMA_PEAK_TFLOPS,
+        "schedule_one_in_flight": sched_one,
         "likelihoods_per_s_lockstep_12": 1.0 / t_b2,
         "frac_of_fp64_peak_lockstep_12": float(n2) ** 3 / 3 / t_b2 / 1e12 / FP64_MFMA_PEAK_TFLOPS,
-        "note": "one in flight: the serial chain of 16 diagonal blocks (57 us each) + panel solves + updates, each a separate "
-                "launch; lock-step 12: what a round of a tuned fit's COBYLA starts is"}
+        "schedule_lockstep_12": sched_12,
+        "note": "one in flight: a one-workspace handle, the whole factorisation as one persistent chain launch (16 diagonal blocks of "
+                "~65 us + ~30 us of device-side hand-offs each; round 4: 57 + 20 + 15..80 us of separate launches per panel); "
+                "lock-step 12: a twelve-workspace handle, what a round of a tuned fit's COBYLA starts is"}
+    res["size_ladder"] = size_ladder(egx, workload, gpu)
     d6 = 64
     x6, y6 = workload.make_training_set(n, d6, seed=42)
     h = egx.GpHandle(x6, y6, mean=0, corr=0, device=gpu, n_workspaces=1)
@@ -752,7 +832,7 @@ def main():
         syrk_flops = float(np.mean([t["syrk_flops"] for t in tim1]))
         syrk_launches = int(tim1[0]["syrk_launches"])
         syrk_tflops = syrk_flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms > 0 else 0.0
-        # ---- ONE lock-step group alone (the unit the timed region keeps three of in flight): its whole factorisation rate.
+        # ---- ONE lock-step group alone (the unit the timed region keeps two of in flight): its whole factorisation rate.
         # (No per-launch figure for the batched launches: inside a group the rest-of-group update runs on a side stream and
         # overlaps the HIP events around the trailing update -- 47.7 TFLOP/s "per launch" beside 58.8 for the whole group.)
         gl = max(1, min(lockstep, 8))

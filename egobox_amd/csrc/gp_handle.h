@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <list>
 #include <condition_variable>
 #include <mutex>
@@ -109,6 +110,23 @@ struct EvalResult {
 
 }  // namespace egx
 
+namespace egx {
+// Slabs shared by the members of a GROUP of models (egx_gp_create_group): k models of one shape -- the experts of a mixture
+// (crates/moe/src/algorithm.rs:167-177), an optimiser's objective and constraint surrogates -- whose matrices sit at the
+// fixed strides a lock-step launch needs, although every member has its own training set.  Freed with the last member.
+struct GroupSlabs {
+    int device = 0, k = 0;
+    double *M = nullptr, *D = nullptr;
+    int *I = nullptr;
+    ~GroupSlabs() {
+        (void)hipSetDevice(device);
+        if (M) (void)hipFree(M);
+        if (D) (void)hipFree(D);
+        if (I) (void)hipFree(I);
+    }
+};
+}  // namespace egx
+
 struct egx_gp {
     int device = 0;
     int n = 0, d = 0, p = 0, h = 0, corr = 0, mean = 0;
@@ -128,6 +146,8 @@ struct egx_gp {
     int *slab_I = nullptr;  // one failure flag per workspace, then (from sync_off on) stride_S hand-off words per workspace
                             // for the pipelined chain kernel (kernels_pipe.hip; zeroed by every factorisation)
     int64_t stride_M = 0, stride_D = 0, stride_S = 0, sync_off = 0;
+    std::shared_ptr<egx::GroupSlabs> group;  // member of a group: slab_M / slab_D / slab_I are VIEWS of slot `group_slot`
+    int group_slot = -1;
     int lockstep = 1;  // candidates of a likelihood batch factored in lock-step (consecutive workspaces), <= ws.size()
     egx::PotrfSchedule sched;  // how this handle factors: decided at create / egx_gp_set_lockstep (schedule_for), kept by shrink
     // exclusive for everything that touches the fitted state or all workspaces; SHARED for egx_gp_likelihood, whose
@@ -194,6 +214,8 @@ int enqueue_eval(egx_gp *gp, Workspace &w, const std::vector<double> &coef, int 
 // `count` evaluations on the consecutive workspaces w0 .. w0 + count - 1, factored in lock-step on the streams of w0
 // W0 != nullptr: the `count` buffers W0 + j n_pad^2 receive C^-T of the candidates, riding along the factorisation
 int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> *coefs, int hcols, double *W0 = nullptr);
+// the same for `count` MODELS of one group (consecutive slots): member j evaluates on its own workspace 0, its own training set
+int enqueue_eval_members(egx_gp *const *gps, int count, const std::vector<double> *coefs, int hcols);
 int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, int keep);  // 0 scalars, 1 fitted state, 2 rho only
 void record_timings(egx_gp *gp, Workspace &w, double host_ms, double solve_ms);
 bool has_nan(const double *theta, int64_t len);

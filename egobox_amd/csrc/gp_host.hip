@@ -343,8 +343,12 @@ int make_coef(const egx_gp *gp, const double *theta, int64_t theta_len, std::vec
 // ONE factorisation launch sequence for all of them (lock-step batch, kernels_chol.hip) with fused forward solves,
 // diagonal gather, async download of (diag C, ft^T, yt^T, info) per candidate.  All asynchronous on the streams of
 // workspace w0; every member's eval_stream is set to it.
-int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> *coefs, int hcols, double *W0) {
-    Workspace &lead = gp->ws[w0];
+// core: evaluation j uses the training set of owners[j] and the workspace wss[j]; the workspaces are consecutive slots of ONE
+// slab (a handle's, or a group's: egx_gp_create_group), the launches run on the streams of the first
+static int enqueue_eval_core(egx_gp *const *owners, Workspace *const *wss, int count, const std::vector<double> *coefs, int hcols,
+                             double *W0) {
+    egx_gp *gp = owners[0];
+    Workspace &lead = *wss[0];
     hipStream_t st = lead.stream;
     PotrfInverse inv;
     if (W0) {  // theta-gradient: C^-T rides along (identity rows first, on the rider's own stream: it is idle here)
@@ -357,7 +361,7 @@ int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> 
         EGX_RC(launch_identity_rows(inv.sw, W0, gp->n_pad, gp->n_pad, count, inv.sW));
     }
     for (int j = 0; j < count; j++) {
-        Workspace &w = gp->ws[w0 + j];
+        Workspace &w = *wss[j];
         w.eval_stream = st;
         std::memcpy(w.h_coef, coefs[j].data(), sizeof(double) * coefs[j].size());
         EGX_HIP_CHECK(hipMemcpyAsync(w.d_coef, w.h_coef, sizeof(double) * coefs[j].size(), hipMemcpyHostToDevice, st));
@@ -365,12 +369,14 @@ int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> 
     EGX_HIP_CHECK(hipMemsetAsync(lead.d_info, 0, sizeof(int) * (size_t)count, st));
     EGX_HIP_CHECK(hipEventRecord(lead.ev[0], st));
     for (int j = 0; j < count; j++) {
-        Workspace &w = gp->ws[w0 + j];
-        EGX_RC(launch_corr_sym(st, gp->corr, gp->d_xT, gp->n_pad, gp->n, gp->d, w.d_coef, hcols, gp->nugget, w.M, gp->ld,
+        Workspace &w = *wss[j];
+        egx_gp *o = owners[j];
+        EGX_RC(launch_corr_sym(st, gp->corr, o->d_xT, gp->n_pad, gp->n, gp->d, w.d_coef, hcols, gp->nugget, w.M, gp->ld,
                                gp->n_pad, w.d_xs));
-        EGX_RC(launch_fill_rows(st, w.M, gp->ld, gp->n_pad, gp->rhs_pad, gp->d_rhsT, gp->n_pad, gp->q, gp->n_pad));
+        EGX_RC(launch_fill_rows(st, w.M, gp->ld, gp->n_pad, gp->rhs_pad, o->d_rhsT, gp->n_pad, gp->q, gp->n_pad));
     }
     EGX_HIP_CHECK(hipEventRecord(lead.ev[1], st));
+    int *lead_sync = dev_sync(gp, (int)(&lead - gp->ws.data()));
     PotrfBatch pb;
     pb.count = count;
     pb.sM = gp->stride_M;
@@ -381,13 +387,13 @@ int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> 
     pb.pipe = gp->sched.pipe;
     pb.whole = gp->sched.whole;
     pb.tail = gp->sched.tail;
-    pb.sync = (gp->sched.pipe || gp->sched.tail) ? dev_sync(gp, w0) : nullptr;  // the chain of a group of panels as one persistent launch (kernels_pipe.hip)
+    pb.sync = (gp->sched.pipe || gp->sched.tail) ? lead_sync : nullptr;  // the chain of a group of panels as one persistent launch (kernels_pipe.hip)
     pb.sS = gp->stride_S;
     EGX_RC(launch_potrf(st, lead.M, gp->ld, gp->n_pad, gp->m_tot, lead.dinv, lead.d_info, lead.lk.s2 ? &lead.lk : nullptr,
                         &lead.trace, &pb, W0 ? &inv : nullptr));
     EGX_HIP_CHECK(hipEventRecord(lead.ev[2], st));
     for (int j = 0; j < count; j++) {
-        Workspace &w = gp->ws[w0 + j];
+        Workspace &w = *wss[j];
         EGX_RC(launch_gather_diag(st, w.M, gp->ld, gp->n, w.d_diag));
         EGX_HIP_CHECK(hipMemcpyAsync(w.h_diag, w.d_diag, sizeof(double) * gp->n, hipMemcpyDeviceToHost, st));
         w.gls_enqueued = gp->gls_device;
@@ -418,6 +424,18 @@ int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> 
     }
     EGX_HIP_CHECK(hipEventRecord(lead.ev[3], st));
     return EGX_SUCCESS;
+}
+
+int enqueue_eval_group(egx_gp *gp, int w0, int count, const std::vector<double> *coefs, int hcols, double *W0) {
+    std::vector<egx_gp *> owners((size_t)count, gp);
+    std::vector<Workspace *> wss((size_t)count);
+    for (int j = 0; j < count; j++) wss[(size_t)j] = &gp->ws[(size_t)(w0 + j)];
+    return enqueue_eval_core(owners.data(), wss.data(), count, coefs, hcols, W0);
+}
+int enqueue_eval_members(egx_gp *const *gps, int count, const std::vector<double> *coefs, int hcols) {
+    std::vector<Workspace *> wss((size_t)count);
+    for (int j = 0; j < count; j++) wss[(size_t)j] = &gps[j]->ws[0];
+    return enqueue_eval_core(gps, wss.data(), count, coefs, hcols, nullptr);
 }
 
 // one evaluation on one workspace (its own streams)
@@ -736,18 +754,11 @@ int backward_solve(egx_gp *gp, Workspace &w) {
     return EGX_SUCCESS;
 }
 
-int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
-    std::vector<double> coef, thfull;
-    int hcols = 1;
-    EGX_RC(make_coef(gp, theta, theta_len, coef, hcols, &thfull));
-    if (has_nan(theta, theta_len)) {
-        set_error("theta contains NaN");
-        return EGX_ERR_INVALID_VALUE;
-    }
-    gp->fitted = false;
+// second half of a fit at fixed theta, behind the evaluation that was enqueued on workspace 0: the host half of the
+// likelihood, gamma = C^-T rho, the fitted state
+static int finalize_tail(egx_gp *gp, const std::vector<double> &coef, int hcols, const std::vector<double> &thfull) {
     Workspace &w = gp->ws[0];
     EvalResult res;
-    EGX_RC(enqueue_eval(gp, w, coef, hcols));
     auto t0 = std::chrono::steady_clock::now();
     EGX_RC(finish_eval(gp, w, res, 1));
     auto t1 = std::chrono::steady_clock::now();
@@ -793,11 +804,23 @@ int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     gp->fit_epoch++;
     gp->small_var_calls = 0;
     float gpu = 0;
-    hipEventElapsedTime(&gpu, w.ev[0], w.ev[3]);
+    hipEventElapsedTime(&gpu, w.eval_stream == w.stream ? w.ev[0] : w.ev[4], w.eval_stream == w.stream ? w.ev[3] : w.ev[4]);
     double host_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() - gpu;
     if (host_ms < 0) host_ms = 0;
-    record_timings(gp, w, host_ms, std::chrono::duration<double, std::milli>(t2 - t1).count());
+    if (w.eval_stream == w.stream) record_timings(gp, w, host_ms, std::chrono::duration<double, std::milli>(t2 - t1).count());
     return EGX_SUCCESS;
+}
+int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
+    std::vector<double> coef, thfull;
+    int hcols = 1;
+    EGX_RC(make_coef(gp, theta, theta_len, coef, hcols, &thfull));
+    if (has_nan(theta, theta_len)) {
+        set_error("theta contains NaN");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    gp->fitted = false;
+    EGX_RC(enqueue_eval(gp, gp->ws[0], coef, hcols));
+    return finalize_tail(gp, coef, hcols, thfull);
 }
 // Candidates pipelined over the handle's workspaces (caller holds gp->mu exclusively and has set the device).
 // The workspaces form SLOTS of gp->lockstep consecutive ones; the candidates of a slot are factored in lock-step by one
@@ -973,6 +996,14 @@ int32_t egx_regression_basis(int32_t mean, const double *x, int64_t n, int64_t d
     return EGX_SUCCESS;
 }
 
+// set by egx_gp_create_group around the creation of its members: the member takes slot `slot` of these slabs
+struct GroupCtx {
+    std::shared_ptr<GroupSlabs> slabs;
+    int slot = 0;
+    int64_t sync_off = 0;
+};
+static thread_local GroupCtx *t_group_ctx = nullptr;
+
 int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double *y, int64_t n, int64_t d,
                       egx_gp **out) {
     if (!out) {
@@ -991,7 +1022,7 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
         return EGX_ERR_INVALID_VALUE;
     }
     if (d < 1 || d > 65535) {
-        set_error("input dimension must be at least 1, got " + std::to_string(d));
+        set_error("input dimension must be between 1 and 65535, got " + std::to_string(d));
         return EGX_ERR_INVALID_VALUE;
     }
     if (cfg.corr < 0 || cfg.corr > 3 || cfg.mean < 0 || cfg.mean > 2) {
@@ -1111,7 +1142,25 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
     gp->stride_D = round_up((int64_t)dinv_doubles(gp->n_pad), 64);
     gp->stride_S = (int64_t)pipe_sync_ints(gp->n_pad, gp->m_tot);
     gp->sync_off = round_up(nws, 64);
-    if (!pool_take(gp, nws)) {  // no destroyed handle of this shape left its resources behind: allocate
+    if (t_group_ctx) {
+        // member of a group (egx_gp_create_group): ONE workspace whose matrix, tile inverses, flag and hand-off words are slot
+        // `slot` of the group's slabs -- the members' matrices sit at the strides a lock-step launch needs
+        GroupCtx &g = *t_group_ctx;
+        nws = 1;
+        gp->group = g.slabs;
+        gp->group_slot = g.slot;
+        gp->slab_M = g.slabs->M + (int64_t)g.slot * gp->stride_M;
+        gp->slab_D = g.slabs->D + (int64_t)g.slot * gp->stride_D;
+        gp->slab_I = g.slabs->I + g.slot;
+        gp->sync_off = g.sync_off + (int64_t)g.slot * gp->stride_S - g.slot;  // dev_sync(gp, 0) = the slot's words
+        EGX_HIPF(dev_malloc(&gp->d_xT, sizeof(double) * 2 * xT.size()));
+        EGX_HIPF(dev_malloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
+        EGX_HIPF(dev_malloc(&gp->d_gamma, sizeof(double) * gp->n_pad));
+        EGX_HIPF(dev_malloc(&gp->d_fit_coef, sizeof(double) * ((size_t)d * (gp->has_w ? gp->h : 1) + 2 * (size_t)d)));
+        gp->ws.resize(1);
+        rc = alloc_workspace(gp, gp->ws[0], 0);
+        if (rc) return fail(rc);
+    } else if (!pool_take(gp, nws)) {  // no destroyed handle of this shape left its resources behind: allocate
         EGX_HIPF(dev_malloc(&gp->d_xT, sizeof(double) * 2 * xT.size()));  // + dev_xs_fit()
         EGX_HIPF(dev_malloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
         EGX_HIPF(dev_malloc(&gp->d_gamma, sizeof(double) * gp->n_pad));
@@ -1149,6 +1198,7 @@ void egx_gp_destroy(egx_gp *gp) {
         if (w.inv_stream) (void)hipStreamSynchronize(w.inv_stream);
     }
     (void)hipGetLastError();
+    if (gp->group) gp->slab_M = gp->slab_D = nullptr, gp->slab_I = nullptr;  // (views of the group's slabs: freed with the last member)
     pool_give(gp);
     if (gp->d_W) hipFree(gp->d_W);
     if (gp->d_neg_invkf) hipFree(gp->d_neg_invkf);
@@ -1321,6 +1371,145 @@ int32_t egx_gp_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     std::unique_lock<std::shared_mutex> lock(gp->mu);
     EGX_RC(set_device(gp));
     return do_finalize(gp, theta, theta_len);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Lock-step across MODELS (round 5): the reference's callers multiply independent models, not only candidates of one model --
+// the expert loop of egobox-moe (crates/moe/src/algorithm.rs:167-177: one GP per cluster) and EGO's objective + constraint
+// surrogates (crates/ego/src/solver/solver_impl.rs:370-391).  Models of ONE shape created into one group of slabs are
+// factored by one launch sequence: the kernels' batch dimension never required the matrices to share a training set.
+// ---------------------------------------------------------------------------------------------
+int32_t egx_gp_create_group(const egx_gp_config *cfg_in, const double *x, const double *y, int64_t n, int64_t d, int32_t k,
+                            egx_gp **out) {
+    if (!out || k < 1 || k > 256) {
+        set_error("egx_gp_create_group: NULL output or a member count outside 1..256");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    for (int32_t j = 0; j < k; j++) out[j] = nullptr;
+    if (!x || !y || n < 2 || d < 1) {
+        set_error("egx_gp_create_group: bad training sets");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    egx_gp_config cfg;
+    if (cfg_in) cfg = *cfg_in; else egx_gp_config_default(&cfg);
+    cfg.n_workspaces = 1;
+    if (egx_device_count() <= 0) {
+        set_error("no HIP device: libegx_gp_hip has no CPU fallback (needs an MI355X / gfx950 GPU)");
+        return EGX_ERR_NO_DEVICE;
+    }
+    int dev = cfg.device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    EGX_HIP_CHECK(hipSetDevice(dev));
+    // the members' geometry (the formulas of egx_gp_create)
+    if (cfg.mean < 0 || cfg.mean > 2) {
+        set_error("unknown regression model");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    const int64_t p = hm::regression_ncols(cfg.mean, d);
+    const int n_pad = (int)round_up(n, n >= 4096 ? kNB : kTile);
+    const int m_tot = n_pad + (int)round_up(p + 1, kRhsPad);
+    const int64_t sM = (int64_t)m_tot * n_pad, sD = round_up((int64_t)dinv_doubles(n_pad), 64), sS = (int64_t)pipe_sync_ints(n_pad, m_tot);
+    GroupCtx ctx;
+    ctx.slabs = std::make_shared<GroupSlabs>();
+    ctx.slabs->device = dev;
+    ctx.slabs->k = k;
+    ctx.sync_off = round_up(k, 64);
+    EGX_HIP_CHECK(dev_malloc(&ctx.slabs->M, sizeof(double) * (size_t)sM * k));
+    EGX_HIP_CHECK(dev_malloc(&ctx.slabs->D, sizeof(double) * (size_t)sD * k));
+    EGX_HIP_CHECK(dev_malloc(&ctx.slabs->I, sizeof(int) * ((size_t)ctx.sync_off + (size_t)sS * k)));
+    int rc = EGX_SUCCESS;
+    for (int32_t j = 0; j < k && rc == EGX_SUCCESS; j++) {
+        ctx.slot = j;
+        t_group_ctx = &ctx;
+        rc = egx_gp_create(&cfg, x + (size_t)j * n * d, y + (size_t)j * n, n, d, &out[j]);
+        t_group_ctx = nullptr;
+    }
+    if (rc != EGX_SUCCESS)
+        for (int32_t j = 0; j < k; j++) {
+            if (out[j]) egx_gp_destroy(out[j]);
+            out[j] = nullptr;
+        }
+    return rc;
+}
+
+// gps[0..k): distinct fitted-or-not models; runs of members of one group in consecutive slots are evaluated in lock-step
+// (up to `cap` per launch sequence), everything else one by one: the results do not depend on which (a matrix gets the
+// same arithmetic alone and in a batch)
+static int multi_run_len(egx_gp *const *gps, int k, int i) {
+    if (!gps[i]->group) return 1;
+    int cap = 12;
+    if (gps[i]->sched.whole) {  // (every diagonal block of a whole-factorisation launch has a workgroup of its own)
+        const int np = (gps[i]->n_pad + kNB - 1) / kNB;
+        cap = std::max(1, std::min(cap, 128 / np));
+    }
+    int len = 1;
+    while (i + len < k && len < cap && gps[i + len]->group == gps[i]->group && gps[i + len]->group_slot == gps[i]->group_slot + len &&
+           gps[i + len]->corr == gps[i]->corr && gps[i + len]->has_w == gps[i]->has_w)
+        len++;
+    return len;
+}
+static int multi_eval(egx_gp *const *gps, int32_t k, const double *thetas, int64_t theta_len, bool finalize, double *lkh,
+                      int32_t *status) {
+    if (!gps || k < 1 || !thetas) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::vector<egx_gp *> order(gps, gps + k);
+    std::sort(order.begin(), order.end());
+    if (std::adjacent_find(order.begin(), order.end()) != order.end() || !order[0]) {
+        set_error("the models of a multi-model call must be distinct handles");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::vector<std::unique_lock<std::shared_mutex>> locks;  // (in address order: two such calls cannot deadlock)
+    for (egx_gp *g : order) locks.emplace_back(g->mu);
+    int first_rc = EGX_SUCCESS;
+    for (int i = 0; i < k;) {
+        const int len = multi_run_len(gps, k, i);
+        EGX_RC(set_device(gps[i]));
+        std::vector<std::vector<double>> coefs((size_t)len), thfull((size_t)len);
+        int hcols = 1;
+        bool nan = false;
+        for (int j = 0; j < len; j++) {
+            const double *th = thetas + (size_t)(i + j) * theta_len;
+            EGX_RC(make_coef(gps[i + j], th, theta_len, coefs[(size_t)j], hcols, &thfull[(size_t)j]));
+            nan = nan || has_nan(th, theta_len);
+        }
+        if (nan) {
+            set_error("theta contains NaN");
+            return EGX_ERR_INVALID_VALUE;
+        }
+        for (int j = 0; j < len; j++) gps[i + j]->fitted = false;
+        if (len > 1) EGX_RC(enqueue_eval_members(gps + i, len, coefs.data(), hcols));
+        else EGX_RC(enqueue_eval(gps[i], gps[i]->ws[0], coefs[0], hcols));
+        for (int j = 0; j < len; j++) {
+            egx_gp *g = gps[i + j];
+            int rc;
+            if (finalize) {
+                rc = finalize_tail(g, coefs[(size_t)j], hcols, thfull[(size_t)j]);
+            } else {
+                EvalResult res;
+                rc = finish_eval(g, g->ws[0], res, 0);
+                if (rc == EGX_SUCCESS) {
+                    if (lkh) lkh[i + j] = res.lkh;
+                    if (status) status[i + j] = res.status;
+                }
+            }
+            if (rc != EGX_SUCCESS && first_rc == EGX_SUCCESS) first_rc = rc;  // (the others still finish: their streams are drained)
+        }
+        i += len;
+    }
+    return first_rc;
+}
+int32_t egx_gp_finalize_multi(egx_gp *const *gps, int32_t k, const double *thetas, int64_t theta_len) {
+    return multi_eval(gps, k, thetas, theta_len, true, nullptr, nullptr);
+}
+int32_t egx_gp_likelihood_multi(egx_gp *const *gps, int32_t k, const double *thetas, int64_t theta_len, double *lkh,
+                                int32_t *status) {
+    if (!lkh || !status) {
+        set_error("NULL output");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    return multi_eval(gps, k, thetas, theta_len, false, lkh, status);
 }
 
 int32_t egx_gp_get_inner(egx_gp *gp, const egx_gp_inner_view *v) {

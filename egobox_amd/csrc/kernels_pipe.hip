@@ -115,6 +115,10 @@ __device__ __forceinline__ T *pipe_uniform(T *p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
     return (T *)(((unsigned long long)hi << 32) | lo);
 }
+__device__ __forceinline__ double *pipe_uniform_lds(pipe_lds_t p) {  // (an LDS address is 32 bits)
+    const unsigned long long u = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)p);
+    return (double *)(pipe_lds_t)u;
+}
 __device__ __forceinline__ PipeArgs pipe_kargs(pipe_kargs_t kv) {  // (kv: the kernel's own kernarg pointer -- inside a
     PipeArgs a;                                                   //  called function the intrinsic yields a null pointer)
     const unsigned long long u = (unsigned long long)kv;
@@ -195,7 +199,7 @@ __device__ __noinline__ int pipe_role_trsm(pipe_kargs_t ka, pipe_lds_t sm3, long
 #else
     tr = nullptr;
 #endif
-    double *sm = (double *)(pipe_lds_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)sm3);
+    double *sm = pipe_uniform_lds(sm3);
     int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
     const int k0 = a.g0 + 256 * p, P = k0 >> 8, base = k0 >> 4;
     const int nbk = (a.n_pad - k0 < 256) ? (a.n_pad - k0) : 256, nb16 = nbk >> 4;
@@ -385,7 +389,7 @@ __device__ __noinline__ int pipe_role_fine(pipe_kargs_t ka, pipe_lds_t sm3, long
 #else
     tr = nullptr;
 #endif
-    double *sm = (double *)(pipe_lds_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)sm3);
+    double *sm = pipe_uniform_lds(sm3);
     int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
     const int k0 = a.g0 + 256 * p, P = k0 >> 8;
     const int R0 = 64 * c_row, C0 = k0 + 256 + 64 * j, c_col = C0 >> 6;
@@ -452,7 +456,7 @@ __device__ __noinline__ int pipe_role_coarse(pipe_kargs_t ka, pipe_lds_t sm3, lo
 #else
     tr = nullptr;
 #endif
-    double *sm = (double *)(pipe_lds_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)sm3);
+    double *sm = pipe_uniform_lds(sm3);
     int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
     const int k0 = a.g0 + 256 * p, P = k0 >> 8;
     const int R0 = 128 * I, C0 = 128 * J;
@@ -504,7 +508,7 @@ __device__ __noinline__ int pipe_role_coarse(pipe_kargs_t ka, pipe_lds_t sm3, lo
 // the workers: ticket -> (task, matrix), until the list is exhausted or the launch is aborted
 __device__ __noinline__ void pipe_worker_loop(pipe_kargs_t ka, pipe_lds_t sm3) {
     const PipeArgs a = pipe_kargs(ka);
-    double *sm = (double *)(pipe_lds_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)sm3);
+    double *sm = pipe_uniform_lds(sm3);
     int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
     int *ticket = a.sync + kPipeHdr + (a.g0 >> 8);
     const int total = a.ntasks * a.nz;

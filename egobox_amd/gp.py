@@ -148,6 +148,33 @@ class GpHandle:
         self.n, self.d, self.p, self.h = n.value, d.value, p.value, h.value
 
     @classmethod
+    def create_group(cls, xs, ys, mean=0, corr=0, nugget=DEFAULT_NUGGET, device=-1):
+        """egx_gp_create_group: k models of ONE shape (xs: k x n x d, ys: k x n) whose matrices share a slab -- the experts of a
+        mixture (crates/moe/src/algorithm.rs:167-177), an optimiser's objective and constraint surrogates -- so that
+        `finalize_multi` / `likelihood_multi` factor them in lock-step.  Returns k ordinary handles."""
+        lib = L.load()
+        xs = np.ascontiguousarray(L.as_f64(xs))
+        ys = np.ascontiguousarray(L.as_f64(ys))
+        if xs.ndim != 3 or ys.ndim != 2 or ys.shape != xs.shape[:2]:
+            raise L.InvalidValueError(L.ERR_INVALID_VALUE, "create_group needs xs (k, n, d) and ys (k, n)")
+        k, n, d = xs.shape
+        cfg = L.GpConfig()
+        lib.egx_gp_config_default(C.byref(cfg))
+        cfg.corr, cfg.mean, cfg.nugget, cfg.device, cfg.n_workspaces = int(corr), int(mean), float(nugget), int(device), 1
+        raw = (C.c_void_p * k)()
+        L.check(lib.egx_gp_create_group(C.byref(cfg), L.dptr(xs), L.dptr(ys), n, d, k, raw))
+        out = []
+        for j in range(k):
+            self = cls.__new__(cls)
+            self._lib, self._h, self._w = lib, C.c_void_p(raw[j]), None
+            self.n, self.d = n, d
+            nn, dd, p, h = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+            L.check(lib.egx_gp_dims(self._h, C.byref(nn), C.byref(dd), C.byref(p), C.byref(h)))
+            self.p, self.h = p.value, h.value
+            out.append(self)
+        return out
+
+    @classmethod
     def _borrow(cls, raw, owner):
         """A view of an egx_gp* owned by something else (the replica inside an `egx_sweep`): every method works, closing it
         does nothing; `owner` is kept alive as long as the view is."""
@@ -428,6 +455,34 @@ def trim():
     return int(L.load().egx_trim())
 
 
+def _handle_array(handles):
+    arr = (C.c_void_p * len(handles))()
+    for j, h in enumerate(handles):
+        arr[j] = getattr(h, "handle", h)._h
+    return arr
+
+
+def finalize_multi(handles, thetas):
+    """egx_gp_finalize_multi: `fit` at fixed theta of several models at once (row j of thetas for handles[j]); members of one
+    group (GpHandle.create_group) are factored in lock-step, each exactly as `finalize` would factor it alone."""
+    thetas = L.as_f64(thetas, 2)
+    if thetas.shape[0] != len(handles):
+        raise L.InvalidValueError(L.ERR_INVALID_VALUE, "one theta row per model")
+    L.check(L.load().egx_gp_finalize_multi(_handle_array(handles), len(handles), L.dptr(thetas), thetas.shape[1]))
+
+
+def likelihood_multi(handles, thetas):
+    """egx_gp_likelihood_multi: (likelihoods, statuses) of several models, row j of thetas for handles[j]."""
+    thetas = L.as_f64(thetas, 2)
+    if thetas.shape[0] != len(handles):
+        raise L.InvalidValueError(L.ERR_INVALID_VALUE, "one theta row per model")
+    lk = np.empty(len(handles))
+    st = np.empty(len(handles), dtype=np.int32)
+    L.check(L.load().egx_gp_likelihood_multi(_handle_array(handles), len(handles), L.dptr(thetas), thetas.shape[1], L.dptr(lk),
+                                              st.ctypes.data_as(C.POINTER(C.c_int32))))
+    return lk, st
+
+
 def set_tuning(knob, value):
     """egx_set_tuning: one of the factorisation's scheduling knobs by name; returns the previous value."""
     old = C.c_int32()
@@ -620,6 +675,36 @@ class GpParams:
             # them, against 0.41 s for a whole tuned fit at n = 4096 and 45 ms at n = 1024.)
             h.shrink(2)
         return GaussianProcess(h, self, n_evals)
+
+    def fit_group(self, xs, ys):
+        """`fit` for k training sets of ONE shape at once (xs: k x n x d, ys: k x n; ThetaTuning::Fixed only, no KPLS): what
+        the expert loop of egobox-moe does one model after the other (crates/moe/src/algorithm.rs:167-177).  The models are
+        created into one group of slabs (egx_gp_create_group) and factored in lock-step (egx_gp_finalize_multi); each is
+        bit for bit the model `fit` returns for its training set.  Returns k GaussianProcess objects."""
+        self.check()
+        t = self._theta_tuning
+        if t.kind != "Fixed" or self._kpls_dim is not None:
+            raise L.InvalidValueError(L.ERR_INVALID_VALUE, "fit_group: fixed theta and no dimension reduction")
+        xs = np.asarray(xs, dtype=np.float64)
+        ys = np.asarray(ys, dtype=np.float64)
+        if ys.ndim == 3 and ys.shape[2] == 1:
+            ys = ys[:, :, 0]
+        hs = GpHandle.create_group(xs, ys, mean=self._mean.code, corr=self._corr.code, nugget=self._nugget, device=self._device)
+        dim = hs[0].h
+        if t.init.size not in (1, dim):
+            for h in hs:
+                h.close()
+            raise L.InvalidValueError(
+                L.ERR_INVALID_VALUE,
+                f"Initial guess for theta should be either 1-dim or dim of xtrain (w_star.ncols()), got {t.init.size}")
+        try:
+            finalize_multi(hs, np.tile(np.atleast_1d(t.init), (len(hs), 1)) if t.init.size == dim
+                           else np.full((len(hs), dim), float(t.init[0])))
+        except Exception:
+            for h in hs:
+                h.close()
+            raise
+        return [GaussianProcess(h, self, 1) for h in hs]
 
 
 class GaussianProcess:

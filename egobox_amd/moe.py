@@ -93,6 +93,8 @@ class GaussianMixture:
         lib = L.load()
         x = np.ascontiguousarray(np.atleast_2d(np.asarray(x, dtype=np.float64)))
         k, nx = self.means.shape
+        if 3 * nx + k > 320:  # (the kernel keeps one point per lane with 3 nx + k doubles of LDS scratch: beyond that, the host form)
+            return self.predict_probas_derivatives(x)
         out = np.empty((x.shape[0], k, nx))
         L.check(lib.egx_gmx_predict_probas_derivatives(int(device), L.dptr(np.ascontiguousarray(self.weights)),
                                                        L.dptr(np.ascontiguousarray(self.means)),
@@ -135,6 +137,28 @@ class GpMixture:
             raise ValueError("one expert per cluster expected")
         self.rank, self.world, self.device = rank, world, device
         self.n_in_flight = 2
+
+    @classmethod
+    def fit_experts(cls, params, cluster_xs, cluster_ys, gmx, recombination="hard", **kw):
+        """The expert loop of egobox-moe (crates/moe/src/algorithm.rs:167-177: one GP per cluster, fitted one after the other)
+        with the experts of EQUAL training-set size fitted in lock-step: `params` is a `GpParams` with ThetaTuning.Fixed,
+        cluster_xs[i] / cluster_ys[i] the training set of cluster i (the clustering itself is out of this package's scope).
+        Clusters of one size go through `GpParams.fit_group` (one launch sequence for all of them), the others through
+        `fit`; every expert is bit for bit what `fit` alone gives."""
+        k = len(cluster_xs)
+        experts = [None] * k
+        by_shape = {}
+        for i in range(k):
+            by_shape.setdefault(np.asarray(cluster_xs[i]).shape, []).append(i)
+        for shape, idx in by_shape.items():
+            if len(idx) > 1:
+                gps = params.fit_group(np.stack([np.asarray(cluster_xs[i], dtype=np.float64) for i in idx]),
+                                       np.stack([np.asarray(cluster_ys[i], dtype=np.float64).reshape(shape[0]) for i in idx]))
+                for i, g in zip(idx, gps):
+                    experts[i] = g
+            else:
+                experts[idx[0]] = params.fit(cluster_xs[idx[0]], cluster_ys[idx[0]])
+        return cls(experts, gmx, recombination, **kw)
 
     def _mine(self, i):
         return i % self.world == self.rank and self.experts[i] is not None

@@ -196,6 +196,24 @@ int32_t egx_gp_likelihood_grad_batch(egx_gp *gp, const double *thetas, int64_t k
  * python/src/gp_mix.rs:202-208): one likelihood evaluation whose factor and
  * inner params stay resident.  Error return when the evaluation fails. */
 int32_t egx_gp_finalize(egx_gp *gp, const double *theta, int64_t theta_len);
+/* Lock-step across MODELS.  The reference's callers multiply independent models, not only candidates of one model: the
+ * expert loop of egobox-moe (crates/moe/src/algorithm.rs:167-177: one GP per cluster, fitted one after the other) and
+ * EGO's objective + constraint surrogates (crates/ego/src/solver/solver_impl.rs:370-391).
+ *   egx_gp_create_group   k models of ONE shape (same n, d, trend, kernel, nugget: `cfg`; training sets x (k x n x d) and
+ *                         y (k x n), one after the other) whose matrices live in one slab at the strides a lock-step launch
+ *                         needs.  out[0..k) are ordinary handles with one workspace each -- every entry point works on them
+ *                         and each is destroyed on its own (the slab goes with the last one).
+ *   egx_gp_finalize_multi `fit` at fixed theta (thetas: k x theta_len, row j for gps[j]) of k DISTINCT handles: members of
+ *                         one group in consecutive slots are factored by ONE launch sequence (up to 12 per sequence), any
+ *                         other handle on its own -- the fitted models are bit for bit what egx_gp_finalize gives each of them
+ *                         (the same kernels on the same values: a matrix never sees its companions).  The first error of
+ *                         any model is returned after all of them have been finished.
+ *   egx_gp_likelihood_multi  the same for the reduced likelihood alone (algorithm.rs:988-1056); status as egx_gp_likelihood. */
+int32_t egx_gp_create_group(const egx_gp_config *cfg, const double *x, const double *y, int64_t n, int64_t d, int32_t k,
+                            egx_gp **out /*k*/);
+int32_t egx_gp_finalize_multi(egx_gp *const *gps, int32_t k, const double *thetas /*k x theta_len*/, int64_t theta_len);
+int32_t egx_gp_likelihood_multi(egx_gp *const *gps, int32_t k, const double *thetas /*k x theta_len*/, int64_t theta_len,
+                                double *lkh /*k*/, int32_t *status /*k*/);
 /* ThetaTuning::Full fit (algorithm.rs:874-948): multistart derivative-free
  * maximisation of the likelihood over log10(theta) in [lo,hi], then finalize.
  * theta0s is (n_starts x h) in LINEAR theta units: the caller supplies the

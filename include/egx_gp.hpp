@@ -100,6 +100,10 @@ class GpParams {
     GpParams &n_workspaces(int n) { n_workspaces_ = n; return *this; }
     // Fit<..>::fit, algorithm.rs:785-980.  x is (n x d) row-major, y has n entries.
     GaussianProcess fit(const double *x, int64_t n, int64_t d, const double *y) const;
+    // `fit` (fixed theta) for k training sets of one shape at once: x (k x n x d), y (k x n).  The expert loop of egobox-moe
+    // (crates/moe/src/algorithm.rs:167-177) with the experts factored in LOCK-STEP (egx_gp_create_group +
+    // egx_gp_finalize_multi); each model is bit for bit what `fit` returns for its training set.
+    std::vector<GaussianProcess> fit_group(const double *x, const double *y, int64_t n, int64_t d, int32_t k) const;
 
   private:
     Mean mean_;
@@ -208,6 +212,34 @@ class GaussianProcess {
     double sigma2_ = 0.0, likelihood_ = 0.0;
     int64_t d_ = 0, n_evals_ = 0;
 };
+
+inline std::vector<GaussianProcess> GpParams::fit_group(const double *x, const double *y, int64_t n, int64_t d, int32_t k) const {
+    if (tuning_.kind != ThetaTuning::Kind::Fixed)
+        throw InvalidValueError(EGX_ERR_INVALID_VALUE, "fit_group: ThetaTuning::Fixed only");
+    egx_gp_config cfg;
+    egx_gp_config_default(&cfg);
+    cfg.corr = (int32_t)corr_;
+    cfg.mean = (int32_t)mean_;
+    cfg.nugget = nugget_;
+    cfg.device = device_;
+    std::vector<egx_gp *> raw((size_t)k, nullptr);
+    check(egx_gp_create_group(&cfg, x, y, n, d, k, raw.data()));
+    std::vector<GaussianProcess> out((size_t)k);
+    for (int32_t j = 0; j < k; j++) {
+        out[(size_t)j].h_.reset(raw[(size_t)j]);
+        out[(size_t)j].d_ = d;
+        out[(size_t)j].n_evals_ = 1;
+    }
+    int64_t hh = 0;
+    check(egx_gp_dims(raw[0], nullptr, nullptr, nullptr, &hh));
+    if (tuning_.init.size() != 1 && tuning_.init.size() != (size_t)hh)
+        throw InvalidValueError(EGX_ERR_INVALID_VALUE, "Initial guess for theta should be either 1-dim or dim of xtrain, got " +
+                                                           std::to_string(tuning_.init.size()));
+    std::vector<double> thetas((size_t)k * (size_t)hh);
+    for (size_t i = 0; i < thetas.size(); i++) thetas[i] = tuning_.init[tuning_.init.size() == 1 ? 0 : i % (size_t)hh];
+    check(egx_gp_finalize_multi(raw.data(), k, thetas.data(), hh));
+    return out;
+}
 
 inline GaussianProcess GpParams::fit(const double *x, int64_t n, int64_t d, const double *y) const {
     egx_gp_config cfg;

@@ -138,3 +138,65 @@ def test_a_hand_off_that_never_arrives_is_an_error_within_the_bound_not_a_hang(e
     knobs("pipe_stall", 1)
     with pytest.raises(egx.EgxError, match="pipelined chain kernel"):
         egx.potrf(a)
+
+
+# ---- lock-step across MODELS (egx_gp_create_group / egx_gp_finalize_multi): the expert loop of egobox-moe
+#      (crates/moe/src/algorithm.rs:167-177), EGO's objective + constraint surrogates (crates/ego/src/solver/solver_impl.rs:370-391)
+@pytest.mark.parametrize("n,d,k,mean,corr", [(700, 4, 5, 0, 0), (2100, 5, 3, 1, 3), (4200, 6, 3, 0, 0)])
+def test_models_of_a_group_fitted_in_lock_step_are_their_lone_fits_bit_for_bit(egx, n, d, k, mean, corr):
+    sets = [_data(n, d, 50 + j) for j in range(k)]
+    thetas = np.stack([np.full(d, 0.35 + 0.05 * j) for j in range(k)])
+    xq = np.random.default_rng(1).uniform(size=(64, d))
+    lone = []
+    for (x, y), th in zip(sets, thetas):
+        with egx.GpHandle(x, y, mean=mean, corr=corr) as h:
+            h.finalize(th)
+            lone.append((h.fitted_scalars(), h.predict(xq), h.predict_var(xq)))
+    hs = egx.GpHandle.create_group(np.stack([s[0] for s in sets]), np.stack([s[1] for s in sets]), mean=mean, corr=corr)
+    try:
+        assert all(h.schedule() == hs[0].schedule() for h in hs)
+        egx.finalize_multi(hs, thetas)
+        for h, want in zip(hs, lone):
+            assert h.fitted_scalars() == want[0]
+            np.testing.assert_array_equal(h.predict(xq), want[1])
+            np.testing.assert_array_equal(h.predict_var(xq), want[2])
+        # the reduced likelihood alone, members in another order and next to a handle that belongs to no group
+        lk_ref = [h.likelihood(th)[0] for h, th in zip(hs, thetas * 1.1)]
+        with egx.GpHandle(*sets[0], mean=mean, corr=corr) as free:
+            order = [2, 0, 1] if k >= 3 else list(range(k))
+            lk, st = egx.likelihood_multi([hs[i] for i in order] + [free], np.concatenate([thetas[order] * 1.1, thetas[:1] * 1.1]))
+            assert np.all(st == 0)
+            for q, i in enumerate(order):
+                assert lk[q] == lk_ref[i]
+            assert lk[-1] == lk_ref[0]                 # the same training set, outside the group: the same bits
+        with pytest.raises(egx.InvalidValueError, match="distinct"):
+            egx.finalize_multi([hs[0], hs[0]], thetas[:2])
+        # members go one by one; the others keep working, alone and together
+        hs[1].close()
+        egx.finalize_multi([hs[0], hs[2]], thetas[[0, 2]])
+        assert hs[0].fitted_scalars() == lone[0][0] and hs[2].fitted_scalars() == lone[2][0]
+        hs[0].finalize(thetas[0])
+        assert hs[0].fitted_scalars() == lone[0][0]
+    finally:
+        for h in hs:
+            h.close()
+
+
+def test_expert_loop_in_lock_step(egx):
+    """GpMixture.fit_experts: clusters of equal size through fit_group, the odd one through fit; predictions of the mixture
+    equal those of a mixture of separately fitted experts."""
+    from egobox_amd.moe import GaussianMixture, GpMixture
+    d = 3
+    sizes = [500, 500, 380, 500]
+    sets = [_data(n, d, 70 + j) for j, n in enumerate(sizes)]
+    params = egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr()).theta_tuning(egx.ThetaTuning.Fixed(np.full(d, 0.4)))
+    rng = np.random.default_rng(2)
+    w = rng.random(4) + 0.5
+    gmx = GaussianMixture(w / w.sum(), rng.random((4, d)), np.array([np.eye(d) * 0.3] * 4), 0.9)
+    mix = GpMixture.fit_experts(params, [s[0] for s in sets], [s[1] for s in sets], gmx, "smooth")
+    ref = GpMixture([params.fit(*s) for s in sets], gmx, "smooth")
+    xq = rng.uniform(size=(200, d))
+    np.testing.assert_array_equal(mix.predict(xq), ref.predict(xq))
+    np.testing.assert_array_equal(mix.predict_var(xq), ref.predict_var(xq))
+    for e in mix.experts + ref.experts:
+        e.close()
