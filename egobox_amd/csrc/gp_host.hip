@@ -754,14 +754,19 @@ int backward_solve(egx_gp *gp, Workspace &w) {
     return EGX_SUCCESS;
 }
 
-// second half of a fit at fixed theta, behind the evaluation that was enqueued on workspace 0: the host half of the
-// likelihood, gamma = C^-T rho, the fitted state
-static int finalize_tail(egx_gp *gp, const std::vector<double> &coef, int hcols, const std::vector<double> &thfull) {
-    Workspace &w = gp->ws[0];
+// second half of a fit at fixed theta, behind the evaluation that was enqueued on workspace 0, in two steps so that several
+// models' tails overlap (egx_gp_finalize_multi): (1) the host half of the likelihood, then gamma = C^-T rho and the fitted
+// state's device copies ENQUEUED on the model's own stream; (2) wait for them, take over the fitted state
+struct FinalizeTail {
     EvalResult res;
-    auto t0 = std::chrono::steady_clock::now();
+    std::chrono::steady_clock::time_point t0, t1;
+};
+static int finalize_tail_enqueue(egx_gp *gp, const std::vector<double> &coef, int hcols, FinalizeTail &ft) {
+    Workspace &w = gp->ws[0];
+    EvalResult &res = ft.res;
+    ft.t0 = std::chrono::steady_clock::now();
     EGX_RC(finish_eval(gp, w, res, 1));
-    auto t1 = std::chrono::steady_clock::now();
+    ft.t1 = std::chrono::steady_clock::now();
     if (res.status == EGX_STATUS_NOT_POSITIVE_DEFINITE) {
         set_error("LinalgError: matrix is not positive definite (pivot " + std::to_string(*w.h_info) + ")");
         return EGX_ERR_LINALG;
@@ -789,9 +794,15 @@ static int finalize_tail(egx_gp *gp, const std::vector<double> &coef, int hcols,
     EGX_HIP_CHECK(hipMemcpyAsync(gp->d_fit_coef, w.d_coef, sizeof(double) * coef.size(), hipMemcpyDeviceToDevice,
                                  w.stream));
     if (hcols == 1) EGX_RC(launch_scale_rows(w.stream, gp->d_xT, gp->n_pad, gp->d, gp->d_fit_coef, dev_xs_fit(gp)));
+    return EGX_SUCCESS;
+}
+static int finalize_tail_complete(egx_gp *gp, const std::vector<double> &coef, int hcols, const std::vector<double> &thfull,
+                                  FinalizeTail &ft) {
+    Workspace &w = gp->ws[0];
+    EvalResult &res = ft.res;
     EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
     auto t2 = std::chrono::steady_clock::now();
-    gp->gamma.assign(w.h_vec, w.h_vec + n);
+    gp->gamma.assign(w.h_vec, w.h_vec + gp->n);
     gp->theta = thfull;
     gp->likelihood = res.lkh;
     gp->sigma2 = res.sigma2n * gp->y_std * gp->y_std;  // algorithm.rs:1048
@@ -803,12 +814,19 @@ static int finalize_tail(egx_gp *gp, const std::vector<double> &coef, int hcols,
     gp->fitted = true;
     gp->fit_epoch++;
     gp->small_var_calls = 0;
-    float gpu = 0;
-    hipEventElapsedTime(&gpu, w.eval_stream == w.stream ? w.ev[0] : w.ev[4], w.eval_stream == w.stream ? w.ev[3] : w.ev[4]);
-    double host_ms = std::chrono::duration<double, std::milli>(t1 - t0).count() - gpu;
-    if (host_ms < 0) host_ms = 0;
-    if (w.eval_stream == w.stream) record_timings(gp, w, host_ms, std::chrono::duration<double, std::milli>(t2 - t1).count());
+    if (w.eval_stream == w.stream) {  // (a model that rode in another model's launch sequence has no timings of its own)
+        float gpu = 0;
+        hipEventElapsedTime(&gpu, w.ev[0], w.ev[3]);
+        double host_ms = std::chrono::duration<double, std::milli>(ft.t1 - ft.t0).count() - gpu;
+        if (host_ms < 0) host_ms = 0;
+        record_timings(gp, w, host_ms, std::chrono::duration<double, std::milli>(t2 - ft.t1).count());
+    }
     return EGX_SUCCESS;
+}
+static int finalize_tail(egx_gp *gp, const std::vector<double> &coef, int hcols, const std::vector<double> &thfull) {
+    FinalizeTail ft;
+    EGX_RC(finalize_tail_enqueue(gp, coef, hcols, ft));
+    return finalize_tail_complete(gp, coef, hcols, thfull, ft);
 }
 int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     std::vector<double> coef, thfull;
@@ -1481,11 +1499,17 @@ static int multi_eval(egx_gp *const *gps, int32_t k, const double *thetas, int64
         for (int j = 0; j < len; j++) gps[i + j]->fitted = false;
         if (len > 1) EGX_RC(enqueue_eval_members(gps + i, len, coefs.data(), hcols));
         else EGX_RC(enqueue_eval(gps[i], gps[i]->ws[0], coefs[0], hcols));
+        std::vector<FinalizeTail> tails((size_t)(finalize ? len : 0));
+        std::vector<int> trc((size_t)len, EGX_SUCCESS);
+        if (finalize)  // (the models' tails -- host half, gamma's back-substitution on each model's own stream -- overlap)
+            for (int j = 0; j < len; j++) trc[(size_t)j] = finalize_tail_enqueue(gps[i + j], coefs[(size_t)j], hcols, tails[(size_t)j]);
         for (int j = 0; j < len; j++) {
             egx_gp *g = gps[i + j];
             int rc;
             if (finalize) {
-                rc = finalize_tail(g, coefs[(size_t)j], hcols, thfull[(size_t)j]);
+                rc = trc[(size_t)j];
+                if (rc == EGX_SUCCESS) rc = finalize_tail_complete(g, coefs[(size_t)j], hcols, thfull[(size_t)j], tails[(size_t)j]);
+                else (void)hipStreamSynchronize(g->ws[0].stream);
             } else {
                 EvalResult res;
                 rc = finish_eval(g, g->ws[0], res, 0);

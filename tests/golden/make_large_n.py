@@ -9,6 +9,7 @@ tests/test_oracle_golden.py) needs ~100 s per likelihood at n = 16384 on 8 cores
                           (sq-exp and Matern-5/2, seed 42, theta = 0.5/sqrt(d))
   grad_n4096_d32_<corr>   theta-gradient of the likelihood (oracle closed form), the largest n whose
                           (pairs, d) table fits comfortably
+  grad_n16384_d32_matern52  the same at config 3's full size (--only grad16384: one n^3 CPU job, ~10 minutes)
   sweep_n16384_d32        config 4: likelihood + status for 28 rows of theta_sweep_candidates(512, 32)
                           (row 0, the first 13 LHS rows, the 14 rows with the smallest sum theta^2) and 3
                           extra lower-bound rows that exercise the not-positive-definite status
@@ -19,7 +20,7 @@ tests/test_oracle_golden.py) needs ~100 s per likelihood at n = 16384 on 8 cores
 Inputs are regenerated in the tests from the same seeds (oracle.lhs_classic / griewank ==
 egobox_amd.workload), so only thetas, scalars and the prediction vectors are stored.
 
-    python tests/golden/make_large_n.py [--only fit|grad|sweep|expert] [--out tests/golden/large_n.json]
+    python tests/golden/make_large_n.py [--only fit|grad|grad16384|sweep|expert|experts] [--out tests/golden/large_n.json]
 
 Parts are merged into an existing output file, so the script can be run piecewise.
 """
@@ -90,6 +91,20 @@ def part_grad(out):
         out[f"grad_n{n}_d{d}_{corr}"] = {"n": n, "d": d, "seed": 42, "corr": corr, "theta": theta.tolist(),
                                           "likelihood": lk, "grad": g.tolist()}
         print(f"grad {corr}: lkh {lk!r} |g| {np.linalg.norm(g):.6e} ({time.time() - t0:.0f}s)", flush=True)
+
+
+def part_grad16384(out):
+    """Config 3 at its full size: the oracle's closed-form theta-gradient at n = 16384, d = 32, Matern-5/2 (one n^3 CPU job:
+    ~2 GB each for R, C^-1, R^-1 and the per-dimension temporaries; ~10 minutes on 8 cores)."""
+    n, d = 16384, 32
+    x = O.lhs_classic(n, d, 42)
+    y = O.griewank(x)
+    theta = np.full(d, 0.5 / math.sqrt(d)) * (1.0 + 0.3 * np.sin(np.arange(d)))
+    t0 = time.time()
+    lk, g = O.likelihood_grad(x, y, theta, O.CONSTANT, O.MATERN52)
+    out[f"grad_n{n}_d{d}_{O.MATERN52}"] = {"n": n, "d": d, "seed": 42, "corr": O.MATERN52, "theta": theta.tolist(),
+                                             "likelihood": lk, "grad": g.tolist()}
+    print(f"grad16384 {O.MATERN52}: lkh {lk!r} |g| {np.linalg.norm(g):.6e} ({time.time() - t0:.0f}s)", flush=True)
 
 
 def part_sweep(out):
@@ -212,6 +227,9 @@ def main():
         save()
     if want("grad"):
         part_grad(out)
+        save()
+    if args.only == "grad16384" or (args.only == "" and f"grad_n16384_d32_{O.MATERN52}" not in out):
+        part_grad16384(out)
         save()
     if want("fit"):
         for _ in part_fit(out):
