@@ -183,6 +183,19 @@ def host_fp64_peak():
         return None
 
 
+def stream_kernel_signature():
+    """sha256 of the source text of the k_gemm_stream template (the kernel `roofline` describes): the committed PMC summary
+    carries the hash it was measured with."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, "egobox_amd", "csrc", "kernels_chol.hip")) as f:
+            txt = f.read()
+        a = txt.rfind("template", 0, txt.index("void k_gemm_stream("))
+        return hashlib.sha256(txt[a:txt.index("\n}\n", a) + 3].encode()).hexdigest()
+    except (OSError, ValueError):
+        return "unknown"
+
+
 def measured_traffic(n, d):
     """HBM/fabric bytes per launch of the update kernel from the committed PMC summary (separate --pmc passes of
     `bench.py --steps 1`), corrected as the MI355X guide prescribes: on gfx950 FETCH_SIZE tallies a 16 B/lane
@@ -869,11 +882,22 @@ def main():
             gq.close()
         traffic, pmc = measured_traffic(n, d)
         # the same counters for the launch `roofline` describes (8 matrices, left-looking long update): committed summary
-        ll_pmc = None
+        # (an OFFLINE measurement: attached only while it still describes this build -- the kernel's source text has the hash
+        #  the summary was taken with and the live launch shape is the measured one; otherwise `traffic` is null)
+        ll_pmc, ll_stale = None, None
         ll_path = os.path.join(ROOT, "profiles", "r04_pmc_lockstep_group_left_looking_summary.json")
         if (n, d) == (16384, 32) and os.path.exists(ll_path):
             with open(ll_path) as f:
                 ll_pmc = json.load(f)
+            sig = stream_kernel_signature()
+            if sig != ll_pmc.get("kernel_source_sha256"):
+                ll_stale = f"k_gemm_stream source changed since the counters were taken ({sig[:12]} != recorded)"
+            elif roof_group is not None and (roof_group["launches"] != ll_pmc.get("launches_per_factorisation") or
+                                             abs(roof_group["flops_per_launch_avg"] / ll_pmc["algorithmic_flops_per_launch"] - 1.0) > 1e-6):
+                ll_stale = "the live launch shape (launches per factorisation / flops per launch) is not the measured one"
+            if ll_stale:
+                sys.stderr.write(f"bench.py: roofline.traffic not attached: {ll_stale}\n")
+                ll_pmc = None
         ok = stats[args.warmup * nb:] == 0
         out = {
             "metric": "gp_fixed_theta_fits_per_sec", "value": fits / elapsed, "unit": "fits/s",
@@ -926,7 +950,11 @@ def main():
                        "the previous group (diagonal blocks, panel solves, in-group updates) shares the chip with it as in "
                        "the product.  Reproduce: rocprofv3 --kernel-trace --stats -- python tools/group_roofline.py, row "
                        "'left-looking long update' of tools/rocpd_stats.py (profiles/r04_group_roofline_kernel_stats.txt)",
+                "traffic_stale": ll_stale,
                 "traffic_source": (None if not ll_pmc else {
+                    "measured": "OFFLINE (round 4), not in this run; attached because the kernel source hash and the live launch "
+                                "shape match the measurement",
+                    "kernel_source_sha256": ll_pmc.get("kernel_source_sha256"),
                     "file": "profiles/r04_pmc_lockstep_group_left_looking_summary.json (from ..._pass1-3.json: separate "
                             "rocprofv3 --pmc passes of tools/group_roofline.py, offline)",
                     "fetch_size_bytes_per_launch_raw": ll_pmc["fetch_bytes_per_launch"],

@@ -36,7 +36,7 @@ constexpr int kNB = 256;        // outer Cholesky block (K of the trailing updat
 constexpr int kDiagTile = 64;   // diagonal tile factored in registers by one wave
 constexpr int kRhsPad = 128;    // rows appended below R for the fused forward solves
 // (round 4: no cap on the input dimension d any more -- the correlation kernels stage the dimensions in chunks of 64;
-//  only the batched x-gradient kernel stops at 256, kernels_corr.hip kXgMaxDim)
+//  the x-gradient kernels need d * (hcols + 5) <= 20480: coefficients and one training point in LDS)
 
 inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
@@ -164,7 +164,6 @@ struct PotrfBatch {
     int64_t sS = 0;          // sS ints apart; nullptr: the chain runs as separate launches (k_potf2_reg, k_panel_trsm16, updates)
     int pipe = 0;            // ... the chain of every group of panels is one chain launch (schedule.h: per handle)
     int whole = 0;           // ... the WHOLE factorisation is one chain launch (every update inside it)
-    int tail = 0;            // ... right-looking: the last `tail` columns are one chain launch
 };
 int potrf_left_for(int n_pad, int lockstep);
 int w_left_for(int n_pad, int lockstep);
@@ -226,10 +225,8 @@ int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot
 int pipe_signal(hipStream_t s, const PotrfBatch &pb, int value);
 void pipe_set_trace(long long *device_buf);  // profiling: 8 words per ticket of the next chain launches (nullptr: off)
 int pipe_enabled();    // EGX_PIPE (default on)
-int pipe_group_max();  // EGX_PIPE_MAX: padded size up to which the chain of every panel group is a chain launch (schedule.h)
-int pipe_tail_cols();  // EGX_PIPE_TAIL (default 0)
-int pipe_whole_max();  // EGX_PIPE_WHOLE: padded size up to which a handle may factor as ONE chain launch (schedule.h)
-int pipe_set_knob(const char *name, int value);  // "pipe", "pipe_wgs", "pipe_rt", "pipe_timeout_ms", "pipe_stall" (tests); INT_MIN = unknown
+void pipe_test_set_workgroups(int wgs);  // tools/pipe_check: grid of the next chain launches (0 = the product's)
+int pipe_set_knob(const char *name, int value);  // "pipe", "pipe_timeout_ms", "pipe_stall" (test hook); INT_MIN = unknown
 int chol_init();  // one-time function attribute setup (dynamic LDS sizes)
 int set_knob(const char *name, int value);  // kernels_chol.hip tuning knobs by name; INT_MIN = unknown
 

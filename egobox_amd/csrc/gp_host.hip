@@ -386,8 +386,7 @@ static int enqueue_eval_core(egx_gp *const *owners, Workspace *const *wss, int c
     pb.w_left = gp->sched.w_left;
     pb.pipe = gp->sched.pipe;
     pb.whole = gp->sched.whole;
-    pb.tail = gp->sched.tail;
-    pb.sync = (gp->sched.pipe || gp->sched.tail) ? lead_sync : nullptr;  // the chain of a group of panels as one persistent launch (kernels_pipe.hip)
+    pb.sync = gp->sched.pipe ? lead_sync : nullptr;  // the chain of a group of panels as one persistent launch (kernels_pipe.hip)
     pb.sS = gp->stride_S;
     EGX_RC(launch_potrf(st, lead.M, gp->ld, gp->n_pad, gp->m_tot, lead.dinv, lead.d_info, lead.lk.s2 ? &lead.lk : nullptr,
                         &lead.trace, &pb, W0 ? &inv : nullptr));
@@ -1343,9 +1342,16 @@ int32_t egx_gp_shrink(egx_gp *gp, int32_t n_keep) {
         set_error("egx_gp_shrink: no memory for the smaller slabs (the handle is unchanged)");
         return EGX_ERR_HIP;
     }
-    EGX_HIP_CHECK(hipMemcpy(nM, gp->slab_M, sizeof(double) * (size_t)gp->stride_M * n_keep, hipMemcpyDeviceToDevice));
-    EGX_HIP_CHECK(hipMemcpy(nD, gp->slab_D, sizeof(double) * (size_t)gp->stride_D * n_keep, hipMemcpyDeviceToDevice));
-    EGX_HIP_CHECK(hipMemcpy(nI, gp->slab_I, sizeof(int) * (size_t)n_keep, hipMemcpyDeviceToDevice));
+    hipError_t ce = hipMemcpy(nM, gp->slab_M, sizeof(double) * (size_t)gp->stride_M * n_keep, hipMemcpyDeviceToDevice);
+    if (ce == hipSuccess) ce = hipMemcpy(nD, gp->slab_D, sizeof(double) * (size_t)gp->stride_D * n_keep, hipMemcpyDeviceToDevice);
+    if (ce == hipSuccess) ce = hipMemcpy(nI, gp->slab_I, sizeof(int) * (size_t)n_keep, hipMemcpyDeviceToDevice);
+    if (ce != hipSuccess) {  // the handle keeps its slabs, the new ones go back
+        (void)hipFree(nM);
+        (void)hipFree(nD);
+        (void)hipFree(nI);
+        set_error(std::string("egx_gp_shrink: copying the kept workspaces failed (the handle is unchanged): ") + hipGetErrorString(ce));
+        return EGX_ERR_HIP;
+    }
     (void)hipFree(gp->slab_M);
     (void)hipFree(gp->slab_D);
     (void)hipFree(gp->slab_I);
@@ -1377,7 +1383,7 @@ int32_t egx_gp_get_schedule(const egx_gp *gp, int32_t *out, int32_t out_len) {
     }
     out[0] = gp->sched.left, out[1] = gp->sched.w_left, out[2] = gp->sched.pipe, out[3] = gp->sched.whole;
     out[4] = gp->sched.group_panels, out[5] = gp->lockstep;
-    if (out_len > 6) out[6] = gp->sched.tail;
+    for (int32_t i = 6; i < out_len; i++) out[i] = 0;  // (reserved)
     return EGX_SUCCESS;
 }
 
@@ -1705,8 +1711,8 @@ int32_t egx_potrf(double *a, int64_t n, int32_t *info) {
     const PotrfSchedule sch = schedule_for(n_pad, 1, 1);
     DevBuf d_sync;  // (ints in double-sized slots)
     PotrfBatch pb;
-    pb.left = sch.left, pb.pipe = sch.pipe, pb.whole = sch.whole, pb.tail = sch.tail;
-    if (sch.pipe || sch.tail) {
+    pb.left = sch.left, pb.pipe = sch.pipe, pb.whole = sch.whole;
+    if (sch.pipe) {
         EGX_RC(d_sync.alloc((pipe_sync_ints(n_pad, n_pad) + 1) / 2));
         pb.sync = reinterpret_cast<int *>(d_sync.p);
     }

@@ -367,7 +367,9 @@ int xgrad_impl(egx_gp *gp, const double *xq, int64_t m, double *gy, double *gv) 
         return EGX_ERR_INVALID_VALUE;
     }
     EGX_RC(set_device(gp));
-    if (m > 0 && m <= 8) return xgrad_small(gp, xq, m, gy, gv);
+    // (the few-query kernel keeps 5 + hcols doubles per input dimension in LDS, the batched one 1 + hcols: very wide
+    //  inputs take the batched form whatever m is)
+    if (m > 0 && m <= 8 && (int64_t)gp->d * (gp->fit_hcols + 5) <= 20480) return xgrad_small(gp, xq, m, gy, gv);
     Workspace &w = gp->ws[0];
     const int n = gp->n, n_pad = gp->n_pad, d = gp->d, p = gp->p, rp = gp->rhs_pad;
     if (gv) EGX_RC(ensure_winv(gp));

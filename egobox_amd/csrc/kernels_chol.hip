@@ -36,6 +36,7 @@
 #include "potf2_blocks.h"
 #include "mfma_gemm_core.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -820,21 +821,18 @@ __global__ void k_gram_reduce(const double *__restrict__ P, int rows, int nsplit
 // =============================================================================================
 // host launchers
 // =============================================================================================
-// Tuning knobs that survive (each read once; everything else that was ever switchable has its A/B in profiles/ and
-// is gone -- DESIGN.md section 4 lists both):
-static int g_potrf_group = 0;         // EGX_POTRF_GROUP: panels per trailing update, 1..8 (0 = by size: 4 from n_pad 14336, else 2)
-static int g_stream_min_tiles = 128;  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles PER MATRIX go to k_gemm_stream
-static int g_stream_tpw = 1;          // EGX_STREAM_TPW: tiles a workgroup of k_gemm_stream walks (1: CUs turn over, the chain squeezes in)
-static int g_gemm_small_max = 1024;   // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used
-static int g_look_min_cols = 3072;    // EGX_LOOK_MIN: look-ahead while at least this many columns trail the next group
-static int g_trsm_group = 0;          // EGX_TRSM_GROUP: panels per update in the solves after the factorisation (0 = 4)
-static int g_lur_side = 1;            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU also in lock-step batches
-static int g_trsm_left = 1;           // EGX_TRSM_LEFT=0: the solves after the factorisation update right-looking (one pass over all later columns per group)
-static int g_tail_merge = 1;          // EGX_TAIL_MERGE=0: without look-ahead the next group's columns and the rest are updated by two launches
-static int g_lur_side_min = 6144;     // EGX_LUR_SIDE_MIN: ... only while at least this many columns trail the look-ahead group
-static int g_w_left = 1;              // EGX_W_LEFT: left-looking update of the C^-T rider 0 never, 1 per handle (w_left_for), 2 always
-static int g_potrf_left = 1;          // EGX_POTRF_LEFT: left-looking group updates (launch_potrf) 0 never, 1 for handles with n_pad >= 14336
-                                      // and a lock-step width >= 8, 2 always
+// The run-time settings that survive (environment, read once; egx_set_tuning for A/B runs inside one process).  With EGX_PIPE
+// and EGX_PIPE_TIMEOUT_MS (kernels_pipe.hip) that makes eight; everything else that was ever switchable is a constant now,
+// its A/B in profiles/ (DESIGN.md appendix B lists them).  Atomics: a setting may change while another thread evaluates --
+// that thread then sees the old or the new value per read, never a torn one (schedules are per handle and not affected).
+static std::atomic<int> g_potrf_group{0};         // EGX_POTRF_GROUP: panels per trailing update, 1..8 (0 = by size: 4 from n_pad 14336, else 2)
+static std::atomic<int> g_stream_min_tiles{128};  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles PER MATRIX go to k_gemm_stream
+static std::atomic<int> g_gemm_small_max{1024};   // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used
+static std::atomic<int> g_look_min_cols{3072};    // EGX_LOOK_MIN: look-ahead while at least this many columns trail the next group
+static std::atomic<int> g_lur_side{1};            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU (bench.py's roofline leg)
+static std::atomic<int> g_potrf_left{1};          // EGX_POTRF_LEFT: left-looking group updates (factor and C^-T rider) 0 never, 1 by schedule.h, 2 always
+constexpr int kTrsmGroupPanels = 4;   // panels per update in the solves after the factorisation
+constexpr int kLurSideMinCols = 6144; // LUr on the side stream only while at least this many columns trail the look-ahead group
 
 int chol_init() {
     static std::once_flag once;
@@ -845,16 +843,10 @@ int chol_init() {
             if (g >= 1 && g <= 8) g_potrf_group = g;
         }
         if (const char *e = std::getenv("EGX_GEMM_SMALL")) g_gemm_small_max = std::atoi(e);
-        if (const char *e = std::getenv("EGX_STREAM_TPW")) g_stream_tpw = std::atoi(e) > 0 ? std::atoi(e) : 1;
         if (const char *e = std::getenv("EGX_STREAM_MIN")) g_stream_min_tiles = std::atoi(e) > 0 ? std::atoi(e) : 1;
         if (const char *e = std::getenv("EGX_LOOK_MIN")) g_look_min_cols = std::atoi(e);
-        if (const char *e = std::getenv("EGX_TRSM_GROUP")) g_trsm_group = std::atoi(e);
         if (const char *e = std::getenv("EGX_LUR_SIDE")) g_lur_side = std::atoi(e);
         if (const char *e = std::getenv("EGX_POTRF_LEFT")) g_potrf_left = std::atoi(e);
-        if (const char *e = std::getenv("EGX_TAIL_MERGE")) g_tail_merge = std::atoi(e);
-        if (const char *e = std::getenv("EGX_TRSM_LEFT")) g_trsm_left = std::atoi(e);
-        if (const char *e = std::getenv("EGX_W_LEFT")) g_w_left = std::atoi(e);
-        if (const char *e = std::getenv("EGX_LUR_SIDE_MIN")) g_lur_side_min = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess && rc_once == EGX_SUCCESS) {
@@ -878,11 +870,7 @@ static ScheduleKnobs schedule_knobs() {
     (void)chol_init();
     ScheduleKnobs k;
     k.potrf_left = g_potrf_left;
-    k.w_left = g_w_left;
     k.pipe = pipe_enabled();
-    k.pipe_max = pipe_group_max();
-    k.pipe_whole = pipe_whole_max();
-    k.pipe_tail = pipe_tail_cols();
     k.potrf_group = g_potrf_group;
     return k;
 }
@@ -899,19 +887,11 @@ int w_left_for(int n_pad, int lockstep) { return schedule_for(n_pad, lockstep, 1
 // value, or INT_MIN for an unknown name.  Not to be called while evaluations are in flight.
 int set_knob(const char *name, int value) {
     (void)chol_init();  // the environment is read first, once; a later call here wins
-    struct { const char *n; int *v; } tab[] = {{"potrf_group", &g_potrf_group}, {"stream_min", &g_stream_min_tiles},
-                                              {"stream_tpw", &g_stream_tpw},   {"gemm_small", &g_gemm_small_max},
-                                              {"look_min", &g_look_min_cols},  {"trsm_group", &g_trsm_group},
-                                              {"lur_side", &g_lur_side},
-                                              {"potrf_left", &g_potrf_left},   {"tail_merge", &g_tail_merge},
-                                              {"trsm_left", &g_trsm_left},     {"w_left", &g_w_left},
-                                              {"lur_side_min", &g_lur_side_min}};
+    struct { const char *n; std::atomic<int> *v; } tab[] = {{"potrf_group", &g_potrf_group}, {"stream_min", &g_stream_min_tiles},
+                                                           {"gemm_small", &g_gemm_small_max}, {"look_min", &g_look_min_cols},
+                                                           {"lur_side", &g_lur_side},         {"potrf_left", &g_potrf_left}};
     for (auto &e : tab)
-        if (std::string(name) == e.n) {
-            const int old = *e.v;
-            *e.v = value;
-            return old;
-        }
+        if (std::string(name) == e.n) return e.v->exchange(value);
     return -2147483647 - 1;
 }
 
@@ -943,14 +923,15 @@ int launch_gemm_nt_sub(hipStream_t s, double *C, int64_t ldc, const double *A, i
             wide_tiles = (int64_t)(M / 128) * (N / 256);
     }
     // (long K loops amortise a tile's prologue / epilogue and the launch: the left-looking group updates, K = all earlier
-    //  columns, stay on the stream kernel down to a handful of tiles)
-    const int64_t min_tiles = (K >= 2048) ? 8 : g_stream_min_tiles;
+    //  columns, stay on the stream kernel down to a handful of tiles.  The rule is by shape, for EVERY caller: the solves
+    //  after the factorisation and the prediction paths with K >= 2048 take the same kernel as the factorisation would)
+    const int64_t min_tiles = (K >= 2048) ? 8 : g_stream_min_tiles.load();
     if (K >= 2 * KC && wide_tiles >= min_tiles) {
         // the launches that fill the chip on their own are the ones the roofline trace follows
         if (used_big_tile) *used_big_tile = wide_tiles >= 512;
         const int nbx = M / 128, nby = N / 256;  // LOWER: column c holds nbx - 2 c tiles (M >= N in the factorisation)
         const int nt = (int)wide_tiles;
-        const dim3 grid((unsigned)((nt + g_stream_tpw - 1) / g_stream_tpw), 1, nz);
+        const dim3 grid((unsigned)nt, 1, nz);  // one tile per workgroup: CUs turn over, a chain beside it squeezes in
         if (lower && tag == 1)
             hipLaunchKernelGGL((k_gemm_stream<true, false, 1>), grid, dim3(512), ST_LDS_BYTES, s, C, ldc, A, lda, B, ldb, K, nbx,
                                nby, nt, info, bt);
@@ -1083,9 +1064,9 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     // from n ~ 14000 on (measured, profiles/r02_run13_group_by_size.txt: n = 16384 -2 %, n = 12288 even, n = 8192 +5 %:
     // the chain of a group gets longer while its trailing update shrinks)
     // the serial chain as ONE persistent launch per group of panels (kernels_pipe.hip) when the caller provides the hand-off
-    // words; up to `pipe_whole_max()` columns the whole factorisation is one such launch (every update inside it)
+    // words; for handles whose schedule says so (schedule.h) the whole factorisation is one such launch (every update inside it)
     const bool have_sync = pb.sync != nullptr && pipe_enabled() != 0;
-    const bool pipe = have_sync && pb.pipe;  // (chain launches per group; pb.tail: for the last columns only)
+    const bool pipe = have_sync && pb.pipe;
     if (have_sync) EGX_HIP_CHECK(hipMemsetAsync(pb.sync, 0, sizeof(int) * (nz > 1 ? (size_t)pb.sS * nz : pipe_sync_ints(n_pad, m_tot)), s));
     const int GW = potrf_group_panels(n_pad) * kNB;
     auto gwidth = [&](int g0) { return (n_pad - g0 < GW) ? (n_pad - g0) : GW; };
@@ -1274,15 +1255,6 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         const int gw = gwidth(g0);
         const int r1 = g0 + gw;  // first row/col of the trailing matrix
         if (r1 >= n_pad) break;  // (right-hand-side rows below the last block were solved by its panel)
-        if (have_sync && !inv && pb.tail > 0 && n_pad - r1 <= pb.tail) {
-            // TAIL (schedule.h): one update brings the whole trailing matrix up to date, one chain launch factors it -- where
-            // the trailing updates are too short to hide the chain, the chain should at least not be cut into launches
-            rc = update(s, r1, r1, m_tot - r1, n_pad - r1, g0, gw, 1, nullptr);
-            if (rc) return rc;
-            rc = launch_potrf_pipe(s, M, ld, n_pad, m_tot, dinv, info, pb, r1, n_pad - r1);
-            if (rc) return rc;
-            break;
-        }
         const int gw1 = gwidth(r1);
         // the cross-stream hand-off costs ~2 x 10 us; below ~3k trailing columns RU is shorter than that (and with
         // several fits in flight the extra hand-offs cost more than they hide: profiles/r02_run23_tail_lookahead_ab.txt)
@@ -1303,7 +1275,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             // profiles/r04_run11_lur_side_lone_ab.txt).  In the last ~6000 columns the chain is what a factorisation waits for and
             // its first panel solve waits for LUr: there LUr runs ALONE in front of RU (250 us instead of 520-770 beside it;
             // n = 16384 lone: 29.85 -> 29.6 ms, profiles/r04_run14_*).  Streams only: the arithmetic is the same either way.
-            hipStream_t slu = (g_lur_side && n_pad >= 14336 && n_pad - r1 - gw1 >= g_lur_side_min) ? s3 : s;
+            hipStream_t slu = (g_lur_side && n_pad >= 14336 && n_pad - r1 - gw1 >= kLurSideMinCols) ? s3 : s;
             if (slu != s) EGX_HIP_CHECK(hipStreamWaitEvent(slu, lk->ev_lu, 0));
             rc = update(slu, r1 + nb1, r1, m_tot - r1 - nb1, gw1, g0, gw, 0, nullptr);
             if (rc) return rc;
@@ -1315,7 +1287,7 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
             rc = inner_factor(s2, r1, gw1, s3, lk->ev_lur);
             if (rc) return rc;
             EGX_HIP_CHECK(hipEventRecord(lk->ev_panel, s2));
-        } else if (!look && g_tail_merge) {
+        } else if (!look) {
             // no look-ahead (small matrices, the last ~3000 columns): nothing runs beside the trailing update, so the next
             // group's columns and the rest are ONE launch (round 4: one ramp-up and one tail instead of two)
             const bool timed = trace && trace->ready && trace->used < GemmTrace::kMax;
@@ -1330,20 +1302,18 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
                 trace->used++;
             }
         } else {
-            // LU: the next group's columns only
+            // LU: the next group's columns only (look-ahead without a side stream)
             rc = update(s, r1, r1, m_tot - r1, gw1, g0, gw, 1, nullptr);
             if (rc) return rc;
-            if (look) {
-                EGX_HIP_CHECK(hipEventRecord(lk->ev_lu, s));
-                EGX_HIP_CHECK(hipStreamWaitEvent(s2, lk->ev_lu, 0));
-                rc = inner_factor(s2, r1, gw1, nullptr, nullptr);
-                if (rc) return rc;
-                EGX_HIP_CHECK(hipEventRecord(lk->ev_panel, s2));
-            }
+            EGX_HIP_CHECK(hipEventRecord(lk->ev_lu, s));
+            EGX_HIP_CHECK(hipStreamWaitEvent(s2, lk->ev_lu, 0));
+            rc = inner_factor(s2, r1, gw1, nullptr, nullptr);
+            if (rc) return rc;
+            EGX_HIP_CHECK(hipEventRecord(lk->ev_panel, s2));
         }
         // RU: the rest of the trailing matrix
         const int r2 = r1 + gw1;
-        if (r2 < n_pad && (look || !g_tail_merge)) {
+        if (r2 < n_pad && look) {
             const bool timed = trace && trace->ready && trace->used < GemmTrace::kMax;
             if (timed) EGX_HIP_CHECK(hipEventRecord(trace->e0[trace->used], s));
             bool big = false;
@@ -1394,12 +1364,12 @@ int launch_trsm_rows(hipStream_t s, const double *M, int64_t ldm, int n_pad, con
     // of the remaining columns per group (K = group width)
     // (groups of four panels: K = 1024 per update of the remaining columns.  The factorisation pays for wide groups with
     //  a longer serial chain; here every row tile is independent, so the width is bounded by the in-group work only)
-    const int GW = (g_trsm_group > 0 ? g_trsm_group : 4) * kNB;
-    // LEFT-looking over the groups (round 4, g_trsm_left; dense right-hand sides only): the columns of group J receive
+    const int GW = kTrsmGroupPanels * kNB;
+    // LEFT-looking over the groups (round 4; dense right-hand sides only): the columns of group J receive
     // the contributions of ALL earlier columns in one update with K = g0 before the group's own block substitution --
     // every tile of RT is read and written once by a long K loop instead of once per earlier group (K = 1024).  With
     // m >= 128 rows a launch always has m / 128 x 4 tiles: none of the underfill a lone factorisation's late updates have.
-    const bool left = g_trsm_left != 0 && !tri_rows;
+    const bool left = !tri_rows;
     for (int g0 = 0; g0 < n_pad; g0 += GW) {
         const int gw = (n_pad - g0 < GW) ? (n_pad - g0) : GW;
         const int gend = g0 + gw;
@@ -1461,7 +1431,7 @@ __global__ __launch_bounds__(256) void k_identity_rows(double *__restrict__ W, i
     }
 }
 
-int trsm_group_cols() { return (g_trsm_group > 0 ? g_trsm_group : 4) * kNB; }
+int trsm_group_cols() { return kTrsmGroupPanels * kNB; }
 
 int launch_identity_rows(hipStream_t s, double *W, int64_t ld, int n_pad, int count, int64_t stride) {
     int rc = chol_init();

@@ -463,20 +463,22 @@ __device__ __forceinline__ double xgrad_factor(double diff, const double *__rest
 }
 
 constexpr int kXgThreads = 128;
+constexpr size_t kLdsBytes = 160 * 1024;  // LDS of one CU (gfx950)
 
-// XAG (64 < d <= kXgMaxDim): the lane's own query coordinates come from global memory (L1 / L2) instead of a
-// [d][kXgThreads] LDS image, which together with the d x 64 training slab would not fit any more
-constexpr int kXgMaxDim = 256;
+// XAG (d > 64): the lane's own query coordinates come from global memory (L1 / L2) instead of a [d][kXgThreads] LDS
+// image, which together with the training slab would not fit any more; the slab is [d][2^js_shift] training points,
+// 64 wide up to d = 256 and narrower beyond (launch_xgrad picks the widest that fits the 160 KB of LDS)
 template <int CORR, int DK, bool VEC, bool XAG = false>
 __global__ __launch_bounds__(kXgThreads) void k_xgrad(const double *__restrict__ xqT, int64_t ldq,
                                                       const double *__restrict__ xT, int64_t ldx, int n, int d,
                                                       const double *__restrict__ coef, int hcols,
                                                       const double *__restrict__ Wt, int64_t ldw, int slabs_per_split,
-                                                      double *__restrict__ out, int m_pad) {
+                                                      double *__restrict__ out, int m_pad, int js_shift) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int jsh = XAG ? js_shift : 6, JS = 1 << jsh;
     double *xa = sm;                                  // [d][kXgThreads]  (not with XAG)
-    double *xj = sm + (XAG ? 0 : d * kXgThreads);     // [d][64]
-    double *cs = xj + d * 64;                         // [d * hcols]
+    double *xj = sm + (XAG ? 0 : d * kXgThreads);     // [d][JS]
+    double *cs = xj + d * JS;                         // [d * hcols]
     const int tid = threadIdx.x;
     const int a = blockIdx.x * kXgThreads + tid;
     const double *xag = xqT + a;
@@ -495,20 +497,20 @@ __global__ __launch_bounds__(kXgThreads) void k_xgrad(const double *__restrict__
             acc[kk] = 0.0;
             xr[kk] = (k0 + kk < d) ? EGX_XA(k0 + kk) : 0.0;
         }
-        for (int j0 = j_lo; j0 < j_hi; j0 += 64) {
+        for (int j0 = j_lo; j0 < j_hi; j0 += JS) {
             __syncthreads();
-            for (int e = tid; e < d * 64; e += kXgThreads) xj[e] = xT[(int64_t)(e >> 6) * ldx + j0 + (e & 63)];
+            for (int e = tid; e < d * JS; e += kXgThreads) xj[e] = xT[(int64_t)(e >> jsh) * ldx + j0 + (e & (JS - 1))];
             __syncthreads();
-            const int jn = (j_hi - j0 < 64) ? (j_hi - j0) : 64;
+            const int jn = (j_hi - j0 < JS) ? (j_hi - j0) : JS;
             for (int jj = 0; jj < jn; jj++) {
                 PairAcc<CORR> pa;
-                for (int k = 0; k < d; k++) pa.add(EGX_XA(k) - xj[k * 64 + jj], cs + k * hcols, hcols);
+                for (int k = 0; k < d; k++) pa.add(EGX_XA(k) - xj[k * JS + jj], cs + k * hcols, hcols);
                 const double wv = VEC ? Wt[j0 + jj] : Wt[(int64_t)(j0 + jj) * ldw + a];
                 const double rw = pa.value() * wv;
 #pragma unroll
                 for (int kk = 0; kk < DK; kk++)
                     if (k0 + kk < d)
-                        acc[kk] = __builtin_fma(rw, xgrad_factor<CORR>(xr[kk] - xj[(k0 + kk) * 64 + jj],
+                        acc[kk] = __builtin_fma(rw, xgrad_factor<CORR>(xr[kk] - xj[(k0 + kk) * JS + jj],
                                                                        cs + (k0 + kk) * hcols, hcols), acc[kk]);
             }
         }
@@ -1044,20 +1046,25 @@ int launch_xgrad(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_
     if (nsplit > slabs) nsplit = slabs;
     const int per = (slabs + nsplit - 1) / nsplit;
     dim3 grid(m_pad / kXgThreads, nsplit);
-    // d <= 64: the lane's query coordinates in LDS; up to kXgMaxDim: from global memory (XAG), the training slab alone in LDS
+    // d <= 64: the lane's query coordinates in LDS; beyond: from global memory (XAG), the training slab alone in LDS,
+    // as many training points wide (64, 32, ... 1) as fit beside the d x hcols coefficients
     const bool xag = d > kCorrDC;
-    if (d > kXgMaxDim) {
-        set_error("x-gradients: input dimension " + std::to_string(d) + " > " + std::to_string(kXgMaxDim) + " is not supported");
+    int js_shift = 6;
+    auto lds_for = [&](int sh) { return (size_t)((xag ? 0 : d * kXgThreads) + ((size_t)d << sh) + (size_t)d * hcols) * sizeof(double); };
+    while (js_shift > 0 && lds_for(js_shift) > kLdsBytes) js_shift--;
+    const size_t lds = lds_for(js_shift);
+    if (lds > kLdsBytes) {
+        set_error("x-gradients: " + std::to_string(d) + " inputs x " + std::to_string(hcols) +
+                  " coefficient columns do not fit the 160 KB of LDS (d * (hcols + 1) <= 20480)");
         return EGX_ERR_UNSUPPORTED;
     }
-    const size_t lds = (size_t)((xag ? 0 : d * kXgThreads) + d * 64 + d * hcols) * sizeof(double);
 #define EGX_XG1(C_, DK_, VEC_, XAG_)                                                                                         \
     {                                                                                                                        \
         if (lds > 65536)                                                                                                     \
             EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xgrad<C_, DK_, VEC_, XAG_>),                 \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
         hipLaunchKernelGGL((k_xgrad<C_, DK_, VEC_, XAG_>), grid, dim3(kXgThreads), lds, s, xqT, ldq, xT, ldx, n, d, coef,    \
-                           hcols, Wt, ldw, per, out, m_pad);                                                                 \
+                           hcols, Wt, ldw, per, out, m_pad, js_shift);                                                       \
     }
 #define EGX_XG(C_, DK_)                                    \
     if (xag) {                                             \
@@ -1082,9 +1089,21 @@ int launch_xgrad(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m_
 int launch_xgrad_point(hipStream_t s, int corr, const double *xqT, int64_t ldq, int m, const double *xT, int64_t ldx, int n,
                        int d, const double *coef, int hcols, const double *wvec, double *out) {
     dim3 grid(m, (n + 255) / 256);
-    const size_t lds = (size_t)(d + d * hcols + 4 * d) * sizeof(double);
-    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL(k_xgrad_point<C_>, grid, dim3(256), lds, s, xqT, ldq, xT, ldx, n, d, coef, hcols,
-                                               wvec, out, m));
+    const size_t lds = (size_t)(d + (size_t)d * hcols + 4 * (size_t)d) * sizeof(double);
+    if (lds > kLdsBytes) {
+        set_error("x-gradients: " + std::to_string(d) + " inputs x " + std::to_string(hcols) +
+                  " coefficient columns do not fit the 160 KB of LDS (d * (hcols + 5) <= 20480)");
+        return EGX_ERR_UNSUPPORTED;
+    }
+#define EGX_XGP(C_)                                                                                                          \
+    {                                                                                                                        \
+        if (lds > 65536)                                                                                                     \
+            EGX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_xgrad_point<C_>),                            \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+        hipLaunchKernelGGL(k_xgrad_point<C_>, grid, dim3(256), lds, s, xqT, ldq, xT, ldx, n, d, coef, hcols, wvec, out, m);  \
+    }
+    EGX_DISPATCH_CORR(corr, EGX_XGP(C_));
+#undef EGX_XGP
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }

@@ -8,11 +8,14 @@
 // panel's columns starts row chunk by row chunk as the solve finishes them, and the next diagonal block starts as soon as
 // its own ten tiles are up to date: no launch boundary, no cross-stream event on the chain.
 //
-// ROLES.  Every workgroup has 1024 threads and takes a TICKET (one device-scope atomicAdd) when it starts:
-//   ticket z < nz          DIAG role for matrix z of the lock-step batch: walks the group's diagonal blocks with
-//                          rb_factor_block<16, PIPE> (potf2_blocks.h), publishing every finished 16-column strip
-//   later tickets          workers: ticket -> (task, matrix) from a task list in an order in which every task depends on
-//                          EARLIER tasks only; a worker that finishes takes the next ticket
+// ROLES.  Every workgroup has 1024 threads.  It first takes a START ticket (one device-scope atomicAdd per launch):
+//   the first np * nz      DIAG workgroups, one per (diagonal block of the group, matrix of the lock-step batch): each factors
+//   workgroups to start    ITS block with rb_factor_block<16, PIPE> (potf2_blocks.h, inlined at the top of the kernel: no
+//                          call, no spill) as soon as the block's ten tiles are up to date, publishing every finished
+//                          16-column strip -- by order of START, not by blockIdx: whatever the dispatcher places first is
+//                          resident, so launches that share the chip cannot starve each other's diagonal blocks
+//   everybody (the DIAG    workers: TASK ticket -> (task, matrix) from a host-built list in an order in which every task
+//   workgroups afterwards) depends on EARLIER tasks only; a worker that finishes takes the next ticket
 //     TRSM(p, rows)        64 * RT rows of the panel below diagonal block p: the register-resident 16-row-tile solve of
 //                          k_panel_trsm16, driven by the strips as they are published (two workgroup barriers per strip,
 //                          the fragments of the next strip prefetched whenever that strip is already there)
@@ -43,6 +46,7 @@
 #include "mfma_gemm_core.h"
 #include "potf2_blocks.h"
 
+#include <atomic>
 #include <climits>
 #include <cstdlib>
 #include <map>
@@ -599,27 +603,21 @@ __global__ __launch_bounds__(1024) void k_potrf_pipe(PipeArgs a) {
 // =============================================================================================
 // host side
 // =============================================================================================
-static int g_pipe = 1;              // EGX_PIPE=0: launch_potrf keeps the chain as separate launches
-static int g_pipe_wgs = 0;          // EGX_PIPE_WGS: workgroups of a chain launch (0: one per compute unit)
-static int g_pipe_shared_wgs = 96;   // EGX_PIPE_SHARED_WGS: workgroups of a chain launch that runs beside other launches of its factorisation
-static int g_pipe_timeout_ms = 2000;  // EGX_PIPE_TIMEOUT_MS: bound of every wait inside the launch
-static int g_pipe_la = 16;           // EGX_PIPE_LA: how many panels ahead of their column's factorisation the coarse updates are queued
-static int g_pipe_max = 4096;           // EGX_PIPE_MAX: padded size up to which launch_potrf uses chain launches per group of panels
-static int g_pipe_tail = 0;             // EGX_PIPE_TAIL: see schedule.h (measured, not adopted)
-static int g_pipe_whole = 4096;         // EGX_PIPE_WHOLE: padded size up to which the WHOLE factorisation is one chain launch
-static long long *g_pipe_trace = nullptr;  // profiling buffer of the NEXT launches (pipe_set_trace; tools/pipe_check)
-static int g_pipe_stall = 0;        // test hook (egx_set_tuning "pipe_stall"): see PipeArgs::stall
+// Run-time settings (egx_set_tuning / environment): EGX_PIPE and EGX_PIPE_TIMEOUT_MS.  What else was switchable while the
+// launch was developed is a constant now, with its measurement: workgroups of a launch (one per compute unit; 96 beside other
+// launches of the same factorisation), the queue order of the coarse updates (16 panels ahead = right-looking), the size up to
+// which the chain is one launch (schedule.h) -- profiles/r05_pipe_*.txt, DESIGN.md appendix B.
+static std::atomic<int> g_pipe{1};               // EGX_PIPE: 0 separate launches everywhere, 1 by the handle's schedule (schedule.h), 2 chain launches per group only
+static std::atomic<int> g_pipe_timeout_ms{2000};  // EGX_PIPE_TIMEOUT_MS: bound of every wait inside the launch
+static std::atomic<int> g_pipe_stall{0};          // TEST HOOK (egx_set_tuning "pipe_stall"): see PipeArgs::stall
+static long long *g_pipe_trace = nullptr;         // profiling buffer of the NEXT launches (pipe_set_trace; tools/pipe_check)
+constexpr int kPipeSharedWgs = 96;  // workgroups of a chain launch that runs beside other launches of its factorisation
+constexpr int kPipeLookAhead = 16;  // how many panels ahead of their column's factorisation the coarse updates are queued
 
 static void pipe_init() {
     static std::once_flag once;
     std::call_once(once, [] {
         if (const char *e = std::getenv("EGX_PIPE")) g_pipe = std::atoi(e);
-        if (const char *e = std::getenv("EGX_PIPE_WGS")) g_pipe_wgs = std::atoi(e);
-        if (const char *e = std::getenv("EGX_PIPE_SHARED_WGS")) g_pipe_shared_wgs = std::atoi(e) > 0 ? std::atoi(e) : 1;
-        if (const char *e = std::getenv("EGX_PIPE_WHOLE")) g_pipe_whole = std::atoi(e);
-        if (const char *e = std::getenv("EGX_PIPE_TAIL")) g_pipe_tail = std::atoi(e);
-        if (const char *e = std::getenv("EGX_PIPE_MAX")) g_pipe_max = std::atoi(e);
-        if (const char *e = std::getenv("EGX_PIPE_LA")) g_pipe_la = std::atoi(e) >= 0 ? std::atoi(e) : 0;
         if (const char *e = std::getenv("EGX_PIPE_TIMEOUT_MS")) g_pipe_timeout_ms = std::atoi(e) > 0 ? std::atoi(e) : 1;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_pipe), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   kPipeLdsBytes);
@@ -628,32 +626,18 @@ static void pipe_init() {
 
 int pipe_set_knob(const char *name, int value) {
     pipe_init();
-    struct { const char *n; int *v; } tab[] = {{"pipe", &g_pipe}, {"pipe_wgs", &g_pipe_wgs},  {"pipe_shared_wgs", &g_pipe_shared_wgs}, {"pipe_la", &g_pipe_la}, {"pipe_whole", &g_pipe_whole}, {"pipe_tail", &g_pipe_tail}, {"pipe_max", &g_pipe_max},
-                                              {"pipe_timeout_ms", &g_pipe_timeout_ms}, {"pipe_stall", &g_pipe_stall}};
+    struct { const char *n; std::atomic<int> *v; } tab[] = {{"pipe", &g_pipe}, {"pipe_timeout_ms", &g_pipe_timeout_ms},
+                                                           {"pipe_stall", &g_pipe_stall}};
     for (auto &e : tab)
-        if (std::string(name) == e.n) {
-            const int old = *e.v;
-            *e.v = value;
-            return old;
-        }
+        if (std::string(name) == e.n) return e.v->exchange(value);
     return INT_MIN;
 }
 void pipe_set_trace(long long *buf) { g_pipe_trace = buf; }
+static int g_pipe_test_wgs = 0;  // tools/pipe_check only: the grid of the next chain launches (the same bits on 3 workgroups and on 256)
+void pipe_test_set_workgroups(int wgs) { g_pipe_test_wgs = wgs; }
 int pipe_enabled() {
     pipe_init();
     return g_pipe;
-}
-int pipe_group_max() {
-    pipe_init();
-    return g_pipe_max;
-}
-int pipe_tail_cols() {
-    pipe_init();
-    return g_pipe_tail;
-}
-int pipe_whole_max() {
-    pipe_init();
-    return g_pipe_whole;
 }
 
 // The task list of the group [g0, g0 + 256 np), in STAGES.  Stage s: the FINE tiles of X(s - 1 -> s) (panel s - 1 into block
@@ -696,7 +680,7 @@ struct PipePlan {
     int ntasks = 0;
 };
 static std::mutex g_plan_mu;
-static std::map<std::tuple<int, int, int, int, int, int, int>, PipePlan> g_plans;
+static std::map<std::tuple<int, int, int, int, int, int>, PipePlan> g_plans;
 
 // word 3 of the batch's hand-off words <- value, in stream order (a one-thread kernel behind the launch it reports on)
 __global__ void k_pipe_signal(int *word, int value) { store_flag(word, value); }
@@ -722,10 +706,10 @@ int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot
     PipePlan plan;
     {
         std::lock_guard<std::mutex> lock(g_plan_mu);
-        const auto key = std::make_tuple(dev, n_pad, m_tot, g0, np, rt, g_pipe_la);
+        const auto key = std::make_tuple(dev, n_pad, m_tot, g0, np, rt);
         auto it = g_plans.find(key);
         if (it == g_plans.end()) {
-            const std::vector<PipeTask> tasks = pipe_tasks(n_pad, m_tot, g0, np, rt, g_pipe_la);
+            const std::vector<PipeTask> tasks = pipe_tasks(n_pad, m_tot, g0, np, rt, kPipeLookAhead);
             PipePlan pl;
             pl.ntasks = (int)tasks.size();
             if (pl.ntasks > 0) {
@@ -776,7 +760,7 @@ int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot
     const long long n_diag = (long long)a.nz * np, want = n_diag + (long long)a.nz * plan.ntasks;
     // (a chain launch that runs BESIDE the launches it waits for or shares the chip with -- look-ahead -- must leave them
     //  compute units: its workgroups fill one each and would otherwise spin on a launch that cannot start)
-    long long wgs = g_pipe_wgs > 0 ? g_pipe_wgs : (shared_chip ? (g_pipe_shared_wgs < n_cu ? g_pipe_shared_wgs : n_cu) : n_cu);
+    long long wgs = g_pipe_test_wgs > 0 ? g_pipe_test_wgs : (shared_chip ? (kPipeSharedWgs < n_cu ? kPipeSharedWgs : n_cu) : n_cu);
     if (wgs > n_cu) wgs = n_cu;
     if (wgs > want) wgs = want;
     if (wgs < n_diag + 1) wgs = n_diag + 1;

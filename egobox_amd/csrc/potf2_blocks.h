@@ -502,19 +502,11 @@ __device__ __forceinline__ bool rb_factor_block(double *__restrict__ D, int64_t 
                     double *px = P + (R * 16 + fr) * RB_LD + f4;
                     *reinterpret_cast<d2_t *>(px) = d2_t{x[0], x[1]};
                     *reinterpret_cast<d2_t *>(px + 2) = d2_t{x[2], x[3]};
-#ifdef RB_DBG_PHASEA
-                    {
-                        double *dst = D + (int64_t)(R * 16 + fr) * ld + k * 16 + f4;
-                        store_d2<PIPE>(dst, d2_t{x[0], x[1]});
-                        store_d2<PIPE>(dst + 2, d2_t{x[2], x[3]});
-                    }
-#else
                     if constexpr (!PIPE) {  // (PIPE: the strip's column goes to global memory from the LDS panel, in phase B)
                         double *dst = D + (int64_t)(R * 16 + fr) * ld + k * 16 + f4;
                         *reinterpret_cast<d2_t *>(dst) = d2_t{x[0], x[1]};
                         *reinterpret_cast<d2_t *>(dst + 2) = d2_t{x[2], x[3]};
                     }
-#endif
                     if (s + 1 < RB_NS && (m_pair & (1u << s))) {  // slot s + 1 is tile (k+1, k+1): T -= X X^T, A' = own LDS rows
                         const double *pa = P + (R * 16 + pr) * RB_LD + f4;
                         const d2_t a01 = *reinterpret_cast<const d2_t *>(pa), a23 = *reinterpret_cast<const d2_t *>(pa + 2);
@@ -530,7 +522,6 @@ __device__ __forceinline__ bool rb_factor_block(double *__restrict__ D, int64_t 
         }
         __syncthreads();
         // ---- phase B: all other tiles right of column k, while wave 0 factors tile (k+1, k+1)
-#ifndef RB_DBG_PHASEA
         if constexpr (PIPE) {
             // PIPE: update wave w first sends row tile w of the strip's column (X_w, in the LDS panel since phase A) to global
             // memory, write-through: the stores leave the TRSM phase (they cost it address registers it does not have, and
@@ -542,7 +533,6 @@ __device__ __forceinline__ bool rb_factor_block(double *__restrict__ D, int64_t 
                 store_d2_sc1(dst + 2, *reinterpret_cast<const d2_t *>(px + 2));
             }
         }
-#endif
 #pragma unroll
         for (int s = 0; s < RB_NS; s++) {
             if (m_upd & (1u << s)) {

@@ -11,39 +11,38 @@
 //   >= 14336              4 .. 7            -                       0      1        0      0       4
 //   >= 14336              >= 8              -                       1      1        0      0       4
 //
-// left / w_left  left-looking group updates of the factorisation / of the theta-gradient's C^-T rider (EGX_POTRF_LEFT,
-//                EGX_W_LEFT: 0 never, 1 by the table, 2 always).  Measured: n = 16384 in lock-step groups of eight +2.3 % on
-//                the sweep, a lone matrix 2.4x slower, n = 8192 -14 % (profiles/r04_run4_*, r04_run5_*, r04_run12_*)
+// left / w_left  left-looking group updates of the factorisation / of the theta-gradient's C^-T rider (EGX_POTRF_LEFT: 0 never,
+//                1 by the table, 2 always).  Measured: n = 16384 in lock-step groups of eight +2.3 % on the sweep, a lone
+//                matrix 2.4x slower, n = 8192 -14 % (profiles/r04_run4_*, r04_run5_*, r04_run12_*)
 // pipe           the serial chain of a group of panels -- diagonal blocks, panel solves, in-group updates -- is ONE persistent
 //                launch with device-side hand-offs (kernels_pipe.hip; EGX_PIPE=0: separate launches everywhere).  Up to
-//                EGX_PIPE_MAX (4096) columns: beyond, a group's panel solves and updates are chip-filling launches of their
+//                kPipeMaxCols (4096) columns: beyond, a group's panel solves and updates are chip-filling launches of their
 //                own right and the chain launch loses against them (n = 8192: 6.4 against 6.0 ms, profiles/r05_pipe_*)
-// whole          ... and the whole factorisation is one such launch (every update inside it); every diagonal block of a chain
-//                launch has a workgroup of its own from the start, hence the bound on workspaces x panels
-// tail           (EGX_PIPE_TAIL columns, default 0 = off) right-looking handles beyond EGX_PIPE_MAX columns with at most two
-//                workspaces: the LAST `tail` columns as one chain launch behind one update of the whole trailing matrix.
-//                Measured and not adopted: n = 16384 30.2 against 28.9 ms, n = 8192 6.8 against 5.9 (the update in front of
-//                the launch is not overlapped with anything; profiles/r05_pipe_check_tail_*.txt)
+// whole          ... and the whole factorisation is one such launch (every update inside it; EGX_PIPE=2: never); every
+//                diagonal block of a chain launch has a workgroup of its own from the start, hence the bound of
+//                kPipeDiagBlocks (32) on workspaces x panels
 // group_panels   panels per trailing update (EGX_POTRF_GROUP; profiles/r02_run13_*: four pay from n ~ 14000 on)
+// (Round 5 also measured a chain launch for the LAST columns of a large right-looking factorisation behind one update of the
+//  whole trailing matrix: n = 16384 30.2 against 28.9 ms, n = 8192 6.8 against 5.9 -- profiles/r05_pipe_check_tail_*.txt; gone.)
 #pragma once
 
 namespace egx {
 
+constexpr int kPipeMaxCols = 4096;   // padded size up to which the chain of a group of panels is one launch
+constexpr int kPipeDiagBlocks = 32;  // ... and the whole factorisation, while workspaces x panels stays within this
+
 struct PotrfSchedule {
-    int left = 0, w_left = 0, pipe = 0, whole = 0, tail = 0, group_panels = 2;
+    int left = 0, w_left = 0, pipe = 0, whole = 0, group_panels = 2;
 };
-struct ScheduleKnobs {
-    int potrf_left = 1, w_left = 1, pipe = 1, pipe_max = 4096, pipe_whole = 4096, pipe_tail = 0, potrf_group = 0;
+struct ScheduleKnobs {  // egx_set_tuning / environment: "potrf_left", "pipe", "potrf_group"
+    int potrf_left = 1, pipe = 1, potrf_group = 0;
 };
 inline PotrfSchedule schedule_table(int n_pad, int lockstep, int n_workspaces, const ScheduleKnobs &k) {
     PotrfSchedule s;
     s.left = k.potrf_left >= 2 || (k.potrf_left == 1 && n_pad >= 14336 && lockstep >= 8);
-    s.w_left = n_pad % 256 == 0 && (k.w_left >= 2 || (k.w_left == 1 && n_pad >= 14336 && lockstep >= 4));
-    s.pipe = k.pipe != 0 && n_pad <= k.pipe_max;
-    s.whole = s.pipe && n_pad <= k.pipe_whole && (long long)n_workspaces * ((n_pad + 255) / 256) <= 32;
-    s.tail = (k.pipe != 0 && k.pipe_tail >= 256 && !s.pipe && !s.left && (long long)n_workspaces * (k.pipe_tail / 256) <= 32)
-                 ? k.pipe_tail / 256 * 256
-                 : 0;
+    s.w_left = n_pad % 256 == 0 && (k.potrf_left >= 2 || (k.potrf_left == 1 && n_pad >= 14336 && lockstep >= 4));
+    s.pipe = k.pipe != 0 && n_pad <= kPipeMaxCols;
+    s.whole = s.pipe && k.pipe == 1 && (long long)n_workspaces * ((n_pad + 255) / 256) <= kPipeDiagBlocks;
     s.group_panels = k.potrf_group ? k.potrf_group : (n_pad >= 14336 ? 4 : 2);
     return s;
 }

@@ -102,13 +102,19 @@ void egx_gp_config_default(egx_gp_config *cfg);
  * EGX_POOL_MAX_GB (environment, default 48, 0 = no pool).  egx_trim frees everything cached and returns the bytes. */
 int64_t egx_trim(void);
 void egx_pool_stats(int64_t *cached_bytes, int64_t *hits, int64_t *misses);
-/* The factorisation's scheduling knobs at run time (the EGX_* environment variables of DESIGN.md section 4, read once at
- * start-up, by name without the prefix, lower case: "potrf_group", "stream_min", "stream_tpw", "gemm_small", "look_min",
- * "trsm_group", "lur_side", "lur_side_min", "potrf_left", "tail_merge", "trsm_left", "w_left").  They move launches between streams and kernels between tile shapes, never the arithmetic
- * inside a kernel; changing "potrf_group" / "stream_min" / "gemm_small" / "potrf_left" / "trsm_left" / "tail_merge" changes
- * which kernel updates a block, or in which order the updates are summed, and hence the rounding.  Process-wide; not while evaluations are in flight.  *previous (optional) receives the old value.
- * Used by bench.py's roofline leg ("lur_side" = 0: the lock-step group's launches run one after the other and have
- * clean per-launch durations) and by A/B measurements inside one process. */
+/* The factorisation's eight scheduling settings at run time (the EGX_* environment variables of DESIGN.md section 4, read
+ * once at start-up; here by name without the prefix, lower case):
+ *   "potrf_group"      panels per trailing update (0 = by size)          "stream_min"  tiles from which the stream kernel is used
+ *   "gemm_small"       tiles below which the 64 x 64 kernel is used      "look_min"    trailing columns down to which the chain looks ahead
+ *   "potrf_left"       left-looking updates 0 never / 1 per handle / 2   "lur_side"    look-ahead update beside (1) or in front of (0) the trailing one
+ *   "pipe"             chain launches 0 never / 1 per handle / 2 per group of panels only
+ *   "pipe_timeout_ms"  bound of every device-side wait of a chain launch (default 2000; exceeded = EGX_ERR_HIP, not a hang)
+ * (plus the test hook "pipe_stall").  They move launches between streams and kernels between tile shapes, never the
+ * arithmetic inside a kernel; "potrf_group" / "stream_min" / "gemm_small" / "potrf_left" / "pipe" change which kernel
+ * updates a block, or the order in which updates are summed, hence the rounding -- and "potrf_left" / "pipe" /
+ * "potrf_group" enter a handle's schedule (egx_gp_get_schedule) when it is CREATED or its lock-step width is set, not
+ * later.  Process-wide, atomic; meant for A/B runs, not for use while evaluations are in flight.  *previous (optional)
+ * receives the old value.  Used by bench.py's roofline leg ("lur_side" = 0: clean per-launch durations) and the tests. */
 int32_t egx_set_tuning(const char *knob, int32_t value, int32_t *previous);
 
 /* ---- host-side helpers (no device needed) -------------------------------- */
@@ -168,7 +174,7 @@ int32_t egx_gp_get_lockstep(const egx_gp *gp);
  * 1-workspace handle at n = 16384 differ by 1e-10 relative).  out[0..5] = { left-looking group updates, left-looking
  * C^-T rider, pipelined chain launches (the chain of a panel group -- diagonal blocks, panel solves, in-group updates: the
  * panel step of `cholesky()`, crates/gp/src/algorithm.rs:1004 -- as one persistent launch), whole factorisation as one such
- * launch, panels per group, lock-step width [, columns at the end of the matrix factored by one chain launch] }; out_len >= 6. */
+ * launch, panels per group, lock-step width }; out_len >= 6 (further slots are set to 0). */
 int32_t egx_gp_get_schedule(const egx_gp *gp, int32_t *out, int32_t out_len);
 /* Give back what only an optimisation needed: the handle keeps its first n_keep (>= 1) workspaces -- workspace 0 holds the
  * fitted factor, which survives -- and frees the others together with the theta-gradient's scratch.  A tuned fit runs its

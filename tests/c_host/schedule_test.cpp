@@ -5,12 +5,11 @@
 #include "../../egobox_amd/csrc/schedule.h"
 
 static int fails = 0;
-static void expect(int n_pad, int lockstep, int nws, const egx::ScheduleKnobs &k, int left, int w_left, int pipe, int whole, int gp,
-                   int tail = 0) {
+static void expect(int n_pad, int lockstep, int nws, const egx::ScheduleKnobs &k, int left, int w_left, int pipe, int whole, int gp) {
     const egx::PotrfSchedule s = egx::schedule_table(n_pad, lockstep, nws, k);
-    if (s.left != left || s.w_left != w_left || s.pipe != pipe || s.whole != whole || s.group_panels != gp || s.tail != tail) {
-        std::printf("n_pad %d lockstep %d workspaces %d: got {%d %d %d %d %d tail %d}, table says {%d %d %d %d %d tail %d}\n", n_pad, lockstep,
-                    nws, s.left, s.w_left, s.pipe, s.whole, s.group_panels, s.tail, left, w_left, pipe, whole, gp, tail);
+    if (s.left != left || s.w_left != w_left || s.pipe != pipe || s.whole != whole || s.group_panels != gp) {
+        std::printf("n_pad %d lockstep %d workspaces %d: got {%d %d %d %d %d}, table says {%d %d %d %d %d}\n", n_pad, lockstep, nws,
+                    s.left, s.w_left, s.pipe, s.whole, s.group_panels, left, w_left, pipe, whole, gp);
         fails++;
     }
 }
@@ -42,7 +41,6 @@ int main() {
                 const egx::PotrfSchedule c = egx::schedule_table(n_pad, w + 100, nws, d);
                 if (a.whole != c.whole || a.group_panels != c.group_panels) fails++;
                 if (a.whole && !(n_pad <= 4096 && nws * ((n_pad + 255) / 256) <= 32)) fails++;
-                if (a.tail && (a.pipe || a.whole || a.left || n_pad <= 4096 || nws > 2)) fails++;
                 if (a.pipe != (n_pad <= 4096)) fails++;
                 if (a.left && !a.w_left && n_pad % 256 == 0) fails++;  // left-looking handles' riders are left-looking too
             }
@@ -50,18 +48,12 @@ int main() {
     egx::ScheduleKnobs k = d;
     k.pipe = 0;
     expect(4096, 1, 1, k, 0, 0, 0, 0, 2);
-    k = d, k.pipe_whole = 0;
+    k = d, k.pipe = 2;                           // chain launches per group of panels only
     expect(4096, 1, 1, k, 0, 0, 1, 0, 2);
-    k = d, k.pipe_max = 1 << 30;
-    expect(8192, 1, 1, k, 0, 0, 1, 0, 2);
-    k = d, k.pipe_tail = 4096;                   // (the tail launch: measured, off by default)
-    expect(16384, 1, 1, k, 0, 0, 0, 0, 4, 4096);
-    expect(16384, 3, 3, k, 0, 0, 0, 0, 4, 0);
-    expect(16384, 8, 8, k, 1, 1, 0, 0, 4, 0);
-    expect(4096, 1, 1, k, 0, 0, 1, 1, 2, 0);
-    k = d, k.potrf_left = 0, k.w_left = 0;
+    expect(8192, 1, 1, k, 0, 0, 0, 0, 2);
+    k = d, k.potrf_left = 0;
     expect(16384, 8, 16, k, 0, 0, 0, 0, 4);
-    k = d, k.potrf_left = 2, k.w_left = 2;
+    k = d, k.potrf_left = 2;
     expect(2048, 1, 1, k, 1, 1, 1, 1, 2);
     k = d, k.potrf_group = 3;
     expect(16384, 8, 16, k, 1, 1, 0, 0, 3);

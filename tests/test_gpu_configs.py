@@ -473,6 +473,68 @@ def test_sweep_fit_on_one_rank_is_the_handle_fit(egx):
     assert ne >= 7 * 25  # every start ran at least GP_COBYLA_MIN_EVAL evaluations
 
 
+_COEXIST = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["EGX_ROOT"])
+import egobox_amd as egx
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+x, y = egx.workload.make_training_set(600, 4, seed=3)
+thetas = egx.theta_sweep_candidates(6, 4, seed=1)
+t = torch.arange(1024, dtype=torch.float64, device="cuda")
+side = torch.cuda.Stream()
+with egx.GpHandle(x, y, n_workspaces=2) as h:
+    want_lk, want_st = h.likelihood_batch(thetas)
+with egx.Sweep(x, y, device=0, rank=0, world=1, id_bytes="new", n_workspaces=2) as sw:
+    assert sw.info()["rccl_ranks"] == 1, "the sweep must hold a real RCCL communicator"
+    n_ok = 0
+    for it in range(100):
+        # torch's collective and the library's all-gather in flight together: torch's on a side stream every other
+        # round, the library's on its own stream, neither synchronised against the other before both are enqueued
+        with torch.cuda.stream(side if it % 2 else torch.cuda.current_stream()):
+            a = t * (it + 1)
+            work = dist.all_reduce(a, async_op=True)
+        if it % 3 == 2:
+            got = sw.allgather(np.array([float(it), -float(it)]))
+            assert got.shape[-1] == 2 and float(np.ravel(got)[0]) == float(it)
+        else:
+            lk, st = sw.likelihood(thetas)
+            assert np.array_equal(lk, want_lk) and np.array_equal(st, want_st)
+        work.wait()
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(a, t * (it + 1))
+        g = [torch.empty_like(t)]
+        dist.all_gather(g, a)
+        assert torch.equal(g[0], a)
+        n_ok += 1
+dist.barrier()
+dist.destroy_process_group()
+print(json.dumps({"rounds": n_ok}))
+"""
+
+
+@pytest.mark.timeout(600)
+def test_library_rccl_communicator_coexists_with_torch_distributed(tmp_path):
+    """Round-4 review, item 9: the library's OWN RCCL communicator (dlopen'ed librccl, ncclAllGather on the sweep's
+    stream) and torch.distributed's NCCL process group in ONE process on one GPU at world = 1: 100 rounds with a torch
+    all-reduce in flight (alternating streams) while the library runs its sharded sweep + all-gather, every result
+    checked, both torn down in order.  (bench.py at N > 1 is exactly this process layout.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EGX_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29647", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "EGX_SWEEP_TRANSPORT"):
+        env.pop(k, None)
+    script = tmp_path / "coexist.py"
+    script.write_text(_COEXIST)
+    out = subprocess.run([sys.executable, str(script)], cwd=root, env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["rounds"] == 100
+
+
 @pytest.mark.timeout(600)
 def test_bench_gpus_2_rehearsal_on_one_gpu():
     """`python bench.py --gpus 2` end to end on the one-GPU box: bench.py starts its two ranks itself, both on GPU 0, the

@@ -1315,15 +1315,56 @@ def test_kpls_with_100_input_dimensions(egx, O):
             np.testing.assert_allclose(vp, vr, rtol=PRED_RTOL, atol=1e-9 * ref.inner.sigma2 + PRED_RTOL * np.abs(vr).max())
 
 
-def test_x_gradients_beyond_256_dimensions_are_refused_not_wrong(egx):
-    n, d = 200, 300
+@pytest.mark.parametrize("corr,d", [(0, 300), (3, 300), (0, 700), (2, 1100)])
+def test_x_gradients_beyond_256_dimensions(egx, corr, d):
+    """Round 5: the batched x-gradient kernel narrows its LDS slab of training points beyond d ~ 300 (64 points wide at
+    d = 300, 16 at d = 700, 8 at d = 1100) instead of refusing d > 256.  Checked by directional central differences of
+    the predictions (themselves oracle-checked at d = 100 / 200 above; the oracle's jacobians cost minutes per point at
+    this d), batched form and the few-query form against each other."""
+    n = 200
     x, y = _data(n, d, seed=5)
-    with egx.GpHandle(x, y, corr=0) as h:
-        h.finalize(egx.workload.default_theta(d))
-        xq = np.random.default_rng(1).random((130, d))
-        assert np.all(np.isfinite(h.predict(xq))) and np.all(h.predict_var(xq) >= 0.0)
-        with pytest.raises(egx.EgxError):
-            h.predict_gradients(xq)
+    theta = egx.workload.default_theta(d) * (2.0 if corr == 0 else 1.0)
+    xq = x.min(0) + (x.max(0) - x.min(0)) * np.random.default_rng(1).random((130, d))
+    with egx.GpHandle(x, y, corr=corr) as h:
+        h.finalize(theta)
+        gy, gv = h.predict_valvar_gradients(xq)
+        assert gy.shape == (130, d) and np.all(np.isfinite(gy)) and np.all(np.isfinite(gv))
+        one = h.predict_valvar_gradients(xq[:1])
+        np.testing.assert_allclose(one[0], gy[:1], rtol=1e-7, atol=1e-9 * np.abs(gy).max())
+        np.testing.assert_allclose(one[1], gv[:1], rtol=1e-6, atol=1e-8 * np.abs(gv).max())
+        rng = np.random.default_rng(9)
+        span = x.max(0) - x.min(0)
+        for a in (0, 1, 64, 129):
+            v = rng.standard_normal(d) * span
+            v /= np.linalg.norm(v)
+            eps = 1e-5
+            yp, vp = h.predict_valvar(np.stack([xq[a] + eps * v, xq[a] - eps * v]))
+            fy, fv = (yp[0] - yp[1]) / (2 * eps), (vp[0] - vp[1]) / (2 * eps)
+            assert gy[a] @ v == pytest.approx(fy, rel=2e-5, abs=1e-6 * np.abs(gy).max())
+            assert gv[a] @ v == pytest.approx(fv, rel=2e-4, abs=1e-5 * np.abs(gv).max())
+
+
+def test_x_gradients_refuse_what_does_not_fit_lds(egx):
+    """d * (hcols + 1) > 20480 doubles (coefficients + ONE training point) cannot be staged in the 160 KB of LDS: refused
+    with a message, never wrong.  Just below that the slab is one training point wide and few queries take the batched
+    form (the few-query kernel needs d * (hcols + 5) doubles)."""
+    n = 64
+    for d, fits in ((10000, True), (10300, False)):
+        x, y = _data(n, d, seed=6)
+        with egx.GpHandle(x, y, corr=0) as h:
+            h.finalize(egx.workload.default_theta(d))
+            xq = x[:3] + 1e-3
+            assert np.all(np.isfinite(h.predict(xq)))
+            if fits:
+                g = h.predict_gradients(xq)
+                v = np.zeros(d)
+                v[::7] = 1.0 / np.sqrt(len(v[::7]))
+                eps = 1e-5
+                yp = h.predict(np.stack([xq[1] + eps * v, xq[1] - eps * v]))
+                assert g[1] @ v == pytest.approx((yp[0] - yp[1]) / (2 * eps), rel=1e-4, abs=1e-6 * np.abs(g).max())
+            else:
+                with pytest.raises(egx.EgxError, match="LDS"):
+                    h.predict_gradients(xq)
 
 
 def test_shrink_gives_the_multistart_workspaces_back(egx):

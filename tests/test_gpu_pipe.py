@@ -41,7 +41,7 @@ def knobs(egx):
 @pytest.mark.parametrize("n", [300, 1000, 2100, 4096])
 def test_chain_launches_agree_with_separate_launches_and_lapack(egx, knobs, n):
     """egx_potrf on a kernel matrix: one chain launch for the whole factorisation (the default up to 4096 columns), chain
-    launches per group of panels (pipe_whole = 0), separate launches (pipe = 0): the same factor to rounding, LAPACK's
+    launches per group of panels (pipe = 2), separate launches (pipe = 0): the same factor to rounding, LAPACK's
     residual."""
     rng = np.random.default_rng(n)
     pts = rng.uniform(size=(n, 3))
@@ -50,7 +50,7 @@ def test_chain_launches_agree_with_separate_launches_and_lapack(egx, knobs, n):
     want = sl.cholesky(a, lower=True)
     res_lapack = np.abs(want @ want.T - a).max()
     facs = {}
-    for name, settings in (("whole", {"pipe": 1, "pipe_whole": 4096}), ("groups", {"pipe": 1, "pipe_whole": 0}), ("separate", {"pipe": 0})):
+    for name, settings in (("whole", {"pipe": 1}), ("groups", {"pipe": 2}), ("separate", {"pipe": 0})):
         for k, v in settings.items():
             knobs(k, v)
         got, info = egx.potrf(a)
@@ -71,9 +71,8 @@ def test_info_is_lapacks_under_chain_launches(egx, knobs, n, bad):
     a = g @ g.T / n + 0.1 * np.eye(n)
     a[bad, bad] = -1.0
     _, info_lapack = sl.lapack.dpotrf(a, lower=1)
-    for whole in (4096, 0):
-        knobs("pipe", 1)
-        knobs("pipe_whole", whole)
+    for form in (1, 2):
+        knobs("pipe", form)
         _, info = egx.potrf(a)
         assert info == info_lapack == bad + 1
 
@@ -105,7 +104,7 @@ def test_likelihood_does_not_depend_on_the_chain_form_beyond_rounding(egx, knobs
     x, y = egx.workload.make_training_set(1500, 8, 42)     # (the benchmark's well-conditioned family: the 1e-8 bar applies)
     th = egx.workload.default_theta(8) * 3.0
     vals = []
-    for settings in ({"pipe": 1, "pipe_whole": 4096}, {"pipe": 1, "pipe_whole": 0}, {"pipe": 0}):
+    for settings in ({"pipe": 1}, {"pipe": 2}, {"pipe": 0}):
         for k, v in settings.items():
             knobs(k, v)
         with egx.GpHandle(x, y) as h:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of run-time knobs at a SMALL size (config 2: n = 4096, d = 8): one fit in flight (latency: the serial chain) and a
 lock-step batch of twelve (a tuned fit's round), per knob setting, interleaved.
-    python tools/ab_small.py "tail_merge=0" "tail_merge=1" [--n 4096] [--d 8]"""
+    python tools/ab_small.py "pipe=0" "pipe=1" [--n 4096] [--d 8]"""
 import argparse
 import os
 import sys

@@ -2,7 +2,7 @@
 // (k_potf2_reg + k_panel_trsm16 + update launches) of launch_potrf, on kernel matrices built on the device:
 //   bits      groups of ONE panel (potrf_group = 1): the chain launch holds a diagonal block and its panel solve only -- the
 //             same arithmetic as the separate launches, so the factors must agree BIT FOR BIT (this checks every hand-off)
-//   groups    the default groups, and the whole factorisation as ONE launch (pipe_whole), queue look-ahead 0 / 1 / 2 / 99:
+//   groups    the default groups, and the whole factorisation as ONE launch:
 //             factor vs the separate launches (relative) and residual max |L L^T - A| / max |A|
 //   batch     lock-step batches: every matrix gets the bits it gets alone
 //   pivot     a matrix that loses a pivot: same `info` as the separate launches, and the launch ends
@@ -74,7 +74,6 @@ __global__ void k_resid(const double *L, int64_t ld, int n, double scale, double
     atomicMax(out, (unsigned long long)__double_as_longlong(e));
 }
 
-static int g_tail = 0;        // PotrfBatch::tail: the last g_tail columns as one chain launch (separate launches before)
 static bool g_whole = false;  // PotrfBatch::whole of the next factorisations (the library decides it per handle)
 struct Problem {
     int n, n_pad, m_tot, nz;
@@ -124,9 +123,8 @@ struct Problem {
         pb.sI = 1;
         pb.sync = pipe ? sync : nullptr;
         pb.sS = (int64_t)sync_n;
-        pb.pipe = (pipe && !g_tail) ? 1 : 0;
-        pb.whole = (g_whole && !g_tail) ? 1 : 0;
-        pb.tail = g_tail;
+        pb.pipe = pipe ? 1 : 0;
+        pb.whole = g_whole ? 1 : 0;
         return launch_potrf(s, M, ld, n_pad, m_tot, dinv, info, lk.s2 ? &lk : nullptr, nullptr, &pb, nullptr);
     }
     std::vector<double> download(int z) {
@@ -266,11 +264,10 @@ static void env_knobs() {
         }
     }
 }
-static int trace_main(int n, int whole, int la, int nz) {
+static int trace_main(int n, int whole, int nz) {
     const double scale = 6.0, nugget = 1e-8;
     pipe_set_knob("pipe_timeout_ms", 500);
     g_whole = (whole ? 1 << 30 : 0) != 0;
-    pipe_set_knob("pipe_la", la);
     env_knobs();
     Problem P;
     P.create(n, nz, n >= 8192);
@@ -290,7 +287,7 @@ static int trace_main(int n, int whole, int la, int nz) {
         CK(hipEventSynchronize(e1));
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("# n=%d nz=%d %s la=%d: launch_potrf %.3f ms%s\n", n, nz, whole ? "WHOLE" : "per-group", la, ms, rep ? " (traced)" : "");
+        printf("# n=%d nz=%d %s: launch_potrf %.3f ms%s\n", n, nz, whole ? "WHOLE" : "per-group", ms, rep ? " (traced)" : "");
     }
     pipe_set_trace(nullptr);
     std::vector<long long> h(cap * 8);
@@ -330,7 +327,7 @@ int main(int argc, char **argv) {
     if (chol_init()) return 1;
     if (argc > 1 && std::string(argv[1]) == "diag") return diag_alone_main();
     if (argc > 1 && std::string(argv[1]) == "trace")
-        return trace_main(argc > 2 ? atoi(argv[2]) : 1024, argc > 3 ? atoi(argv[3]) : 1, argc > 4 ? atoi(argv[4]) : 1, argc > 5 ? atoi(argv[5]) : 1);
+        return trace_main(argc > 2 ? atoi(argv[2]) : 1024, argc > 3 ? atoi(argv[3]) : 1, argc > 4 ? atoi(argv[4]) : 1);
     const int max_n = argc > 1 ? atoi(argv[1]) : 8192;
     const double scale = 6.0, nugget = 1e-8;  // cond ~ 1e8..1e10: the refinement step of the solves is exercised
     pipe_set_knob("pipe_timeout_ms", 500);
@@ -373,10 +370,8 @@ int main(int argc, char **argv) {
         CK(hipDeviceSynchronize());
         const std::vector<double> ref = P.download(0);
         const double res_ref = residual(P, 0, scale, nugget, 11);
-        struct Mode { int whole, la; };
-        for (Mode m : {Mode{0, 1}, Mode{1 << 30, 0}, Mode{1 << 30, 1}, Mode{1 << 30, 2}, Mode{1 << 30, 99}}) {
-            g_whole = (m.whole) != 0;
-            pipe_set_knob("pipe_la", m.la);
+        for (int whole : {0, 1}) {
+            g_whole = whole != 0;
             P.build(0, scale, nugget, 11);
             if (P.factor(0, true)) return 3;
             CK(hipDeviceSynchronize());
@@ -385,32 +380,10 @@ int main(int argc, char **argv) {
             compare(P, ref, P.download(0), rel, same);
             const double res = residual(P, 0, scale, nugget, 11);
             verdict(rel < 2e-5 && res < 50 * std::max(res_ref, 1e-15) && P.abort_word() == 0 && P.infos()[0] == 0,
-                    "groups  n=%d %s la=%d: vs separate launches %.2e, residual %.2e (separate launches %.2e), info %d abort %d", n,
-                    m.whole ? "WHOLE" : "per-group", m.la, rel, res, res_ref, P.infos()[0], P.abort_word());
+                    "groups  n=%d %s: vs separate launches %.2e, residual %.2e (separate launches %.2e), info %d abort %d", n,
+                    whole ? "WHOLE" : "per-group", rel, res, res_ref, P.infos()[0], P.abort_word());
         }
-        g_whole = (0) != 0;
-        pipe_set_knob("pipe_la", 1);
-        P.destroy();
-    }
-    // ---------------------------------------------------------------- tail: the last columns of a larger matrix as one chain launch
-    for (int n : {5000, 8192}) {
-        if (n > max_n) continue;
-        Problem P;
-        P.create(n, 1, true);
-        P.build(0, scale, nugget, 13);
-        if (P.factor(0, false)) return 3;
-        CK(hipDeviceSynchronize());
-        const std::vector<double> ref = P.download(0);
-        g_tail = 4096;
-        P.build(0, scale, nugget, 13);
-        if (P.factor(0, true)) return 3;
-        CK(hipDeviceSynchronize());
-        g_tail = 0;
-        double rel;
-        bool same;
-        compare(P, ref, P.download(0), rel, same);
-        verdict(rel < 2e-5 && P.abort_word() == 0 && P.infos()[0] == 0, "tail    n=%d, last 4096 columns as one chain launch: vs separate launches %.2e, info %d abort %d", n, rel,
-                P.infos()[0], P.abort_word());
+        g_whole = false;
         P.destroy();
     }
     // ---------------------------------------------------------------- lock-step batches: the bits a matrix gets alone
@@ -439,7 +412,7 @@ int main(int argc, char **argv) {
         bool ok2 = true;
         const std::vector<double> full = B.download(1);
         for (int wgs : {3, 17}) {
-            pipe_set_knob("pipe_wgs", wgs);
+            pipe_test_set_workgroups(wgs);
             B.build(0, scale, nugget, 23);
             if (B.factor(0, true)) return 3;
             CK(hipDeviceSynchronize());
@@ -448,7 +421,7 @@ int main(int argc, char **argv) {
             compare(B, full, B.download(1), rel, same);
             ok2 = ok2 && same && B.abort_word() == 0;
         }
-        pipe_set_knob("pipe_wgs", 0);
+        pipe_test_set_workgroups(0);
         verdict(ok2, "grid    n=%d nz=%d %s: the same bits on 3, 17 and all workgroups", n, nz, whole ? "WHOLE" : "per-group");
         B.destroy(), S.destroy();
     }
@@ -515,21 +488,11 @@ int main(int argc, char **argv) {
             const double t_grp = time_factor(P, true, scale, nugget, reps);
             printf("time    n=%5d nz=%d separate %8.3f ms (%5.1f TFLOP/s) | chain per group %8.3f ms (%5.1f)", n, nz, t_sep, fl / t_sep * 1e-9,
                    t_grp, fl / t_grp * 1e-9);
-            if (n > 4096 && nz == 1) {
-                g_tail = 4096;
-                const double t = time_factor(P, true, scale, nugget, reps);
-                g_tail = 0;
-                printf(" | tail 4096 %8.3f ms (%5.1f)", t, fl / t * 1e-9);
-            }
             if (n <= 4096) {
-                for (int la : {0, 1, 2, 4}) {
-                    g_whole = (1 << 30) != 0;
-                    pipe_set_knob("pipe_la", la);
-                    const double t = time_factor(P, true, scale, nugget, reps);
-                    printf(" | whole la=%d %8.3f ms (%5.1f)", la, t, fl / t * 1e-9);
-                }
-                g_whole = (0) != 0;
-                pipe_set_knob("pipe_la", 1);
+                g_whole = true;
+                const double t = time_factor(P, true, scale, nugget, reps);
+                printf(" | whole %8.3f ms (%5.1f)", t, fl / t * 1e-9);
+                g_whole = false;
             }
             printf(" abort %d\n", P.abort_word());
             fflush(stdout);

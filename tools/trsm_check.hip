@@ -1,11 +1,15 @@
 // Backward error of the solves after a factorisation (launch_trsm_rows: predict_var, theta-gradient) on an ill-conditioned
 // kernel matrix: residual of X L^T = B with and without the refinement step of k_panel_trsm (EGX_TRSM_REFINE=0).
 #include "../egobox_amd/csrc/kernels_chol.hip"
+#include "../egobox_amd/csrc/kernels_pipe.hip"  // (launch_potrf refers to the chain launch)
 #include <cstdio>
 #include <vector>
 #include <cmath>
 #include <random>
-namespace egx { void set_error(const std::string &m) { fprintf(stderr, "error: %s\n", m.c_str()); } }
+namespace egx {
+void set_error(const std::string &m) { fprintf(stderr, "error: %s\n", m.c_str()); }
+hipError_t dev_malloc_bytes(void **p, size_t bytes) { return hipMalloc(p, bytes); }
+}  // namespace egx
 using namespace egx;
 int main() {
     const int n = 1024, m = 128;
