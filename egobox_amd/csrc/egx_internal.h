@@ -78,6 +78,18 @@ int launch_uptri_solve_pair(hipStream_t s, const double *W, int64_t ld, int n, i
 int launch_fill_rows(hipStream_t s, double *M, int64_t ld, int r0, int rows_pad, const double *src,
                      int64_t lds, int nrows, int ncols);
 int launch_gather_diag(hipStream_t s, const double *M, int64_t ld, int n, double *out);
+// per-candidate pointers of a lock-step batch, passed by value to the batched front-end / tail kernels (kernels_corr.hip)
+struct EvalBatchPtrs {
+    static constexpr int kMax = 16;  // the widest lock-step batch (egx_gp_set_lockstep)
+    const double *xT[kMax], *coef[kMax], *rhsT[kMax];
+    double *xs[kMax], *M[kMax];
+    double *h_diag[kMax], *h_rows[kMax];  // pinned host memory, written by the device
+    int *h_info[kMax];
+    const int *d_info[kMax];
+};
+int launch_eval_front_batch(hipStream_t s, int corr, const EvalBatchPtrs &b, int count, int64_t ldx, int n, int d, int hcols,
+                            double nugget, int64_t ld, int n_pad, int rhs_pad, int q);
+int launch_eval_tail(hipStream_t s, const EvalBatchPtrs &b, int count, int64_t ld, int n, int n_pad, int q, int rows, const int *sync);
 // per-row reductions over the first n columns of rows [0, m): s0[q] = sum rt^2, sl[q*p + l] = sum rt*ft_l
 int launch_row_reduce(hipStream_t s, const double *RT, int64_t ld, int m, int n, const double *ftT,
                       int64_t ldf, int p, double *s0, double *sl);

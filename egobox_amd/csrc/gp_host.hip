@@ -71,16 +71,13 @@ static int alloc_workspace(egx_gp *gp, Workspace &w, int index) {
     EGX_HIP_CHECK(hipStreamCreateWithFlags(&w.inv_stream, hipStreamNonBlocking));
     EGX_HIP_CHECK(hipEventCreateWithFlags(&w.ev_inv_grp, hipEventDisableTiming));
     EGX_HIP_CHECK(hipEventCreateWithFlags(&w.ev_inv_done, hipEventDisableTiming));
-    {
-        const char *la = std::getenv("EGX_LOOKAHEAD");
-        if (!la || la[0] != '0') {
-            int lo = 0, hi = 0;
-            EGX_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            EGX_HIP_CHECK(hipStreamCreateWithPriority(&w.lk.s2, hipStreamNonBlocking, hi));
-            EGX_HIP_CHECK(hipStreamCreateWithPriority(&w.lk.s3, hipStreamNonBlocking, hi));
-            for (hipEvent_t *e : {&w.lk.ev_lu, &w.lk.ev_lur, &w.lk.ev_panel, &w.lk.ev_a, &w.lk.ev_b})
-                EGX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        }
+    {  // the look-ahead chain's stream and the side stream of the split updates (launch_potrf): high priority
+        int lo = 0, hi = 0;
+        EGX_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        EGX_HIP_CHECK(hipStreamCreateWithPriority(&w.lk.s2, hipStreamNonBlocking, hi));
+        EGX_HIP_CHECK(hipStreamCreateWithPriority(&w.lk.s3, hipStreamNonBlocking, hi));
+        for (hipEvent_t *e : {&w.lk.ev_lu, &w.lk.ev_lur, &w.lk.ev_panel, &w.lk.ev_a, &w.lk.ev_b})
+            EGX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     const int hmax = gp->has_w ? gp->h : 1;
     EGX_HIP_CHECK(dev_malloc(&w.d_coef, sizeof(double) * (size_t)gp->d * hmax));
@@ -368,13 +365,27 @@ static int enqueue_eval_core(egx_gp *const *owners, Workspace *const *wss, int c
     }
     EGX_HIP_CHECK(hipMemsetAsync(lead.d_info, 0, sizeof(int) * (size_t)count, st));
     EGX_HIP_CHECK(hipEventRecord(lead.ev[0], st));
-    for (int j = 0; j < count; j++) {
-        Workspace &w = *wss[j];
-        egx_gp *o = owners[j];
-        EGX_RC(launch_corr_sym(st, gp->corr, o->d_xT, gp->n_pad, gp->n, gp->d, w.d_coef, hcols, gp->nugget, w.M, gp->ld,
-                               gp->n_pad, w.d_xs));
-        EGX_RC(launch_fill_rows(st, w.M, gp->ld, gp->n_pad, gp->rhs_pad, o->d_rhsT, gp->n_pad, gp->q, gp->n_pad));
-    }
+    // the candidates' pointers for the batched front-end and tail launches (by value in the kernel arguments)
+    EvalBatchPtrs bp;
+    const bool batched = count > 1 && count <= EvalBatchPtrs::kMax;
+    if (batched)
+        for (int j = 0; j < count; j++) {
+            Workspace &w = *wss[j];
+            bp.xT[j] = owners[j]->d_xT, bp.coef[j] = w.d_coef, bp.rhsT[j] = owners[j]->d_rhsT, bp.xs[j] = w.d_xs, bp.M[j] = w.M;
+            bp.h_diag[j] = w.h_diag, bp.h_rows[j] = w.h_rows, bp.h_info[j] = w.h_info, bp.d_info[j] = w.d_info;
+        }
+    int front = batched ? launch_eval_front_batch(st, gp->corr, bp, count, gp->n_pad, gp->n, gp->d, hcols, gp->nugget, gp->ld,
+                                                  gp->n_pad, gp->rhs_pad, gp->q)
+                        : EGX_ERR_UNSUPPORTED;
+    if (front != EGX_SUCCESS && front != EGX_ERR_UNSUPPORTED) return front;
+    if (front == EGX_ERR_UNSUPPORTED)  // a lone candidate, Matern with KPLS weights (hcols > 1) or d > 64: launch by launch
+        for (int j = 0; j < count; j++) {
+            Workspace &w = *wss[j];
+            egx_gp *o = owners[j];
+            EGX_RC(launch_corr_sym(st, gp->corr, o->d_xT, gp->n_pad, gp->n, gp->d, w.d_coef, hcols, gp->nugget, w.M, gp->ld,
+                                   gp->n_pad, w.d_xs));
+            EGX_RC(launch_fill_rows(st, w.M, gp->ld, gp->n_pad, gp->rhs_pad, o->d_rhsT, gp->n_pad, gp->q, gp->n_pad));
+        }
     EGX_HIP_CHECK(hipEventRecord(lead.ev[1], st));
     int *lead_sync = dev_sync(gp, (int)(&lead - gp->ws.data()));
     PotrfBatch pb;
@@ -391,10 +402,15 @@ static int enqueue_eval_core(egx_gp *const *owners, Workspace *const *wss, int c
     EGX_RC(launch_potrf(st, lead.M, gp->ld, gp->n_pad, gp->m_tot, lead.dinv, lead.d_info, lead.lk.s2 ? &lead.lk : nullptr,
                         &lead.trace, &pb, W0 ? &inv : nullptr));
     EGX_HIP_CHECK(hipEventRecord(lead.ev[2], st));
+    // what the host needs back.  A batch: ONE launch writes every candidate's diagonal, solved right-hand-side rows, info and
+    // hand-off diagnostics straight into its pinned host buffers (k_eval_tail); a lone candidate: a gather + copies
+    if (batched) EGX_RC(launch_eval_tail(st, bp, count, gp->ld, gp->n, gp->n_pad, gp->q, gp->gls_device ? 0 : 1, pb.sync));
     for (int j = 0; j < count; j++) {
         Workspace &w = *wss[j];
-        EGX_RC(launch_gather_diag(st, w.M, gp->ld, gp->n, w.d_diag));
-        EGX_HIP_CHECK(hipMemcpyAsync(w.h_diag, w.d_diag, sizeof(double) * gp->n, hipMemcpyDeviceToHost, st));
+        if (!batched) {
+            EGX_RC(launch_gather_diag(st, w.M, gp->ld, gp->n, w.d_diag));
+            EGX_HIP_CHECK(hipMemcpyAsync(w.h_diag, w.d_diag, sizeof(double) * gp->n, hipMemcpyDeviceToHost, st));
+        }
         w.gls_enqueued = gp->gls_device;
         if (gp->gls_device) {
             // p > 1: ft never leaves the device.  Gram matrix of the solved rows [ft | yt] (split-K MFMA, fixed-order
@@ -407,19 +423,17 @@ static int enqueue_eval_core(egx_gp *const *owners, Workspace *const *wss, int c
             EGX_RC(launch_potrf(st, w.d_gram, g, g, g, w.d_gdinv, w.d_ginfo));
             EGX_HIP_CHECK(hipMemcpyAsync(w.h_gram, w.d_gram, sizeof(double) * (size_t)g * g, hipMemcpyDeviceToHost, st));
             EGX_HIP_CHECK(hipMemcpyAsync(w.h_ginfo, w.d_ginfo, sizeof(int), hipMemcpyDeviceToHost, st));
-        } else {
+        } else if (!batched) {
             EGX_HIP_CHECK(hipMemcpyAsync(w.h_rows, w.M + (size_t)gp->n_pad * gp->ld,
                                          sizeof(double) * (size_t)gp->q * gp->n_pad, hipMemcpyDeviceToHost, st));
         }
+        w.sync_lead = pb.sync;  // word 0 of the LEAD's hand-off words: non-zero iff a bounded wait inside a chain launch ran out
+        if (batched) continue;
         EGX_HIP_CHECK(hipMemcpyAsync(w.h_info, w.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
-        // word 0 of the LEAD's hand-off words: non-zero iff a bounded wait inside a chain launch of this group ran out
-        if (pb.sync) {
+        if (pb.sync)
             EGX_HIP_CHECK(hipMemcpyAsync(w.h_info + 1, pb.sync, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
-            w.sync_lead = pb.sync;
-        } else {  // (a handle whose schedule has no chain launches never touches its hand-off words)
+        else  // (a handle whose schedule has no chain launches never touches its hand-off words)
             w.h_info[1] = 0;
-            w.sync_lead = nullptr;
-        }
     }
     EGX_HIP_CHECK(hipEventRecord(lead.ev[3], st));
     return EGX_SUCCESS;
@@ -930,7 +944,7 @@ int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t t
 // =================================================================================================
 // C ABI
 // =================================================================================================
-// Lock-step width of a handle with nws workspaces (or the EGX_LOCKSTEP environment variable).  Large matrices: 8 wide from 16
+// Lock-step width of a handle with nws workspaces (egx_gp_set_lockstep changes it).  Large matrices: 8 wide from 16
 // workspaces on, else 4; up to 12 for n_pad <= 4096, where an evaluation is bound by launch latency and the chain (a tuned
 // fit's 11 COBYLA starts are then ONE launch sequence per round).  Round 3 (right-looking, n = 16384; in flight / width ->
 // fits/s): 12 / 4 40.7, 24 / 6 40.8, 24 / 8 41.3, 32 / 8 40.8, 36 / 12 41.2 -- three groups in flight were the constant.  Round 4
@@ -938,7 +952,6 @@ int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t t
 // 36 / 12 41.2 -- TWO groups in flight (profiles/r04_run6_left_looking_in_flight_and_width.txt).
 static int default_lockstep(int nws, int n_pad) {
     int ls = n_pad <= 4096 ? 12 : (nws >= 16 ? 8 : 4);
-    if (const char *e = std::getenv("EGX_LOCKSTEP")) ls = std::atoi(e);
     return ls < 1 ? 1 : (ls > nws ? nws : ls);
 }
 

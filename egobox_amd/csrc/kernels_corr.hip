@@ -212,8 +212,8 @@ __global__ __launch_bounds__(1024 / RI) void k_corr_sym(const double *__restrict
 // accumulation is left per pair and dimension.  Same 64x64 tile per workgroup, same grid, same stores (a row of 64 results
 // per wave instruction: 512 contiguous bytes).
 template <int CORR>
-__global__ __launch_bounds__(256) void k_corr_sym_srow(const double *__restrict__ xs, int64_t ldx, int n, int d, double diag,
-                                                       double *__restrict__ M, int64_t ld) {
+__device__ __forceinline__ void corr_sym_srow_body(const double *__restrict__ xs, int64_t ldx, int n, int d, double diag,
+                                                   double *__restrict__ M, int64_t ld) {
     const int t = blockIdx.x >> 2, sub = blockIdx.x & 3;
     int I = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
     while (I * (I + 1) / 2 > t) I--;
@@ -261,6 +261,26 @@ __global__ __launch_bounds__(256) void k_corr_sym_srow(const double *__restrict_
         else if (i == j) vv = diag;                       // 1 + nugget, algorithm.rs:997
         M[(int64_t)i * ld + j] = vv;
     }
+}
+template <int CORR>
+__global__ __launch_bounds__(256) void k_corr_sym_srow(const double *__restrict__ xs, int64_t ldx, int n, int d, double diag,
+                                                       double *__restrict__ M, int64_t ld) {
+    corr_sym_srow_body<CORR>(xs, ldx, n, d, diag, M, ld);
+}
+// ... for the candidates of a lock-step batch in ONE launch (blockIdx.y = candidate): the same workgroups doing the same
+// arithmetic, a twelfth of the launches (n = 4096 in lock-step 12: 12 x 3 front-end launches of ~20 + 5 + 5 us, serial on the
+// lead's stream, were 4 % of a batch -- profiles/r05_n4096_lockstep12_timeline.txt)
+template <int CORR>
+__global__ __launch_bounds__(256) void k_corr_sym_srow_batch(EvalBatchPtrs b, int64_t ldx, int n, int d, double diag, int64_t ld) {
+    corr_sym_srow_body<CORR>(b.xs[blockIdx.y], ldx, n, d, diag, b.M[blockIdx.y], ld);
+}
+
+__global__ void k_scale_rows_batch(EvalBatchPtrs b, int64_t ldx, int d) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ldx) return;
+    const double *xT = b.xT[blockIdx.y], *coef = b.coef[blockIdx.y];
+    double *xs = b.xs[blockIdx.y];
+    for (int k = 0; k < d; k++) xs[(int64_t)k * ldx + i] = coef[k] * xT[(int64_t)k * ldx + i];
 }
 
 // xs[k][i] = coef[k] * xT[k][i] over the (d x ldx) k-major array (hcols == 1)
@@ -623,6 +643,34 @@ __global__ void k_gather_diag(const double *__restrict__ M, int64_t ld, int n, d
     if (i < n) out[i] = M[(int64_t)i * ld + i];
 }
 
+__global__ void k_fill_rows_batch(EvalBatchPtrs b, int64_t ld, int r0, int rows_pad, int64_t lds, int nrows, int ncols) {
+    double *M = b.M[blockIdx.y];
+    const double *src = b.rhsT[blockIdx.y];
+    const int64_t total = (int64_t)rows_pad * ld;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(e / ld);
+        const int i = (int)(e % ld);
+        M[(int64_t)(r0 + l) * ld + i] = (l < nrows && i < ncols) ? src[(int64_t)l * lds + i] : 0.0;
+    }
+}
+
+// What the host needs of `count` finished evaluations, written STRAIGHT into each candidate's pinned host buffers (device-
+// visible, fine grained: complete when the launch is) by one launch: blockIdx.z = candidate, blockIdx.y = 0: the factor's
+// diagonal (n), 1 .. q: the solved right-hand-side rows (q x n_pad, only with `rows`), plus `info` and the eight hand-off
+// diagnostics words of the chain launches.  Replaces a gather kernel and four device-to-host copies PER CANDIDATE (~38 us
+// each, serial on the lead's stream: 0.46 ms of the 8.7 ms of twelve n = 4096 candidates).
+__global__ __launch_bounds__(256) void k_eval_tail(EvalBatchPtrs b, int64_t ld, int n, int n_pad, int rows, const int *__restrict__ sync) {
+    const int z = blockIdx.z, y = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const double *M = b.M[z];
+    if (y == 0) {
+        if (i < n) b.h_diag[z][i] = M[(int64_t)i * ld + i];
+        if (i < 9) b.h_info[z][i] = (i == 0) ? *b.d_info[z] : (sync ? sync[i - 1] : 0);
+    } else if (rows && i < n_pad) {
+        b.h_rows[z][(int64_t)(y - 1) * n_pad + i] = M[(int64_t)(n_pad + y - 1) * ld + i];
+    }
+}
+
 // Device-side GLS (algorithm.rs:1007-1032 for p > 1 trend columns), helpers around the Gram matrix of [ft | yt]:
 // G (rows x rows, ldg) <- -Gneg on the lower triangle of the leading q x q block, identity on the padding diagonal
 __global__ void k_gram_finish(const double *__restrict__ Gneg, double *__restrict__ G, int64_t ldg, int rows, int q) {
@@ -950,11 +998,8 @@ int launch_corr_sym(hipStream_t s, int corr, const double *xT, int64_t ldx, int 
     dim3 grid((unsigned)(4 * (nt2 * (nt2 + 1) / 2)));
     const int dc = d < kCorrDC ? d : kCorrDC;  // dimensions staged at a time
     const size_t lds = (size_t)2 * dc * 64 * sizeof(double);
-    static const int srow = [] {  // EGX_CORR_SROW=0: the LDS-only form (0.51 vs 0.42 ms sq-exp, 1.10 vs 0.76 at d = 64:
-        const char *e = std::getenv("EGX_CORR_SROW");  // profiles/r03_run11_k1_scalar_rows_ab.txt)
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-    if (hcols == 1 && xs_scratch != nullptr && srow && d <= kCorrDC) {
+    // (the LDS-only form was measured against it: 0.51 vs 0.42 ms sq-exp, 1.10 vs 0.76 at d = 64: profiles/r03_run11_k1_scalar_rows_ab.txt)
+    if (hcols == 1 && xs_scratch != nullptr && d <= kCorrDC) {
         // scalar-row form on prescaled inputs (xs_scratch: d x ldx doubles, owned by the caller's workspace); d > 64: the
         // LDS-only form below, which stages the dimensions in chunks
         hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((ldx + 255) / 256)), dim3(256), 0, s, xT, ldx, d, coef, xs_scratch);
@@ -1015,11 +1060,7 @@ int launch_predict_mean(hipStream_t s, int corr, const double *xqT, int64_t ldq,
     if (nsplit > slabs) nsplit = slabs;
     const int per = (slabs + nsplit - 1) / nsplit;
     nsplit = (slabs + per - 1) / per;
-    static const int srow = [] {  // EGX_CORR_SROW=0: the LDS-only forms here and in launch_corr_sym
-        const char *e = std::getenv("EGX_CORR_SROW");
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-    if (hcols == 1 && xs_prescaled != nullptr && srow && d <= kCorrDC) {
+    if (hcols == 1 && xs_prescaled != nullptr && d <= kCorrDC) {
         const size_t lds_s = (size_t)(d * 64 + 256) * sizeof(double);
         EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_predict_mean_srow<C_>), dim3(m_pad / 64, nsplit), dim3(256), lds_s, s, xqT,
                                                    ldq, xs_prescaled, ldx, n_pad, d, coef, gamma, racc, per, m_pad));
@@ -1125,6 +1166,28 @@ int launch_uptri_solve_pair(hipStream_t s, const double *W, int64_t ld, int n, i
 int launch_fill_rows(hipStream_t s, double *M, int64_t ld, int r0, int rows_pad, const double *src, int64_t lds,
                      int nrows, int ncols) {
     hipLaunchKernelGGL(k_fill_rows, dim3(1024), dim3(256), 0, s, M, ld, r0, rows_pad, src, lds, nrows, ncols);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+// correlation matrices + right-hand-side rows of `count` candidates (scalar-row form only: hcols == 1, d <= 64; the caller
+// falls back to launch_corr_sym / launch_fill_rows per candidate otherwise): returns EGX_ERR_UNSUPPORTED without launching
+int launch_eval_front_batch(hipStream_t s, int corr, const EvalBatchPtrs &b, int count, int64_t ldx, int n, int d, int hcols,
+                            double nugget, int64_t ld, int n_pad, int rhs_pad, int q) {
+    if (hcols != 1 || d > kCorrDC || count < 1 || count > EvalBatchPtrs::kMax) return EGX_ERR_UNSUPPORTED;
+    const int nt2 = n_pad / 128;
+    const dim3 grid((unsigned)(4 * (nt2 * (nt2 + 1) / 2)), (unsigned)count);
+    const size_t lds = (size_t)d * 64 * sizeof(double);
+    hipLaunchKernelGGL(k_scale_rows_batch, dim3((unsigned)((ldx + 255) / 256), (unsigned)count), dim3(256), 0, s, b, ldx, d);
+    EGX_DISPATCH_CORR(corr, hipLaunchKernelGGL((k_corr_sym_srow_batch<C_>), grid, dim3(256), lds, s, b, ldx, n, d, 1.0 + nugget, ld));
+    hipLaunchKernelGGL(k_fill_rows_batch, dim3(256, (unsigned)count), dim3(256), 0, s, b, ld, n_pad, rhs_pad, ldx, q, n_pad);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+int launch_eval_tail(hipStream_t s, const EvalBatchPtrs &b, int count, int64_t ld, int n, int n_pad, int q, int rows, const int *sync) {
+    hipLaunchKernelGGL(k_eval_tail, dim3((unsigned)((n_pad + 255) / 256), (unsigned)(rows ? 1 + q : 1), (unsigned)count), dim3(256), 0, s, b,
+                       ld, n, n_pad, rows, sync);
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
 }

@@ -22,7 +22,9 @@
 //                diagonal block of a chain launch has a workgroup of its own from the start, hence the bound of
 //                kPipeDiagBlocks (32) on workspaces x panels
 // group_panels   panels per trailing update (EGX_POTRF_GROUP; profiles/r02_run13_*: four pay from n ~ 14000 on)
-// (Round 5 also measured a chain launch for the LAST columns of a large right-looking factorisation behind one update of the
+// (Round 5 also measured (a) look-ahead further down the matrix for lock-step widths >= 4 -- 1024 instead of 3072 trailing
+//  columns: n = 4096 in lock-step 12 unchanged, 7.9 ms of launches per batch either way, because a chain launch that shares the
+//  chip runs 3x longer than alone, profiles/r05_look_by_width_discarded.txt -- and (b) a chain launch for the LAST columns of a large right-looking factorisation behind one update of the
 //  whole trailing matrix: n = 16384 30.2 against 28.9 ms, n = 8192 6.8 against 5.9 -- profiles/r05_pipe_check_tail_*.txt; gone.)
 #pragma once
 

@@ -146,11 +146,14 @@ def main():
                     help="unix time at which the (single) timed fit starts: bench.py's cpu_baseline_concurrent runs several "
                          "of these processes side by side, the reference's rayon-parallel multistart shape")
     ap.add_argument("--tiled", type=int, default=0, help="(internal) time the tiled task-parallel Cholesky with this many threads")
-    ap.add_argument("--tiled-threads", default="32,64,96,128",
-                    help="OpenMP thread counts tried for the tiled Cholesky (each in a process of its own; '' = skip)")
+    ap.add_argument("--tile", type=int, default=512, help="(internal, with --tiled) tile size")
+    ap.add_argument("--tiled-threads", default="32:512,48:512,64:512,64:1024,96:512",
+                    help="threads:tile settings tried for the tiled Cholesky (each in a process of its own, threads bound to "
+                         "cores; '' = skip).  scipy's OpenBLAS serves at most 64 concurrent callers: beyond, it aborts the "
+                         "process (measured on the GPU box's 256-thread host) and the setting is listed with its error")
     args = ap.parse_args()
     if args.tiled:
-        print(json.dumps(tiled_potrf_seconds(args.n, args.d, args.tiled)), flush=True)
+        print(json.dumps(tiled_potrf_seconds(args.n, args.d, args.tiled, nb=args.tile)), flush=True)
         return
     best, tried = None, []
     for t in [int(v) for v in str(args.blas_threads).split(",") if v.strip() != ""]:
@@ -164,20 +167,24 @@ def main():
     import subprocess
     tiled = []
     ncpu = os.cpu_count() or 1
-    for th in [int(v) for v in str(args.tiled_threads).split(",") if v.strip() != ""]:
+    for setting in [v.strip() for v in str(args.tiled_threads).split(",") if v.strip() != ""]:
+        th, _, tile = setting.partition(":")
+        th, tile = int(th), int(tile or 512)
         if th > ncpu and tiled:
             continue
+        out = None
         try:
             out = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", "--n", str(args.n), "--d", str(args.d), "--tiled",
-                                  str(min(th, ncpu))], capture_output=True, text=True, timeout=600,
-                                 cwd=os.path.dirname(_HERE), env=dict(os.environ, OMP_PROC_BIND="spread"))
+                                  str(min(th, ncpu)), "--tile", str(tile)], capture_output=True, text=True, timeout=600,
+                                 cwd=os.path.dirname(_HERE), env=dict(os.environ, OMP_PROC_BIND="spread", OMP_PLACES="cores"))
             rec = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:  # noqa: BLE001 - a setting the BLAS cannot serve must not cost the baseline
-            rec = {"threads": th, "error": f"{type(e).__name__}: {e}"[:200]}
+            rec = {"threads": th, "tile": tile, "error": f"{type(e).__name__}: {e}"[:120],
+                   "exit_code": getattr(out, "returncode", None), "stderr_tail": (out.stderr[-300:] if out is not None else None)}
         tiled.append(rec)
     ok = [r for r in tiled if r.get("info") == 0]
     best["tiled_cholesky"] = {"settings_tried": tiled,
-                              "what": "oracle/tiled_chol.c: right-looking tiled Cholesky, 512 x 512 tiles, single-threaded OpenBLAS "
+                              "what": "oracle/tiled_chol.c: right-looking tiled Cholesky, square tiles, single-threaded OpenBLAS "
                                       "dpotrf / dtrsm / dsyrk / dgemm as OpenMP tasks with data dependences"}
     if ok:
         tb = min(ok, key=lambda r: r["potrf_s"])

@@ -1,6 +1,7 @@
 // Host check of the schedule table (egobox_amd/csrc/schedule.h): the documented rows, the knobs' meaning, and that nothing
 // but (padded size, lock-step width, workspaces) enters.  Built and run by tests/test_tile_tables_cpu.py (g++, no GPU).
 #include <cstdio>
+#include <initializer_list>
 
 #include "../../egobox_amd/csrc/schedule.h"
 
