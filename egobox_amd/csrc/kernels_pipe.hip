@@ -760,7 +760,12 @@ int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot
     const long long n_diag = (long long)a.nz * np, want = n_diag + (long long)a.nz * plan.ntasks;
     // (a chain launch that runs BESIDE the launches it waits for or shares the chip with -- look-ahead -- must leave them
     //  compute units: its workgroups fill one each and would otherwise spin on a launch that cannot start)
-    long long wgs = g_pipe_test_wgs > 0 ? g_pipe_test_wgs : (shared_chip ? (kPipeSharedWgs < n_cu ? kPipeSharedWgs : n_cu) : n_cu);
+    #ifdef EGX_DEV_KNOBS
+    const int shared_wgs = dev_env("EGX_DEV_PIPE_SHARED_WGS", kPipeSharedWgs);
+#else
+    const int shared_wgs = kPipeSharedWgs;
+#endif
+    long long wgs = g_pipe_test_wgs > 0 ? g_pipe_test_wgs : (shared_chip ? (shared_wgs < n_cu ? shared_wgs : n_cu) : n_cu);
     if (wgs > n_cu) wgs = n_cu;
     if (wgs > want) wgs = want;
     if (wgs < n_diag + 1) wgs = n_diag + 1;

@@ -39,11 +39,23 @@ struct PotrfSchedule {
 struct ScheduleKnobs {  // egx_set_tuning / environment: "potrf_left", "pipe", "potrf_group"
     int potrf_left = 1, pipe = 1, potrf_group = 0;
 };
+#ifdef EGX_DEV_KNOBS  // (scratch builds for A/B measurements only: tools/dev_build.sh; never in the product library)
+}  // namespace egx
+#include <cstdlib>
+namespace egx {
+inline int dev_env(const char *name, int dflt) {
+    const char *e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
+}
+#define EGX_PIPE_MAX_COLS dev_env("EGX_DEV_PIPE_MAX", kPipeMaxCols)
+#else
+#define EGX_PIPE_MAX_COLS kPipeMaxCols
+#endif
 inline PotrfSchedule schedule_table(int n_pad, int lockstep, int n_workspaces, const ScheduleKnobs &k) {
     PotrfSchedule s;
     s.left = k.potrf_left >= 2 || (k.potrf_left == 1 && n_pad >= 14336 && lockstep >= 8);
     s.w_left = n_pad % 256 == 0 && (k.potrf_left >= 2 || (k.potrf_left == 1 && n_pad >= 14336 && lockstep >= 4));
-    s.pipe = k.pipe != 0 && n_pad <= kPipeMaxCols;
+    s.pipe = k.pipe != 0 && n_pad <= EGX_PIPE_MAX_COLS;
     s.whole = s.pipe && k.pipe == 1 && (long long)n_workspaces * ((n_pad + 255) / 256) <= kPipeDiagBlocks;
     s.group_panels = k.potrf_group ? k.potrf_group : (n_pad >= 14336 ? 4 : 2);
     return s;
