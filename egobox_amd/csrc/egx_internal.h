@@ -204,6 +204,13 @@ int launch_syrk_uptri_neg(hipStream_t s, double *C, int64_t ldc, const double *W
 // dinv <- inverses of the 64x64 diagonal tiles of a given lower factor (model load path)
 int launch_diag_tile_inverses(hipStream_t s, const double *M, int64_t ld, int n_pad, double *dinv);
 // Wall ((n_pad/256) x 256 x 256) <- transposed inverses of the 256x256 diagonal blocks of the factor
+// per-model pointers of a lock-step back-substitution (egx_gp_finalize_multi), by value in the kernel arguments
+struct SolveBatchPtrs {
+    static constexpr int kMax = 16;
+    const double *M[kMax], *dinv[kMax];
+    double *dW[kMax], *rhs[kMax], *vec[kMax];
+};
+int launch_backward_solve_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64_t ld, int n_pad);
 int launch_block_inverse(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *dinv, double *Wall);
 // xout (n_pad) <- C^-T v ; v (n_pad) is destroyed   (needs launch_block_inverse first)
 int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *Wall, double *v,

@@ -809,6 +809,61 @@ static int finalize_tail_enqueue(egx_gp *gp, const std::vector<double> &coef, in
     if (hcols == 1) EGX_RC(launch_scale_rows(w.stream, gp->d_xT, gp->n_pad, gp->d, gp->d_fit_coef, dev_xs_fit(gp)));
     return EGX_SUCCESS;
 }
+// ... of the members of a group that were evaluated in lock-step (egx_gp_finalize_multi): the host halves one after the other,
+// then ONE launch sequence for all back-substitutions (launch_backward_solve_batch: 65 launches instead of 65 per model -- the
+// command processor serialises such ~5 us launches however many streams or host threads issue them: eight n = 8192 experts
+// 36.9 -> X ms, profiles/r05_expert_group_*.txt) on the stream the evaluation ran on, and the fitted state's device copies.
+// rcs[j] / errs[j]: per-model outcome of the host half (a model that failed is left out of the launches).
+static int finalize_tails_lockstep(egx_gp *const *gps, int len, const std::vector<double> *coefs, int hcols, FinalizeTail *tails,
+                                   int *rcs, std::string *errs) {
+    hipStream_t st = gps[0]->ws[0].eval_stream;
+    SolveBatchPtrs bp;
+    int live[SolveBatchPtrs::kMax], nlive = 0;
+    for (int j = 0; j < len; j++) {
+        egx_gp *gp = gps[j];
+        Workspace &w = gp->ws[0];
+        FinalizeTail &ft = tails[j];
+        ft.t0 = std::chrono::steady_clock::now();
+        int rc = finish_eval(gp, w, ft.res, 1);
+        ft.t1 = std::chrono::steady_clock::now();
+        if (rc == EGX_SUCCESS && ft.res.status != EGX_STATUS_OK) {
+            rc = ft.res.status == EGX_STATUS_NOT_POSITIVE_DEFINITE ? EGX_ERR_LINALG : EGX_ERR_LIKELIHOOD;
+            set_error(ft.res.status == EGX_STATUS_NOT_POSITIVE_DEFINITE
+                          ? "LinalgError: matrix is not positive definite (pivot " + std::to_string(*w.h_info) + ")"
+                          : ft.res.status == EGX_STATUS_ILL_CONDITIONED_F
+                                ? std::string("LikelihoodComputation computation error: F is too ill conditioned. Poor combination of "
+                                              "regression model and observations.")
+                                : std::string("LikelihoodComputation computation error: ft is too ill conditioned, try another theta again"));
+        }
+        rcs[j] = rc;
+        if (rc != EGX_SUCCESS) {
+            errs[j] = last_error_string();
+            continue;
+        }
+        if (!w.dW) EGX_HIP_CHECK(dev_malloc(&w.dW, sizeof(double) * (size_t)((gp->n_pad + kNB - 1) / kNB) * 65536));
+        if (!ft.res.rho_on_device) {
+            std::memset(w.h_vec, 0, sizeof(double) * gp->n_pad);
+            std::memcpy(w.h_vec, ft.res.rho.data(), sizeof(double) * gp->n);
+            EGX_HIP_CHECK(hipMemcpyAsync(w.d_rhs, w.h_vec, sizeof(double) * gp->n_pad, hipMemcpyHostToDevice, st));
+        }
+        bp.M[nlive] = w.M, bp.dinv[nlive] = w.dinv, bp.dW[nlive] = w.dW, bp.rhs[nlive] = w.d_rhs, bp.vec[nlive] = w.d_vec;
+        live[nlive++] = j;
+    }
+    if (nlive == 0) return EGX_SUCCESS;
+    egx_gp *g0 = gps[live[0]];
+    EGX_RC(launch_backward_solve_batch(st, bp, nlive, g0->ld, g0->n_pad));  // gamma = C^-T rho (algorithm.rs:1034)
+    for (int q = 0; q < nlive; q++) {
+        egx_gp *gp = gps[live[q]];
+        Workspace &w = gp->ws[0];
+        const size_t nb = sizeof(double) * gp->n_pad;
+        EGX_HIP_CHECK(hipMemcpyAsync(gp->d_gamma, w.d_vec, nb, hipMemcpyDeviceToDevice, st));
+        EGX_HIP_CHECK(hipMemcpyAsync(w.h_vec, w.d_vec, nb, hipMemcpyDeviceToHost, st));
+        EGX_HIP_CHECK(hipMemcpyAsync(gp->d_fit_coef, w.d_coef, sizeof(double) * coefs[live[q]].size(), hipMemcpyDeviceToDevice, st));
+        if (hcols == 1) EGX_RC(launch_scale_rows(st, gp->d_xT, gp->n_pad, gp->d, gp->d_fit_coef, dev_xs_fit(gp)));
+    }
+    EGX_HIP_CHECK(hipStreamSynchronize(st));
+    return EGX_SUCCESS;
+}
 static int finalize_tail_complete(egx_gp *gp, const std::vector<double> &coef, int hcols, const std::vector<double> &thfull,
                                   FinalizeTail &ft) {
     Workspace &w = gp->ws[0];
@@ -1520,15 +1575,25 @@ static int multi_eval(egx_gp *const *gps, int32_t k, const double *thetas, int64
         else EGX_RC(enqueue_eval(gps[i], gps[i]->ws[0], coefs[0], hcols));
         std::vector<FinalizeTail> tails((size_t)(finalize ? len : 0));
         std::vector<int> trc((size_t)len, EGX_SUCCESS);
-        if (finalize)  // (the models' tails -- host half, gamma's back-substitution on each model's own stream -- overlap)
-            for (int j = 0; j < len; j++) trc[(size_t)j] = finalize_tail_enqueue(gps[i + j], coefs[(size_t)j], hcols, tails[(size_t)j]);
+        std::vector<std::string> terr((size_t)len);
+        if (finalize && len > 1 && len <= SolveBatchPtrs::kMax) {
+            EGX_RC(finalize_tails_lockstep(gps + i, len, coefs.data(), hcols, tails.data(), trc.data(), terr.data()));
+        } else if (finalize) {
+            for (int j = 0; j < len; j++) {
+                trc[(size_t)j] = finalize_tail_enqueue(gps[i + j], coefs[(size_t)j], hcols, tails[(size_t)j]);
+                if (trc[(size_t)j] != EGX_SUCCESS) terr[(size_t)j] = last_error_string();
+            }
+        }
         for (int j = 0; j < len; j++) {
             egx_gp *g = gps[i + j];
             int rc;
             if (finalize) {
                 rc = trc[(size_t)j];
                 if (rc == EGX_SUCCESS) rc = finalize_tail_complete(g, coefs[(size_t)j], hcols, thfull[(size_t)j], tails[(size_t)j]);
-                else (void)hipStreamSynchronize(g->ws[0].stream);
+                else {
+                    if (!terr[(size_t)j].empty()) set_error(terr[(size_t)j]);
+                    (void)hipStreamSynchronize(g->ws[0].stream);
+                }
             } else {
                 EvalResult res;
                 rc = finish_eval(g, g->ws[0], res, 0);

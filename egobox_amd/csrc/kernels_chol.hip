@@ -667,8 +667,8 @@ __global__ __launch_bounds__(256, 1) void k_diag_tile_inverses(const double *__r
 // ---------------------------------------------------------------------------------------------
 // W (256 x 256 row-major per block, upper triangular) = Linv^T built from the 64x64 tile inverses:
 //   W(c,c) = dinv_c^T ;  W(c,t) = -[ W(c, c..t-1) L(t, c..t-1)^T ] dinv_t^T   for t > c
-__global__ __launch_bounds__(512, 2) void k_block_inv256(const double *__restrict__ M, int64_t ld, int n_pad,
-                                                         const double *__restrict__ dinv, double *__restrict__ Wall) {
+__device__ __forceinline__ void block_inv256_body(const double *__restrict__ M, int64_t ld, int n_pad,
+                                                  const double *__restrict__ dinv, double *__restrict__ Wall) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int b = blockIdx.x, k0 = b * 256;
     const int nbk = (n_pad - k0 < 256) ? (n_pad - k0) : 256, nt = nbk / 64;
@@ -709,12 +709,22 @@ __global__ __launch_bounds__(512, 2) void k_block_inv256(const double *__restric
             __syncthreads();
         }
 }
+__global__ __launch_bounds__(512, 2) void k_block_inv256(const double *__restrict__ M, int64_t ld, int n_pad,
+                                                         const double *__restrict__ dinv, double *__restrict__ Wall) {
+    block_inv256_body(M, ld, n_pad, dinv, Wall);
+}
+// ... of several models at once (blockIdx.y = model; egx_gp_finalize_multi): the back-substitutions of eight experts are
+// 8 x 65 launches of ~5 us that the command processor serialises however many streams and host threads issue them -- in
+// lock-step they are 65 (profiles/r05_expert_group_*.txt)
+__global__ __launch_bounds__(512, 2) void k_block_inv256_batch(SolveBatchPtrs b, int64_t ld, int n_pad) {
+    block_inv256_body(b.M[blockIdx.y], ld, n_pad, b.dinv[blockIdx.y], b.dW[blockIdx.y]);
+}
 
 // x = W v for one 256-block (W upper triangular).  grid = 8 workgroups x 32 rows: each wave owns 8 rows and
 // streams them with all loads of 4 rows in flight (one workgroup alone is HBM-latency bound: 24 us).
 // x is written to xout (a separate buffer: other workgroups still read v).
-__global__ __launch_bounds__(256) void k_trsv_w(const double *__restrict__ W, int nbk, const double *__restrict__ v,
-                                                double *__restrict__ xout) {
+__device__ __forceinline__ void trsv_w_body(const double *__restrict__ W, int nbk, const double *__restrict__ v,
+                                            double *__restrict__ xout) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const double v0 = (lane < nbk) ? v[lane] : 0.0, v1 = (lane + 64 < nbk) ? v[lane + 64] : 0.0;
     const double v2 = (lane + 128 < nbk) ? v[lane + 128] : 0.0, v3 = (lane + 192 < nbk) ? v[lane + 192] : 0.0;
@@ -735,10 +745,18 @@ __global__ __launch_bounds__(256) void k_trsv_w(const double *__restrict__ W, in
         }
     }
 }
+__global__ __launch_bounds__(256) void k_trsv_w(const double *__restrict__ W, int nbk, const double *__restrict__ v,
+                                                double *__restrict__ xout) {
+    trsv_w_body(W, nbk, v, xout);
+}
+__global__ __launch_bounds__(256) void k_trsv_w_batch(SolveBatchPtrs b, int blk, int k0, int nbk) {
+    const int z = blockIdx.y;
+    trsv_w_body(b.dW[z] + (int64_t)blk * 65536, nbk, b.rhs[z] + k0, b.vec[z] + k0);
+}
 
 // v[j] -= sum_i Mrow[i*ld + j] * x[i]  for j < ncols ; grid = ncols/64
-__global__ __launch_bounds__(256) void k_gemv_t_update(const double *__restrict__ Mrow, int64_t ld, int nbk,
-                                                       const double *__restrict__ x, double *__restrict__ v) {
+__device__ __forceinline__ void gemv_t_update_body(const double *__restrict__ Mrow, int64_t ld, int nbk,
+                                                   const double *__restrict__ x, double *__restrict__ v) {
     __shared__ double xs[256];
     __shared__ double red[4][64];
     const int tid = threadIdx.x, g = tid >> 6, jl = tid & 63;
@@ -756,6 +774,14 @@ __global__ __launch_bounds__(256) void k_gemv_t_update(const double *__restrict_
     red[g][jl] = part;
     __syncthreads();
     if (g == 0) v[j] -= ((red[0][jl] + red[1][jl]) + red[2][jl]) + red[3][jl];
+}
+__global__ __launch_bounds__(256) void k_gemv_t_update(const double *__restrict__ Mrow, int64_t ld, int nbk,
+                                                       const double *__restrict__ x, double *__restrict__ v) {
+    gemv_t_update_body(Mrow, ld, nbk, x, v);
+}
+__global__ __launch_bounds__(256) void k_gemv_t_update_batch(SolveBatchPtrs b, int64_t ld, int k0, int nbk) {
+    const int z = blockIdx.y;
+    gemv_t_update_body(b.M[z] + (int64_t)k0 * ld, ld, nbk, b.vec[z] + k0, b.rhs[z]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1495,6 +1521,23 @@ int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const d
         if (k0 > 0)
             hipLaunchKernelGGL(k_gemv_t_update, dim3(k0 / 64), dim3(256), 0, s, M + (int64_t)k0 * ld, ld, nbk,
                                (const double *)(xout + k0), v);
+    }
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+
+// vec[j] (n_pad) <- C_j^-T rhs[j] for `count` models of one shape: launch_block_inverse + launch_trsv_t in lock-step
+int launch_backward_solve_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64_t ld, int n_pad) {
+    int rc = chol_init();
+    if (rc) return rc;
+    constexpr int lds = GemmShape<64, 64, 16, 32, 512>::LDS_BYTES;
+    const int nblocks = (n_pad + kNB - 1) / kNB;
+    hipLaunchKernelGGL(k_block_inv256_batch, dim3((unsigned)nblocks, (unsigned)count), dim3(512), lds, s, b, ld, n_pad);
+    for (int blk = nblocks - 1; blk >= 0; blk--) {
+        const int k0 = blk * kNB;
+        const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;
+        hipLaunchKernelGGL(k_trsv_w_batch, dim3(8, (unsigned)count), dim3(256), 0, s, b, blk, k0, nbk);
+        if (k0 > 0) hipLaunchKernelGGL(k_gemv_t_update_batch, dim3((unsigned)(k0 / 64), (unsigned)count), dim3(256), 0, s, b, ld, k0, nbk);
     }
     EGX_HIP_CHECK(hipGetLastError());
     return EGX_SUCCESS;
