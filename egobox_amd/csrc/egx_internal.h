@@ -210,7 +210,8 @@ struct SolveBatchPtrs {
     const double *M[kMax], *dinv[kMax];
     double *dW[kMax], *rhs[kMax], *vec[kMax];
 };
-int launch_backward_solve_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64_t ld, int n_pad);
+int launch_block_inverse_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64_t ld, int n_pad);
+int launch_trsv_t_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64_t ld, int n_pad);
 int launch_block_inverse(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *dinv, double *Wall);
 // xout (n_pad) <- C^-T v ; v (n_pad) is destroyed   (needs launch_block_inverse first)
 int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *Wall, double *v,

@@ -83,6 +83,7 @@ struct Workspace {
     double *h_rows = nullptr;  // pinned: q x n_pad solved RHS rows (ft^T, yt^T)
     double *h_diag = nullptr;  // pinned: n
     double *h_vec = nullptr;   // pinned: n_pad
+    bool block_inv_ready = false;  // dW holds the inverse blocks of the factor now in M (launched ahead of the host's GLS: finalize)
     int *h_info = nullptr;     // pinned: [0] the factorisation's info, [1..8] the abort word + diagnostics of its chain launches
     // theta-gradient scratch (lazy, gp_fit.hip): the workgroups' partial sums, the reduced sums, their pinned copy
     double *d_gpart = nullptr, *d_gout = nullptr, *h_gout = nullptr;

@@ -759,10 +759,21 @@ int eval_one(egx_gp *gp, int widx, const double *theta, int64_t theta_len, EvalR
 }
 
 // w.d_vec <- C^-T w.d_rhs  (block inverses are rebuilt: the factor in w.M has just changed)
+static int ensure_block_inverse_buffer(egx_gp *gp, Workspace &w) {
+    if (!w.dW) EGX_HIP_CHECK(dev_malloc(&w.dW, sizeof(double) * (size_t)((gp->n_pad + kNB - 1) / kNB) * 65536));
+    return EGX_SUCCESS;
+}
+// The inverse blocks only need the factor, not the host's half of the likelihood: a fit launches them right behind the
+// evaluation, so that they run while the host waits for the read-back and does its GLS (84 us off a fit's critical path)
+static int prelaunch_block_inverse(egx_gp *gp, Workspace &w, hipStream_t st) {
+    EGX_RC(ensure_block_inverse_buffer(gp, w));
+    EGX_RC(launch_block_inverse(st, w.M, gp->ld, gp->n_pad, w.dinv, w.dW));
+    w.block_inv_ready = true;
+    return EGX_SUCCESS;
+}
 int backward_solve(egx_gp *gp, Workspace &w) {
-    if (!w.dW)
-        EGX_HIP_CHECK(dev_malloc(&w.dW, sizeof(double) * (size_t)((gp->n_pad + kNB - 1) / kNB) * 65536));
-    EGX_RC(launch_block_inverse(w.stream, w.M, gp->ld, gp->n_pad, w.dinv, w.dW));
+    if (!w.block_inv_ready) EGX_RC(prelaunch_block_inverse(gp, w, w.stream));
+    w.block_inv_ready = false;
     EGX_RC(launch_trsv_t(w.stream, w.M, gp->ld, gp->n_pad, w.dW, w.d_rhs, w.d_vec));
     return EGX_SUCCESS;
 }
@@ -810,7 +821,7 @@ static int finalize_tail_enqueue(egx_gp *gp, const std::vector<double> &coef, in
     return EGX_SUCCESS;
 }
 // ... of the members of a group that were evaluated in lock-step (egx_gp_finalize_multi): the host halves one after the other,
-// then ONE launch sequence for all back-substitutions (launch_backward_solve_batch: 65 launches instead of 65 per model -- the
+// then ONE launch sequence for all back-substitutions (launch_trsv_t_batch: 64 launches instead of 64 per model -- the
 // command processor serialises such ~5 us launches however many streams or host threads issue them: eight n = 8192 experts
 // 36.9 -> X ms, profiles/r05_expert_group_*.txt) on the stream the evaluation ran on, and the fitted state's device copies.
 // rcs[j] / errs[j]: per-model outcome of the host half (a model that failed is left out of the launches).
@@ -840,7 +851,6 @@ static int finalize_tails_lockstep(egx_gp *const *gps, int len, const std::vecto
             errs[j] = last_error_string();
             continue;
         }
-        if (!w.dW) EGX_HIP_CHECK(dev_malloc(&w.dW, sizeof(double) * (size_t)((gp->n_pad + kNB - 1) / kNB) * 65536));
         if (!ft.res.rho_on_device) {
             std::memset(w.h_vec, 0, sizeof(double) * gp->n_pad);
             std::memcpy(w.h_vec, ft.res.rho.data(), sizeof(double) * gp->n);
@@ -851,7 +861,7 @@ static int finalize_tails_lockstep(egx_gp *const *gps, int len, const std::vecto
     }
     if (nlive == 0) return EGX_SUCCESS;
     egx_gp *g0 = gps[live[0]];
-    EGX_RC(launch_backward_solve_batch(st, bp, nlive, g0->ld, g0->n_pad));  // gamma = C^-T rho (algorithm.rs:1034)
+    EGX_RC(launch_trsv_t_batch(st, bp, nlive, g0->ld, g0->n_pad));  // gamma = C^-T rho (algorithm.rs:1034); inverse blocks: multi_eval
     for (int q = 0; q < nlive; q++) {
         egx_gp *gp = gps[live[q]];
         Workspace &w = gp->ws[0];
@@ -906,6 +916,7 @@ int do_finalize(egx_gp *gp, const double *theta, int64_t theta_len) {
     }
     gp->fitted = false;
     EGX_RC(enqueue_eval(gp, gp->ws[0], coef, hcols));
+    EGX_RC(prelaunch_block_inverse(gp, gp->ws[0], gp->ws[0].stream));
     return finalize_tail(gp, coef, hcols, thfull);
 }
 // Candidates pipelined over the handle's workspaces (caller holds gp->mu exclusively and has set the device).
@@ -1573,6 +1584,19 @@ static int multi_eval(egx_gp *const *gps, int32_t k, const double *thetas, int64
         for (int j = 0; j < len; j++) gps[i + j]->fitted = false;
         if (len > 1) EGX_RC(enqueue_eval_members(gps + i, len, coefs.data(), hcols));
         else EGX_RC(enqueue_eval(gps[i], gps[i]->ws[0], coefs[0], hcols));
+        if (finalize && len > 1 && len <= SolveBatchPtrs::kMax) {
+            // the members' inverse blocks (for gamma's back-substitution) right behind the evaluation, in lock-step: they only need
+            // the factors and run while the host waits for the read-back and does the models' GLS
+            SolveBatchPtrs ib;
+            for (int j = 0; j < len; j++) {
+                Workspace &w = gps[i + j]->ws[0];
+                EGX_RC(ensure_block_inverse_buffer(gps[i + j], w));
+                ib.M[j] = w.M, ib.dinv[j] = w.dinv, ib.dW[j] = w.dW, ib.rhs[j] = w.d_rhs, ib.vec[j] = w.d_vec;
+            }
+            EGX_RC(launch_block_inverse_batch(gps[i]->ws[0].eval_stream, ib, len, gps[i]->ld, gps[i]->n_pad));
+        } else if (finalize) {
+            for (int j = 0; j < len; j++) EGX_RC(prelaunch_block_inverse(gps[i + j], gps[i + j]->ws[0], gps[i + j]->ws[0].stream));
+        }
         std::vector<FinalizeTail> tails((size_t)(finalize ? len : 0));
         std::vector<int> trc((size_t)len, EGX_SUCCESS);
         std::vector<std::string> terr((size_t)len);

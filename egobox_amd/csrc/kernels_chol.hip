@@ -1526,13 +1526,18 @@ int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const d
     return EGX_SUCCESS;
 }
 
-// vec[j] (n_pad) <- C_j^-T rhs[j] for `count` models of one shape: launch_block_inverse + launch_trsv_t in lock-step
-int launch_backward_solve_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64_t ld, int n_pad) {
+// launch_block_inverse / launch_trsv_t for `count` models of one shape in lock-step (blockIdx.y = model):
+// dW[j] <- the 256 x 256 inverse blocks of factor j;  vec[j] (n_pad) <- C_j^-T rhs[j]
+int launch_block_inverse_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64_t ld, int n_pad) {
     int rc = chol_init();
     if (rc) return rc;
     constexpr int lds = GemmShape<64, 64, 16, 32, 512>::LDS_BYTES;
+    hipLaunchKernelGGL(k_block_inv256_batch, dim3((unsigned)((n_pad + kNB - 1) / kNB), (unsigned)count), dim3(512), lds, s, b, ld, n_pad);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
+}
+int launch_trsv_t_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64_t ld, int n_pad) {
     const int nblocks = (n_pad + kNB - 1) / kNB;
-    hipLaunchKernelGGL(k_block_inv256_batch, dim3((unsigned)nblocks, (unsigned)count), dim3(512), lds, s, b, ld, n_pad);
     for (int blk = nblocks - 1; blk >= 0; blk--) {
         const int k0 = blk * kNB;
         const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;

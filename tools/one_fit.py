@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A few fixed-theta fits at one size, nothing else: the command profiled for timelines
-(`rocprofv3 --kernel-trace -- python tools/one_fit.py [n] [d] [reps] [corr] [width]`; width > 1: likelihood batches of that many
+(`rocprofv3 --kernel-trace -- python tools/one_fit.py [n] [d] [reps] [corr] [width] [workspaces]`; width > 1: likelihood batches of that many
 candidates on a handle with as many workspaces, in lock-step -- a round of a tuned fit's starts)."""
 import os
 import sys
@@ -18,14 +18,15 @@ corr = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # 0 sq-exp, 1 abs-exp, 2 Ma
 x, y = egx.workload.make_training_set(n, d, 42)
 th = egx.workload.default_theta(d)
 width = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+nws = int(sys.argv[6]) if len(sys.argv) > 6 else width  # workspaces (candidates per batch): nws / width slots in flight
 if width > 1:
-    h = egx.GpHandle(x, y, corr=corr, n_workspaces=width)
+    h = egx.GpHandle(x, y, corr=corr, n_workspaces=nws)
     h.set_lockstep(width)
     print("schedule", h.schedule(), flush=True)
     for i in range(reps):
         t0 = time.perf_counter()
-        lk, st = h.likelihood_batch(np.stack([th * (1 + 0.01 * (i * width + c)) for c in range(width)]))
-        print(f"batch {i}: {1e3 * (time.perf_counter() - t0):.3f} ms for {width} candidates, statuses ok {int((st == 0).sum())}  {h.timings()}",
+        lk, st = h.likelihood_batch(np.stack([th * (1 + 0.01 * (i * nws + c)) for c in range(nws)]))
+        print(f"batch {i}: {1e3 * (time.perf_counter() - t0):.3f} ms for {nws} candidates in slots of {width}, statuses ok {int((st == 0).sum())}  {h.timings()}",
               flush=True)
     h.close()
     sys.exit(0)
