@@ -885,8 +885,10 @@ def main():
         # (an OFFLINE measurement: attached only while it still describes this build -- the kernel's source text has the hash
         #  the summary was taken with and the live launch shape is the measured one; otherwise `traffic` is null)
         ll_pmc, ll_stale = None, None
-        ll_path = os.path.join(ROOT, "profiles", "r04_pmc_lockstep_group_left_looking_summary.json")
-        if (n, d) == (16384, 32) and os.path.exists(ll_path):
+        import glob
+        ll_found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_lockstep_group_left_looking_summary.json")))
+        ll_path = ll_found[-1] if ll_found else ""  # the latest round's measurement
+        if (n, d) == (16384, 32) and ll_path:
             with open(ll_path) as f:
                 ll_pmc = json.load(f)
             sig = stream_kernel_signature()
@@ -952,11 +954,11 @@ def main():
                        "'left-looking long update' of tools/rocpd_stats.py (profiles/r04_group_roofline_kernel_stats.txt)",
                 "traffic_stale": ll_stale,
                 "traffic_source": (None if not ll_pmc else {
-                    "measured": "OFFLINE (round 4), not in this run; attached because the kernel source hash and the live launch "
-                                "shape match the measurement",
+                    "measured": "OFFLINE, not in this run; attached because the kernel source hash and the live launch shape match "
+                                "the measurement",
                     "kernel_source_sha256": ll_pmc.get("kernel_source_sha256"),
-                    "file": "profiles/r04_pmc_lockstep_group_left_looking_summary.json (from ..._pass1-3.json: separate "
-                            "rocprofv3 --pmc passes of tools/group_roofline.py, offline)",
+                    "file": "profiles/" + os.path.basename(ll_path) + " (from ..._pass1-3.json: separate rocprofv3 --pmc passes of "
+                            "tools/group_roofline.py, tools/gpu_pmc_r05.sh + tools/pmc_group_summary.py, offline)",
                     "fetch_size_bytes_per_launch_raw": ll_pmc["fetch_bytes_per_launch"],
                     "write_size_bytes_per_launch_raw": ll_pmc["write_bytes_per_launch"],
                     "correction": ll_pmc["correction"], "l2_hit_rate": ll_pmc["l2_hit_rate"],
