@@ -324,9 +324,19 @@ __device__ __noinline__ int pipe_role_trsm(pipe_kargs_t ka, pipe_lds_t sm3, long
     for (int k = 0; k < 16; k++) {
         if (k < nb16) {
             have = (k + 1 < nb16) && (avail >= base + k + 2);
-            if (have) stage_load(k + 1);
+            // a QUARTER of the panel's columns (four strips, one per wave residue) is complete with this strip: its stores are
+            // drained in front of the barrier and the rows' progress word is raised behind it -- FINE tasks contract quarter by
+            // quarter, so the update of the next diagonal block is three quarters done when the last strip arrives
+            const bool qend = (k & 3) == 3 || k + 1 == nb16;
+            if (have && !qend) stage_load(k + 1);
             if (sw == (k & 3)) solve(k);
+            if (qend) {
+                drain_stores();  // (in front of the next strip's fetch: the wait is for the stores only)
+                if (have) stage_load(k + 1);
+            }
             __syncthreads();  // X_k is in LDS
+            if (qend && tid == 0)
+                for (int c = 0; c < RT; c++) store_flag(S + a.off_rowT + P * a.NC + c0 + c, (k >> 2) + 1);
             {
                 const double *Lb = Ls + (k & 1) * kTrsmLBuf;
                 d2_t b01[RT], b23[RT];
@@ -373,18 +383,21 @@ __device__ __noinline__ int pipe_role_trsm(pipe_kargs_t ka, pipe_lds_t sm3, long
             }
         }
     }
-    drain_stores();
-    __syncthreads();
-    if (tid == 0)
-        for (int c = 0; c < RT; c++) store_flag(S + a.off_rowT + P * a.NC + c0 + c, 1);
-    return 0;
+    return 0;  // (the last strip closed the last quarter: drained and published above)
 }
 
 // ---------------------------------------------------------------------------------------------
-// FINE: C (64 x 64 at rows 64 c_row, columns k0 + 256 + 64 j) -= A B^T over panel p's 256 columns.  Wave quadruple q
-// contracts k in [64 q, 64 q + 64) through its own LDS staging area; quadruple 0 adds the partial tiles in the order
-// 0, 1, 2, 3 and subtracts.
+// FINE: C (64 x 64 at rows 64 c_row, columns k0 + 256 + 64 j) -= A B^T over panel p's 256 columns, QUARTER BY QUARTER as
+// the TRSM tasks of the two row chunks publish them (rowT counts finished quarters): a quarter's 64 x 64 pieces of A and B
+// come through LDS (one agent-scope 32-byte piece of each per thread: every byte crosses the fabric once), wave w owns the
+// 16 x 16 sub-tile (w / 4, w % 4) and contracts the quarter with sixteen MFMAs, in ascending k -- no cross-wave reduction.
+// When the last strip of the panel arrives, the quarters before it are done: what is left on the chain is one quarter and
+// the tile's read-modify-write.  (Operands straight from L2 into the MFMAs, without LDS, were 4x the fabric traffic -- every
+// row slice is used by four waves -- and 64 us per task instead of 17: profiles/r05_fine_quarters.txt)
 // ---------------------------------------------------------------------------------------------
+constexpr int kFineLd = 68;                    // doubles per staged row (64 + 4: conflict-free 32-byte fragment reads)
+constexpr int kFineBuf = 2 * 64 * kFineLd;     // A and B pieces of one quarter
+static_assert(2 * kFineBuf <= kPipeLdsDoubles, "LDS of the FINE role");
 __device__ __noinline__ int pipe_role_fine(pipe_kargs_t ka, pipe_lds_t sm3, long long *tr, int z, int p, int c_row, int j) {
     const PipeArgs a = pipe_kargs(ka);
     z = pipe_uniform(z), p = pipe_uniform(p), c_row = pipe_uniform(c_row), j = pipe_uniform(j);
@@ -396,53 +409,69 @@ __device__ __noinline__ int pipe_role_fine(pipe_kargs_t ka, pipe_lds_t sm3, long
     double *sm = pipe_uniform_lds(sm3);
     int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
     const int k0 = a.g0 + 256 * p, P = k0 >> 8;
+    const int nq = ((a.n_pad - k0 < 256) ? (a.n_pad - k0) : 256) >> 6;  // quarters of panel p
     const int R0 = 64 * c_row, C0 = k0 + 256 + 64 * j, c_col = C0 >> 6;
     double *Mz = a.M + (int64_t)z * a.sM;
     const int *info = a.info + (int64_t)z * a.sI;
     int *S = a.sync + (int64_t)z * a.sS;
-    const int r = pipe_wg_wait<false>(s_ctl, [&]() {  // (operands and the C tile are read with agent-scope loads: no fence)
-        int rr = load_flag(info) != 0 ? 1 : 0;
-        if (rr == 0) rr = pipe_wait_ge(S + a.off_rowT + P * a.NC + c_row, 1, a.sync, info, a.timeout, (4 << 28) | ((p) << 20) | ((c_row) & 0xfffff));
-        if (rr == 0) rr = pipe_wait_ge(S + a.off_rowT + P * a.NC + c_col, 1, a.sync, info, a.timeout, (5 << 28) | ((p) << 20) | ((c_row) & 0xfffff));
-        if (rr == 0 && p > 0) rr = pipe_wait_ge(S + a.off_cver + (R0 >> 7) * a.NJ + (C0 >> 7), p, a.sync, info, a.timeout, (6 << 28) | ((p) << 20) | ((c_row) & 0xfffff));
-        return rr;
-    });
-    if (r) return r;
-    if (tr && threadIdx.x == 0) tr[3] = wall_clock64();
-    const int tid = threadIdx.x, q = tid >> 8, tl = tid & 255, lane = tid & 63, lw = tl >> 6;
-    double4_t acc[2][2];
+    const int tid = threadIdx.x, lane = tid & 63, frow = lane & 15, fk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int prow = ((frow & 3) << 2) | (frow >> 2);  // pi(frow), see rb_factor_block
+    // staging: thread -> row tid / 16 of the 64, doubles [4 (tid % 16), + 4) of the quarter's 64 columns
+    const int srow = tid >> 4, spart = (tid & 15) * 4;
+    const double *Ag = Mz + (int64_t)(R0 + srow) * a.ld + k0 + spart;
+    const double *Bg = Mz + (int64_t)(C0 + srow) * a.ld + k0 + spart;
+    // accumulator layout as everywhere here: lane (frow, fk), register i <-> C[frow][4 fk + i] of the sub-tile; the operand
+    // whose rows index the tile's COLUMNS is read at row pi(frow), the one whose rows index the tile's ROWS at row frow
+    const int a_off = (16 * (wave >> 2) + frow) * kFineLd + 4 * fk, b_off = 64 * kFineLd + (16 * (wave & 3) + prow) * kFineLd + 4 * fk;
+    double *Cp = Mz + (int64_t)(R0 + 16 * (wave >> 2) + frow) * a.ld + C0 + 16 * (wave & 3) + 4 * fk;
+    double4_t acc = double4_t{0.0, 0.0, 0.0, 0.0};
+    d2_t c01 = d2_t{0.0, 0.0}, c23 = d2_t{0.0, 0.0};
+    int done = 0;
+    while (done < nq) {
+        if (tid == 0) {  // the next quarter of both row chunks -- and how many more are there already
+            int rr = (done == 0 && load_flag(info) != 0) ? 1 : 0;
+            const int *fr = S + a.off_rowT + P * a.NC + c_row, *fc = S + a.off_rowT + P * a.NC + c_col;
+            if (rr == 0) rr = pipe_wait_ge(fr, done + 1, a.sync, info, a.timeout, (4 << 28) | ((p) << 20) | ((c_row) & 0xfffff));
+            if (rr == 0) rr = pipe_wait_ge(fc, done + 1, a.sync, info, a.timeout, (5 << 28) | ((p) << 20) | ((c_row) & 0xfffff));
+            int av = load_flag(fr);
+            const int av2 = load_flag(fc);
+            av = av < av2 ? av : av2;
+            av = av < nq ? av : nq;
+            if (rr == 0 && av == nq && p > 0)  // with the last quarter the tile itself: every earlier panel's update has been applied
+                rr = pipe_wait_ge(S + a.off_cver + (R0 >> 7) * a.NJ + (C0 >> 7), p, a.sync, info, a.timeout, (6 << 28) | ((p) << 20) | ((c_row) & 0xfffff));
+            s_ctl[0] = rr;
+            s_ctl[4] = av;
+        }
+        __syncthreads();
+        const int r = s_ctl[0], avail = s_ctl[4];
+        __syncthreads();
+        if (r) return r;
+        if (tr && done == 0 && threadIdx.x == 0) tr[3] = wall_clock64();
+        if (avail == nq) {  // (operands and the C tile are read with agent-scope loads: no fence; in flight with the staging loads)
+            c01 = load_d2_sc1(Cp);
+            c23 = load_d2_sc1(Cp + 2);
+        }
+        for (int q = done; q < avail; q++) {
+            double *buf = sm + (q & 1) * kFineBuf;
+            const d2_t a0 = load_d2_sc1(Ag + 64 * q), a1 = load_d2_sc1(Ag + 64 * q + 2);
+            const d2_t b0 = load_d2_sc1(Bg + 64 * q), b1 = load_d2_sc1(Bg + 64 * q + 2);
+            *reinterpret_cast<d2_t *>(buf + srow * kFineLd + spart) = a0;
+            *reinterpret_cast<d2_t *>(buf + srow * kFineLd + spart + 2) = a1;
+            *reinterpret_cast<d2_t *>(buf + 64 * kFineLd + srow * kFineLd + spart) = b0;
+            *reinterpret_cast<d2_t *>(buf + 64 * kFineLd + srow * kFineLd + spart + 2) = b1;
+            __syncthreads();  // (two buffers: the next quarter's stores cannot overtake this one's reads)
 #pragma unroll
-    for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++) acc[mi][ni] = double4_t{0.0, 0.0, 0.0, 0.0};
-    gemm_core<64, 64, 32, 32, 256, true>(Mz + (int64_t)R0 * a.ld + k0 + 64 * q, a.ld, Mz + (int64_t)C0 * a.ld + k0 + 64 * q, a.ld, 64, acc,
-                                   sm + q * kFineStage2, tl);
-    // (gemm_core ends behind a workgroup barrier: the staging areas are free)
-    const int rl = (lw >> 1) * 32 + (lane >> 4), cl = (lw & 1) * 32 + (lane & 15);  // + 16 mi + 4 r, + 16 ni
-    if (q > 0) {
-        double *part = sm + (q - 1) * 4096;
-#pragma unroll
-        for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (int rr = 0; rr < 4; rr++) part[(rl + 16 * mi + 4 * rr) * 64 + cl + 16 * ni] = acc[mi][ni][rr];
+            for (int kb = 0; kb < 4; kb++) {
+                const d2_t av0 = *reinterpret_cast<const d2_t *>(buf + b_off + 16 * kb), av1 = *reinterpret_cast<const d2_t *>(buf + b_off + 16 * kb + 2);
+                const d2_t bv0 = *reinterpret_cast<const d2_t *>(buf + a_off + 16 * kb), bv1 = *reinterpret_cast<const d2_t *>(buf + a_off + 16 * kb + 2);
+                RB_MFMA4(acc, 0, av0, av1, bv0[0], bv0[1], bv1[0], bv1[1]);
+            }
+        }
+        done = avail;
     }
-    __syncthreads();
-    if (q == 0) {
-        double *Ct = Mz + (int64_t)(R0 + rl) * a.ld + C0 + cl;
-#pragma unroll
-        for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (int rr = 0; rr < 4; rr++) {
-                    const int e = (rl + 16 * mi + 4 * rr) * 64 + cl + 16 * ni;
-                    const double sum = ((acc[mi][ni][rr] + sm[e]) + sm[4096 + e]) + sm[8192 + e];
-                    double *cp = Ct + (int64_t)(16 * mi + 4 * rr) * a.ld + 16 * ni;
-                    __hip_atomic_store(cp, load_sc1(cp) - sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-    }
+    store_d2_sc1(Cp, d2_t{c01[0] - acc[0], c01[1] - acc[1]});
+    store_d2_sc1(Cp + 2, d2_t{c23[0] - acc[2], c23[1] - acc[3]});
     drain_stores();
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(S + a.off_fcnt + (P + 1) * a.NC + c_row, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -468,13 +497,14 @@ __device__ __noinline__ int pipe_role_coarse(pipe_kargs_t ka, pipe_lds_t sm3, lo
     const int *info = a.info + (int64_t)z * a.sI;
     int *S = a.sync + (int64_t)z * a.sS;
     int *ver = S + a.off_cver + I * a.NJ + J;
+    const int nqp = ((a.n_pad - k0 < 256) ? (a.n_pad - k0) : 256) >> 6;  // rowT counts the finished QUARTERS of a row chunk
     const int r = pipe_wg_wait(s_ctl, [&]() {
         int rr = load_flag(info) != 0 ? 1 : 0;
         const int *rowT = S + a.off_rowT + P * a.NC;
-        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I, 1, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
-        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I + 1, 1, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
-        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * J, 1, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
-        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * J + 1, 1, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
+        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I, nqp, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
+        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I + 1, nqp, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
+        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * J, nqp, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
+        if (rr == 0) rr = pipe_wait_ge(rowT + 2 * J + 1, nqp, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
         if (rr == 0 && p > 0) rr = pipe_wait_ge(ver, p, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
         return rr;
     });
