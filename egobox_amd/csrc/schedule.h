@@ -4,9 +4,9 @@
 // egx_gp_shrink: all evaluations of a handle agree bit for bit (egx_gp_get_schedule shows the decision).
 //
 //   n_pad (padded size)   lock-step width   workspaces x panels     left   w_left   pipe   whole   panels per group
-//   <= 4096               any               <= 32                   0      0        1      1       (one launch)
+//   <= 7168               any               <= 32                   0      0        1      1       (one launch)
 //   <= 4096               any               >  32                   0      0        1      0       2
-//   4097 .. 14335         any               -                       0      0        0      0       2
+//   4097 .. 14335         any               >  32 or n_pad > 7168   0      0        0      0       2
 //   >= 14336              < 4               -                       0      0        0      0       4
 //   >= 14336              4 .. 7            -                       0      1        0      0       4
 //   >= 14336              >= 8              -                       1      1        0      0       4
@@ -20,7 +20,10 @@
 //                own right and the chain launch loses against them (n = 8192: 6.4 against 6.0 ms, profiles/r05_pipe_*)
 // whole          ... and the whole factorisation is one such launch (every update inside it; EGX_PIPE=2: never); every
 //                diagonal block of a chain launch has a workgroup of its own from the start, hence the bound of
-//                kPipeDiagBlocks (32) on workspaces x panels
+//                kPipeDiagBlocks (32) on workspaces x panels.  Up to kPipeWholeMaxCols (7168) columns: one matrix at
+//                n = 4608 / 5120 / 6144 / 7168 / 7680 / 8192: 1.63 / 1.98 / 2.90 / 4.24 / 5.32 / 6.5 ms against 2.32 / 2.72 / 3.52 /
+//                4.64 / 5.35 / 5.9 ms of separate launches (the in-launch 128 x 128 update tasks are slower than the stream
+//                kernel, and from ~8000 columns on the updates are what a factorisation is: profiles/r05_whole_launch_size_ab.txt)
 // group_panels   panels per trailing update (EGX_POTRF_GROUP; profiles/r02_run13_*: four pay from n ~ 14000 on)
 // (Round 5 also measured (a) look-ahead further down the matrix for lock-step widths >= 4 -- 1024 instead of 3072 trailing
 //  columns: n = 4096 in lock-step 12 unchanged, 7.9 ms of launches per batch either way, because a chain launch that shares the
@@ -30,8 +33,9 @@
 
 namespace egx {
 
-constexpr int kPipeMaxCols = 4096;   // padded size up to which the chain of a group of panels is one launch
-constexpr int kPipeDiagBlocks = 32;  // ... and the whole factorisation, while workspaces x panels stays within this
+constexpr int kPipeMaxCols = 4096;       // padded size up to which the chain of a group of panels is one launch
+constexpr int kPipeWholeMaxCols = 7168;  // ... up to which the WHOLE factorisation is one launch,
+constexpr int kPipeDiagBlocks = 32;      // while workspaces x panels stays within this
 
 struct PotrfSchedule {
     int left = 0, w_left = 0, pipe = 0, whole = 0, group_panels = 2;
@@ -48,15 +52,17 @@ inline int dev_env(const char *name, int dflt) {
     return e ? std::atoi(e) : dflt;
 }
 #define EGX_PIPE_MAX_COLS dev_env("EGX_DEV_PIPE_MAX", kPipeMaxCols)
+#define EGX_PIPE_WHOLE_MAX_COLS dev_env("EGX_DEV_PIPE_WHOLE_MAX", kPipeWholeMaxCols)
 #else
 #define EGX_PIPE_MAX_COLS kPipeMaxCols
+#define EGX_PIPE_WHOLE_MAX_COLS kPipeWholeMaxCols
 #endif
 inline PotrfSchedule schedule_table(int n_pad, int lockstep, int n_workspaces, const ScheduleKnobs &k) {
     PotrfSchedule s;
     s.left = k.potrf_left >= 2 || (k.potrf_left == 1 && n_pad >= 14336 && lockstep >= 8);
     s.w_left = n_pad % 256 == 0 && (k.potrf_left >= 2 || (k.potrf_left == 1 && n_pad >= 14336 && lockstep >= 4));
-    s.pipe = k.pipe != 0 && n_pad <= EGX_PIPE_MAX_COLS;
-    s.whole = s.pipe && k.pipe == 1 && (long long)n_workspaces * ((n_pad + 255) / 256) <= kPipeDiagBlocks;
+    s.whole = k.pipe == 1 && n_pad <= EGX_PIPE_WHOLE_MAX_COLS && (long long)n_workspaces * ((n_pad + 255) / 256) <= kPipeDiagBlocks;
+    s.pipe = k.pipe != 0 && (n_pad <= EGX_PIPE_MAX_COLS || s.whole);
     s.group_panels = k.potrf_group ? k.potrf_group : (n_pad >= 14336 ? 4 : 2);
     return s;
 }

@@ -23,7 +23,11 @@ int main() {
     expect(4096, 12, 12, d, 0, 0, 1, 0, 2);   // a tuned fit's twelve starts: chain launches per group
     expect(2176, 6, 6, d, 0, 0, 1, 0, 2);     // 6 x 9 > 32
     expect(1024, 8, 8, d, 0, 0, 1, 1, 2);     // 8 x 4 = 32
-    expect(4352, 1, 1, d, 0, 0, 0, 0, 2);        // beyond 4096 columns: separate launches
+    expect(4352, 1, 1, d, 0, 0, 1, 1, 2);        // a lone matrix up to 7168 columns: still one launch
+    expect(7168, 1, 1, d, 0, 0, 1, 1, 2);
+    expect(4352, 2, 2, d, 0, 0, 0, 0, 2);        // beyond 4096 columns with more diagonal blocks than 32: separate launches
+    expect(7424, 1, 1, d, 0, 0, 0, 0, 2);
+    expect(8192, 1, 1, d, 0, 0, 0, 0, 2);
     expect(8192, 2, 2, d, 0, 0, 0, 0, 2);
     expect(8192, 12, 12, d, 0, 0, 0, 0, 2);
     expect(14336, 1, 1, d, 0, 0, 0, 0, 4);
@@ -38,11 +42,11 @@ int main() {
         for (int w = 1; w <= 16; w++)
             for (int nws = w; nws <= 24; nws += 5) {
                 const egx::PotrfSchedule a = egx::schedule_table(n_pad, w, nws, d), b = egx::schedule_table(n_pad, w, nws + 100, d);
-                if (a.left != b.left || a.w_left != b.w_left || a.group_panels != b.group_panels || a.pipe != b.pipe) fails++;
+                if (a.left != b.left || a.w_left != b.w_left || a.group_panels != b.group_panels || (n_pad <= 4096 && a.pipe != b.pipe)) fails++;
                 const egx::PotrfSchedule c = egx::schedule_table(n_pad, w + 100, nws, d);
                 if (a.whole != c.whole || a.group_panels != c.group_panels) fails++;
-                if (a.whole && !(n_pad <= 4096 && nws * ((n_pad + 255) / 256) <= 32)) fails++;
-                if (a.pipe != (n_pad <= 4096)) fails++;
+                if (a.whole && !(n_pad <= 7168 && nws * ((n_pad + 255) / 256) <= 32)) fails++;
+                if (a.pipe != (n_pad <= 4096 || a.whole)) fails++;
                 if (a.left && !a.w_left && n_pad % 256 == 0) fails++;  // left-looking handles' riders are left-looking too
             }
     // the knobs

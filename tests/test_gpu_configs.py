@@ -914,7 +914,10 @@ def test_theta_gradient_batch_is_bit_identical_to_single_candidates(egx, n, d, c
     thetas = base * 10.0 ** rng.uniform(-0.15, 0.15, (7, d))
     thetas[2, 0] = np.nan                      # answered at once (algorithm.rs:885-891)
     thetas[4] = 1e-7                           # R = ones + nugget: not positive definite in floating point (if the size allows)
-    with egx.GpHandle(x, y, corr=corr, n_workspaces=1) as h1:
+    # (another handle of the SAME shape: the schedule -- hence the bits -- is a property of (size, workspaces, lock-step width),
+    #  egx_gp_get_schedule; a one-workspace handle of 4352 columns factors as one chain launch, this one by separate launches)
+    with egx.GpHandle(x, y, corr=corr, n_workspaces=nws) as h1:
+        h1.set_lockstep(width)
         single = [h1.likelihood_grad(t) for t in thetas]
         again = [h1.likelihood_grad(t) for t in thetas[:2]]
     for a, b in zip(single[:2], again):

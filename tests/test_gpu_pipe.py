@@ -78,8 +78,8 @@ def test_info_is_lapacks_under_chain_launches(egx, knobs, n, bad):
 
 
 def test_schedule_is_reported_and_survives_shrink(egx):
-    """egx_gp_get_schedule: a small one-workspace handle factors as ONE chain launch, a handle with many workspaces per group,
-    a large one by separate launches; egx_gp_shrink does not change what the handle was created with."""
+    """egx_gp_get_schedule: a one-workspace handle up to 7168 columns factors as ONE chain launch, a small handle with many
+    workspaces per group, a larger one with several workspaces by separate launches; egx_gp_shrink does not change what the handle was created with."""
     x, y = _data(900, 4, 1)
     with egx.GpHandle(x, y, n_workspaces=1) as h:
         s = h.schedule()
@@ -94,10 +94,18 @@ def test_schedule_is_reported_and_survives_shrink(egx):
         assert h.schedule() == {**s, "lockstep": 1}      # the width is capped, the schedule stays
         lk1, st1 = h.likelihood(th)
         assert st0 == st1 == 0 and lk0 == lk1           # ... and so do the bits
-    x, y = _data(4200, 4, 2)
-    with egx.GpHandle(x, y, n_workspaces=1) as h:
+    x, y = egx.workload.make_training_set(4200, 8, 3)   # (the benchmark's well-conditioned family)
+    th = egx.workload.default_theta(8) * 3.0
+    with egx.GpHandle(x, y, n_workspaces=1) as h:       # a lone matrix up to 7168 columns: still one launch (17 diagonal blocks)
+        s = h.schedule()
+        assert s["pipelined_chain"] == 1 and s["whole_factorisation_launch"] == 1
+        lk_whole, st = h.likelihood(th)
+        assert st == 0
+    with egx.GpHandle(x, y, n_workspaces=2) as h:       # 2 x 17 diagonal blocks > 32, beyond 4096 columns: separate launches
         s = h.schedule()
         assert s["pipelined_chain"] == 0 and s["whole_factorisation_launch"] == 0
+        lk_sep, st = h.likelihood(th)
+        assert st == 0 and abs(lk_whole - lk_sep) <= 1e-9 * abs(lk_sep)
 
 
 def test_likelihood_does_not_depend_on_the_chain_form_beyond_rounding(egx, knobs):
