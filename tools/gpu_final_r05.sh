@@ -18,7 +18,7 @@ prof() {  # name command...
 prof bench_default python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > /dev/null
 grep '^{' $O/bench_default_run.txt > $O/bench_default_under_rocprof.json
 prof group_roofline python $GRAFT_REPO_ROOT/tools/group_roofline.py 16384 32 8 4 > /dev/null
-for leg in "n4096_one_fit 4096 8 6 0 1" "n4096_lockstep12 4096 8 5 0 12" "n8192_one_fit 8192 16 5 0 1" "n8192_lockstep12 8192 16 4 0 12" "n16384_one_fit 16384 32 4 0 1" "n2048_one_fit 2048 8 6 0 1"; do
+for leg in "n4096_one_fit 4096 8 6 0 1" "n4096_lockstep12 4096 8 5 0 12" "n8192_one_fit 8192 16 5 0 1" "n8192_lockstep12 8192 16 4 0 12" "n16384_one_fit 16384 32 4 0 1" "n2048_one_fit 2048 8 6 0 1" "n6144_one_fit 6144 16 5 0 1"; do
   set -- $leg; name=$1; shift
   db=$(prof $name python $GRAFT_REPO_ROOT/tools/one_fit.py "$@")
   [ -n "$db" ] && python tools/timeline.py $db $O/${name}_timeline.txt >> $O/${name}_run.txt 2>&1
