@@ -414,7 +414,7 @@ def other_configs(egx, workload, gpu):
         "frac_of_fp64_peak_lockstep_12": float(n2) ** 3 / 3 / t_b2 / 1e12 / FP64_MFMA_PEAK_TFLOPS,
         "schedule_lockstep_12": sched_12,
         "note": "one in flight: a one-workspace handle, the whole factorisation as one persistent chain launch (16 diagonal blocks of "
-                "~65 us + ~30 us of device-side hand-offs each; round 4: 57 + 20 + 15..80 us of separate launches per panel); "
+                "~62 us + ~15-20 us of device-side hand-offs each; round 4: 57 + 20 + 15..80 us of separate launches per panel); "
                 "lock-step 12: a twelve-workspace handle, what a round of a tuned fit's COBYLA starts is"}
     res["size_ladder"] = size_ladder(egx, workload, gpu)
     d6 = 64

@@ -1809,7 +1809,7 @@ int32_t egx_potrf(double *a, int64_t n, int32_t *info) {
     EGX_RC(d_info.alloc(1));
     EGX_HIP_CHECK(hipMemset(d_info.p, 0, sizeof(double)));
     EGX_HIP_CHECK(hipMemcpy(d_M.p, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
-    // the schedule a one-workspace handle of this size gets (schedule.h): up to 4096 columns one chain launch
+    // the schedule a one-workspace handle of this size gets (schedule.h): up to 7168 columns one chain launch
     const PotrfSchedule sch = schedule_for(n_pad, 1, 1);
     DevBuf d_sync;  // (ints in double-sized slots)
     PotrfBatch pb;
