@@ -19,8 +19,9 @@
 //     TRSM(p, rows)        64 * RT rows of the panel below diagonal block p: the register-resident 16-row-tile solve of
 //                          k_panel_trsm16, driven by the strips as they are published (two workgroup barriers per strip,
 //                          the fragments of the next strip prefetched whenever that strip is already there)
-//     FINE(p, i, j)        64 x 64 tile of block column p + 1 (the NEXT panel: on the chain) -= P_p P_p^T, K = 256 split over
-//                          the four wave quadruples of the workgroup, partial tiles summed through LDS in a fixed order
+//     FINE(p, i, j)        64 x 64 tile of block column p + 1 (the NEXT panel: on the chain) -= P_p P_p^T, QUARTER BY QUARTER of the
+//                          panel's 256 columns as the TRSM tasks of its two row chunks publish them: sixteen waves x one
+//                          16 x 16 sub-tile, the quarter's operands through LDS, ascending k, no reduction across waves
 //     COARSE(p, I, J)      128 x 128 tile of the group's columns beyond the next panel -= P_p P_p^T, K = 256
 // Because tickets are taken in order by workgroups that are RESIDENT, every task's producers are finished, running, or
 // held by a resident workgroup that only waits for still earlier tasks: no dispatch-order or placement assumption, no
@@ -33,7 +34,8 @@
 //                        its diagonal tile, the tile's inverse + refinement flag: write-through (sc1) stores, drained by
 //                        every storing wave in front of a workgroup barrier, then one relaxed agent-scope flag store;
 //                        the consumer reads them with agent-scope loads (they bypass its L1)
-//   rowT[P][c]           TRSM -> FINE / COARSE: the 64-row chunk c of panel P is solved (sc1 stores + drain + flag)
+//   rowT[P][c]           TRSM -> FINE / COARSE: how many QUARTERS (four strips = 64 columns) of panel P are solved for the 64-row
+//                        chunk c (sc1 stores + drain + flag per quarter); COARSE waits for all of them
 //   fcnt[Q][c]           FINE -> TRSM / DIAG: fine tiles of block column Q, row chunk c, that are up to date
 //   cver[I][J]           COARSE -> COARSE / FINE: updates of this launch applied to the 128 x 128 tile (I, J)
 // A task first waits (ONE lane polls, relaxed loads + s_sleep), then ONE agent-scope acquire drops the stale lines of its
@@ -135,8 +137,8 @@ __device__ __forceinline__ PipeArgs pipe_kargs(pipe_kargs_t kv) {  // (kv: the k
     return a;
 }
 
-constexpr int kFineStage2 = 2 * GemmShape<64, 64, 32, 32, 256>::STAGE;  // doubles of LDS per K quarter of a FINE task
-constexpr int kPipeLdsDoubles = 4 * kFineStage2;                         // 147 456 B: the largest role's
+constexpr int kFineStage2 = 2 * GemmShape<64, 64, 32, 32, 256>::STAGE;  // (a quarter of the launch's LDS: the unit the roles' areas are sized in)
+constexpr int kPipeLdsDoubles = 4 * kFineStage2;                         // 147 456 B: the COARSE role's two stages
 constexpr int kPipeLdsBytes = kPipeLdsDoubles * 8 + 64;                  // + the control words
 static_assert(kPipeLdsDoubles * 8 >= RB_LDS_BYTES && kPipeLdsDoubles >= 2 * GemmShape<128, 128, 32, 32, 1024>::STAGE,
               "LDS of the other roles");
