@@ -38,7 +38,7 @@ def knobs(egx):
         egx.set_tuning(k, v)
 
 
-@pytest.mark.parametrize("n", [300, 1000, 2100, 4096])
+@pytest.mark.parametrize("n", [300, 1000, 2100, 4096, 5000])
 def test_chain_launches_agree_with_separate_launches_and_lapack(egx, knobs, n):
     """egx_potrf on a kernel matrix: one chain launch for the whole factorisation (the default up to 4096 columns), chain
     launches per group of panels (pipe = 2), separate launches (pipe = 0): the same factor to rounding, LAPACK's
