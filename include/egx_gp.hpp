@@ -238,6 +238,15 @@ inline std::vector<GaussianProcess> GpParams::fit_group(const double *x, const d
     std::vector<double> thetas((size_t)k * (size_t)hh);
     for (size_t i = 0; i < thetas.size(); i++) thetas[i] = tuning_.init[tuning_.init.size() == 1 ? 0 : i % (size_t)hh];
     check(egx_gp_finalize_multi(raw.data(), k, thetas.data(), hh));
+    for (int32_t j = 0; j < k; j++) {  // theta() / variance() / likelihood() of every member, as `fit` leaves them
+        GaussianProcess &gp = out[(size_t)j];
+        gp.theta_.resize((size_t)hh);
+        egx_gp_inner_view view{};
+        view.theta = gp.theta_.data();
+        view.sigma2 = &gp.sigma2_;
+        view.likelihood = &gp.likelihood_;
+        check(egx_gp_get_inner(raw[(size_t)j], &view));
+    }
     return out;
 }
 

@@ -4,6 +4,7 @@
 //   golden A                      doc/Gpx_Tutorial.ipynb cell 14 (theta printed, likelihood / variance to full precision)
 //   theta0 length check           :829-838     (a panic in the reference, InvalidValueError here)
 //   the round-3 members of the mirror (value + variance gradients in one pass, likelihood batch, mixture recombination, pool)
+//   the round-5 members: fit_group (models of one shape fitted in lock-step), schedule()
 // through include/egx_gp.hpp -> C ABI -> GPU.  Exit code = number of failed checks.
 #include <cmath>
 #include <cstdio>
@@ -181,6 +182,41 @@ static void test_round3_mirror() {
     EXPECT(trim() > 0 && pool_stats().cached_bytes == 0);
 }
 
+// Round 5 through the mirror: fit_group (egx_gp_create_group + egx_gp_finalize_multi: the expert loop of
+// crates/moe/src/algorithm.rs:167-177 in lock-step) gives every model bit for bit what `fit` gives it alone, with its fitted
+// scalars in place; schedule() reports how a handle factors.
+static void test_round5_mirror() {
+    const int k = 3, n = 40, d = 2;
+    std::vector<double> xs((size_t)k * n * d), ys((size_t)k * n);
+    for (int e = 0; e < k; e++)
+        for (int i = 0; i < n; i++) {
+            const double u = (i * 0.6180339887 + 0.13 * e), v = (i * 0.7548776662 + 0.29 * e);
+            const double x0 = 10.0 * (u - std::floor(u)) - 5.0, x1 = 10.0 * (v - std::floor(v));
+            xs[((size_t)e * n + i) * d] = x0, xs[((size_t)e * n + i) * d + 1] = x1;
+            ys[(size_t)e * n + i] = std::sin(0.7 * x0) * std::cos(0.4 * x1) + 0.1 * e * x0;
+        }
+    const auto params = GaussianProcess::params(Mean::Linear, Corr::Matern52).theta_tuning(ThetaTuning::Fixed({0.3, 0.2}));
+    auto group = params.fit_group(xs.data(), ys.data(), n, d, k);
+    EXPECT((int)group.size() == k);
+    const double xq[6] = {-1.3, 2.5, 4.0, 4.0, 0.0, 7.5};
+    for (int e = 0; e < k; e++) {
+        auto lone = params.fit(xs.data() + (size_t)e * n * d, n, d, ys.data() + (size_t)e * n);
+        EXPECT(group[(size_t)e].theta().size() == 2 && group[(size_t)e].theta()[0] == 0.3 && group[(size_t)e].theta()[1] == 0.2);
+        EXPECT(group[(size_t)e].likelihood() == lone.likelihood() && group[(size_t)e].variance() == lone.variance());
+        auto pg = group[(size_t)e].predict_valvar(xq, 3), pl = lone.predict_valvar(xq, 3);
+        for (int i = 0; i < 3; i++) EXPECT(pg.first[i] == pl.first[i] && pg.second[i] == pl.second[i]);
+        const auto sg = group[(size_t)e].schedule(), sl = lone.schedule();
+        EXPECT(sg == sl && sg[2] == 1 && sg[3] == 1);  // 128 columns: the whole factorisation is one chain launch
+    }
+    bool threw = false;
+    try {
+        (void)GaussianProcess::params(Mean::Constant, Corr::SquaredExponential).fit_group(xs.data(), ys.data(), n, d, k);  // tuned: not for groups
+    } catch (const InvalidValueError &) {
+        threw = true;
+    }
+    EXPECT(threw);
+}
+
 int main() {
     if (egx_device_count() < 1) {
         std::fprintf(stderr, "no HIP device\n");
@@ -192,6 +228,7 @@ int main() {
     test_bug_var_derivatives();
     test_errors();
     test_round3_mirror();
+    test_round5_mirror();
     std::printf("%s (%d failed checks)\n", failures ? "FAILED" : "OK", failures);
     return failures;
 }
