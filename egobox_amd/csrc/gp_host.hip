@@ -367,7 +367,9 @@ static int enqueue_eval_core(egx_gp *const *owners, Workspace *const *wss, int c
     EGX_HIP_CHECK(hipEventRecord(lead.ev[0], st));
     // the candidates' pointers for the batched front-end and tail launches (by value in the kernel arguments)
     EvalBatchPtrs bp;
-    const bool batched = count > 1 && count <= EvalBatchPtrs::kMax;
+    // (a lone candidate takes the same route: its tail is then one launch instead of a gather + four copies -- 30 us of a
+    //  0.12-0.4 ms evaluation at n = 128 ... 1024)
+    const bool batched = count >= 1 && count <= EvalBatchPtrs::kMax;
     if (batched)
         for (int j = 0; j < count; j++) {
             Workspace &w = *wss[j];
@@ -378,7 +380,7 @@ static int enqueue_eval_core(egx_gp *const *owners, Workspace *const *wss, int c
                                                   gp->n_pad, gp->rhs_pad, gp->q)
                         : EGX_ERR_UNSUPPORTED;
     if (front != EGX_SUCCESS && front != EGX_ERR_UNSUPPORTED) return front;
-    if (front == EGX_ERR_UNSUPPORTED)  // a lone candidate, Matern with KPLS weights (hcols > 1) or d > 64: launch by launch
+    if (front == EGX_ERR_UNSUPPORTED)  // Matern with KPLS weights (hcols > 1) or d > 64: launch by launch
         for (int j = 0; j < count; j++) {
             Workspace &w = *wss[j];
             egx_gp *o = owners[j];
@@ -402,8 +404,8 @@ static int enqueue_eval_core(egx_gp *const *owners, Workspace *const *wss, int c
     EGX_RC(launch_potrf(st, lead.M, gp->ld, gp->n_pad, gp->m_tot, lead.dinv, lead.d_info, lead.lk.s2 ? &lead.lk : nullptr,
                         &lead.trace, &pb, W0 ? &inv : nullptr));
     EGX_HIP_CHECK(hipEventRecord(lead.ev[2], st));
-    // what the host needs back.  A batch: ONE launch writes every candidate's diagonal, solved right-hand-side rows, info and
-    // hand-off diagnostics straight into its pinned host buffers (k_eval_tail); a lone candidate: a gather + copies
+    // what the host needs back: ONE launch writes every candidate's diagonal, solved right-hand-side rows, info and hand-off
+    // diagnostics straight into its pinned host buffers (k_eval_tail); beyond 16 candidates (never today): a gather + copies each
     if (batched) EGX_RC(launch_eval_tail(st, bp, count, gp->ld, gp->n, gp->n_pad, gp->q, gp->gls_device ? 0 : 1, pb.sync));
     for (int j = 0; j < count; j++) {
         Workspace &w = *wss[j];
