@@ -47,6 +47,7 @@
 #include "egx_internal.h"
 #include "mfma_gemm_core.h"
 #include "potf2_blocks.h"
+#include "pipe_tasks.h"
 
 #include <atomic>
 #include <climits>
@@ -58,10 +59,6 @@
 
 namespace egx {
 
-enum { PT_TRSM = 0, PT_FINE = 1, PT_COARSE = 2, PT_DIAG = 3 };
-struct PipeTask {
-    int type, p, a, b;  // TRSM: a = first 64-row chunk (absolute); FINE: a = row chunk, b = column tile 0..3; COARSE: a = I, b = J (128-tiles, absolute)
-};
 
 // sync words of one matrix (ints): [0] abort (the launch's: matrix 0's), [1] strips published, [2] scratch (stalled strips of
 // the timeout test), [4..7] diagnostics of the first wait that ran out, [8 + P] task ticket and [8 + NP + P] start ticket of the
@@ -672,40 +669,7 @@ int pipe_enabled() {
     return g_pipe;
 }
 
-// The task list of the group [g0, g0 + 256 np), in STAGES.  Stage s: the FINE tiles of X(s - 1 -> s) (panel s - 1 into block
-// column s: what DIAG(s) and TRSM(s) wait for -- the diagonal block's tiles first, then row chunk by row chunk), DIAG(s), the
-// TRSM tasks of panel s (rows of the next diagonal block first), then the COARSE tiles of the updates X(p -> q), q >= p + 2,
-// with max(p + 1, q - la) == s in the order of their panels.  la = 0 queues
-// every update just in time (left-looking order), a large la right behind its panel (right-looking order); in every such
-// order a task depends on EARLIER entries only (X(p -> q) follows TRSM(p) and X(p - 1 -> q)), which is what makes the
-// ticket scheme of the kernel deadlock free.
-static std::vector<PipeTask> pipe_tasks(int n_pad, int m_tot, int g0, int np, int rt, int la) {
-    std::vector<PipeTask> v;
-    auto width = [&](int p) { const int k0 = g0 + 256 * p; return (n_pad - k0 < 256) ? (n_pad - k0) : 256; };
-    for (int s = 0; s < np; s++) {
-        auto coarse = [&](bool own_column) {  // COARSE: X(p -> q), q >= p + 2, of this stage
-            for (int p = 0; p + 1 < np; p++)
-                for (int q = p + 2; q < np; q++) {
-                    const int stage = (p + 1 > q - la) ? p + 1 : q - la;
-                    if (stage != s || (q == s) != own_column) continue;
-                    const int cq = g0 + 256 * q;
-                    for (int J = cq / 128; J < (cq + width(q)) / 128; J++)
-                        for (int I = J; I < m_tot / 128; I++) v.push_back({PT_COARSE, p, I, J});
-                }
-        };
-        coarse(true);  // (la == 0 only: block column s itself still has coarse updates to receive, ahead of its fine ones)
-        if (s > 0) {   // FINE: panel s - 1 into block column s
-            const int c0 = (g0 + 256 * s) / 64;
-            for (int c = c0; c < m_tot / 64; c++)
-                for (int j = 0; j < width(s) / 64; j++)
-                    if (c - c0 >= j) v.push_back({PT_FINE, s - 1, c, j});  // (tiles above the diagonal block's diagonal: none)
-        }
-        const int r0 = g0 + 256 * s + width(s);
-        for (int c = r0 / 64; c + rt <= m_tot / 64; c += rt) v.push_back({PT_TRSM, s, c, 0});
-        coarse(false);  // (behind the chain's own tasks: nothing of this stage waits for them)
-    }
-    return v;
-}
+// (the task list of a launch and its order: pipe_tasks.h, host-testable)
 
 struct PipePlan {
     PipeTask *d_tasks = nullptr;
