@@ -13,6 +13,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libegx_gp_hip.so")
+#: the same library built with -DEGX_TEST_HOOKS (the "pipe_stall" knob, grid / trace overrides of the chain launch): loaded
+#: instead of the product library only when EGX_TEST_LIBRARY=1 is set -- by tests that force a hand-off to fail, in a
+#: process of their own.  Never the default, never used by bench.py.
+TEST_LIB_PATH = os.path.join(_HERE, "lib", "_dev", "libegx_gp_hip_testhooks.so")
 
 # return codes / status values (egx_rc, egx_status)
 SUCCESS, ERR_INVALID_VALUE, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_FITTED, ERR_LINALG, ERR_LIKELIHOOD, ERR_UNSUPPORTED, ERR_PEER = range(9)
@@ -54,6 +58,7 @@ SIGNATURES = [
     ("egx_trim", C.c_int64, []),
     ("egx_set_tuning", C.c_int32, [C.c_char_p, C.c_int32, c_int32_p]),
     ("egx_pool_stats", None, [c_int64_p, c_int64_p, c_int64_p]),
+    ("egx_chain_stats", None, [c_int64_p, c_int64_p]),
     ("egx_normalize", C.c_int32, [c_double_p, C.c_int64, C.c_int64, c_double_p, c_double_p, c_double_p]),
     ("egx_regression_ncols", C.c_int64, [C.c_int32, C.c_int64]),
     ("egx_regression_basis", C.c_int32, [C.c_int32, c_double_p, C.c_int64, C.c_int64, c_double_p]),
@@ -174,11 +179,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = TEST_LIB_PATH if os.environ.get("EGX_TEST_LIBRARY") == "1" else LIB_PATH
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C egobox_amd/csrc`).  egobox_amd has no fallback compute path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, res, args in SIGNATURES:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res

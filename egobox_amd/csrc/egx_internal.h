@@ -176,6 +176,10 @@ struct PotrfBatch {
     int64_t sS = 0;          // sS ints apart; nullptr: the chain runs as separate launches (k_potf2_reg, k_panel_trsm16, updates)
     int pipe = 0;            // ... the chain of every group of panels is one chain launch (schedule.h: per handle)
     int whole = 0;           // ... the WHOLE factorisation is one chain launch (every update inside it)
+    int group_panels = 0;    // panels per trailing update, from the handle's schedule (0: by size, potrf_group_panels): launch_potrf
+                             // never reads the process-wide knobs for a handle that carries its schedule
+    int seqs = 1;            // launch sequences of this handle that may be in flight at once (workspaces / lock-step width):
+                             // beyond two, a look-ahead chain launch waits for its columns on the STREAM, not on the device
 };
 int potrf_left_for(int n_pad, int lockstep);
 int w_left_for(int n_pad, int lockstep);
@@ -243,10 +247,15 @@ size_t pipe_sync_ints(int n_pad, int m_tot);
 int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
                       const PotrfBatch &pb, int g0, int gw, int ext_need = 0, int shared_chip = 0);
 int pipe_signal(hipStream_t s, const PotrfBatch &pb, int value);
+int pipe_enabled();    // EGX_PIPE (default on); 0 as well when the launch cannot be set up on this device
+bool pipe_fits(int nz, int np);  // one workgroup per diagonal block (np panels of nz matrices) + a worker fit the CURRENT device
+int pipe_prepare(int n_pad, int m_tot, const PotrfSchedule &sched);  // build + upload the task lists a handle of this shape launches
+size_t pipe_release_plans();     // egx_trim: free every task list (synchronises the devices that hold one); bytes freed
+int pipe_set_knob(const char *name, int value);  // "pipe", "pipe_timeout_ms" (+ "pipe_stall" in test builds); INT_MIN = unknown
+#ifdef EGX_TEST_HOOKS  // egobox_amd/lib/_dev/libegx_gp_hip_testhooks.so and tools/pipe_check only
 void pipe_set_trace(long long *device_buf);  // profiling: 8 words per ticket of the next chain launches (nullptr: off)
-int pipe_enabled();    // EGX_PIPE (default on)
-void pipe_test_set_workgroups(int wgs);  // tools/pipe_check: grid of the next chain launches (0 = the product's)
-int pipe_set_knob(const char *name, int value);  // "pipe", "pipe_timeout_ms", "pipe_stall" (test hook); INT_MIN = unknown
+void pipe_test_set_workgroups(int wgs);      // grid of the next chain launches (0 = the product's)
+#endif
 int chol_init();  // one-time function attribute setup (dynamic LDS sizes)
 int set_knob(const char *name, int value);  // kernels_chol.hip tuning knobs by name; INT_MIN = unknown
 

@@ -72,6 +72,12 @@ struct Workspace {
     double *d_rhs = nullptr;   // n_pad (rho, destroyed by the back-substitution)
     int *d_info = nullptr;
     const int *sync_lead = nullptr;  // hand-off words of the lead of the lock-step group this evaluation ran in (diagnostics)
+    // what finish_eval needs to enqueue this evaluation once more, alone and by separate launches, when a chain launch ran into
+    // its wait bound: coefficient columns and count (the coefficients themselves are still in h_coef), the C^-T buffer of the
+    // theta-gradient's rider, and whether this already IS the second attempt
+    int retry_hcols = 1, retry_ncoef = 0;
+    double *retry_W = nullptr;
+    bool retried = false;
     // device-side GLS (p > 1 trend columns): Gram matrix of [ft | yt] and its factor, all (rhs_pad x rhs_pad)
     double *d_gneg = nullptr, *d_gram = nullptr, *d_gdinv = nullptr, *d_gramP = nullptr, *d_beta = nullptr,
            *d_part = nullptr;

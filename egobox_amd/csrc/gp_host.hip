@@ -8,6 +8,10 @@
 namespace egx {
 
 static thread_local std::string g_last_error;
+// EGX_PIPE_RETRY (egx_set_tuning "pipe_retry"): an evaluation whose chain launch ran into its wait bound is enqueued once more by
+// separate launches (1, default) or reported as EGX_ERR_HIP at once (0); the counters behind egx_chain_stats
+static std::atomic<int> g_pipe_retry{[] { const char *e = std::getenv("EGX_PIPE_RETRY"); return e ? std::atoi(e) : 1; }()};
+static std::atomic<int64_t> g_chain_aborts{0}, g_chain_retries{0};
 void set_error(const std::string &msg) { g_last_error = msg; }
 const std::string &last_error_string() { return g_last_error; }
 
@@ -342,8 +346,9 @@ int make_coef(const egx_gp *gp, const double *theta, int64_t theta_len, std::vec
 // workspace w0; every member's eval_stream is set to it.
 // core: evaluation j uses the training set of owners[j] and the workspace wss[j]; the workspaces are consecutive slots of ONE
 // slab (a handle's, or a group's: egx_gp_create_group), the launches run on the streams of the first
+// separate: the chain by separate launches whatever the handle's schedule says (finish_eval's retry of an aborted chain launch)
 static int enqueue_eval_core(egx_gp *const *owners, Workspace *const *wss, int count, const std::vector<double> *coefs, int hcols,
-                             double *W0) {
+                             double *W0, bool separate = false) {
     egx_gp *gp = owners[0];
     Workspace &lead = *wss[0];
     hipStream_t st = lead.stream;
@@ -397,10 +402,18 @@ static int enqueue_eval_core(egx_gp *const *owners, Workspace *const *wss, int c
     pb.sI = 1;
     pb.left = gp->sched.left;  // (the handle's schedule: schedule_for, egx_internal.h)
     pb.w_left = gp->sched.w_left;
-    pb.pipe = gp->sched.pipe;
-    pb.whole = gp->sched.whole;
-    pb.sync = gp->sched.pipe ? lead_sync : nullptr;  // the chain of a group of panels as one persistent launch (kernels_pipe.hip)
+    pb.pipe = separate ? 0 : gp->sched.pipe;
+    pb.whole = separate ? 0 : gp->sched.whole;
+    pb.group_panels = gp->sched.group_panels;
+    pb.seqs = gp->lockstep > 0 ? ((int)gp->ws.size() + gp->lockstep - 1) / gp->lockstep : 1;
+    pb.sync = pb.pipe ? lead_sync : nullptr;  // the chain of a group of panels as one persistent launch (kernels_pipe.hip)
     pb.sS = gp->stride_S;
+    for (int j = 0; j < count; j++) {  // what finish_eval needs to run this evaluation once more, alone, by separate launches
+        wss[j]->retry_hcols = hcols;
+        wss[j]->retry_W = W0 ? W0 + (size_t)j * (size_t)gp->n_pad * gp->n_pad : nullptr;
+        wss[j]->retry_ncoef = (int)coefs[j].size();
+        wss[j]->retried = separate;
+    }
     EGX_RC(launch_potrf(st, lead.M, gp->ld, gp->n_pad, gp->m_tot, lead.dinv, lead.d_info, lead.lk.s2 ? &lead.lk : nullptr,
                         &lead.trace, &pb, W0 ? &inv : nullptr));
     EGX_HIP_CHECK(hipEventRecord(lead.ev[2], st));
@@ -601,6 +614,20 @@ int finish_eval(egx_gp *gp, Workspace &w, EvalResult &out, int keep) {
     EGX_HIP_CHECK(hipStreamSynchronize(w.eval_stream));
     const int n = gp->n, p = gp->p, n_pad = gp->n_pad;
     out = EvalResult();
+    if (w.h_info[1] != 0) g_chain_aborts++;
+    if (w.h_info[1] != 0 && g_pipe_retry.load() != 0 && !w.retried) {
+        // A bounded wait inside a chain launch ran out (EGX_PIPE_TIMEOUT_MS): waves pre-empted under multi-process sharing of the
+        // GPU or a debugger are enough -- nothing numerical, and the reference's cholesky() (algorithm.rs:1004) never fails for
+        // such a reason (the objective only ever sees numerical errors, :893-896).  The evaluation is enqueued ONCE more, alone,
+        // on the separate-launch schedule of the same handle (no device-side wait anywhere); only if that fails too is it an
+        // error.  (The factor then carries the separate-launch rounding, 1e-10 from the chain launch's: schedule.h.)
+        g_chain_retries++;
+        egx_gp *owner = gp;
+        Workspace *wp = &w;
+        const std::vector<double> coef(w.h_coef, w.h_coef + w.retry_ncoef);
+        EGX_RC(enqueue_eval_core(&owner, &wp, 1, &coef, w.retry_hcols, w.retry_W, true));
+        EGX_HIP_CHECK(hipStreamSynchronize(w.eval_stream));
+    }
     if (w.h_info[1] != 0) {  // (never seen outside the test that forces it: a hand-off inside k_potrf_pipe did not arrive)
         std::string more;
         {   // the launches' tickets and this matrix' published strips, for the report
@@ -1060,7 +1087,12 @@ int32_t egx_device_count(void) {
     return c;
 }
 
-int64_t egx_trim(void) { return (int64_t)pool_trim(-1); }
+int64_t egx_trim(void) { return (int64_t)(pool_trim(-1) + pipe_release_plans()); }
+
+void egx_chain_stats(int64_t *aborted, int64_t *retried) {
+    if (aborted) *aborted = g_chain_aborts.load();
+    if (retried) *retried = g_chain_retries.load();
+}
 
 int32_t egx_set_tuning(const char *knob, int32_t value, int32_t *previous) {
     if (!knob) {
@@ -1069,6 +1101,7 @@ int32_t egx_set_tuning(const char *knob, int32_t value, int32_t *previous) {
     }
     int old = set_knob(knob, value);
     if (old == -2147483647 - 1) old = pipe_set_knob(knob, value);  // the chain kernel's knobs (kernels_pipe.hip)
+    if (old == -2147483647 - 1 && std::string(knob) == "pipe_retry") old = g_pipe_retry.exchange(value);
     if (old == -2147483647 - 1) {
         set_error(std::string("egx_set_tuning: unknown knob '") + knob + "'");
         return EGX_ERR_INVALID_VALUE;
@@ -1307,6 +1340,8 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
     }
     gp->lockstep = default_lockstep(nws, gp->n_pad);  // candidates of a likelihood batch factored in lock-step: egx_gp_set_lockstep
     gp->sched = schedule_for(gp->n_pad, gp->lockstep, nws);
+    rc = pipe_prepare(gp->n_pad, gp->m_tot, gp->sched);  // the chain launches' task lists: not inside the first evaluation
+    if (rc) return fail(rc);
     *out = gp;
     return EGX_SUCCESS;
 }
@@ -1411,7 +1446,8 @@ int32_t egx_gp_set_lockstep(egx_gp *gp, int32_t width) {
     const int nws = (int)gp->ws.size();
     gp->lockstep = width == 0 ? default_lockstep(nws, gp->n_pad) : (width > nws ? nws : width);
     gp->sched = schedule_for(gp->n_pad, gp->lockstep, nws);
-    return EGX_SUCCESS;
+    EGX_RC(set_device(gp));
+    return pipe_prepare(gp->n_pad, gp->m_tot, gp->sched);
 }
 
 int32_t egx_gp_get_lockstep(const egx_gp *gp) { return gp ? gp->lockstep : 0; }
@@ -1609,27 +1645,46 @@ static int multi_eval(egx_gp *const *gps, int32_t k, const double *thetas, int64
             set_error("theta contains NaN");
             return EGX_ERR_INVALID_VALUE;
         }
+        // (every member evaluates on its workspace 0 and is UN-FITTED by the call -- also by egx_gp_likelihood_multi, unlike
+        //  egx_gp_likelihood, which keeps a fitted handle with spare workspaces fitted: include/egx_gp.h says so)
         for (int j = 0; j < len; j++) gps[i + j]->fitted = false;
-        if (len > 1) EGX_RC(enqueue_eval_members(gps + i, len, coefs.data(), hcols));
-        else EGX_RC(enqueue_eval(gps[i], gps[i]->ws[0], coefs[0], hcols));
+        // An error between here and the members' host halves must not leave work in flight on the lead's stream that writes into
+        // the other members' pinned buffers, nor their eval_stream pointing at a stream of a handle that may be destroyed first:
+        // drain the lead's stream and hand every member its own stream back before returning.
+        auto bail = [&](int rc_in) {
+            const std::string msg = last_error_string();
+            (void)hipStreamSynchronize(gps[i]->ws[0].stream);
+            for (int j = 0; j < len; j++) gps[i + j]->ws[0].eval_stream = gps[i + j]->ws[0].stream;
+            (void)hipGetLastError();
+            set_error(msg);
+            return rc_in;
+        };
+#define EGX_RC_BAIL(call)                    \
+    do {                                     \
+        const int _rc = (call);              \
+        if (_rc) return bail(_rc);           \
+    } while (0)
+        if (len > 1) EGX_RC_BAIL(enqueue_eval_members(gps + i, len, coefs.data(), hcols));
+        else EGX_RC_BAIL(enqueue_eval(gps[i], gps[i]->ws[0], coefs[0], hcols));
         if (finalize && len > 1 && len <= SolveBatchPtrs::kMax) {
             // the members' inverse blocks (for gamma's back-substitution) right behind the evaluation, in lock-step: they only need
             // the factors and run while the host waits for the read-back and does the models' GLS
             SolveBatchPtrs ib;
             for (int j = 0; j < len; j++) {
                 Workspace &w = gps[i + j]->ws[0];
-                EGX_RC(ensure_block_inverse_buffer(gps[i + j], w));
+                EGX_RC_BAIL(ensure_block_inverse_buffer(gps[i + j], w));
                 ib.M[j] = w.M, ib.dinv[j] = w.dinv, ib.dW[j] = w.dW, ib.rhs[j] = w.d_rhs, ib.vec[j] = w.d_vec;
             }
-            EGX_RC(launch_block_inverse_batch(gps[i]->ws[0].eval_stream, ib, len, gps[i]->ld, gps[i]->n_pad));
+            EGX_RC_BAIL(launch_block_inverse_batch(gps[i]->ws[0].eval_stream, ib, len, gps[i]->ld, gps[i]->n_pad));
         } else if (finalize) {
-            for (int j = 0; j < len; j++) EGX_RC(prelaunch_block_inverse(gps[i + j], gps[i + j]->ws[0], gps[i + j]->ws[0].stream));
+            for (int j = 0; j < len; j++) EGX_RC_BAIL(prelaunch_block_inverse(gps[i + j], gps[i + j]->ws[0], gps[i + j]->ws[0].stream));
         }
         std::vector<FinalizeTail> tails((size_t)(finalize ? len : 0));
         std::vector<int> trc((size_t)len, EGX_SUCCESS);
         std::vector<std::string> terr((size_t)len);
         if (finalize && len > 1 && len <= SolveBatchPtrs::kMax) {
-            EGX_RC(finalize_tails_lockstep(gps + i, len, coefs.data(), hcols, tails.data(), trc.data(), terr.data()));
+            EGX_RC_BAIL(finalize_tails_lockstep(gps + i, len, coefs.data(), hcols, tails.data(), trc.data(), terr.data()));
+#undef EGX_RC_BAIL
         } else if (finalize) {
             for (int j = 0; j < len; j++) {
                 trc[(size_t)j] = finalize_tail_enqueue(gps[i + j], coefs[(size_t)j], hcols, tails[(size_t)j]);
@@ -1863,22 +1918,31 @@ int32_t egx_potrf(double *a, int64_t n, int32_t *info) {
     const PotrfSchedule sch = schedule_for(n_pad, 1, 1);
     DevBuf d_sync;  // (ints in double-sized slots)
     PotrfBatch pb;
-    pb.left = sch.left, pb.pipe = sch.pipe, pb.whole = sch.whole;
+    pb.left = sch.left, pb.pipe = sch.pipe, pb.whole = sch.whole, pb.group_panels = sch.group_panels;
     if (sch.pipe) {
         EGX_RC(d_sync.alloc((pipe_sync_ints(n_pad, n_pad) + 1) / 2));
         pb.sync = reinterpret_cast<int *>(d_sync.p);
     }
     EGX_RC(launch_potrf(0, d_M.p, n_pad, n_pad, n_pad, d_dinv.p, reinterpret_cast<int *>(d_info.p), nullptr, nullptr, &pb));
-    EGX_HIP_CHECK(hipMemcpy(hp.data(), d_M.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost));
-    EGX_HIP_CHECK(hipMemcpy(info, d_info.p, sizeof(int), hipMemcpyDeviceToHost));
     if (pb.sync) {
         int aborted = 0;
         EGX_HIP_CHECK(hipMemcpy(&aborted, pb.sync, sizeof(int), hipMemcpyDeviceToHost));
+        if (aborted) g_chain_aborts++;
+        if (aborted && g_pipe_retry.load() != 0) {  // once more by separate launches (see finish_eval)
+            g_chain_retries++;
+            aborted = 0;
+            pb.pipe = pb.whole = 0, pb.sync = nullptr;
+            EGX_HIP_CHECK(hipMemset(d_info.p, 0, sizeof(double)));
+            EGX_HIP_CHECK(hipMemcpy(d_M.p, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
+            EGX_RC(launch_potrf(0, d_M.p, n_pad, n_pad, n_pad, d_dinv.p, reinterpret_cast<int *>(d_info.p), nullptr, nullptr, &pb));
+        }
         if (aborted) {
             set_error("egx_potrf: a wait inside the pipelined chain kernel exceeded EGX_PIPE_TIMEOUT_MS");
             return EGX_ERR_HIP;
         }
     }
+    EGX_HIP_CHECK(hipMemcpy(hp.data(), d_M.p, sizeof(double) * hp.size(), hipMemcpyDeviceToHost));
+    EGX_HIP_CHECK(hipMemcpy(info, d_info.p, sizeof(int), hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < n; i++)
         for (int64_t j = 0; j < n; j++) a[i * n + j] = (j <= i) ? hp[(size_t)i * n_pad + j] : 0.0;
     return EGX_SUCCESS;

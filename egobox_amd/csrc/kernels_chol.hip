@@ -1091,10 +1091,15 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     // the chain of a group gets longer while its trailing update shrinks)
     // the serial chain as ONE persistent launch per group of panels (kernels_pipe.hip) when the caller provides the hand-off
     // words; for handles whose schedule says so (schedule.h) the whole factorisation is one such launch (every update inside it)
-    const bool have_sync = pb.sync != nullptr && pipe_enabled() != 0;
-    const bool pipe = have_sync && pb.pipe;
+    // (pb.pipe / pb.whole / pb.group_panels come from the HANDLE's schedule, decided when it was created: nothing here reads the
+    //  process-wide knobs, so egx_set_tuning never changes the arithmetic of a handle that exists -- egx_gp_get_schedule stays
+    //  true.  A device on which the launch does not fit -- one workgroup per diagonal block and matrix: a partitioned GPU -- takes
+    //  the separate launches for the whole factorisation.)
+    const int GW = (pb.group_panels > 0 ? pb.group_panels : potrf_group_panels(n_pad)) * kNB;
+    const bool have_sync = pb.sync != nullptr && pb.pipe != 0 &&
+                           pipe_fits((int)nz, ((pb.whole || GW > n_pad ? n_pad : GW) + kNB - 1) / kNB);
+    const bool pipe = have_sync;
     if (have_sync) EGX_HIP_CHECK(hipMemsetAsync(pb.sync, 0, sizeof(int) * (nz > 1 ? (size_t)pb.sS * nz : pipe_sync_ints(n_pad, m_tot)), s));
-    const int GW = potrf_group_panels(n_pad) * kNB;
     auto gwidth = [&](int g0) { return (n_pad - g0 < GW) ? (n_pad - g0) : GW; };
     // panels of one group on stream `st`; `side` != nullptr splits every in-group update into the next diagonal block
     // (on st) and the rest (on side); `first_wait` is waited for before the FIRST panel solve (the rest of the update
@@ -1103,9 +1108,13 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         if (pipe) {  // one launch: diagonal blocks, panel solves and in-group updates hand over to each other on the device
             // (first_wait -- the rest of the update that brought this group's columns up to date, on another stream -- is
             //  waited for ON THE DEVICE by the first panel's solve tasks: pipe_signal behind that update)
-            const int rc2 = launch_potrf_pipe(st, M, ld, n_pad, m_tot, dinv, info, pb, g0, gw, first_wait ? g0 / kNB + 1 : 0, st != s);
+            //  With more than two launch sequences of the handle in flight the workgroups that spin on that word -- 96 per launch,
+            //  one compute unit each -- could leave the update they wait for no unit to run on (3 x 96 > 256): the STREAM waits then.
+            const bool on_device = first_wait != nullptr && pb.seqs <= 2;
+            if (first_wait && !on_device) EGX_HIP_CHECK(hipStreamWaitEvent(st, first_wait, 0));
+            const int rc2 = launch_potrf_pipe(st, M, ld, n_pad, m_tot, dinv, info, pb, g0, gw, on_device ? g0 / kNB + 1 : 0, st != s);
             // (... and by the stream behind the launch: a matrix that lost a pivot skips its tasks without waiting for anything)
-            if (rc2 == EGX_SUCCESS && first_wait) EGX_HIP_CHECK(hipStreamWaitEvent(st, first_wait, 0));
+            if (rc2 == EGX_SUCCESS && on_device) EGX_HIP_CHECK(hipStreamWaitEvent(st, first_wait, 0));
             return rc2;
         }
         hipEvent_t pending = first_wait;

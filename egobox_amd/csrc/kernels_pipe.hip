@@ -49,6 +49,12 @@
 #include "potf2_blocks.h"
 #include "pipe_tasks.h"
 
+#define EGX_RC_PIPE(call)     \
+    do {                      \
+        int _rc = (call);     \
+        if (_rc) return _rc;  \
+    } while (0)
+
 #include <atomic>
 #include <climits>
 #include <cstdlib>
@@ -632,51 +638,147 @@ __global__ __launch_bounds__(1024) void k_potrf_pipe(PipeArgs a) {
 // =============================================================================================
 // host side
 // =============================================================================================
-// Run-time settings (egx_set_tuning / environment): EGX_PIPE and EGX_PIPE_TIMEOUT_MS.  What else was switchable while the
-// launch was developed is a constant now, with its measurement: workgroups of a launch (one per compute unit; 96 beside other
-// launches of the same factorisation), the queue order of the coarse updates (16 panels ahead = right-looking), the size up to
-// which the chain is one launch (schedule.h) -- profiles/r05_pipe_*.txt, DESIGN.md appendix B.
+// Run-time settings (egx_set_tuning / environment): EGX_PIPE, EGX_PIPE_TIMEOUT_MS and EGX_PIPE_RETRY (gp_host.hip).  What else
+// was switchable while the launch was developed is a constant now, with its measurement: workgroups of a launch (one per
+// compute unit; 96 beside other launches of the same factorisation), the queue order of the coarse updates (16 panels ahead =
+// right-looking), the size up to which the chain is one launch (schedule.h) -- profiles/r05_pipe_*.txt, DESIGN.md appendix B.
 static std::atomic<int> g_pipe{1};               // EGX_PIPE: 0 separate launches everywhere, 1 by the handle's schedule (schedule.h), 2 chain launches per group only
 static std::atomic<int> g_pipe_timeout_ms{2000};  // EGX_PIPE_TIMEOUT_MS: bound of every wait inside the launch
-static std::atomic<int> g_pipe_stall{0};          // TEST HOOK (egx_set_tuning "pipe_stall"): see PipeArgs::stall
-static long long *g_pipe_trace = nullptr;         // profiling buffer of the NEXT launches (pipe_set_trace; tools/pipe_check)
 constexpr int kPipeSharedWgs = 96;  // workgroups of a chain launch that runs beside other launches of its factorisation
 constexpr int kPipeLookAhead = 16;  // how many panels ahead of their column's factorisation the coarse updates are queued
+#ifdef EGX_TEST_HOOKS
+// TEST HOOKS: compiled into egobox_amd/lib/_dev/libegx_gp_hip_testhooks.so (and tools/pipe_check) only -- the product library
+// has neither the "pipe_stall" knob nor a way to set the grid or a trace buffer.
+static std::atomic<int> g_pipe_stall{0};   // egx_set_tuning "pipe_stall": see PipeArgs::stall
+static long long *g_pipe_trace = nullptr;  // profiling buffer of the NEXT launches (pipe_set_trace; tools/pipe_check)
+static int g_pipe_test_wgs = 0;            // the grid of the next chain launches (the same bits on 3 workgroups and on 256)
+void pipe_set_trace(long long *buf) { g_pipe_trace = buf; }
+void pipe_test_set_workgroups(int wgs) { g_pipe_test_wgs = wgs; }
+#endif
 
-static void pipe_init() {
+// one-time setup; EGX_SUCCESS, or EGX_ERR_HIP when the launch cannot get its dynamic LDS (the caller then takes separate launches)
+static int pipe_init() {
     static std::once_flag once;
+    static int rc_once = EGX_SUCCESS;
     std::call_once(once, [] {
         if (const char *e = std::getenv("EGX_PIPE")) g_pipe = std::atoi(e);
         if (const char *e = std::getenv("EGX_PIPE_TIMEOUT_MS")) g_pipe_timeout_ms = std::atoi(e) > 0 ? std::atoi(e) : 1;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_pipe), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  kPipeLdsBytes);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_pipe), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 kPipeLdsBytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            rc_once = EGX_ERR_HIP;
+        }
     });
+    return rc_once;
 }
 
 int pipe_set_knob(const char *name, int value) {
-    pipe_init();
+    (void)pipe_init();
     struct { const char *n; std::atomic<int> *v; } tab[] = {{"pipe", &g_pipe}, {"pipe_timeout_ms", &g_pipe_timeout_ms},
-                                                           {"pipe_stall", &g_pipe_stall}};
+#ifdef EGX_TEST_HOOKS
+                                                           {"pipe_stall", &g_pipe_stall},
+#endif
+    };
     for (auto &e : tab)
         if (std::string(name) == e.n) return e.v->exchange(value);
     return INT_MIN;
 }
-void pipe_set_trace(long long *buf) { g_pipe_trace = buf; }
-static int g_pipe_test_wgs = 0;  // tools/pipe_check only: the grid of the next chain launches (the same bits on 3 workgroups and on 256)
-void pipe_test_set_workgroups(int wgs) { g_pipe_test_wgs = wgs; }
-int pipe_enabled() {
-    pipe_init();
-    return g_pipe;
+int pipe_enabled() { return pipe_init() == EGX_SUCCESS ? g_pipe.load() : 0; }
+
+// compute units of a device (per device: a process may drive a partitioned and a whole GPU)
+static int pipe_device_cus(int dev) {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    hipDeviceProp_t prop;
+    int n = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+    else (void)hipGetLastError();
+    cus[dev] = n;
+    return n;
+}
+// does a chain launch over `np` panels of `nz` matrices fit the CURRENT device?  (every diagonal block has a workgroup of its
+// own, resident from the start, one workgroup per compute unit: launch_potrf takes separate launches when this says no)
+bool pipe_fits(int nz, int np) {
+    int dev = 0;
+    if (pipe_init() != EGX_SUCCESS || hipGetDevice(&dev) != hipSuccess) return false;
+    return (long long)nz * np + 1 <= pipe_device_cus(dev);
 }
 
 // (the task list of a launch and its order: pipe_tasks.h, host-testable)
-
+// A plan = the task list of one (device, shape, group) on the device.  Built when a handle is created (pipe_prepare: no
+// allocation and no copy inside the first launch), kept for the life of the process or until egx_trim (pipe_release_plans).
 struct PipePlan {
     PipeTask *d_tasks = nullptr;
     int ntasks = 0;
 };
 static std::mutex g_plan_mu;
 static std::map<std::tuple<int, int, int, int, int, int>, PipePlan> g_plans;
+
+static int pipe_plan_get(int dev, int n_pad, int m_tot, int g0, int np, int rt, PipePlan &out) {
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    const auto key = std::make_tuple(dev, n_pad, m_tot, g0, np, rt);
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) {
+        const std::vector<PipeTask> tasks = pipe_tasks(n_pad, m_tot, g0, np, rt, kPipeLookAhead);
+        PipePlan pl;
+        pl.ntasks = (int)tasks.size();
+        if (pl.ntasks > 0) {
+            EGX_HIP_CHECK(dev_malloc(&pl.d_tasks, sizeof(PipeTask) * tasks.size()));
+            // (synchronous: the source is a temporary.  Handles prepare their plans at creation, so this is not on a launch path
+            //  except for callers without a handle -- egx_potrf, the tools -- and after egx_trim)
+            const hipError_t e = hipMemcpy(pl.d_tasks, tasks.data(), sizeof(PipeTask) * tasks.size(), hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(pl.d_tasks);
+                EGX_HIP_CHECK(e);
+            }
+        }
+        it = g_plans.emplace(key, pl).first;
+    }
+    out = it->second;
+    return EGX_SUCCESS;
+}
+// the plans a handle of this shape and schedule will launch, on the current device (egx_gp_create / egx_gp_set_lockstep)
+int pipe_prepare(int n_pad, int m_tot, const PotrfSchedule &sched) {
+    if (!sched.pipe || pipe_init() != EGX_SUCCESS) return EGX_SUCCESS;
+    int dev = 0;
+    EGX_HIP_CHECK(hipGetDevice(&dev));
+    PipePlan pl;
+    if (sched.whole) return pipe_plan_get(dev, n_pad, m_tot, 0, (n_pad + 255) / 256, 1, pl);
+    const int GW = sched.group_panels * 256;
+    for (int g0 = 0; g0 < n_pad; g0 += GW) {
+        const int gw = (n_pad - g0 < GW) ? (n_pad - g0) : GW;
+        EGX_RC_PIPE(pipe_plan_get(dev, n_pad, m_tot, g0, (gw + 255) / 256, 1, pl));
+    }
+    return EGX_SUCCESS;
+}
+// egx_trim: the task lists go with the pooled handles (every device is synchronised first: a launch in flight reads its list).
+// Returns the bytes given back.
+size_t pipe_release_plans() {
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    size_t bytes = 0;
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    int synced = -1;
+    for (auto &kv : g_plans) {
+        const int dev = std::get<0>(kv.first);
+        if (!kv.second.d_tasks) continue;
+        if (dev != synced) {
+            if (hipSetDevice(dev) != hipSuccess) continue;
+            (void)hipDeviceSynchronize();
+            synced = dev;
+        }
+        (void)hipFree(kv.second.d_tasks);
+        bytes += sizeof(PipeTask) * (size_t)kv.second.ntasks;
+    }
+    g_plans.clear();
+    if (have_cur) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+    return bytes;
+}
 
 // word 3 of the batch's hand-off words <- value, in stream order (a one-thread kernel behind the launch it reports on)
 __global__ void k_pipe_signal(int *word, int value) { store_flag(word, value); }
@@ -688,7 +790,10 @@ int pipe_signal(hipStream_t s, const PotrfBatch &pb, int value) {
 
 int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
                       const PotrfBatch &pb, int g0, int gw, int ext_need, int shared_chip) {
-    pipe_init();
+    if (pipe_init() != EGX_SUCCESS) {
+        set_error("potrf_pipe: the chain launch cannot get its dynamic LDS on this device");
+        return EGX_ERR_HIP;
+    }
     if (!pb.sync || g0 % 256 || gw <= 0 || (m_tot - n_pad) % 128 || n_pad % 128) {
         set_error("potrf_pipe: needs sync words, a group that starts on a panel boundary and padded sizes");
         return EGX_ERR_INVALID_VALUE;
@@ -700,22 +805,7 @@ int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot
     //  spilled registers and was only meant for panels taller than the sizes chain launches are used for: removed)
     const int rt = 1;
     PipePlan plan;
-    {
-        std::lock_guard<std::mutex> lock(g_plan_mu);
-        const auto key = std::make_tuple(dev, n_pad, m_tot, g0, np, rt);
-        auto it = g_plans.find(key);
-        if (it == g_plans.end()) {
-            const std::vector<PipeTask> tasks = pipe_tasks(n_pad, m_tot, g0, np, rt, kPipeLookAhead);
-            PipePlan pl;
-            pl.ntasks = (int)tasks.size();
-            if (pl.ntasks > 0) {
-                EGX_HIP_CHECK(dev_malloc(&pl.d_tasks, sizeof(PipeTask) * tasks.size()));
-                EGX_HIP_CHECK(hipMemcpy(pl.d_tasks, tasks.data(), sizeof(PipeTask) * tasks.size(), hipMemcpyHostToDevice));
-            }
-            it = g_plans.emplace(key, pl).first;
-        }
-        plan = it->second;
-    }
+    EGX_RC_PIPE(pipe_plan_get(dev, n_pad, m_tot, g0, np, rt, plan));
     const PipeLayout l = pipe_layout(n_pad, m_tot);
     PipeArgs a;
     a.M = M;
@@ -742,30 +832,32 @@ int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot
     a.off_cver = l.off_cver;
     a.rt = rt;
     a.ext_need = ext_need;
-    a.stall = g_pipe_stall;
     a.timeout = (long long)g_pipe_timeout_ms * 100000ll;
+#ifdef EGX_TEST_HOOKS
+    a.stall = g_pipe_stall;
     a.trace = g_pipe_trace;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        hipDeviceProp_t prop;
-        EGX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int test_wgs = g_pipe_test_wgs;
+#else
+    a.stall = 0;
+    a.trace = nullptr;
+    const int test_wgs = 0;
+#endif
+    const int n_cu = pipe_device_cus(dev);
     // the DIAG workgroups (one per diagonal block and matrix, resident from the start) + workers, never more than one
     // workgroup per compute unit: every workgroup of the grid is resident, whatever the dispatch order
     const long long n_diag = (long long)a.nz * np, want = n_diag + (long long)a.nz * plan.ntasks;
     // (a chain launch that runs BESIDE the launches it waits for or shares the chip with -- look-ahead -- must leave them
     //  compute units: its workgroups fill one each and would otherwise spin on a launch that cannot start)
-    #ifdef EGX_DEV_KNOBS
+#ifdef EGX_DEV_KNOBS
     const int shared_wgs = dev_env("EGX_DEV_PIPE_SHARED_WGS", kPipeSharedWgs);
 #else
     const int shared_wgs = kPipeSharedWgs;
 #endif
-    long long wgs = g_pipe_test_wgs > 0 ? g_pipe_test_wgs : (shared_chip ? (shared_wgs < n_cu ? shared_wgs : n_cu) : n_cu);
+    long long wgs = test_wgs > 0 ? test_wgs : (shared_chip ? (shared_wgs < n_cu ? shared_wgs : n_cu) : n_cu);
     if (wgs > n_cu) wgs = n_cu;
     if (wgs > want) wgs = want;
     if (wgs < n_diag + 1) wgs = n_diag + 1;
-    if (n_diag + 1 > n_cu) {
+    if (n_diag + 1 > n_cu) {  // (launch_potrf asks pipe_fits first and never gets here)
         set_error("potrf_pipe: more diagonal blocks in one chain launch than compute units");
         return EGX_ERR_INVALID_VALUE;
     }

@@ -497,6 +497,14 @@ def pool_stats():
     return {"cached_bytes": b.value, "hits": h.value, "misses": m.value}
 
 
+def chain_stats():
+    """egx_chain_stats: evaluations whose chain launch ran into its wait bound, and how many of them were run again by separate
+    launches (process-wide, since start-up)."""
+    a, r = C.c_int64(), C.c_int64()
+    L.load().egx_chain_stats(C.byref(a), C.byref(r))
+    return {"aborted": a.value, "retried": r.value}
+
+
 # ---- builder (crates/gp/src/parameters.rs:93-313) ---------------------------------------------------
 class GpParams:
     def __init__(self, mean=None, corr=None):

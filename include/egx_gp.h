@@ -102,14 +102,24 @@ void egx_gp_config_default(egx_gp_config *cfg);
  * EGX_POOL_MAX_GB (environment, default 48, 0 = no pool).  egx_trim frees everything cached and returns the bytes. */
 int64_t egx_trim(void);
 void egx_pool_stats(int64_t *cached_bytes, int64_t *hits, int64_t *misses);
-/* The factorisation's eight scheduling settings at run time (the EGX_* environment variables of DESIGN.md section 4, read
+/* Chain launches (the serial chain of a factorisation as one persistent launch) bound every device-side
+ * wait by EGX_PIPE_TIMEOUT_MS.  A wait that runs out -- waves pre-empted while several processes share the GPU, a debugger --
+ * is not a numerical event and the reference's cholesky() (crates/gp/src/algorithm.rs:1004) knows no such failure (the
+ * objective only ever sees numerical errors, :893-896): the evaluation is run ONCE more, alone, by separate launches of the
+ * same handle, and only a second failure is reported as EGX_ERR_HIP ("pipe_retry" = 0 / EGX_PIPE_RETRY=0: report at once).
+ * Process-wide counters since start-up: *aborted = evaluations whose chain launch ran into the bound, *retried = those that
+ * were run again.  Either pointer may be NULL. */
+void egx_chain_stats(int64_t *aborted, int64_t *retried);
+/* The factorisation's scheduling settings at run time (the EGX_* environment variables of DESIGN.md section 4, read
  * once at start-up; here by name without the prefix, lower case):
  *   "potrf_group"      panels per trailing update (0 = by size)          "stream_min"  tiles from which the stream kernel is used
  *   "gemm_small"       tiles below which the 64 x 64 kernel is used      "look_min"    trailing columns down to which the chain looks ahead
  *   "potrf_left"       left-looking updates 0 never / 1 per handle / 2   "lur_side"    look-ahead update beside (1) or in front of (0) the trailing one
  *   "pipe"             chain launches 0 never / 1 per handle / 2 per group of panels only
- *   "pipe_timeout_ms"  bound of every device-side wait of a chain launch (default 2000; exceeded = EGX_ERR_HIP, not a hang)
- * (plus the test hook "pipe_stall").  They move launches between streams and kernels between tile shapes, never the
+ *   "pipe_timeout_ms"  bound of every device-side wait of a chain launch (default 2000; exceeded = one retry by separate
+ *                      launches, see egx_chain_stats -- never a hang)
+ *   "pipe_retry"       1 (default): that retry; 0: EGX_ERR_HIP at once
+ * (the test hook "pipe_stall" exists only in the test build of the library, -DEGX_TEST_HOOKS).  They move launches between streams and kernels between tile shapes, never the
  * arithmetic inside a kernel; "potrf_group" / "stream_min" / "gemm_small" / "potrf_left" / "pipe" change which kernel
  * updates a block, or the order in which updates are summed, hence the rounding -- and "potrf_left" / "pipe" /
  * "potrf_group" enter a handle's schedule (egx_gp_get_schedule) when it is CREATED or its lock-step width is set, not
@@ -214,7 +224,10 @@ int32_t egx_gp_finalize(egx_gp *gp, const double *theta, int64_t theta_len);
  *                         other handle on its own -- the fitted models are bit for bit what egx_gp_finalize gives each of them
  *                         (the same kernels on the same values: a matrix never sees its companions).  The first error of
  *                         any model is returned after all of them have been finished.
- *   egx_gp_likelihood_multi  the same for the reduced likelihood alone (algorithm.rs:988-1056); status as egx_gp_likelihood. */
+ *   egx_gp_likelihood_multi  the same for the reduced likelihood alone (algorithm.rs:988-1056); status as egx_gp_likelihood.
+ *                         NOTE: both calls evaluate on every member's workspace 0, where a fitted model's factor lives: a fitted
+ *                         member is UN-FITTED by egx_gp_likelihood_multi too (egx_gp_likelihood keeps a fitted handle with spare
+ *                         workspaces fitted; call egx_gp_finalize[_multi] again before predicting). */
 int32_t egx_gp_create_group(const egx_gp_config *cfg, const double *x, const double *y, int64_t n, int64_t d, int32_t k,
                             egx_gp **out /*k*/);
 int32_t egx_gp_finalize_multi(egx_gp *const *gps, int32_t k, const double *thetas /*k x theta_len*/, int64_t theta_len);

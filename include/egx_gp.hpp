@@ -369,6 +369,14 @@ inline PoolStats pool_stats() {
     return s;
 }
 
+// chain launches that ran into their wait bound, and how many of those evaluations were run again by separate launches
+struct ChainStats { int64_t aborted = 0, retried = 0; };
+inline ChainStats chain_stats() {
+    ChainStats s;
+    egx_chain_stats(&s.aborted, &s.retried);
+    return s;
+}
+
 // Kriging = constant mean + squared exponential, algorithm.rs:244-249
 struct Kriging {
     static GpParams params() { return GpParams(Mean::Constant, Corr::SquaredExponential); }

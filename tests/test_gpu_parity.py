@@ -995,6 +995,20 @@ def test_no_device_memory_leak_over_handle_lifecycles(egx, O):
     # no GROWTH (the runtime's own sub-allocator may hand back a few 2 MiB blocks more or less than before: observed
     # +68 MiB free after the 25 cycles)
     assert free0 - free1 < 64 << 20, (free0, free1)
+    # ... and over 20 DISTINCT shapes (every one leaves pooled slabs and, for the sizes that take chain launches, a device task
+    # list per shape behind): egx_trim gives all of it back -- the pool reads zero and the free memory is where it was
+    for j in range(20):
+        n = 300 + 137 * j
+        xj, yj = _data(n, 3, seed=80 + j)
+        with egx.GpHandle(xj, yj, n_workspaces=1 + j % 3) as h:
+            h.finalize(np.full(3, 0.7))
+            h.predict_valvar(xj[:5])
+    assert egx.pool_stats()["cached_bytes"] > 0
+    freed = egx.trim()
+    assert freed > 0 and egx.pool_stats()["cached_bytes"] == 0
+    torch.cuda.synchronize()
+    free2, _ = torch.cuda.mem_get_info()
+    assert free0 - free2 < 64 << 20, (free0, free2)
 
 
 def test_randomised_parity_sweep(egx, O):
