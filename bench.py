@@ -27,6 +27,7 @@ labelled by mode.  `other_configs`: bounded side measurements of BASELINE config
 """
 import argparse
 import json
+import math
 import os
 import subprocess
 import sys
@@ -588,6 +589,66 @@ def dry_launch(args, rank, world):
     return 0 if ok else 1
 
 
+# ---- the printed line: numbers first, <= 7 KB (the driver keeps the last 8 KB of stdout) -------------------------------------
+DETAILS_FILE = os.path.join("profiles", "bench_last_run_details.json")
+_DROP_KEYS = {"metric_note", "thread_settings_tried", "settings_tried", "traffic_source", "how", "kernel", "launch_shape", "note",
+              "note_numa", "traffic_measured", "query", "first_handle_in_process", "rccl_version", "pool", "traffic_stale",
+              "extra_rows_note", "flops_per_launch_avg", "likelihood_checksum_ok_rows", "correction", "what", "reading"}
+_DROP_ORDER = ["cpu_baseline_reference_shaped", "roofline_kernel_alone", "corr_build_roofline", "cpu_baseline_concurrent",
+               "pcie_inclusive", "last_step_balance", "stage_ms_single_fit", "vendor_yardstick", "roofline_single_matrix"]
+
+
+def _schedule_word(s):
+    """a handle's schedule (GpHandle.schedule()) as one word"""
+    if s.get("flow"):
+        form = "flow"
+    elif s.get("whole_factorisation_launch"):
+        form = "whole"
+    elif s.get("pipelined_chain"):
+        form = "chain/group"
+    else:
+        form = "left" if s.get("left_looking") else "separate"
+    return f"{form},g{s.get('panels_per_group')},w{s.get('lockstep')}"
+
+
+def _compact(o, key=None):
+    if isinstance(o, dict):
+        if key == "schedule" and "panels_per_group" in o:
+            return _schedule_word(o)
+        return {k: _compact(v, k) for k, v in o.items() if k not in _DROP_KEYS}
+    if isinstance(o, (list, tuple)):
+        return [_compact(v) for v in o]
+    if isinstance(o, float):
+        return float(f"{o:.5g}") if math.isfinite(o) else None
+    if isinstance(o, str) and len(o) > 100 and key not in ("workload", "sample", "error"):
+        return o[:97] + "..."
+    return o
+
+
+def compact_line(out, limit=7000):
+    """The full record goes to profiles/bench_last_run_details.json (and gpurun_out/ when it exists); the printed line keeps
+    the contract's keys, `roofline`, `cpu_baseline` and the numbers of every leg, without the prose and the settings tables."""
+    for path in (os.path.join(ROOT, DETAILS_FILE), os.path.join(ROOT, "gpurun_out", "bench_last_run_details.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    json.dump(out, f, indent=1)
+        except OSError:
+            pass
+    line = _compact(out)
+    line["config"]["workload"] = (f"dense GP fixed-theta fit (corr build + Cholesky + likelihood), sq-exp, n={out['config']['n']} "
+                                  f"d={out['config']['d']}, LHS + Griewank; theta sweep, {out['config']['sweep_batch_per_step']} per step")
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict) and isinstance(cb.get("sample"), str):
+        cb["sample"] = cb["sample"][:160]
+    line["details"] = DETAILS_FILE
+    for k in _DROP_ORDER:
+        if len(json.dumps(line, separators=(",", ":"))) <= limit:
+            break
+        line.pop(k, None)
+    return json.dumps(line, separators=(",", ":"))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -810,6 +871,31 @@ def main():
                        "best_likelihood": float(np.max(np.where(okc, l4, -np.inf)))}
         except Exception as e:  # noqa: BLE001
             config4 = {"error": f"{type(e).__name__}: {e}"[:300]}
+    # What ONE rank sees at N = 8 (no 8-GPU node is available to this build; the driver's SCALE run is the measurement):
+    # 192 per step over 8 GPUs = 24 candidates per rank and step = three lock-step groups of eight, two in flight, then one --
+    # and the all-gather after every step.  This rank drives exactly that through the same collective entry point; the implied
+    # 8-GPU figure is 8 x its rate (candidates are independent, X and y replicated: nothing else is shared between ranks).
+    n8_emulation = None
+    if world == 1 and use_lib and not args.no_extra_configs and nb >= 24:
+        try:
+            share = nb // 8
+            c8 = cands[:12 * share].reshape(12, share, d)
+            for i in range(2):
+                sw.likelihood(c8[i])
+            barrier()
+            t8 = time.perf_counter()
+            for i in range(2, 12):
+                sw.likelihood(c8[i])
+            barrier()
+            t8 = (time.perf_counter() - t8) / 10
+            n8_emulation = {"candidates_per_rank_and_step": share, "steps": 10, "ms_per_step": t8 * 1e3,
+                            "fits_per_s_this_rank": share / t8, "implied_8gpu_fits_per_s": 8 * share / t8,
+                            "implied_scaling_over_n1_value": 8 * share / t8 / (args.steps * nb / elapsed),
+                            "drain_cost_frac": 1.0 - share / t8 / (args.steps * nb / elapsed),
+                            "what": "one rank's share of a 192-candidate step at N = 8 (three groups of eight: two in flight, then "
+                                    "one), an all-gather per step; 8 x this rank's rate"}
+        except Exception as e:  # noqa: BLE001
+            n8_emulation = {"error": f"{type(e).__name__}: {e}"[:300]}
     sw.close()
     if use_lib and info["rccl_ranks"] != world and not rehearsal:
         sys.stderr.write(f"bench.py: the library's RCCL communicator has {info['rccl_ranks']} ranks, world is {world}\n")
@@ -1044,6 +1130,8 @@ def main():
             out.setdefault("other_configs", {})["tuned_fit_11_starts_sharded"] = tuned
         if config4 is not None:
             out.setdefault("other_configs", {})["config4_sweep_512"] = config4
+        if n8_emulation is not None:
+            out["n8_rank_emulation"] = n8_emulation
         if not args.no_cpu_baseline and world == 1:
             torch.cuda.synchronize()
             cb = cpu_baseline(n, d)
@@ -1071,7 +1159,7 @@ def main():
             rs = cpu_baseline_reference_shaped(n, d)
             if rs is not None:
                 out["cpu_baseline_reference_shaped"] = rs
-        print(json.dumps(out), flush=True)
+        print(compact_line(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

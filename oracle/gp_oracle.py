@@ -199,15 +199,22 @@ def corr_jacobian(kind, x, xtrain, theta, weights):
         def factor(v):
             return 1.0 + q * v if kind == MATERN32 else 1.0 + q * v + (5.0 / 3.0) * v * v
 
+        # (entries of theta_w that are exactly zero -- every off-diagonal one when the weights are the identity -- are skipped:
+        #  factor(0) == 1.0 and their derivative term is 0.0 * finite, so the reference's full loops give the same bits; without
+        #  the skip the four nested loops are nx^4 vector operations per point, 8e9 at nx = 300)
         a = np.ones(n)
         for j in range(nx):
             for l in range(theta_w.shape[1]):
+                if theta_w[j, l] == 0.0:
+                    continue
                 a = a * factor(theta_w[j, l] * abs_d[:, j])
         b = np.exp(-q * abs_d.dot(theta_w).sum(axis=1))
         db = -q * np.abs(w).dot(theta)[None, :] * sign_d * (a * b)[:, None]
         da = np.zeros((n, nx))
         for j in range(nx):
             for k in range(theta_w.shape[1]):
+                if theta_w[j, k] == 0.0:
+                    continue
                 if kind == MATERN32:
                     deriv = q * theta_w[j, k] * sign_d[:, j]
                 else:
@@ -216,7 +223,7 @@ def corr_jacobian(kind, x, xtrain, theta, weights):
                 term = np.ones(n)
                 for p in range(nx):
                     for l in range(theta_w.shape[1]):
-                        if l != k or p != j:
+                        if (l != k or p != j) and theta_w[p, l] != 0.0:
                             term = term * factor(theta_w[p, l] * abs_d[:, p])
                 da[:, j] += deriv * term
         return db + da * b[:, None]

@@ -20,7 +20,12 @@ tests/test_oracle_golden.py) needs ~100 s per likelihood at n = 16384 on 8 cores
 Inputs are regenerated in the tests from the same seeds (oracle.lhs_classic / griewank ==
 egobox_amd.workload), so only thetas, scalars and the prediction vectors are stored.
 
-    python tests/golden/make_large_n.py [--only fit|grad|grad16384|sweep|expert|experts] [--out tests/golden/large_n.json]
+  xgrad_n200_d300_<corr>  x-gradients of mean and variance (oracle's restated jacobians, algorithm.rs:510-617) at d = 300 --
+                          beyond the 256 dimensions a training slab of 64 points fits LDS with -- on query rows 0 and 1 of
+                          tests/test_gpu_parity.py::test_x_gradients_beyond_256_dimensions (--only xgrad300; the oracle's
+                          product-over-all-but-one Matern jacobian costs minutes per point at this d)
+
+    python tests/golden/make_large_n.py [--only fit|grad|grad16384|sweep|expert|experts|xgrad300] [--out tests/golden/large_n.json]
 
 Parts are merged into an existing output file, so the script can be run piecewise.
 """
@@ -201,6 +206,26 @@ def part_experts(out):
                     "hard_predict": per_y[c, rows].tolist(), "hard_predict_var": per_v[c, rows].tolist()}}
 
 
+def part_xgrad300(out):
+    """x-gradients at d = 300 against the oracle itself (not finite differences of the library's own predictions): the training
+    set, theta and query points of tests/test_gpu_parity.py::test_x_gradients_beyond_256_dimensions, rows 0 and 1."""
+    ms = _multistart()
+    n, d = 200, 300
+    x = O.lhs_classic(n, d, 5)   # == egobox_amd.workload.make_training_set(n, d, seed=5)
+    y = O.griewank(x)
+    xq = x.min(0) + (x.max(0) - x.min(0)) * np.random.default_rng(1).random((130, d))
+    for corr_id, corr in ((0, O.SQEXP), (3, O.MATERN52)):
+        theta = np.full(d, 0.5 / math.sqrt(d)) * (2.0 if corr_id == 0 else 1.0)
+        t0 = time.time()
+        gp = O.fit_fixed(x, y, theta, O.CONSTANT, corr)
+        gy, gv = gp.predict_valvar_gradients(xq[:2])
+        out[f"xgrad_n{n}_d{d}_{corr}"] = {
+            "n": n, "d": d, "seed": 5, "corr": corr, "corr_id": corr_id, "theta": theta.tolist(),
+            "query": "x.min(0) + (x.max(0) - x.min(0)) * default_rng(1).random((130, 300)), rows 0 and 1",
+            "likelihood": gp.likelihood, "predict_gradients": gy.tolist(), "predict_var_gradients": gv.tolist()}
+        print(f"xgrad300 {corr}: |gy| {np.linalg.norm(gy):.6e} |gv| {np.linalg.norm(gv):.6e} ({time.time() - t0:.0f}s)", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -230,6 +255,9 @@ def main():
         save()
     if args.only == "grad16384" or (args.only == "" and f"grad_n16384_d32_{O.MATERN52}" not in out):
         part_grad16384(out)
+        save()
+    if args.only == "xgrad300" or (args.only == "" and f"xgrad_n200_d300_{O.SQEXP}" not in out):
+        part_xgrad300(out)
         save()
     if want("fit"):
         for _ in part_fit(out):

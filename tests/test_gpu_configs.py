@@ -680,12 +680,21 @@ def test_config5_eight_experts_n8192_d16_m100000(egx, large):
     n, d, m, k = rec["n"], rec["d"], 100000, 8
     theta = np.array(rec["theta"])
     xq = np.random.default_rng(7).random((m, d))
-    experts = []
-    for e in range(k):
-        x, y = _data(n, d, 7 + e)
-        experts.append(egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr())
-                       .theta_tuning(egx.ThetaTuning.Fixed(theta)).fit(x, y))
+    # round 6: the eight experts are created as ONE group and fitted in lock-step (GpParams.fit_group -> egx_gp_create_group +
+    # egx_gp_finalize_multi: the expert loop of crates/moe/src/algorithm.rs:167-177 as one launch sequence), so every assertion
+    # below -- all against the ORACLE experts of large_n.json -- pins the group path at config 5's full size
+    sets = [_data(n, d, 7 + e) for e in range(k)]
+    experts = (egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr())
+               .theta_tuning(egx.ThetaTuning.Fixed(theta)).fit_group(np.stack([s_[0] for s_ in sets]), np.stack([s_[1] for s_ in sets])))
     try:
+        # ... and one of them once more on its own: the lone fit gives the same bits
+        lone = egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr()) \
+            .theta_tuning(egx.ThetaTuning.Fixed(theta)).fit(*sets[3])
+        try:
+            assert lone.likelihood() == experts[3].likelihood() and lone.variance() == experts[3].variance()
+            np.testing.assert_array_equal(lone.predict(xq[:64]), experts[3].predict(xq[:64]))
+        finally:
+            lone.close()
         assert experts[0].likelihood() == pytest.approx(rec["likelihood"], rel=LK_RTOL)
         assert experts[0].variance() == pytest.approx(rec["sigma2"], rel=1e-8)
         # experts 1..7: the oracle's likelihood, variance and 100 predictions each (tests/golden/make_large_n.py --only experts)

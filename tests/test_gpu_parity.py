@@ -1333,8 +1333,9 @@ def test_kpls_with_100_input_dimensions(egx, O):
 def test_x_gradients_beyond_256_dimensions(egx, corr, d):
     """Round 5: the batched x-gradient kernel narrows its LDS slab of training points beyond d ~ 300 (64 points wide at
     d = 300, 16 at d = 700, 8 at d = 1100) instead of refusing d > 256.  Checked by directional central differences of
-    the predictions (themselves oracle-checked at d = 100 / 200 above; the oracle's jacobians cost minutes per point at
-    this d), batched form and the few-query form against each other."""
+    the predictions (themselves oracle-checked at d = 100 / 200 above), batched form and the few-query form against each
+    other -- and, round 6, at d = 300 against the ORACLE's jacobians (algorithm.rs:510-617 restated) on query rows 0 and 1
+    (tests/golden/large_n.json `xgrad_n200_d300_*`, make_large_n.py --only xgrad300)."""
     n = 200
     x, y = _data(n, d, seed=5)
     theta = egx.workload.default_theta(d) * (2.0 if corr == 0 else 1.0)
@@ -1343,6 +1344,18 @@ def test_x_gradients_beyond_256_dimensions(egx, corr, d):
         h.finalize(theta)
         gy, gv = h.predict_valvar_gradients(xq)
         assert gy.shape == (130, d) and np.all(np.isfinite(gy)) and np.all(np.isfinite(gv))
+        if d == 300:
+            import json
+            import os
+            with open(os.path.join(os.path.dirname(__file__), "golden", "large_n.json")) as f:
+                fx = json.load(f)["xgrad_n200_d300_" + ("SquaredExponential" if corr == 0 else "Matern52")]
+            assert fx["corr_id"] == corr and np.array_equal(np.array(fx["theta"]), theta)
+            lk, st = h.likelihood(theta)
+            assert st == 0 and abs(lk - fx["likelihood"]) <= 1e-8 * abs(fx["likelihood"])
+            h.finalize(theta)
+            ry, rv = np.array(fx["predict_gradients"]), np.array(fx["predict_var_gradients"])
+            np.testing.assert_allclose(gy[:2], ry, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(ry).max())
+            np.testing.assert_allclose(gv[:2], rv, rtol=PRED_RTOL, atol=PRED_RTOL * np.abs(rv).max())
         one = h.predict_valvar_gradients(xq[:1])
         np.testing.assert_allclose(one[0], gy[:1], rtol=1e-7, atol=1e-9 * np.abs(gy).max())
         np.testing.assert_allclose(one[1], gv[:1], rtol=1e-6, atol=1e-8 * np.abs(gv).max())

@@ -269,7 +269,11 @@ def test_three_lockstep_slots_with_look_ahead_chain_launches_in_flight(egx):
 
 # ---- lock-step across MODELS (egx_gp_create_group / egx_gp_finalize_multi): the expert loop of egobox-moe
 #      (crates/moe/src/algorithm.rs:167-177), EGO's objective + constraint surrogates (crates/ego/src/solver/solver_impl.rs:370-391)
-@pytest.mark.parametrize("n,d,k,mean,corr", [(700, 4, 5, 0, 0), (2100, 5, 3, 1, 3), (4200, 6, 3, 0, 0)])
+# (a group takes the schedule of a LONE handle of its shape -- that is what makes a member's fit bit for bit its lone fit --, so
+#  up to 7168 columns it is ONE whole-factorisation launch with grid.z = members; k = 12 at n = 1000 is the widest such launch:
+#  48 diagonal blocks, beyond the 32 a handle's own workspaces are allowed.  The "chain launch per group of panels" row of
+#  schedule.h is taken by handles with many WORKSPACES only, never by a group: test_three_lockstep_slots_... runs it.)
+@pytest.mark.parametrize("n,d,k,mean,corr", [(700, 4, 5, 0, 0), (2100, 5, 3, 1, 3), (4200, 6, 3, 0, 0), (1000, 3, 12, 0, 0)])
 def test_models_of_a_group_fitted_in_lock_step_are_their_lone_fits_bit_for_bit(egx, n, d, k, mean, corr):
     sets = [_data(n, d, 50 + j) for j in range(k)]
     thetas = np.stack([np.full(d, 0.35 + 0.05 * j) for j in range(k)])
