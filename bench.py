@@ -622,7 +622,7 @@ def _compact(o, key=None):
         if key is not None and ("checksum" in key or "likelihood" in key):
             return o  # (what the tests and the N > 1 consistency checks compare: every digit)
         return float(f"{o:.5g}") if math.isfinite(o) else None
-    if isinstance(o, str) and len(o) > 100 and key not in ("workload", "sample", "error"):
+    if isinstance(o, str) and len(o) > 100 and key not in ("workload", "sample", "error", "collective"):
         return o[:97] + "..."
     return o
 

@@ -176,6 +176,7 @@ struct PotrfBatch {
     int64_t sS = 0;          // sS ints apart; nullptr: the chain runs as separate launches (k_potf2_reg, k_panel_trsm16, updates)
     int pipe = 0;            // ... the chain of every group of panels is one chain launch (schedule.h: per handle)
     int whole = 0;           // ... the WHOLE factorisation is one chain launch (every update inside it)
+    int flow = 0;            // ... the whole factorisation is one FLOW launch (pipe_flow.h; one matrix per launch)
     int group_panels = 0;    // panels per trailing update, from the handle's schedule (0: by size, potrf_group_panels): launch_potrf
                              // never reads the process-wide knobs for a handle that carries its schedule
     int seqs = 1;            // launch sequences of this handle that may be in flight at once (workspaces / lock-step width):
@@ -247,6 +248,11 @@ size_t pipe_sync_ints(int n_pad, int m_tot);
 int launch_potrf_pipe(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info,
                       const PotrfBatch &pb, int g0, int gw, int ext_need = 0, int shared_chip = 0);
 int pipe_signal(hipStream_t s, const PotrfBatch &pb, int value);
+// The WHOLE factorisation of ONE large matrix as a flow launch (k_potrf_flow; pipe_flow.h: critical stage lists + bulk-class
+// rounds per column, round 6); pb.sync as for the chain launch (pipe_sync_ints covers both).  flow_fits: 256-column panels and
+// a workgroup per diagonal block + workers on the current device.
+int launch_potrf_flow(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info, const PotrfBatch &pb);
+bool flow_fits(int n_pad);
 int pipe_enabled();    // EGX_PIPE (default on); 0 as well when the launch cannot be set up on this device
 bool pipe_fits(int nz, int np);  // one workgroup per diagonal block (np panels of nz matrices) + a worker fit the CURRENT device
 int pipe_prepare(int n_pad, int m_tot, const PotrfSchedule &sched);  // build + upload the task lists a handle of this shape launches
@@ -255,6 +261,8 @@ int pipe_set_knob(const char *name, int value);  // "pipe", "pipe_timeout_ms" (+
 #ifdef EGX_TEST_HOOKS  // egobox_amd/lib/_dev/libegx_gp_hip_testhooks.so and tools/pipe_check only
 void pipe_set_trace(long long *device_buf);  // profiling: 8 words per ticket of the next chain launches (nullptr: off)
 void pipe_test_set_workgroups(int wgs);      // grid of the next chain launches (0 = the product's)
+void pipe_set_trace_cap(int slots);          // slots of the trace buffer (flow launches take them from a counter)
+void flow_test_set_leads(int lead_short, int lead_long);  // FlowArgs::lead_* of the next flow launches (-1: the product's)
 #endif
 int chol_init();  // one-time function attribute setup (dynamic LDS sizes)
 int set_knob(const char *name, int value);  // kernels_chol.hip tuning knobs by name; INT_MIN = unknown

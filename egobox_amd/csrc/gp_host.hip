@@ -404,9 +404,10 @@ static int enqueue_eval_core(egx_gp *const *owners, Workspace *const *wss, int c
     pb.w_left = gp->sched.w_left;
     pb.pipe = separate ? 0 : gp->sched.pipe;
     pb.whole = separate ? 0 : gp->sched.whole;
+    pb.flow = separate || count > 1 ? 0 : gp->sched.flow;
     pb.group_panels = gp->sched.group_panels;
     pb.seqs = gp->lockstep > 0 ? ((int)gp->ws.size() + gp->lockstep - 1) / gp->lockstep : 1;
-    pb.sync = pb.pipe ? lead_sync : nullptr;  // the chain of a group of panels as one persistent launch (kernels_pipe.hip)
+    pb.sync = pb.pipe || pb.flow ? lead_sync : nullptr;  // the chain of a group of panels as one persistent launch (kernels_pipe.hip)
     pb.sS = gp->stride_S;
     for (int j = 0; j < count; j++) {  // what finish_eval needs to run this evaluation once more, alone, by separate launches
         wss[j]->retry_hcols = hcols;

@@ -1096,9 +1096,10 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     //  true.  A device on which the launch does not fit -- one workgroup per diagonal block and matrix: a partitioned GPU -- takes
     //  the separate launches for the whole factorisation.)
     const int GW = (pb.group_panels > 0 ? pb.group_panels : potrf_group_panels(n_pad)) * kNB;
-    const bool have_sync = pb.sync != nullptr && pb.pipe != 0 &&
-                           pipe_fits((int)nz, ((pb.whole || GW > n_pad ? n_pad : GW) + kNB - 1) / kNB);
-    const bool pipe = have_sync;
+    const bool flow = pb.sync != nullptr && pb.flow != 0 && nz == 1 && flow_fits(n_pad);
+    const bool have_sync = flow || (pb.sync != nullptr && pb.pipe != 0 &&
+                                    pipe_fits((int)nz, ((pb.whole || GW > n_pad ? n_pad : GW) + kNB - 1) / kNB));
+    const bool pipe = have_sync && !flow;
     if (have_sync) EGX_HIP_CHECK(hipMemsetAsync(pb.sync, 0, sizeof(int) * (nz > 1 ? (size_t)pb.sS * nz : pipe_sync_ints(n_pad, m_tot)), s));
     auto gwidth = [&](int g0) { return (n_pad - g0 < GW) ? (n_pad - g0) : GW; };
     // panels of one group on stream `st`; `side` != nullptr splits every in-group update into the next diagonal block
@@ -1208,8 +1209,8 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     };
     // (decided per HANDLE, never by the number of matrices in a launch: a matrix gets the same bits in any batch -- and with or
     //  without the theta-gradient's rider: its substitution then follows the launch group by group instead of riding along)
-    if (pipe && pb.whole) {
-        rc = launch_potrf_pipe(s, M, ld, n_pad, m_tot, dinv, info, pb, 0, n_pad);
+    if (flow || (pipe && pb.whole)) {
+        rc = flow ? launch_potrf_flow(s, M, ld, n_pad, m_tot, dinv, info, pb) : launch_potrf_pipe(s, M, ld, n_pad, m_tot, dinv, info, pb, 0, n_pad);
         if (rc) return rc;
         if (inv) {
             for (int g0 = 0; g0 < n_pad; g0 += GW) {

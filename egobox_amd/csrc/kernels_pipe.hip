@@ -48,6 +48,7 @@
 #include "mfma_gemm_core.h"
 #include "potf2_blocks.h"
 #include "pipe_tasks.h"
+#include "pipe_flow.h"
 
 #define EGX_RC_PIPE(call)     \
     do {                      \
@@ -86,7 +87,10 @@ static PipeLayout pipe_layout(int n_pad, int m_tot) {
     l.total = (l.total + 63) / 64 * 64;
     return l;
 }
-size_t pipe_sync_ints(int n_pad, int m_tot) { return (size_t)pipe_layout(n_pad, m_tot).total; }
+size_t pipe_sync_ints(int n_pad, int m_tot) {
+    const PipeLayout l = pipe_layout(n_pad, m_tot);
+    return (size_t)l.total + (size_t)flow_layout(l.NP, l.total).total;  // + the flow launch's words (pipe_flow.h)
+}
 
 struct PipeArgs {
     double *M;
@@ -486,9 +490,12 @@ __device__ __noinline__ int pipe_role_fine(pipe_kargs_t ka, pipe_lds_t sm3, long
 // ---------------------------------------------------------------------------------------------
 // COARSE: C (128 x 128 tile (I, J), absolute) -= A B^T over panel p's 256 columns; sixteen waves x 32 x 32
 // ---------------------------------------------------------------------------------------------
-__device__ __noinline__ int pipe_role_coarse(pipe_kargs_t ka, pipe_lds_t sm3, long long *tr, int z, int p, int I, int J) {
+// last != 0 (flow launch, pipe_flow.h): this is the LAST update of the tile's column block (panel p into block column p + 1, rows
+// below its diagonal block): the two 64-row chunks of the tile also count two fine tiles each towards fcnt, what the solve of
+// those rows waits for
+__device__ __noinline__ int pipe_role_coarse(pipe_kargs_t ka, pipe_lds_t sm3, long long *tr, int z, int p, int I, int J, int last = 0) {
     const PipeArgs a = pipe_kargs(ka);
-    z = pipe_uniform(z), p = pipe_uniform(p), I = pipe_uniform(I), J = pipe_uniform(J);
+    z = pipe_uniform(z), p = pipe_uniform(p), I = pipe_uniform(I), J = pipe_uniform(J), last = pipe_uniform(last);
 #ifdef EGX_PIPE_TRACE
     tr = pipe_uniform(tr);
 #else
@@ -540,7 +547,13 @@ __device__ __noinline__ int pipe_role_coarse(pipe_kargs_t ka, pipe_lds_t sm3, lo
                                    __HIP_MEMORY_SCOPE_AGENT);
     drain_stores();
     __syncthreads();
-    if (tid == 0) store_flag(ver, p + 1);
+    if (tid == 0) {
+        store_flag(ver, p + 1);
+        if (last) {
+            __hip_atomic_fetch_add(S + a.off_fcnt + (P + 1) * a.NC + 2 * I, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(S + a.off_fcnt + (P + 1) * a.NC + 2 * I + 1, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     return 0;
 }
 
@@ -636,6 +649,440 @@ __global__ __launch_bounds__(1024) void k_potrf_pipe(PipeArgs a) {
 }
 
 // =============================================================================================
+// FLOW: the whole factorisation of a large matrix as ONE launch with critical and bulk-class work (pipe_flow.h has the
+// shape of the lists, the gates and the deadlock argument; round 6)
+// =============================================================================================
+struct FlowArgs {
+    PipeArgs p;          // (first: the roles read the launch arguments through a pointer to it)
+    const int *coff;     // [NP + 1] first critical task of every stage in p.tasks
+    int NI;              // 128-row tiles of the matrix (m_tot / 128)
+    int RMAX, off_open, off_cnext, off_rcur, off_rcnt, off_pre, off_last, off_trace;
+    int lead_short, lead_long;  // a workgroup with a diagonal block ahead of it stops taking short / long tasks this many blocks before its own
+    int trace_cap;       // trace slots (profiling builds)
+};
+typedef const __attribute__((address_space(4))) FlowArgs *flow_kargs_t;
+__device__ __forceinline__ FlowArgs flow_kargs(flow_kargs_t kv) {
+    const unsigned long long u = (unsigned long long)kv;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    flow_kargs_t k = (flow_kargs_t)(((unsigned long long)hi << 32) | lo);
+    FlowArgs a;
+    a.p = pipe_kargs((pipe_kargs_t)k);
+    a.coff = k->coff, a.NI = k->NI, a.RMAX = k->RMAX, a.off_open = k->off_open, a.off_cnext = k->off_cnext, a.off_rcur = k->off_rcur;
+    a.off_rcnt = k->off_rcnt, a.off_pre = k->off_pre, a.off_last = k->off_last, a.off_trace = k->off_trace;
+    a.lead_short = k->lead_short, a.lead_long = k->lead_long, a.trace_cap = k->trace_cap;
+    return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BULK: C (128 rows x 256 columns: row tile I of block column q) -= A B^T over the panels [p0, p1) (K = 512): the stream
+// kernel's LDS-DMA ring (k_gemm_stream, kernels_chol.hip: unpadded [384][16] chunk image, XOR-swizzled 16-byte slots, three
+// 48 KB stages, prefetch distance two, one counted wait + one barrier per chunk in the MIDDLE of the chunk's MFMAs) re-cut for
+// the launch's sixteen waves: a wave owns 32 x 64 of the tile (64 accumulator registers of its 128) and three of a chunk's 48
+// LDS-DMA pieces.  Accumulators start as -C; the tile is stored write-through and its two 128-column halves are versioned.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBulkRows = 384, kBulkStage = kBulkRows * KC, kBulkStages = 3;
+static_assert(kBulkStages * kBulkStage <= kPipeLdsDoubles, "LDS of the BULK role");
+typedef __attribute__((address_space(3))) void *pipe_lds_void_t;
+typedef const __attribute__((address_space(1))) void *pipe_gbl_void_t;
+
+__device__ __noinline__ int pipe_role_bulk(pipe_kargs_t ka, pipe_lds_t sm3, long long *tr, int z, int q, int I, int p0, int p1) {
+    const PipeArgs a = pipe_kargs(ka);
+    z = pipe_uniform(z), q = pipe_uniform(q), I = pipe_uniform(I), p0 = pipe_uniform(p0), p1 = pipe_uniform(p1);
+#ifdef EGX_PIPE_TRACE
+    tr = pipe_uniform(tr);
+#else
+    tr = nullptr;
+#endif
+    double *smem = pipe_uniform_lds(sm3);
+    int *s_ctl = reinterpret_cast<int *>(smem + kPipeLdsDoubles);
+    double *Mz = a.M + (int64_t)z * a.sM;
+    const int *info = a.info + (int64_t)z * a.sI;
+    int *S = a.sync + (int64_t)z * a.sS;
+    const bool top = I == 2 * q;  // the tile's right half lies above the diagonal: computed, never read, not versioned
+    int *ver0 = S + a.off_cver + I * a.NJ + 2 * q, *ver1 = ver0 + 1;
+    {
+        const int r = pipe_wg_wait(s_ctl, [&]() {
+            int rr = load_flag(info) != 0 ? 1 : 0;
+            const int *rowT = S + a.off_rowT + (p1 - 1) * a.NC;  // (a row chunk solved for panel p1 - 1 is solved for every earlier panel)
+            const int who = (10 << 28) | (p0 << 20) | ((I * 1024 + q) & 0xfffff);
+            if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I, 4, a.sync, info, a.timeout, who);
+            if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I + 1, 4, a.sync, info, a.timeout, who);
+            for (int c = 4 * q; c < 4 * q + 4 && rr == 0; c++) rr = pipe_wait_ge(rowT + c, 4, a.sync, info, a.timeout, who);
+            if (rr == 0) rr = pipe_wait_ge(ver0, p0, a.sync, info, a.timeout, who);
+            if (rr == 0 && !top) rr = pipe_wait_ge(ver1, p0, a.sync, info, a.timeout, who);
+            return rr;
+        });
+        if (r) return r;
+    }
+    if (tr && threadIdx.x == 0) tr[3] = wall_clock64();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t ld = a.ld;
+    const double *A = Mz + (int64_t)(128 * I) * ld + 256 * p0;
+    const double *B = Mz + (int64_t)(256 * q) * ld + 256 * p0;
+    const int nch = (256 * (p1 - p0)) / KC;
+    // ---- load side: wave w fills the 8-row groups w of A and w, w + 16 of B of every stage
+    const int lrow = lane >> 3;
+    const int sw_ld = (4 * wave + (lane >> 4)) & 7;  // ((row >> 1) & 7) of this lane's row, the same for the three groups
+    const unsigned lpart = (unsigned)(((lane & 7) ^ sw_ld) * 2);
+    const unsigned offA = (unsigned)((8 * wave + lrow) * (int)ld) + lpart;
+    unsigned offB[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) offB[i] = (unsigned)((8 * (wave + 16 * i) + lrow) * (int)ld) + lpart;
+    auto issue = [&](int stage, int ch) {
+        double *dst = smem + stage * kBulkStage + wave * 128;  // group g starts at g * 8 rows * 16 doubles
+        __builtin_amdgcn_global_load_lds((pipe_gbl_void_t)(A + ch * KC + offA), (pipe_lds_void_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((pipe_gbl_void_t)(B + ch * KC + offB[0]), (pipe_lds_void_t)(dst + 2048), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((pipe_gbl_void_t)(B + ch * KC + offB[1]), (pipe_lds_void_t)(dst + 2048 + 2048), 16, 0, 0);
+    };
+    issue(0, 0);
+    if (nch > 1) issue(1, 1);
+    // ---- compute side: wave (w / 4, w % 4) owns rows [32 (w / 4), + 32) x columns [64 (w % 4), + 64)
+    const int wm0 = (wave >> 2) * 32, wn0 = (wave & 3) * 64;
+    const int frow = lane & 15, fk = lane >> 4;
+    int foff[2];
+    foff[0] = frow * KC + ((fk ^ ((frow >> 1) & 7)) << 1);
+    foff[1] = foff[0] ^ 8;
+    const int aoff = wm0 * KC, boff = (128 + wn0) * KC;
+    double *Ct = Mz + (int64_t)(128 * I + wm0) * ld + 256 * q + wn0;
+    unsigned coff[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) coff[r] = (unsigned)(((lane >> 4) + 4 * r) * (int)ld + (lane & 15));
+    double4_t acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[mi][ni][r] = -Ct[(int64_t)mi * 16 * ld + ni * 16 + coff[r]];
+    auto read_half = [&](int st, int kb, d2_t (&av)[2], d2_t (&bv)[4]) {
+        const double *As = smem + st * kBulkStage + aoff, *Bs = smem + st * kBulkStage + boff;
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++) av[mi] = *reinterpret_cast<const d2_t *>(As + mi * 16 * KC + foff[kb]);
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) bv[ni] = *reinterpret_cast<const d2_t *>(Bs + ni * 16 * KC + foff[kb]);
+    };
+    auto mma_quarter = [&](const d2_t (&av)[2], const d2_t (&bv)[4], int h) {
+#pragma unroll
+        for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mi][h], bv[ni][h], acc[mi][ni], 0, 0, 0);
+    };
+    d2_t a0[2], b0[4];
+    if (nch > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_half(0, 0, a0, b0);
+    int stage = 0;
+    for (int ch = 0; ch < nch; ch++) {
+        d2_t a1[2], b1[4];
+        read_half(stage, 1, a1, b1);
+        mma_quarter(a0, b0, 0);
+        mma_quarter(a0, b0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool next = ch + 1 < nch, more = ch + 2 < nch;
+        const int st1 = (stage == kBulkStages - 1) ? 0 : stage + 1;
+        if (next) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own pieces of chunk ch + 1 (the only ones in flight)
+            __builtin_amdgcn_s_barrier();
+            if (more) issue(stage == 0 ? 2 : stage - 1, ch + 2);  // chunk ch + 2 -> stage of chunk ch - 1
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_quarter(a1, b1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (next) read_half(st1, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_quarter(a1, b1, 1);
+        stage = st1;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) asm volatile("" : "+v"(coff[r]));
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                __hip_atomic_store(Ct + (int64_t)mi * 16 * ld + ni * 16 + coff[r], -acc[mi][ni][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) {
+        store_flag(ver0, p1);
+        if (!top) store_flag(ver1, p1);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The scheduler of a flow launch: every workgroup runs it between tasks.  Wave 0 looks -- all in one pass of parallel
+// loads -- at the open stage's ticket counter and at the first unfinished round of (up to) 64 columns from the scan hint on;
+// a critical ticket wins, then the nearest column's released round.  `my_block` >= 0: this workgroup owns a diagonal block
+// and leaves (return 3) once that block is `lead` blocks away, taking long (bulk) tasks only while it is `lead_long` away.
+// Returns 0 = the factorisation's lists are exhausted, 2 = the launch is aborted.
+// ---------------------------------------------------------------------------------------------
+__device__ __noinline__ int flow_worker_loop(flow_kargs_t kf, pipe_lds_t sm3, int z, int my_block) {
+    const FlowArgs f = flow_kargs(kf);
+    const PipeArgs &a = f.p;
+    const pipe_kargs_t ka = (pipe_kargs_t)kf;
+    z = pipe_uniform(z), my_block = pipe_uniform(my_block);
+    double *sm = pipe_uniform_lds(sm3);
+    int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
+    int *S = a.sync + (int64_t)z * a.sS;
+    const FlowShape sh{a.NP, a.NC, f.NI};
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int stage_guess = 0;       // the stage this workgroup last saw open (a wrong guess only costs the slow path)
+    long long idle_since = 0;  // wall clock of the first pass without work since the last task (0: not idle)
+    for (;;) {
+        // ---- decide (wave 0), publish in s_ctl[8 ..]: [8] kind (0 none / retry, 1 critical, 2 bulk-class, 3 leave for the
+        //      diagonal block, 4 exhausted, 5 aborted), [9] stage or column, [10] ticket or round, [11] ticket in the round
+        if (wave == 0) {
+            int kind = 0, w0 = 0, w1 = 0, w2 = 0;
+            const int cur = load_flag(S + 1) >> 4;  // diagonal blocks finished (16 strips each)
+            bool allow_short = true, allow_long = true;
+            if (my_block >= 0) {
+                allow_short = my_block - cur > f.lead_short;
+                allow_long = my_block - cur > f.lead_long;
+            }
+            // (a workgroup that owns block p never holds a ticket that could wait for block p: it only takes critical tickets of
+            //  stages < p -- the fast path below touches the stage it last saw open -- and nothing at all once stage p is open)
+            if (load_flag(a.sync) != 0) kind = 5;
+            else if (!allow_short || (my_block >= 0 && stage_guess >= my_block)) kind = 3;
+            else {
+                // critical: one atomicAdd on the stage last seen open
+                int Sopen = stage_guess;
+                int t = -1;
+                if (lane == 0) {
+                    const int cnt = f.coff[Sopen + 1] - f.coff[Sopen];
+                    if (load_flag(S + f.off_cnext + Sopen) < cnt) {
+                        t = __hip_atomic_fetch_add(S + f.off_cnext + Sopen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (t >= cnt) t = -1;
+                    }
+                }
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (t >= 0) kind = 1, w0 = Sopen, w1 = t;
+                else {
+                    // slow path: the open stage, its counter; try to open the next one
+                    Sopen = load_flag(S + f.off_open);
+                    const int cnt = f.coff[Sopen + 1] - f.coff[Sopen];
+                    const int taken = load_flag(S + f.off_cnext + Sopen);
+                    if (my_block >= 0 && Sopen >= my_block) {
+                        stage_guess = Sopen;
+                        kind = 3;
+                    } else if (Sopen != stage_guess && taken < cnt) {
+                        stage_guess = Sopen;  // (tickets there: next pass)
+                        kind = 0, w0 = 1;     // w0 = 1: retry at once, not idle
+                    } else {
+                        stage_guess = Sopen;
+                        if (taken >= cnt && Sopen + 1 < a.NP) {
+                            const int s1 = Sopen + 1;  // gates G2 / G3 of pipe_flow.h (G1: taken >= cnt)
+                            const bool g2 = load_flag(S + f.off_last + s1) >= flow_need_last(sh, s1) &&
+                                            load_flag(S + f.off_pre + s1) >= flow_need_pre(sh, s1);
+                            const bool g3 = s1 + 1 >= a.NP || load_flag(S + f.off_pre + s1 + 1) >= flow_need_pre(sh, s1 + 1);
+                            if (g2 && g3) {
+                                if (lane == 0) __hip_atomic_fetch_max(S + f.off_open, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                stage_guess = s1;
+                                kind = 0, w0 = 1;
+                            }
+                        }
+                        if (kind == 0 && w0 == 0 && allow_long) {
+                            // bulk-class: lane l looks at column q0 + l
+                            const int hint = load_flag(S + f.off_open + 1);
+                            const int q0 = (hint >> 8) == Sopen ? (hint & 255) : Sopen + 1;  // (column Sopen itself is complete: gate G2)
+                            bool unfinished = false;
+                            for (int qb = q0 < 2 ? 2 : q0; qb < a.NP && kind == 0; qb += 64) {
+                                const int q = qb + lane;
+                                int r = -1, tsize = 0;
+                                bool more = false;  // the column still has rounds to hand out, now or later
+                                if (q < a.NP) {
+                                    const int nr = flow_nrounds(q);
+                                    r = load_flag(S + f.off_rcur + q);
+                                    for (int it = 0; it < 3 && r < nr; it++) {
+                                        if (flow_round_release_stage(q, r) > Sopen) break;
+                                        tsize = flow_round_size(sh, q, r);
+                                        if (load_flag(S + f.off_rcnt + q * f.RMAX + r) < tsize) break;
+                                        r++;  // every ticket of round r is taken: the next round may be claimed
+                                        tsize = 0;
+                                    }
+                                    more = r < nr;
+                                    if (r > load_flag(S + f.off_rcur + q))
+                                        __hip_atomic_fetch_max(S + f.off_rcur + q, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                                const unsigned long long have = __builtin_amdgcn_ballot_w64(tsize > 0);
+                                unfinished = unfinished || __builtin_amdgcn_ballot_w64(more) != 0;
+                                unsigned long long left = have;
+                                while (left && kind == 0) {  // the nearest column first; a lost race moves on to the next one
+                                    const int l = __builtin_ctzll(left);
+                                    left &= left - 1;
+                                    int tk = -1;
+                                    if (lane == l) {
+                                        tk = __hip_atomic_fetch_add(S + f.off_rcnt + q * f.RMAX + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        if (tk >= tsize) tk = -1;
+                                    }
+                                    tk = __builtin_amdgcn_readlane(tk, l);
+                                    if (tk >= 0) kind = 2, w0 = qb + l, w1 = __builtin_amdgcn_readlane(r, l), w2 = tk;
+                                }
+                                if (kind == 0 && have == 0 && qb == (q0 < 2 ? 2 : q0)) {
+                                    // nothing in the first 64 columns from the hint: move the hint past the columns that are done
+                                    const unsigned long long busy = __builtin_amdgcn_ballot_w64(more);
+                                    const int adv = busy ? __builtin_ctzll(busy) : 64;
+                                    if (lane == 0 && adv > 0)
+                                        __hip_atomic_fetch_max(S + f.off_open + 1, (Sopen << 8) | ((qb + adv) < 255 ? (qb + adv) : 255), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                            }
+                            // exhausted: the last stage is open and fully claimed, no column has a round left
+                            if (kind == 0 && !unfinished && Sopen == a.NP - 1 && taken >= cnt && q0 <= 2) kind = 4;
+                            else if (kind == 0 && !unfinished && Sopen == a.NP - 1 && taken >= cnt) {
+                                // (the hint skipped columns: look at all of them once more before leaving)
+                                bool any = false;
+                                for (int qb = 2; qb < a.NP; qb += 64) {
+                                    const int q = qb + lane;
+                                    const bool m = q < a.NP && load_flag(S + f.off_rcur + q) < flow_nrounds(q);
+                                    any = any || __builtin_amdgcn_ballot_w64(m) != 0;
+                                }
+                                if (!any) kind = 4;
+                            }
+                        }
+                    }
+                }
+            }
+            if (kind == 0 && w0 == 0) {  // idle: nothing to take right now
+                const long long now = wall_clock64();
+                if (idle_since == 0) idle_since = now;
+                else if (now - idle_since > a.timeout) {
+                    if (lane == 0 && __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                        store_flag(a.sync + 4, (11 << 28) | (stage_guess << 20));
+                        store_flag(a.sync + 5, f.off_open);
+                        store_flag(a.sync + 6, a.NP - 1);
+                        store_flag(a.sync + 7, load_flag(S + f.off_open));
+                    }
+                    kind = 5;
+                }
+                if (kind == 0) __builtin_amdgcn_s_sleep(32);
+            } else {
+                idle_since = 0;
+            }
+            if (lane == 0) s_ctl[8] = kind, s_ctl[9] = w0, s_ctl[10] = w1, s_ctl[11] = w2;
+        }
+        __syncthreads();
+        const int kind = s_ctl[8], w0 = s_ctl[9], w1 = s_ctl[10], w2 = s_ctl[11];
+        __syncthreads();
+        if (kind == 0) continue;
+        if (kind == 3) return 3;
+        if (kind == 4) return 0;
+        if (kind == 5) return 2;
+        long long *tr = nullptr;
+#ifdef EGX_PIPE_TRACE
+        if (a.trace) {
+            if (tid == 0) s_ctl[12] = __hip_atomic_fetch_add(a.sync + f.off_trace, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const int slot = s_ctl[12];
+            __syncthreads();
+            if (slot < f.trace_cap) tr = a.trace + 8 * (int64_t)slot;
+        }
+#endif
+        int r;
+        if (kind == 1) {
+            const PipeTask task = a.tasks[f.coff[w0] + w1];
+            if (tr && tid == 0) {
+                tr[0] = task.type | (task.p << 8) | (z << 16);
+                tr[1] = (unsigned)task.a | ((long long)task.b << 32);
+                tr[2] = wall_clock64();
+                tr[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((long long)blockIdx.x << 8);
+            }
+            if (task.type == PT_TRSM) r = pipe_role_trsm<1>(ka, (pipe_lds_t)sm, tr, z, task.p, task.a);
+            else if (task.type == PT_FINE) r = pipe_role_fine(ka, (pipe_lds_t)sm, tr, z, task.p, task.a, task.b);
+            else r = pipe_role_coarse(ka, (pipe_lds_t)sm, tr, z, task.p, task.a, task.b, task.type == PT_COARSE_LAST ? 1 : 0);
+        } else {
+            const FlowBulkTask bt = flow_round_task(sh, w0, w1, w2);
+            if (tr && tid == 0) {
+                tr[0] = bt.type | (bt.p0 << 8) | (z << 16) | ((long long)w0 << 24);
+                tr[1] = (unsigned)bt.I | ((long long)bt.J << 32);
+                tr[2] = wall_clock64();
+                tr[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((long long)blockIdx.x << 8);
+            }
+            if (bt.type == PT_BULK) r = pipe_role_bulk(ka, (pipe_lds_t)sm, tr, z, w0, bt.I, bt.p0, bt.p1);
+            else r = pipe_role_coarse(ka, (pipe_lds_t)sm, tr, z, bt.p0, bt.I, bt.J, 0);
+            // (a matrix that lost a pivot -- r == 1 -- still counts its tasks: the gates must open for the launch to end)
+            if (r != 2 && tid == 0)
+                __hip_atomic_fetch_add(S + (bt.last ? f.off_last : f.off_pre) + w0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tr && tid == 0) tr[4] = wall_clock64();
+        if (r == 2) return 2;
+    }
+}
+
+// One workgroup per compute unit.  The first NP to START own the diagonal blocks 0 .. NP - 1 (start ticket, as in k_potrf_pipe):
+// each works as everybody else until its block is near, factors it INLINE (rb_factor_block: no call, no spill), and is a
+// worker again.  One matrix per launch (z = 0): lock-step batches keep the schedules of rounds 3 to 5.
+__global__ __launch_bounds__(1024) void k_potrf_flow(FlowArgs f) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const PipeArgs &a = f.p;
+    int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
+    if (threadIdx.x == 0)
+        s_ctl[3] = __hip_atomic_fetch_add(a.sync + kPipeHdr + a.NP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int start = s_ctl[3];
+    __syncthreads();
+    const flow_kargs_t kf = (flow_kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    if (start < a.NP) {
+        const int p = start, k0 = 256 * p;
+        int rc = 3;
+        if (p > f.lead_short) rc = flow_worker_loop(kf, (pipe_lds_t)sm, 0, p);
+        if (rc == 2) return;
+        if (rc == 3) {
+            int *info = a.info;
+            int *S = a.sync;
+#ifdef EGX_PIPE_TRACE
+            long long *tr = nullptr;
+            if (a.trace) {
+                if (threadIdx.x == 0) s_ctl[12] = __hip_atomic_fetch_add(a.sync + f.off_trace, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                const int slot = s_ctl[12];
+                __syncthreads();
+                if (slot < f.trace_cap) tr = a.trace + 8 * (int64_t)slot;
+            }
+            if (tr && threadIdx.x == 0) {
+                tr[0] = PT_DIAG | (p << 8);
+                tr[1] = 0;
+                tr[2] = wall_clock64();
+                tr[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((long long)blockIdx.x << 8);
+            }
+#endif
+            const int r = pipe_wg_wait(s_ctl, [&]() {
+                int rr = load_flag(info) != 0 ? 1 : 0;
+                const int *fc = S + a.off_fcnt + p * a.NC + (k0 >> 6);
+                for (int i = 0; i < 4 && rr == 0 && p > 0; i++) rr = pipe_wait_ge(fc + i, i + 1, a.sync, info, a.timeout, (8 << 28) | (p << 20));
+                return rr;
+            });
+            if (r == 2) return;
+            if (r == 0) {
+                RbPublish pub;
+                pub.base = k0 >> 4;
+                pub.strips = S + 1;
+                if (a.stall && pub.base + 16 >= a.stall) pub.strips = S + 2;  // (test hook: this block's strips are never seen)
+#ifdef EGX_PIPE_TRACE
+                pub.trace = tr;
+                if (tr && threadIdx.x == 0) tr[3] = wall_clock64();
+#endif
+                (void)rb_factor_block<16, true>(a.M + (int64_t)k0 * a.ld + k0, a.ld, 256, a.dinv + (int64_t)(k0 / 64) * 4096, info, k0, a.n_pad, sm,
+                                                pub);
+#ifdef EGX_PIPE_TRACE
+                if (tr && threadIdx.x == 0) tr[4] = wall_clock64();
+#endif
+            } else if (threadIdx.x == 0) {
+                // (the matrix lost a pivot earlier: the block is not factored, but its strips count as published so that the
+                //  workgroups ahead of their own blocks leave their loops and the launch ends)
+                __hip_atomic_fetch_max(S + 1, (k0 >> 4) + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+    }
+    (void)flow_worker_loop(kf, (pipe_lds_t)sm, 0, -1);
+}
+
+// =============================================================================================
 // host side
 // =============================================================================================
 // Run-time settings (egx_set_tuning / environment): EGX_PIPE, EGX_PIPE_TIMEOUT_MS and EGX_PIPE_RETRY (gp_host.hip).  What else
@@ -652,8 +1099,12 @@ constexpr int kPipeLookAhead = 16;  // how many panels ahead of their column's f
 static std::atomic<int> g_pipe_stall{0};   // egx_set_tuning "pipe_stall": see PipeArgs::stall
 static long long *g_pipe_trace = nullptr;  // profiling buffer of the NEXT launches (pipe_set_trace; tools/pipe_check)
 static int g_pipe_test_wgs = 0;            // the grid of the next chain launches (the same bits on 3 workgroups and on 256)
+static int g_pipe_trace_cap = 0;           // slots of that buffer (flow launches allocate trace slots from a counter)
+static int g_flow_lead_short = -1, g_flow_lead_long = -1;  // tools/flow_check: FlowArgs::lead_* of the next flow launches
 void pipe_set_trace(long long *buf) { g_pipe_trace = buf; }
+void pipe_set_trace_cap(int slots) { g_pipe_trace_cap = slots; }
 void pipe_test_set_workgroups(int wgs) { g_pipe_test_wgs = wgs; }
+void flow_test_set_leads(int lead_short, int lead_long) { g_flow_lead_short = lead_short, g_flow_lead_long = lead_long; }
 #endif
 
 // one-time setup; EGX_SUCCESS, or EGX_ERR_HIP when the launch cannot get its dynamic LDS (the caller then takes separate launches)
@@ -665,7 +1116,9 @@ static int pipe_init() {
         if (const char *e = std::getenv("EGX_PIPE_TIMEOUT_MS")) g_pipe_timeout_ms = std::atoi(e) > 0 ? std::atoi(e) : 1;
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_pipe), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  kPipeLdsBytes);
-        if (e != hipSuccess) {
+        const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_potrf_flow), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  kPipeLdsBytes);
+        if (e != hipSuccess || e2 != hipSuccess) {
             (void)hipGetLastError();
             rc_once = EGX_ERR_HIP;
         }
@@ -741,11 +1194,52 @@ static int pipe_plan_get(int dev, int n_pad, int m_tot, int g0, int np, int rt, 
     out = it->second;
     return EGX_SUCCESS;
 }
+// ---- flow launch (pipe_flow.h): the critical lists of all stages, one after the other, and where each stage starts
+struct FlowPlan {
+    PipeTask *d_tasks = nullptr;
+    int *d_coff = nullptr;
+    int ntasks = 0;
+};
+static std::map<std::tuple<int, int, int>, FlowPlan> g_flow_plans;  // (device, n_pad, m_tot); under g_plan_mu
+static int flow_plan_get(int dev, int n_pad, int m_tot, FlowPlan &out) {
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    const auto key = std::make_tuple(dev, n_pad, m_tot);
+    auto it = g_flow_plans.find(key);
+    if (it == g_flow_plans.end()) {
+        const int NP = n_pad / 256;
+        std::vector<PipeTask> tasks;
+        std::vector<int> coff((size_t)NP + 1, 0);
+        for (int s = 0; s < NP; s++) {
+            const std::vector<PipeTask> st = flow_stage_tasks(n_pad, m_tot, s);
+            coff[(size_t)s] = (int)tasks.size();
+            tasks.insert(tasks.end(), st.begin(), st.end());
+        }
+        coff[(size_t)NP] = (int)tasks.size();
+        FlowPlan pl;
+        pl.ntasks = (int)tasks.size();
+        EGX_HIP_CHECK(dev_malloc(&pl.d_tasks, sizeof(PipeTask) * (tasks.size() + 1)));
+        hipError_t e = dev_malloc(&pl.d_coff, sizeof(int) * coff.size());
+        if (e == hipSuccess) e = hipMemcpy(pl.d_tasks, tasks.data(), sizeof(PipeTask) * tasks.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(pl.d_coff, coff.data(), sizeof(int) * coff.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(pl.d_tasks);
+            if (pl.d_coff) (void)hipFree(pl.d_coff);
+            EGX_HIP_CHECK(e);
+        }
+        it = g_flow_plans.emplace(key, pl).first;
+    }
+    out = it->second;
+    return EGX_SUCCESS;
+}
 // the plans a handle of this shape and schedule will launch, on the current device (egx_gp_create / egx_gp_set_lockstep)
 int pipe_prepare(int n_pad, int m_tot, const PotrfSchedule &sched) {
     if (!sched.pipe || pipe_init() != EGX_SUCCESS) return EGX_SUCCESS;
     int dev = 0;
     EGX_HIP_CHECK(hipGetDevice(&dev));
+    if (sched.flow) {
+        FlowPlan fp;
+        return flow_plan_get(dev, n_pad, m_tot, fp);
+    }
     PipePlan pl;
     if (sched.whole) return pipe_plan_get(dev, n_pad, m_tot, 0, (n_pad + 255) / 256, 1, pl);
     const int GW = sched.group_panels * 256;
@@ -775,9 +1269,81 @@ size_t pipe_release_plans() {
         bytes += sizeof(PipeTask) * (size_t)kv.second.ntasks;
     }
     g_plans.clear();
+    for (auto &kv : g_flow_plans) {
+        const int dev = std::get<0>(kv.first);
+        if (dev != synced) {
+            if (hipSetDevice(dev) != hipSuccess) continue;
+            (void)hipDeviceSynchronize();
+            synced = dev;
+        }
+        if (kv.second.d_tasks) (void)hipFree(kv.second.d_tasks);
+        if (kv.second.d_coff) (void)hipFree(kv.second.d_coff);
+        bytes += sizeof(PipeTask) * (size_t)kv.second.ntasks;
+    }
+    g_flow_plans.clear();
     if (have_cur) (void)hipSetDevice(cur);
     (void)hipGetLastError();
     return bytes;
+}
+
+bool flow_fits(int n_pad) {  // one workgroup per diagonal block + workers on the CURRENT device; 256-column panels throughout
+    int dev = 0;
+    if (n_pad % 256 || n_pad / 256 > 254 || pipe_init() != EGX_SUCCESS || hipGetDevice(&dev) != hipSuccess) return false;
+    return n_pad / 256 + 8 <= pipe_device_cus(dev);
+}
+// The whole factorisation of ONE matrix (pb.count == 1) as a flow launch.  The hand-off words (pb.sync: pipe_sync_ints ints,
+// zeroed by launch_potrf) carry the chain launch's words and, behind them, the flow launch's (flow_layout).
+int launch_potrf_flow(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info, const PotrfBatch &pb) {
+    if (pipe_init() != EGX_SUCCESS) {
+        set_error("potrf_flow: the launch cannot get its dynamic LDS on this device");
+        return EGX_ERR_HIP;
+    }
+    if (!pb.sync || n_pad % 256 || (m_tot - n_pad) % 128 || pb.count > 1) {
+        set_error("potrf_flow: needs sync words, 256-column panels, padded right-hand-side rows and ONE matrix");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    int dev = 0;
+    EGX_HIP_CHECK(hipGetDevice(&dev));
+    FlowPlan plan;
+    EGX_RC_PIPE(flow_plan_get(dev, n_pad, m_tot, plan));
+    const PipeLayout l = pipe_layout(n_pad, m_tot);
+    const FlowLayout fl = flow_layout(l.NP, l.total);
+    FlowArgs f;
+    PipeArgs &a = f.p;
+    a.M = M, a.ld = ld, a.n_pad = n_pad, a.m_tot = m_tot, a.dinv = dinv, a.info = info, a.sync = pb.sync;
+    a.sM = pb.sM, a.sD = pb.sD, a.sS = pb.sS, a.sI = pb.sI, a.nz = 1, a.g0 = 0, a.np = l.NP;
+    a.tasks = plan.d_tasks, a.ntasks = plan.ntasks;
+    a.NP = l.NP, a.NC = l.NC, a.NJ = l.NJ, a.off_rowT = l.off_rowT, a.off_fcnt = l.off_fcnt, a.off_cver = l.off_cver;
+    a.rt = 1, a.ext_need = 0;
+    a.timeout = (long long)g_pipe_timeout_ms * 100000ll;
+    f.coff = plan.d_coff;
+    f.NI = m_tot / 128;
+    f.RMAX = fl.RMAX, f.off_open = fl.off_open, f.off_cnext = fl.off_cnext, f.off_rcur = fl.off_rcur, f.off_rcnt = fl.off_rcnt;
+    f.off_pre = fl.off_pre, f.off_last = fl.off_last, f.off_trace = fl.off_trace;
+    f.lead_short = 1, f.lead_long = 3;
+    f.trace_cap = 0;
+    int test_wgs = 0;
+#ifdef EGX_TEST_HOOKS
+    a.stall = g_pipe_stall;
+    a.trace = g_pipe_trace;
+    f.trace_cap = g_pipe_trace ? g_pipe_trace_cap : 0;
+    test_wgs = g_pipe_test_wgs;
+    if (g_flow_lead_short >= 0) f.lead_short = g_flow_lead_short;
+    if (g_flow_lead_long >= 0) f.lead_long = g_flow_lead_long;
+#else
+    a.stall = 0;
+    a.trace = nullptr;
+#endif
+    const int n_cu = pipe_device_cus(dev);
+    int wgs = test_wgs > 0 ? test_wgs : n_cu;
+    if (wgs > n_cu) wgs = n_cu;
+    if (wgs < l.NP + 1) {
+        set_error("potrf_flow: more diagonal blocks than compute units");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    hipLaunchKernelGGL(k_potrf_flow, dim3((unsigned)wgs), dim3(1024), kPipeLdsBytes, s, f);
+    EGX_HIP_CHECK(hipGetLastError());
+    return EGX_SUCCESS;
 }
 
 // word 3 of the batch's hand-off words <- value, in stream order (a one-thread kernel behind the launch it reports on)

@@ -35,9 +35,9 @@
 #include "pipe_tasks.h"
 
 #ifdef __HIPCC__
-#define EGX_HD __host__ __device__ __forceinline__
+#define EGX_FLOW_HD __host__ __device__ __forceinline__
 #else
-#define EGX_HD inline
+#define EGX_FLOW_HD inline
 #endif
 
 namespace egx {
@@ -50,19 +50,19 @@ struct FlowShape {
 };
 
 // ---- column q: its rounds ---------------------------------------------------------------------
-EGX_HD int flow_nbulk(int q) { return q / kFlowGP - 1 > 0 ? q / kFlowGP - 1 : 0; }
-EGX_HD int flow_first_single(int q) { return kFlowGP * flow_nbulk(q); }                     // B(q)
-EGX_HD int flow_nsingles(int q) { return q >= 2 ? q - 1 - flow_first_single(q) : 0; }       // panels [B(q), q - 1)
-EGX_HD int flow_nrounds(int q) { return flow_nbulk(q) + flow_nsingles(q); }
-EGX_HD bool flow_round_is_bulk(int q, int r) { return r < flow_nbulk(q); }
+EGX_FLOW_HD int flow_nbulk(int q) { return q / kFlowGP - 1 > 0 ? q / kFlowGP - 1 : 0; }
+EGX_FLOW_HD int flow_first_single(int q) { return kFlowGP * flow_nbulk(q); }                     // B(q)
+EGX_FLOW_HD int flow_nsingles(int q) { return q >= 2 ? q - 1 - flow_first_single(q) : 0; }       // panels [B(q), q - 1)
+EGX_FLOW_HD int flow_nrounds(int q) { return flow_nbulk(q) + flow_nsingles(q); }
+EGX_FLOW_HD bool flow_round_is_bulk(int q, int r) { return r < flow_nbulk(q); }
 // the newest source panel of round r, + 1: the round is released once that STAGE is open
-EGX_HD int flow_round_release_stage(int q, int r) {
+EGX_FLOW_HD int flow_round_release_stage(int q, int r) {
     return flow_round_is_bulk(q, r) ? kFlowGP * r + kFlowGP : flow_first_single(q) + (r - flow_nbulk(q)) + 1;
 }
-EGX_HD bool flow_round_is_last_single(int q, int r) { return !flow_round_is_bulk(q, r) && r == flow_nrounds(q) - 1; }
+EGX_FLOW_HD bool flow_round_is_last_single(int q, int r) { return !flow_round_is_bulk(q, r) && r == flow_nrounds(q) - 1; }
 // tickets of round r: far = one per 128-row tile from the column's diagonal block down; near = the lower 128-tiles of both
 // 128-column halves, without the three tiles of the diagonal block when it is the last near round
-EGX_HD int flow_round_size(const FlowShape &sh, int q, int r) {
+EGX_FLOW_HD int flow_round_size(const FlowShape &sh, int q, int r) {
     const int nrt = sh.NI - 2 * q;
     if (flow_round_is_bulk(q, r)) return nrt;
     return flow_round_is_last_single(q, r) ? 2 * (nrt - 2) : 2 * nrt - 1;
@@ -73,7 +73,7 @@ struct FlowBulkTask {
     int I, J;    // PT_BULK: 128-row tile I, column block q (J unused = q); PT_COARSE: 128-tiles (I, J)
     int last;    // counts towards last_done (the last near round) instead of pre_done
 };
-EGX_HD FlowBulkTask flow_round_task(const FlowShape &sh, int q, int r, int t) {
+EGX_FLOW_HD FlowBulkTask flow_round_task(const FlowShape &sh, int q, int r, int t) {
     FlowBulkTask k;
     k.last = 0;
     if (flow_round_is_bulk(q, r)) {
@@ -95,20 +95,20 @@ EGX_HD FlowBulkTask flow_round_task(const FlowShape &sh, int q, int r, int t) {
     return k;
 }
 // completions the gates wait for
-EGX_HD int flow_need_pre(const FlowShape &sh, int q) {
+EGX_FLOW_HD int flow_need_pre(const FlowShape &sh, int q) {
     int n = 0;
     for (int r = 0; r < flow_nrounds(q); r++)
         if (!flow_round_is_last_single(q, r)) n += flow_round_size(sh, q, r);
     return n;
 }
-EGX_HD int flow_need_last(const FlowShape &sh, int q) { return q >= 2 ? 2 * (sh.NI - 2 * q - 2) : 0; }
+EGX_FLOW_HD int flow_need_last(const FlowShape &sh, int q) { return q >= 2 ? 2 * (sh.NI - 2 * q - 2) : 0; }
 
 // ---- hand-off words of the flow launch (ints, behind the chain launch's: PipeLayout) -------------
 struct FlowLayout {
     int RMAX;  // round counters per column
     int off_open, off_cnext, off_rcur, off_rcnt, off_pre, off_last, off_trace, total;
 };
-EGX_HD FlowLayout flow_layout(int NP, int base) {
+EGX_FLOW_HD FlowLayout flow_layout(int NP, int base) {
     FlowLayout l;
     l.RMAX = NP / kFlowGP + 3;
     l.off_open = base;            // [0] highest open stage, [1] columns' scan hint (stage << 8 | column), [2] workers that have left

@@ -39,6 +39,7 @@ constexpr int kPipeDiagBlocks = 32;      // while workspaces x panels stays with
 
 struct PotrfSchedule {
     int left = 0, w_left = 0, pipe = 0, whole = 0, group_panels = 2;
+    int flow = 0;  // the whole factorisation of ONE matrix per launch as a flow launch (pipe_flow.h, round 6)
 };
 struct ScheduleKnobs {  // egx_set_tuning / environment: "potrf_left", "pipe", "potrf_group"
     int potrf_left = 1, pipe = 1, potrf_group = 0;

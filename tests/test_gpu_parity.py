@@ -1000,8 +1000,8 @@ def test_no_device_memory_leak_over_handle_lifecycles(egx, O):
     for j in range(20):
         n = 300 + 137 * j
         xj, yj = _data(n, 3, seed=80 + j)
-        with egx.GpHandle(xj, yj, n_workspaces=1 + j % 3) as h:
-            h.finalize(np.full(3, 0.7))
+        with egx.GpHandle(xj, yj, corr=1, n_workspaces=1 + j % 3) as h:   # (absolute exponential: well conditioned at any density)
+            h.finalize(np.full(3, 1.0))
             h.predict_valvar(xj[:5])
     assert egx.pool_stats()["cached_bytes"] > 0
     freed = egx.trim()

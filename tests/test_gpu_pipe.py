@@ -126,10 +126,8 @@ _FORCED_TIMEOUT_SCRIPT = r"""
 import sys, time, json
 import numpy as np
 import egobox_amd as egx
-rng = np.random.default_rng(4)
-x = rng.uniform(size=(1000, 4))
-y = np.sin(3 * x[:, 0]) + x[:, 1:].sum(axis=1) ** 2 + 0.1 * rng.standard_normal(1000)
-th = np.full(4, 0.3)
+x, y = egx.workload.make_training_set(1000, 4, 4)   # (the benchmark's well-conditioned family: chain and separate launches agree to 1e-10)
+th = egx.workload.default_theta(4) * 3.0
 out = {}
 with egx.GpHandle(x, y) as h:
     assert h.schedule()["pipelined_chain"] == 1

@@ -75,6 +75,7 @@ __global__ void k_resid(const double *L, int64_t ld, int n, double scale, double
 }
 
 static bool g_whole = false;  // PotrfBatch::whole of the next factorisations (the library decides it per handle)
+static bool g_flow = false;   // PotrfBatch::flow: the whole factorisation as a FLOW launch (pipe_flow.h)
 struct Problem {
     int n, n_pad, m_tot, nz;
     int64_t ld;
@@ -125,6 +126,7 @@ struct Problem {
         pb.sS = (int64_t)sync_n;
         pb.pipe = pipe ? 1 : 0;
         pb.whole = g_whole ? 1 : 0;
+        pb.flow = g_flow && pipe ? 1 : 0;
         return launch_potrf(s, M, ld, n_pad, m_tot, dinv, info, lk.s2 ? &lk : nullptr, nullptr, &pb, nullptr);
     }
     std::vector<double> download(int z) {
@@ -323,8 +325,190 @@ static int trace_main(int n, int whole, int nz) {
     return 0;
 }
 
+// ---- FLOW launches (k_potrf_flow, pipe_flow.h): factor vs the separate launches, residual, info; median times of the forms
+static int flow_main(int argc, char **argv) {
+    const double scale = 6.0, nugget = 1e-8;
+    pipe_set_knob("pipe_timeout_ms", 2000);
+    std::vector<int> sizes;
+    for (int i = 2; i < argc; i++) sizes.push_back(atoi(argv[i]));
+    if (sizes.empty()) sizes = {2048, 4096, 6144, 8192};
+    for (int n : sizes) {
+        Problem P;
+        P.create(n, 1, n >= 8192);
+        if (P.n_pad % 256) {
+            printf("SKIP n=%d: n_pad %d is not a multiple of 256\n", n, P.n_pad);
+            P.destroy();
+            continue;
+        }
+        g_flow = false, g_whole = false;
+        P.build(0, scale, nugget, 11);
+        if (P.factor(0, false)) return 3;
+        CK(hipDeviceSynchronize());
+        const std::vector<double> ref = P.download(0);
+        const double res_ref = residual(P, 0, scale, nugget, 11);
+        g_flow = true;
+        P.build(0, scale, nugget, 11);
+        if (P.factor(0, true)) return 3;
+        CK(hipDeviceSynchronize());
+        double rel;
+        bool same;
+        compare(P, ref, P.download(0), rel, same);
+        const double res = residual(P, 0, scale, nugget, 11);
+        std::vector<int> hdr(8);
+        CK(hipMemcpy(hdr.data(), P.sync, 32, hipMemcpyDeviceToHost));
+        verdict(rel < 2e-5 && res < 50 * std::max(res_ref, 1e-15) && P.abort_word() == 0 && P.infos()[0] == 0,
+                "flow    n=%d: vs separate launches %.2e, residual %.2e (separate %.2e), info %d abort %d (who %x word %d want %d saw %d)", n, rel, res,
+                res_ref, P.infos()[0], P.abort_word(), hdr[4], hdr[5], hdr[6], hdr[7]);
+        if (P.abort_word() != 0) {
+            P.destroy();
+            continue;
+        }
+        // a second time: the same bits (the schedule is dynamic, the arithmetic is not)
+        const std::vector<double> first = P.download(0);
+        P.build(0, scale, nugget, 11);
+        if (P.factor(0, true)) return 3;
+        CK(hipDeviceSynchronize());
+        compare(P, first, P.download(0), rel, same);
+        verdict(same, "flow    n=%d: a second run gives %s", n, same ? "the same bits" : "DIFFERENT bits");
+        // a lost pivot: info as the separate launches, the launch ends
+        if (n <= 8192) {
+            const int bad = n / 2 + 77;
+            auto spoil = [&]() {
+                const double v = -1.0;
+                CK(hipMemcpy(P.M + (size_t)bad * P.ld + bad, &v, 8, hipMemcpyHostToDevice));
+            };
+            g_flow = false;
+            P.build(0, scale, nugget, 11);
+            CK(hipDeviceSynchronize());
+            spoil();
+            if (P.factor(0, false)) return 3;
+            CK(hipDeviceSynchronize());
+            const int info_ref = P.infos()[0];
+            g_flow = true;
+            P.build(0, scale, nugget, 11);
+            CK(hipDeviceSynchronize());
+            spoil();
+            if (P.factor(0, true)) return 3;
+            CK(hipDeviceSynchronize());
+            verdict(P.infos()[0] == info_ref && info_ref == bad + 1 && P.abort_word() == 0, "flow    n=%d: lost pivot, info %d (separate %d), abort %d", n,
+                    P.infos()[0], info_ref, P.abort_word());
+        }
+        g_flow = false;
+        const double t_sep = time_factor(P, false, scale, nugget, 5);
+        double t_whole = 0.0;
+        if (P.n_pad <= 8192) {
+            g_whole = true;
+            t_whole = time_factor(P, true, scale, nugget, 5);
+            g_whole = false;
+        }
+        g_flow = true;
+        const double t_flow = time_factor(P, true, scale, nugget, 5);
+        g_flow = false;
+        const double fl = (double)n * n * n / 3.0;
+        printf("time    n=%d: separate %.3f ms, whole chain launch %.3f ms, FLOW %.3f ms = %.1f TFLOP/s (%.3f of 78.6)\n", n, t_sep, t_whole, t_flow,
+               fl / (t_flow * 1e-3) / 1e12, fl / (t_flow * 1e-3) / 1e12 / 78.6);
+        fflush(stdout);
+        P.destroy();
+    }
+    printf("%s\n", g_fail ? "FLOW CHECK FAILED" : "flow check ok");
+    return g_fail ? 1 : 0;
+}
+
+// one traced flow factorisation: every task with the times it was taken / became ready / finished (100 MHz clock)
+static int ftrace_main(int n, int verbose) {
+    const double scale = 6.0, nugget = 1e-8;
+    pipe_set_knob("pipe_timeout_ms", 2000);
+    env_knobs();
+    Problem P;
+    P.create(n, 1, false);
+    const size_t cap = 1 << 19;
+    long long *d_tr;
+    CK(hipMalloc(&d_tr, cap * 64));
+    g_flow = true;
+    float ms = 0;
+    for (int rep = 0; rep < 2; rep++) {
+        P.build(0, scale, nugget, 3);
+        CK(hipMemset(d_tr, 0, cap * 64));
+        pipe_set_trace(rep ? d_tr : nullptr);
+        pipe_set_trace_cap((int)cap);
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, 0));
+        if (P.factor(0, true)) return 3;
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("# n=%d FLOW: launch_potrf %.3f ms%s, abort %d\n", n, ms, rep ? " (traced)" : "", P.abort_word());
+    }
+    pipe_set_trace(nullptr);
+    std::vector<long long> h(cap * 8);
+    CK(hipMemcpy(h.data(), d_tr, cap * 64, hipMemcpyDeviceToHost));
+    struct Rec { long long take, ready, done, w0, w1, xcc, p6, p7; };
+    std::vector<Rec> recs;
+    long long t0 = -1, t1 = 0;
+    for (size_t i = 0; i < cap; i++) {
+        const long long *r = &h[i * 8];
+        if (r[2] == 0) continue;
+        recs.push_back({r[2], r[3], r[4], r[0], r[1], r[5], r[6], r[7]});
+        if (t0 < 0 || r[2] < t0) t0 = r[2];
+        if (r[4] > t1) t1 = r[4];
+    }
+    std::sort(recs.begin(), recs.end(), [](const Rec &a, const Rec &b) { return a.take < b.take; });
+    const char *names[] = {"TRSM", "FINE", "COARSE", "DIAG", "LAST", "BULK"};
+    double busy[6] = {0}, waitt[6] = {0};
+    int cnt[6] = {0};
+    printf("# %zu tasks in %.1f us; times in us from the first ticket\n", recs.size(), (t1 - t0) * 0.01);
+    double prev_diag_done = 0;
+    for (const Rec &r : recs) {
+        const int type = (int)(r.w0 & 255), p = (int)((r.w0 >> 8) & 255);
+        if (type > 5) continue;
+        const double a = (r.take - t0) * 0.01, b = (r.ready - t0) * 0.01, c = (r.done - t0) * 0.01;
+        cnt[type]++, busy[type] += c - b, waitt[type] += b - a;
+        if (type == PT_DIAG) {
+            printf("DIAG p=%2d taken %9.1f ready %9.1f done %9.1f (factor %6.1f, from the previous block's end to ready %7.1f) first strip %8.1f\n", p, a, b, c, c - b,
+                   b - prev_diag_done, (r.p6 - t0) * 0.01);
+            prev_diag_done = c;
+        } else if (verbose) {
+            printf("%9.2f %8.2f %8.2f (%6.2f %6.2f) %-6s p=%d a=%d b=%d q=%d xcd=%d wg=%d\n", a, b, c, b - a, c - b, names[type], p, (int)(unsigned)r.w1,
+                   (int)(r.w1 >> 32), (int)((r.w0 >> 24) & 255), (int)(r.xcc & 15), (int)(r.xcc >> 8));
+        }
+    }
+    double tot = 0;
+    for (int ty = 0; ty < 6; ty++)
+        if (cnt[ty]) {
+            printf("# %-6s %6d tasks: mean wait %8.2f us, mean work %8.2f us, total work %10.1f us\n", names[ty], cnt[ty], waitt[ty] / cnt[ty], busy[ty] / cnt[ty],
+                   busy[ty]);
+            tot += busy[ty] + waitt[ty];
+        }
+    printf("# workgroup time accounted for by tasks (work + in-task wait): %.3f of 256 x %.1f us\n", tot / (256.0 * (t1 - t0) * 0.01), (t1 - t0) * 0.01);
+    // occupancy over time: busy workgroups per 50-us slice, by class
+    const double slice = ms > 4 ? 100.0 : 25.0;
+    const int ns = (int)((t1 - t0) * 0.01 / slice) + 1;
+    std::vector<double> occ_b(ns, 0.0), occ_c(ns, 0.0), occ_w(ns, 0.0);
+    for (const Rec &r : recs) {
+        const int type = (int)(r.w0 & 255);
+        if (type > 5 || !r.done) continue;
+        const double a = (r.take - t0) * 0.01, b = (r.ready - t0) * 0.01, c = (r.done - t0) * 0.01;
+        auto add = [&](std::vector<double> &v, double x0, double x1) {
+            for (int i = (int)(x0 / slice); i <= (int)(x1 / slice) && i < ns; i++) {
+                const double lo = std::max(x0, i * slice), hi = std::min(x1, (i + 1) * slice);
+                if (hi > lo) v[i] += (hi - lo) / slice;
+            }
+        };
+        add(occ_w, a, b);
+        add(type == PT_BULK ? occ_b : occ_c, b, c);
+    }
+    printf("# per %.0f-us slice: workgroups in BULK work | other work | waiting inside a task\n", slice);
+    for (int i = 0; i < ns; i++) printf("occ %8.0f %6.1f %6.1f %6.1f\n", i * slice, occ_b[i], occ_c[i], occ_w[i]);
+    P.destroy();
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (chol_init()) return 1;
+    if (argc > 1 && std::string(argv[1]) == "flow") return flow_main(argc, argv);
+    if (argc > 1 && std::string(argv[1]) == "ftrace") return ftrace_main(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 0);
     if (argc > 1 && std::string(argv[1]) == "diag") return diag_alone_main();
     if (argc > 1 && std::string(argv[1]) == "trace")
         return trace_main(argc > 2 ? atoi(argv[2]) : 1024, argc > 3 ? atoi(argv[3]) : 1, argc > 4 ? atoi(argv[4]) : 1);
