@@ -513,6 +513,11 @@ __device__ __noinline__ int pipe_role_coarse(pipe_kargs_t ka, pipe_lds_t sm3, lo
     const int r = pipe_wg_wait(s_ctl, [&]() {
         int rr = load_flag(info) != 0 ? 1 : 0;
         const int *rowT = S + a.off_rowT + P * a.NC;
+        {   // (all five words in one round of loads: the flow launch claims these tasks when they can start)
+            const int f0 = load_flag(rowT + 2 * I), f1 = load_flag(rowT + 2 * I + 1), f2 = load_flag(rowT + 2 * J), f3 = load_flag(rowT + 2 * J + 1);
+            const int v = p > 0 ? load_flag(ver) : 0;
+            if ((rr == 0) & (f0 >= nqp) & (f1 >= nqp) & (f2 >= nqp) & (f3 >= nqp) & (v >= p)) return 0;
+        }
         if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I, nqp, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
         if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I + 1, nqp, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
         if (rr == 0) rr = pipe_wait_ge(rowT + 2 * J, nqp, a.sync, info, a.timeout, (7 << 28) | ((p) << 20) | ((I * 1024 + J) & 0xfffff));
@@ -654,9 +659,10 @@ __global__ __launch_bounds__(1024) void k_potrf_pipe(PipeArgs a) {
 // =============================================================================================
 struct FlowArgs {
     PipeArgs p;          // (first: the roles read the launch arguments through a pointer to it)
-    const int *coff;     // [NP + 1] first critical task of every stage in p.tasks
+    const int *coff;     // [NP + 1] first HEAD task of every stage in p.tasks
     int NI;              // 128-row tiles of the matrix (m_tot / 128)
-    int RMAX, off_open, off_cnext, off_rcur, off_rcnt, off_pre, off_last, off_trace;
+    int RMAX, off_open, off_cnext, off_lnext, off_tnext, off_rcur, off_rcnt, off_trace;
+    int bulk_pairs;      // a workgroup may take two consecutive far tiles with one claim (one look of the scheduler per two tiles)
     int lead_short, lead_long;  // a workgroup with a diagonal block ahead of it stops taking short / long tasks this many blocks before its own
     int trace_cap;       // trace slots (profiling builds)
 };
@@ -668,7 +674,7 @@ __device__ __forceinline__ FlowArgs flow_kargs(flow_kargs_t kv) {
     FlowArgs a;
     a.p = pipe_kargs((pipe_kargs_t)k);
     a.coff = k->coff, a.NI = k->NI, a.RMAX = k->RMAX, a.off_open = k->off_open, a.off_cnext = k->off_cnext, a.off_rcur = k->off_rcur;
-    a.off_rcnt = k->off_rcnt, a.off_pre = k->off_pre, a.off_last = k->off_last, a.off_trace = k->off_trace;
+    a.off_rcnt = k->off_rcnt, a.off_lnext = k->off_lnext, a.off_tnext = k->off_tnext, a.off_trace = k->off_trace, a.bulk_pairs = k->bulk_pairs;
     a.lead_short = k->lead_short, a.lead_long = k->lead_long, a.trace_cap = k->trace_cap;
     return a;
 }
@@ -705,6 +711,11 @@ __device__ __noinline__ int pipe_role_bulk(pipe_kargs_t ka, pipe_lds_t sm3, long
             int rr = load_flag(info) != 0 ? 1 : 0;
             const int *rowT = S + a.off_rowT + (p1 - 1) * a.NC;  // (a row chunk solved for panel p1 - 1 is solved for every earlier panel)
             const int who = (10 << 28) | (p0 << 20) | ((I * 1024 + q) & 0xfffff);
+            {   // the usual case -- the scheduler looked before it claimed -- is one round of parallel loads, not eight one after the other
+                const int f0 = load_flag(rowT + 2 * I), f1 = load_flag(rowT + 2 * I + 1), c0 = load_flag(rowT + 4 * q), c1 = load_flag(rowT + 4 * q + 1),
+                          c2 = load_flag(rowT + 4 * q + 2), c3 = load_flag(rowT + 4 * q + 3), v0 = load_flag(ver0), v1 = top ? p0 : load_flag(ver1);
+                if ((rr == 0) & (f0 >= 4) & (f1 >= 4) & (c0 >= 4) & (c1 >= 4) & (c2 >= 4) & (c3 >= 4) & (v0 >= p0) & (v1 >= p0)) return 0;
+            }
             if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I, 4, a.sync, info, a.timeout, who);
             if (rr == 0) rr = pipe_wait_ge(rowT + 2 * I + 1, 4, a.sync, info, a.timeout, who);
             for (int c = 4 * q; c < 4 * q + 4 && rr == 0; c++) rr = pipe_wait_ge(rowT + c, 4, a.sync, info, a.timeout, who);
@@ -828,122 +839,217 @@ __device__ __noinline__ int flow_worker_loop(flow_kargs_t kf, pipe_lds_t sm3, in
     double *sm = pipe_uniform_lds(sm3);
     int *s_ctl = reinterpret_cast<int *>(sm + kPipeLdsDoubles);
     int *S = a.sync + (int64_t)z * a.sS;
+    const int *info = a.info + (int64_t)z * a.sI;
     const FlowShape sh{a.NP, a.NC, f.NI};
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int stage_guess = 0;       // the stage this workgroup last saw open (a wrong guess only costs the slow path)
+    int stage_guess = 0;       // the stage whose head this workgroup last saw open (a wrong guess only costs the slow path)
     long long idle_since = 0;  // wall clock of the first pass without work since the last task (0: not idle)
+    // Would this near-class task (COARSE, also as LAST) start at once?  (rows solved for its panel, the tile up to date)
+    // (all loads first, one decision at the end: `&&` would make every load wait for the one before it -- a pass of this
+    //  scheduler is a handful of L2 round trips of ~1 us each, and 256 workgroups make one per task)
+    auto near_ready = [&](int p, int I, int J) {
+        const int *rowT = S + a.off_rowT + p * a.NC;
+        const int r0 = load_flag(rowT + 2 * I), r1 = load_flag(rowT + 2 * I + 1), r2 = load_flag(rowT + 2 * J), r3 = load_flag(rowT + 2 * J + 1);
+        const int v = load_flag(S + a.off_cver + I * a.NJ + J);
+        return (r0 >= 4) & (r1 >= 4) & (r2 >= 4) & (r3 >= 4) & (v >= p);
+    };
     for (;;) {
         // ---- decide (wave 0), publish in s_ctl[8 ..]: [8] kind (0 none / retry, 1 critical, 2 bulk-class, 3 leave for the
-        //      diagonal block, 4 exhausted, 5 aborted), [9] stage or column, [10] ticket or round, [11] ticket in the round
+        //      diagonal block, 4 exhausted, 5 aborted); critical: [9] stage, [10] ticket, [11] list (0 head, 1 solves, 2 last
+        //      updates of the tail); bulk-class: [9] column, [10] round, [11] first ticket, [12] tickets (1 or 2)
         if (wave == 0) {
-            int kind = 0, w0 = 0, w1 = 0, w2 = 0;
-            const int cur = load_flag(S + 1) >> 4;  // diagonal blocks finished (16 strips each)
+            int kind = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 1;
+            const int strips = load_flag(S + 1);
+            const int cur = strips >> 4;               // diagonal blocks finished (16 strips each)
+            const bool failed = load_flag(info) != 0;  // (a matrix that lost a pivot: every task returns at once; nothing is "ready")
+            const int aborted = load_flag(a.sync);
             bool allow_short = true, allow_long = true;
             if (my_block >= 0) {
                 allow_short = my_block - cur > f.lead_short;
                 allow_long = my_block - cur > f.lead_long;
             }
-            // (a workgroup that owns block p never holds a ticket that could wait for block p: it only takes critical tickets of
-            //  stages < p -- the fast path below touches the stage it last saw open -- and nothing at all once stage p is open)
-            if (load_flag(a.sync) != 0) kind = 5;
+            // (a workgroup that owns block p never holds a ticket that could wait for block p: no head ticket of a stage >= p -- the
+            //  tails and the bulk-class rounds only ever wait for blocks that are finished when the ticket is taken)
+            if (aborted != 0) kind = 5;
             else if (!allow_short || (my_block >= 0 && stage_guess >= my_block)) kind = 3;
             else {
-                // critical: one atomicAdd on the stage last seen open
-                int Sopen = stage_guess;
+                // ---- (A) the head of the stage last seen open: its next ticket
+                int Sh = stage_guess;
                 int t = -1;
+                bool exhausted = false;
                 if (lane == 0) {
-                    const int cnt = f.coff[Sopen + 1] - f.coff[Sopen];
-                    if (load_flag(S + f.off_cnext + Sopen) < cnt) {
-                        t = __hip_atomic_fetch_add(S + f.off_cnext + Sopen, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (t >= cnt) t = -1;
+                    const int cnt = f.coff[Sh + 1] - f.coff[Sh];
+                    const int nxt = load_flag(S + f.off_cnext + Sh);
+                    exhausted = nxt >= cnt;
+                    if (!exhausted) {
+                        const PipeTask tk = a.tasks[f.coff[Sh] + nxt];
+                        bool rdy = true;
+                        if (!failed) {
+                            // (what a CHECKED claim may wait for inside its task is RUNNING, never merely claimed: a ticket obtained
+                            //  unchecked -- after losing the race for the one looked at -- may sit on an unclaimed producer, and nothing
+                            //  that was claimed with a look must queue up behind it)
+                            if (tk.type == PT_TRSM) {
+                                // its rows' fine tiles are in, the blocks before its own are factored: its block starts within ~25 us
+                                const int fc = tk.p == 0 ? 4 : load_flag(S + a.off_fcnt + tk.p * a.NC + tk.a);
+                                rdy = (strips >= 16 * tk.p) & (fc >= 4);
+                            } else if (tk.type == PT_FINE) {
+                                // both solves it streams behind have published a quarter, its tile is up to date
+                                const int *rowT = S + a.off_rowT + tk.p * a.NC;
+                                const int r0 = load_flag(rowT + tk.a), r1 = load_flag(rowT + 4 * (tk.p + 1) + tk.b);
+                                const int v = load_flag(S + a.off_cver + (tk.a >> 1) * a.NJ + 2 * (tk.p + 1) + (tk.b >> 1));
+                                rdy = (r0 >= 1) & (r1 >= 1) & (v >= tk.p);
+                            } else rdy = near_ready(tk.p, tk.a, tk.b);
+                        }
+                        if (rdy) {
+                            t = __hip_atomic_fetch_add(S + f.off_cnext + Sh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (t >= cnt) t = -1, exhausted = true;
+                        }
                     }
                 }
                 t = __builtin_amdgcn_readfirstlane(t);
-                if (t >= 0) kind = 1, w0 = Sopen, w1 = t;
-                else {
-                    // slow path: the open stage, its counter; try to open the next one
-                    Sopen = load_flag(S + f.off_open);
-                    const int cnt = f.coff[Sopen + 1] - f.coff[Sopen];
-                    const int taken = load_flag(S + f.off_cnext + Sopen);
-                    if (my_block >= 0 && Sopen >= my_block) {
-                        stage_guess = Sopen;
-                        kind = 3;
-                    } else if (Sopen != stage_guess && taken < cnt) {
-                        stage_guess = Sopen;  // (tickets there: next pass)
-                        kind = 0, w0 = 1;     // w0 = 1: retry at once, not idle
-                    } else {
-                        stage_guess = Sopen;
-                        if (taken >= cnt && Sopen + 1 < a.NP) {
-                            const int s1 = Sopen + 1;  // gates G2 / G3 of pipe_flow.h (G1: taken >= cnt)
-                            const bool g2 = load_flag(S + f.off_last + s1) >= flow_need_last(sh, s1) &&
-                                            load_flag(S + f.off_pre + s1) >= flow_need_pre(sh, s1);
-                            const bool g3 = s1 + 1 >= a.NP || load_flag(S + f.off_pre + s1 + 1) >= flow_need_pre(sh, s1 + 1);
-                            if (g2 && g3) {
-                                if (lane == 0) __hip_atomic_fetch_max(S + f.off_open, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                stage_guess = s1;
-                                kind = 0, w0 = 1;
+                exhausted = __builtin_amdgcn_readfirstlane((int)exhausted) != 0;
+                if (t >= 0) kind = 1, w0 = Sh, w1 = t, w2 = 0;
+                else if (exhausted) {
+                    // every ticket of this head is taken: the next head opens (or has been opened by somebody else meanwhile)
+                    const int So = load_flag(S + f.off_open);
+                    if (So != stage_guess) stage_guess = So, kind = 0, w0 = 1;  // (w0 = 1: look again at once, not idle)
+                    else if (So + 1 < a.NP) {
+                        if (lane == 0) __hip_atomic_fetch_max(S + f.off_open, So + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        stage_guess = So + 1, kind = 0, w0 = 1;
+                    }
+                    Sh = stage_guess;
+                }
+                if (kind == 0 && my_block >= 0 && stage_guess >= my_block) kind = 3, w0 = 0;
+                // ---- (B) the tails of the open stages, oldest first: lane 2 k + w looks at list w (0 solves, 1 last updates) of stage tlo + k
+                if (kind == 0 && w0 == 0) {
+                    const int tlo = load_flag(S + f.off_open + 2);
+                    const int st = tlo + (lane >> 1), which = lane & 1;
+                    int nxt = 0, size = 0, key = 0x7fffffff;
+                    bool done = false;  // this list has no ticket left
+                    if (lane < 16 && st <= Sh && st < a.NP) {
+                        size = which ? flow_lt_size(sh, st) : flow_tt_size(sh, st);
+                        nxt = load_flag(S + (which ? f.off_lnext : f.off_tnext) + st);
+                        done = nxt >= size;
+                        if (!done) {
+                            bool rdy = true;
+                            if (!failed) {
+                                if (which) {
+                                    const PipeTask tk = flow_lt_task(st, nxt);
+                                    rdy = near_ready(tk.p, tk.a, tk.b);
+                                } else {
+                                    const PipeTask tk = flow_tt_task(st, nxt);
+                                    const int fc = st == 0 ? 4 : load_flag(S + a.off_fcnt + st * a.NC + tk.a);
+                                    rdy = (fc >= 4) & (strips >= 16 * (st + 1));
+                                }
                             }
+                            if (rdy) key = 2 * st + which;
                         }
-                        if (kind == 0 && w0 == 0 && allow_long) {
-                            // bulk-class: lane l looks at column q0 + l
-                            const int hint = load_flag(S + f.off_open + 1);
-                            const int q0 = (hint >> 8) == Sopen ? (hint & 255) : Sopen + 1;  // (column Sopen itself is complete: gate G2)
-                            bool unfinished = false;
-                            for (int qb = q0 < 2 ? 2 : q0; qb < a.NP && kind == 0; qb += 64) {
-                                const int q = qb + lane;
-                                int r = -1, tsize = 0;
-                                bool more = false;  // the column still has rounds to hand out, now or later
-                                if (q < a.NP) {
-                                    const int nr = flow_nrounds(q);
-                                    r = load_flag(S + f.off_rcur + q);
-                                    for (int it = 0; it < 3 && r < nr; it++) {
-                                        if (flow_round_release_stage(q, r) > Sopen) break;
-                                        tsize = flow_round_size(sh, q, r);
-                                        if (load_flag(S + f.off_rcnt + q * f.RMAX + r) < tsize) break;
-                                        r++;  // every ticket of round r is taken: the next round may be claimed
-                                        tsize = 0;
-                                    }
-                                    more = r < nr;
-                                    if (r > load_flag(S + f.off_rcur + q))
-                                        __hip_atomic_fetch_max(S + f.off_rcur + q, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                }
-                                const unsigned long long have = __builtin_amdgcn_ballot_w64(tsize > 0);
-                                unfinished = unfinished || __builtin_amdgcn_ballot_w64(more) != 0;
-                                unsigned long long left = have;
-                                while (left && kind == 0) {  // the nearest column first; a lost race moves on to the next one
-                                    const int l = __builtin_ctzll(left);
-                                    left &= left - 1;
-                                    int tk = -1;
-                                    if (lane == l) {
-                                        tk = __hip_atomic_fetch_add(S + f.off_rcnt + q * f.RMAX + r, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                        if (tk >= tsize) tk = -1;
-                                    }
-                                    tk = __builtin_amdgcn_readlane(tk, l);
-                                    if (tk >= 0) kind = 2, w0 = qb + l, w1 = __builtin_amdgcn_readlane(r, l), w2 = tk;
-                                }
-                                if (kind == 0 && have == 0 && qb == (q0 < 2 ? 2 : q0)) {
-                                    // nothing in the first 64 columns from the hint: move the hint past the columns that are done
-                                    const unsigned long long busy = __builtin_amdgcn_ballot_w64(more);
-                                    const int adv = busy ? __builtin_ctzll(busy) : 64;
-                                    if (lane == 0 && adv > 0)
-                                        __hip_atomic_fetch_max(S + f.off_open + 1, (Sopen << 8) | ((qb + adv) < 255 ? (qb + adv) : 255), __ATOMIC_RELAXED,
-                                                               __HIP_MEMORY_SCOPE_AGENT);
-                                }
-                            }
-                            // exhausted: the last stage is open and fully claimed, no column has a round left
-                            if (kind == 0 && !unfinished && Sopen == a.NP - 1 && taken >= cnt && q0 <= 2) kind = 4;
-                            else if (kind == 0 && !unfinished && Sopen == a.NP - 1 && taken >= cnt) {
-                                // (the hint skipped columns: look at all of them once more before leaving)
-                                bool any = false;
-                                for (int qb = 2; qb < a.NP; qb += 64) {
-                                    const int q = qb + lane;
-                                    const bool m = q < a.NP && load_flag(S + f.off_rcur + q) < flow_nrounds(q);
-                                    any = any || __builtin_amdgcn_ballot_w64(m) != 0;
-                                }
-                                if (!any) kind = 4;
-                            }
+                    }
+                    // the oldest stage's lists both exhausted (and its head open): it leaves the window
+                    const unsigned long long dmask = __builtin_amdgcn_ballot_w64(done);
+                    if ((dmask & 3) == 3 && tlo <= Sh && lane == 0) __hip_atomic_fetch_max(S + f.off_open + 2, tlo + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long left = __builtin_amdgcn_ballot_w64(key != 0x7fffffff);
+                    for (int tries = 0; tries < 3 && left && kind == 0; tries++) {
+                        int best = -1, best_key = 0x7fffffff;
+                        for (unsigned long long m = left; m; m &= m - 1) {
+                            const int l = __builtin_ctzll(m);
+                            const int k = __builtin_amdgcn_readlane(key, l);
+                            if (k < best_key) best_key = k, best = l;
                         }
+                        left &= ~(1ull << best);
+                        int tk = -1;
+                        if (lane == best) {
+                            tk = __hip_atomic_fetch_add(S + (which ? f.off_lnext : f.off_tnext) + st, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (tk >= size) tk = -1;
+                        }
+                        tk = __builtin_amdgcn_readlane(tk, best);
+                        if (tk >= 0) kind = 1, w0 = tlo + (best >> 1), w1 = tk, w2 = 1 + (best & 1);
+                    }
+                }
+                // ---- (C) bulk-class: lane l looks at column q0 + l: the first round with tickets left, released, and whose NEXT ticket
+                //      would start at once.  A workgroup that takes a tile whose rows are not solved yet, or whose previous round still
+                //      runs, sits inside the task and is lost to everybody (n = 16384 without this look: 320 us of waiting per 130-us
+                //      tile, 83 ms per factorisation).  Rows are solved top-down and tickets run top-down, so "not yet" holds for the
+                //      tickets behind it too.
+                if (kind == 0 && w0 == 0 && allow_long) {
+                    // (every column from 2 on, 64 per look: heads run ahead of the tails, so columns well before the open head may
+                    //  still be receiving rounds)
+                    bool unfinished = false;
+                    for (int qb = 2; qb < a.NP && kind == 0; qb += 64) {
+                        const int q = qb + lane;
+                        int r = -1, tsize = 0, key = 0x7fffffff, nxt = 0;
+                        bool more = false;   // the column still has rounds to hand out, now or later
+                        bool two = false;    // ... and the ticket behind the next one is a far tile that would start at once as well
+                        if (q < a.NP) {
+                            const int nr = flow_nrounds(q);
+                            r = load_flag(S + f.off_rcur + q);
+                            const int r_was = r;
+                            for (int it = 0; it < 3 && r < nr; it++) {
+                                if (flow_round_release_stage(q, r) > Sh) break;
+                                tsize = flow_round_size(sh, q, r);
+                                nxt = load_flag(S + f.off_rcnt + q * f.RMAX + r);
+                                if (nxt < tsize) break;
+                                r++;  // every ticket of round r is taken: the next round may be claimed
+                                tsize = 0;
+                            }
+                            more = r < nr;
+                            if (r > r_was) __hip_atomic_fetch_max(S + f.off_rcur + q, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (tsize > 0 && !failed) {
+                                const FlowBulkTask bt = flow_round_task(sh, q, r, nxt);
+                                bool rdy;
+                                if (bt.type == PT_BULK) {
+                                    const int *rowT = S + a.off_rowT + (bt.p1 - 1) * a.NC;
+                                    const int *cv = S + a.off_cver + bt.I * a.NJ;
+                                    const int r0 = load_flag(rowT + 2 * bt.I), r1 = load_flag(rowT + 2 * bt.I + 1);
+                                    const int c0 = load_flag(rowT + 4 * q), c1 = load_flag(rowT + 4 * q + 1), c2 = load_flag(rowT + 4 * q + 2),
+                                              c3 = load_flag(rowT + 4 * q + 3);
+                                    const int v0 = load_flag(cv + 2 * q), v1 = load_flag(cv + 2 * q + 1);
+                                    // the row tile below it, for a claim of two (its rows and its tile; the column's rows are the same)
+                                    const bool pair = nxt + 1 < tsize && nxt >= 2 + kFlowWindow / 2;  // (never the diagonal block's or the window's tiles: the chain waits for those)
+                                    const int r2 = pair ? load_flag(rowT + 2 * bt.I + 2) : 0, r3 = pair ? load_flag(rowT + 2 * bt.I + 3) : 0;
+                                    const int v2 = pair ? load_flag(cv + a.NJ + 2 * q) : 0, v3 = pair ? load_flag(cv + a.NJ + 2 * q + 1) : 0;
+                                    rdy = (r0 >= 4) & (r1 >= 4) & (c0 >= 4) & (c1 >= 4) & (c2 >= 4) & (c3 >= 4) & (v0 >= bt.p0) & ((bt.I == 2 * q) | (v1 >= bt.p0));
+                                    two = rdy & pair & (r2 >= 4) & (r3 >= 4) & (v2 >= bt.p0) & (v3 >= bt.p0) & (f.bulk_pairs != 0);
+                                } else {
+                                    rdy = near_ready(bt.p0, bt.I, bt.J);
+                                }
+                                if (!rdy) tsize = 0;
+                            }
+                            // the two columns next to the chain first, then the OLDEST round (a column that falls rounds behind
+                            // becomes a chain of its own at the end: its rounds run one after the other on every tile)
+                            if (tsize > 0) key = q <= Sh + 2 ? q : 1024 + flow_round_release_stage(q, r) * 256 + q;
+                        }
+                        unsigned long long left = __builtin_amdgcn_ballot_w64(tsize > 0);
+                        unfinished = unfinished || __builtin_amdgcn_ballot_w64(more) != 0;
+                        for (int tries = 0; tries < 4 && left && kind == 0; tries++) {
+                            int best = -1, best_key = 0x7fffffff;
+                            for (unsigned long long m = left; m; m &= m - 1) {
+                                const int l = __builtin_ctzll(m);
+                                const int k = __builtin_amdgcn_readlane(key, l);
+                                if (k < best_key) best_key = k, best = l;
+                            }
+                            left &= ~(1ull << best);
+                            int tk = -1, got = 1;
+                            if (lane == best) {
+                                got = two ? 2 : 1;
+                                tk = __hip_atomic_fetch_add(S + f.off_rcnt + q * f.RMAX + r, got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (tk >= tsize) tk = -1;
+                                else if (tk + got > tsize) got = tsize - tk;
+                            }
+                            tk = __builtin_amdgcn_readlane(tk, best);
+                            if (tk >= 0) kind = 2, w0 = qb + best, w1 = __builtin_amdgcn_readlane(r, best), w2 = tk, w3 = __builtin_amdgcn_readlane(got, best);
+                        }
+                    }
+                    // exhausted: the last head is open and fully claimed, every tail is exhausted, no column has a round left
+                    if (kind == 0 && !unfinished && Sh == a.NP - 1 && exhausted && load_flag(S + f.off_open + 2) >= a.NP) {
+                        bool any = false;
+                        for (int qb = 2; qb < a.NP; qb += 64) {
+                            const int q = qb + lane;
+                            const bool m = q < a.NP && load_flag(S + f.off_rcur + q) < flow_nrounds(q);
+                            any = any || __builtin_amdgcn_ballot_w64(m) != 0;
+                        }
+                        if (!any) kind = 4;
                     }
                 }
             }
@@ -952,7 +1058,7 @@ __device__ __noinline__ int flow_worker_loop(flow_kargs_t kf, pipe_lds_t sm3, in
                 if (idle_since == 0) idle_since = now;
                 else if (now - idle_since > a.timeout) {
                     if (lane == 0 && __hip_atomic_fetch_add(a.sync, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                        store_flag(a.sync + 4, (11 << 28) | (stage_guess << 20));
+                        store_flag(a.sync + 4, (11 << 28) | (stage_guess << 20) | (load_flag(S + f.off_open + 2) & 0xfffff));
                         store_flag(a.sync + 5, f.off_open);
                         store_flag(a.sync + 6, a.NP - 1);
                         store_flag(a.sync + 7, load_flag(S + f.off_open));
@@ -963,53 +1069,52 @@ __device__ __noinline__ int flow_worker_loop(flow_kargs_t kf, pipe_lds_t sm3, in
             } else {
                 idle_since = 0;
             }
-            if (lane == 0) s_ctl[8] = kind, s_ctl[9] = w0, s_ctl[10] = w1, s_ctl[11] = w2;
+            if (lane == 0) s_ctl[8] = kind, s_ctl[9] = w0, s_ctl[10] = w1, s_ctl[11] = w2, s_ctl[13] = w3;
         }
         __syncthreads();
-        const int kind = s_ctl[8], w0 = s_ctl[9], w1 = s_ctl[10], w2 = s_ctl[11];
+        const int kind = s_ctl[8], w0 = s_ctl[9], w1 = s_ctl[10], w2 = s_ctl[11], w3 = s_ctl[13];
         __syncthreads();
         if (kind == 0) continue;
         if (kind == 3) return 3;
         if (kind == 4) return 0;
         if (kind == 5) return 2;
-        long long *tr = nullptr;
+        for (int rep = 0; rep < (kind == 2 ? w3 : 1); rep++) {
+            long long *tr = nullptr;
 #ifdef EGX_PIPE_TRACE
-        if (a.trace) {
-            if (tid == 0) s_ctl[12] = __hip_atomic_fetch_add(a.sync + f.off_trace, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            const int slot = s_ctl[12];
-            __syncthreads();
-            if (slot < f.trace_cap) tr = a.trace + 8 * (int64_t)slot;
-        }
+            if (a.trace) {
+                if (tid == 0) s_ctl[12] = __hip_atomic_fetch_add(a.sync + f.off_trace, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                const int slot = s_ctl[12];
+                __syncthreads();
+                if (slot < f.trace_cap) tr = a.trace + 8 * (int64_t)slot;
+            }
 #endif
-        int r;
-        if (kind == 1) {
-            const PipeTask task = a.tasks[f.coff[w0] + w1];
-            if (tr && tid == 0) {
-                tr[0] = task.type | (task.p << 8) | (z << 16);
-                tr[1] = (unsigned)task.a | ((long long)task.b << 32);
-                tr[2] = wall_clock64();
-                tr[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((long long)blockIdx.x << 8);
+            int r;
+            if (kind == 1) {
+                const PipeTask task = w2 == 0 ? a.tasks[f.coff[w0] + w1] : (w2 == 1 ? flow_tt_task(w0, w1) : flow_lt_task(w0, w1));
+                if (tr && tid == 0) {
+                    tr[0] = task.type | (task.p << 8) | (z << 16) | ((long long)w2 << 32);
+                    tr[1] = (unsigned)task.a | ((long long)task.b << 32);
+                    tr[2] = wall_clock64();
+                    tr[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((long long)blockIdx.x << 8);
+                }
+                if (task.type == PT_TRSM) r = pipe_role_trsm<1>(ka, (pipe_lds_t)sm, tr, z, task.p, task.a);
+                else if (task.type == PT_FINE) r = pipe_role_fine(ka, (pipe_lds_t)sm, tr, z, task.p, task.a, task.b);
+                else r = pipe_role_coarse(ka, (pipe_lds_t)sm, tr, z, task.p, task.a, task.b, task.type == PT_COARSE_LAST ? 1 : 0);
+            } else {
+                const FlowBulkTask bt = flow_round_task(sh, w0, w1, w2 + rep);
+                if (tr && tid == 0) {
+                    tr[0] = bt.type | (bt.p0 << 8) | (z << 16) | ((long long)w0 << 24);
+                    tr[1] = (unsigned)bt.I | ((long long)bt.J << 32);
+                    tr[2] = wall_clock64();
+                    tr[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((long long)blockIdx.x << 8);
+                }
+                if (bt.type == PT_BULK) r = pipe_role_bulk(ka, (pipe_lds_t)sm, tr, z, w0, bt.I, bt.p0, bt.p1);
+                else r = pipe_role_coarse(ka, (pipe_lds_t)sm, tr, z, bt.p0, bt.I, bt.J, 0);
             }
-            if (task.type == PT_TRSM) r = pipe_role_trsm<1>(ka, (pipe_lds_t)sm, tr, z, task.p, task.a);
-            else if (task.type == PT_FINE) r = pipe_role_fine(ka, (pipe_lds_t)sm, tr, z, task.p, task.a, task.b);
-            else r = pipe_role_coarse(ka, (pipe_lds_t)sm, tr, z, task.p, task.a, task.b, task.type == PT_COARSE_LAST ? 1 : 0);
-        } else {
-            const FlowBulkTask bt = flow_round_task(sh, w0, w1, w2);
-            if (tr && tid == 0) {
-                tr[0] = bt.type | (bt.p0 << 8) | (z << 16) | ((long long)w0 << 24);
-                tr[1] = (unsigned)bt.I | ((long long)bt.J << 32);
-                tr[2] = wall_clock64();
-                tr[5] = __builtin_amdgcn_s_getreg((3 << 11) | 20) | ((long long)blockIdx.x << 8);
-            }
-            if (bt.type == PT_BULK) r = pipe_role_bulk(ka, (pipe_lds_t)sm, tr, z, w0, bt.I, bt.p0, bt.p1);
-            else r = pipe_role_coarse(ka, (pipe_lds_t)sm, tr, z, bt.p0, bt.I, bt.J, 0);
-            // (a matrix that lost a pivot -- r == 1 -- still counts its tasks: the gates must open for the launch to end)
-            if (r != 2 && tid == 0)
-                __hip_atomic_fetch_add(S + (bt.last ? f.off_last : f.off_pre) + w0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tr && tid == 0) tr[4] = wall_clock64();
+            if (r == 2) return 2;
         }
-        if (tr && tid == 0) tr[4] = wall_clock64();
-        if (r == 2) return 2;
     }
 }
 
@@ -1208,7 +1313,7 @@ static int flow_plan_get(int dev, int n_pad, int m_tot, FlowPlan &out) {
     if (it == g_flow_plans.end()) {
         const int NP = n_pad / 256;
         std::vector<PipeTask> tasks;
-        std::vector<int> coff((size_t)NP + 1, 0);
+        std::vector<int> coff((size_t)NP + 1, 0);  // first head task of every stage
         for (int s = 0; s < NP; s++) {
             const std::vector<PipeTask> st = flow_stage_tasks(n_pad, m_tot, s);
             coff[(size_t)s] = (int)tasks.size();
@@ -1319,7 +1424,8 @@ int launch_potrf_flow(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot
     f.coff = plan.d_coff;
     f.NI = m_tot / 128;
     f.RMAX = fl.RMAX, f.off_open = fl.off_open, f.off_cnext = fl.off_cnext, f.off_rcur = fl.off_rcur, f.off_rcnt = fl.off_rcnt;
-    f.off_pre = fl.off_pre, f.off_last = fl.off_last, f.off_trace = fl.off_trace;
+    f.off_lnext = fl.off_lnext, f.off_tnext = fl.off_tnext, f.off_trace = fl.off_trace;
+    f.bulk_pairs = n_pad >= 8192 ? 1 : 0;  // (small matrices: one tile per claim keeps the last rounds balanced)
     f.lead_short = 1, f.lead_long = 3;
     f.trace_cap = 0;
     int test_wgs = 0;
@@ -1330,6 +1436,7 @@ int launch_potrf_flow(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot
     test_wgs = g_pipe_test_wgs;
     if (g_flow_lead_short >= 0) f.lead_short = g_flow_lead_short;
     if (g_flow_lead_long >= 0) f.lead_long = g_flow_lead_long;
+    if (const char *e = std::getenv("EGX_DEV_FLOW_PAIRS")) f.bulk_pairs = std::atoi(e);
 #else
     a.stall = 0;
     a.trace = nullptr;

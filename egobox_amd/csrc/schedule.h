@@ -10,6 +10,7 @@
 //   >= 14336              < 4               -                       0      0        0      0       4
 //   >= 14336              4 .. 7            -                       0      1        0      0       4
 //   >= 14336              >= 8              -                       1      1        0      0       4
+//   5376 .. 14080         1                 1 workspace, no group   the whole factorisation is ONE FLOW launch (flow = 1; pipe_flow.h)
 //
 // left / w_left  left-looking group updates of the factorisation / of the theta-gradient's C^-T rider (EGX_POTRF_LEFT: 0 never,
 //                1 by the table, 2 always).  Measured: n = 16384 in lock-step groups of eight +2.3 % on the sweep, a lone
@@ -33,6 +34,8 @@
 
 namespace egx {
 
+constexpr int kFlowMinCols = 5120;       // a LONE handle (one workspace, not a member of a group) beyond this padded size ...
+constexpr int kFlowMaxCols = 14336;      // ... and below this one factors as ONE flow launch (pipe_flow.h, round 6)
 constexpr int kPipeMaxCols = 4096;       // padded size up to which the chain of a group of panels is one launch
 constexpr int kPipeWholeMaxCols = 7168;  // ... up to which the WHOLE factorisation is one launch,
 constexpr int kPipeDiagBlocks = 32;      // while workspaces x panels stays within this
@@ -65,6 +68,12 @@ inline PotrfSchedule schedule_table(int n_pad, int lockstep, int n_workspaces, c
     s.whole = k.pipe == 1 && n_pad <= EGX_PIPE_WHOLE_MAX_COLS && (long long)n_workspaces * ((n_pad + 255) / 256) <= kPipeDiagBlocks;
     s.pipe = k.pipe != 0 && (n_pad <= EGX_PIPE_MAX_COLS || s.whole);
     s.group_panels = k.potrf_group ? k.potrf_group : (n_pad >= 14336 ? 4 : 2);
+    // flow: measured on one matrix (tools/pipe_check flow, profiles/r06_flow_sizes.txt; ms, separate launches / whole chain launch /
+    // flow): n = 4096 1.95 / 1.37 / 1.47, 5120 2.89 / 1.94 / 1.92, 6144 3.97 / 2.77 / 2.62, 7168 5.21 / 4.16 / 3.57,
+    // 8192 5.85 / 6.45 / 4.93, 10240 9.55 / - / 8.57, 12288 14.67 / - / 13.68, 14336 20.72 / - / 21.02, 16384 28.92 / - / 30.38.
+    // One matrix per launch: handles with several workspaces and the members of a group (egx_gp_create_group clears the bit) keep
+    // the rows above -- `whole` / `pipe` stay set as what such a handle falls back to (a retry, a device the launch does not fit).
+    s.flow = k.pipe == 1 && n_workspaces == 1 && lockstep <= 1 && n_pad % 256 == 0 && n_pad > kFlowMinCols && n_pad < kFlowMaxCols;
     return s;
 }
 

@@ -223,9 +223,9 @@ class GpHandle:
 
     def schedule(self):
         """egx_gp_get_schedule: how this handle factors (decided per handle, so all its evaluations agree bit for bit)."""
-        out = (C.c_int32 * 6)()
-        L.check(self._lib.egx_gp_get_schedule(self._h, out, 6))
-        keys = ("left_looking", "left_looking_rider", "pipelined_chain", "whole_factorisation_launch", "panels_per_group", "lockstep")
+        out = (C.c_int32 * 7)()
+        L.check(self._lib.egx_gp_get_schedule(self._h, out, 7))
+        keys = ("left_looking", "left_looking_rider", "pipelined_chain", "whole_factorisation_launch", "panels_per_group", "lockstep", "flow")
         return dict(zip(keys, [int(v) for v in out]))
 
     def shrink(self, n_keep=1):

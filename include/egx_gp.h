@@ -184,7 +184,9 @@ int32_t egx_gp_get_lockstep(const egx_gp *gp);
  * 1-workspace handle at n = 16384 differ by 1e-10 relative).  out[0..5] = { left-looking group updates, left-looking
  * C^-T rider, pipelined chain launches (the chain of a panel group -- diagonal blocks, panel solves, in-group updates: the
  * panel step of `cholesky()`, crates/gp/src/algorithm.rs:1004 -- as one persistent launch), whole factorisation as one such
- * launch, panels per group, lock-step width }; out_len >= 6 (further slots are set to 0). */
+ * launch, panels per group, lock-step width }; out_len >= 6.  out[6] (when out_len >= 7): the whole factorisation as ONE FLOW
+ * launch -- critical stage lists + bulk-class rounds per column, csrc/pipe_flow.h; round 6: a lone one-workspace handle that
+ * is not a member of a group, padded size 5376 .. 14080.  Further slots are set to 0. */
 int32_t egx_gp_get_schedule(const egx_gp *gp, int32_t *out, int32_t out_len);
 /* Give back what only an optimisation needed: the handle keeps its first n_keep (>= 1) workspaces -- workspace 0 holds the
  * fitted factor, which survives -- and frees the others together with the theta-gradient's scratch.  A tuned fit runs its

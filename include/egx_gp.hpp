@@ -179,10 +179,11 @@ class GaussianProcess {
     // a tuned model ran its multistart on several workspaces; the resident model needs one (plus one for likelihood
     // evaluations that must not un-fit it)
     void shrink(int32_t n_keep = 1) { check(egx_gp_shrink(h_.get(), n_keep)); }
-    // { left-looking, left-looking rider, pipelined chain launches, whole-factorisation launch, panels per group, lock-step width }
-    std::array<int32_t, 6> schedule() const {
-        std::array<int32_t, 6> s{};
-        check(egx_gp_get_schedule(h_.get(), s.data(), 6));
+    // { left-looking, left-looking rider, pipelined chain launches, whole-factorisation launch, panels per group, lock-step width,
+    //   flow launch }
+    std::array<int32_t, 7> schedule() const {
+        std::array<int32_t, 7> s{};
+        check(egx_gp_get_schedule(h_.get(), s.data(), 7));
         return s;
     }
     int32_t set_lockstep(int32_t width) {  // candidates per launch sequence (0 = the library's choice); returns the width in force

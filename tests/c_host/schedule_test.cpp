@@ -37,6 +37,14 @@ int main() {
     expect(16384, 8, 16, d, 1, 1, 0, 0, 4);
     expect(16384, 8, 8, d, 1, 1, 0, 0, 4);
     expect(14400, 8, 8, d, 1, 0, 0, 0, 4);       // (the rider's left-looking form needs 256-column panels throughout)
+    // round 6: a lone one-workspace handle between 5376 and 14080 columns factors as ONE flow launch (the other bits stay what
+    // such a handle falls back to); never with several workspaces, a lock-step width, odd panels, or EGX_PIPE != 1
+    auto flow = [&](int n_pad, int w, int nws, const egx::ScheduleKnobs &kk) { return egx::schedule_table(n_pad, w, nws, kk).flow; };
+    for (int n_pad : {5376, 6144, 7168, 8192, 12288, 14080})
+        if (!flow(n_pad, 1, 1, d)) std::printf("n_pad %d: a lone handle should take the flow launch\n", n_pad), fails++;
+    for (int n_pad : {1024, 4096, 5120, 14336, 16384})
+        if (flow(n_pad, 1, 1, d)) std::printf("n_pad %d: no flow launch at this size\n", n_pad), fails++;
+    if (flow(8192, 1, 2, d) || flow(8192, 2, 2, d) || flow(8320, 1, 1, d)) std::printf("flow needs one workspace, width 1, 256-column panels\n"), fails++;
     // the width enters through the lock-step thresholds only, the workspaces through the whole-launch bound only
     for (int n_pad = 128; n_pad <= 20480; n_pad += 128)
         for (int w = 1; w <= 16; w++)
@@ -53,7 +61,9 @@ int main() {
     egx::ScheduleKnobs k = d;
     k.pipe = 0;
     expect(4096, 1, 1, k, 0, 0, 0, 0, 2);
+    if (flow(8192, 1, 1, k)) std::printf("EGX_PIPE=0 must switch the flow launch off\n"), fails++;
     k = d, k.pipe = 2;                           // chain launches per group of panels only
+    if (flow(8192, 1, 1, k)) std::printf("EGX_PIPE=2 must switch the flow launch off\n"), fails++;
     expect(4096, 1, 1, k, 0, 0, 1, 0, 2);
     expect(8192, 1, 1, k, 0, 0, 0, 0, 2);
     k = d, k.potrf_left = 0;

@@ -687,12 +687,17 @@ def test_config5_eight_experts_n8192_d16_m100000(egx, large):
     experts = (egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr())
                .theta_tuning(egx.ThetaTuning.Fixed(theta)).fit_group(np.stack([s_[0] for s_ in sets]), np.stack([s_[1] for s_ in sets])))
     try:
-        # ... and one of them once more on its own: the lone fit gives the same bits
+        # ... and one of them once more on its own.  (A lone one-workspace handle of this size factors as ONE flow launch since
+        # round 6 -- schedule()["flow"] -- the members of a group in lock-step by separate launches: two rows of csrc/schedule.h,
+        # the same sums in another order, 1e-10 apart; the bit-for-bit identity of group and lone fits holds where both take
+        # the same row: tests/test_gpu_pipe.py.)
         lone = egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr()) \
             .theta_tuning(egx.ThetaTuning.Fixed(theta)).fit(*sets[3])
         try:
-            assert lone.likelihood() == experts[3].likelihood() and lone.variance() == experts[3].variance()
-            np.testing.assert_array_equal(lone.predict(xq[:64]), experts[3].predict(xq[:64]))
+            assert lone.handle.schedule()["flow"] == 1 and experts[3].handle.schedule()["flow"] == 0
+            assert lone.likelihood() == pytest.approx(experts[3].likelihood(), rel=1e-10)
+            assert lone.variance() == pytest.approx(experts[3].variance(), rel=1e-9)
+            np.testing.assert_allclose(lone.predict(xq[:64]), experts[3].predict(xq[:64]), rtol=1e-8)
         finally:
             lone.close()
         assert experts[0].likelihood() == pytest.approx(rec["likelihood"], rel=LK_RTOL)

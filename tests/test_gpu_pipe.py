@@ -108,6 +108,61 @@ def test_schedule_is_reported_and_survives_shrink(egx):
         assert st == 0 and abs(lk_whole - lk_sep) <= 1e-9 * abs(lk_sep)
 
 
+@pytest.mark.parametrize("n", [5600, 6400, 8192])
+def test_flow_launch_agrees_with_separate_launches_and_lapack(egx, knobs, n):
+    """Round 6: a lone matrix between 5376 and 14080 padded columns factors as ONE flow launch (csrc/pipe_flow.h, k_potrf_flow:
+    critical heads / tails per stage, bulk-class rounds per column with 128 x 256 LDS-DMA tiles, look-before-claim).  egx_potrf
+    takes the schedule of a one-workspace handle: the factor against LAPACK and against the separate launches (pipe = 0), the
+    same bits on a second call (the schedule is dynamic, the arithmetic is not), LAPACK's info for a lost pivot."""
+    rng = np.random.default_rng(n)
+    pts = rng.uniform(size=(n, 3))
+    a = np.exp(-6.0 * ((pts[:, None, 0] - pts[None, :, 0]) ** 2 + (pts[:, None, 1] - pts[None, :, 1]) ** 2 + (pts[:, None, 2] - pts[None, :, 2]) ** 2))
+    a[np.diag_indices(n)] += 1e-8
+    want = sl.cholesky(a, lower=True)
+    res_lapack = np.abs(want @ want.T - a).max()
+    s0 = egx.chain_stats()
+    got, info = egx.potrf(a)
+    assert info == 0 and np.abs(got @ got.T - a).max() <= 10 * max(res_lapack, 1e-15)
+    again, _ = egx.potrf(a)
+    np.testing.assert_array_equal(got, again)
+    knobs("pipe", 0)
+    sep, info = egx.potrf(a)
+    knobs("pipe", 1)
+    assert info == 0 and np.abs(got - sep).max() <= 2e-5 * np.abs(want).max()
+    bad = n // 2 + 77
+    a[bad, bad] = -1.0
+    _, info_lapack = sl.lapack.dpotrf(a, lower=1)
+    _, info = egx.potrf(a)
+    assert info == info_lapack == bad + 1
+    assert egx.chain_stats() == s0          # no launch ran into its wait bound
+
+
+def test_a_lone_handle_takes_the_flow_launch_and_its_likelihood_is_the_separate_launches_to_rounding(egx, knobs):
+    x, y = egx.workload.make_training_set(6000, 8, 11)       # (the benchmark's well-conditioned family: the 1e-8 bar applies)
+    th = egx.workload.default_theta(8) * 3.0
+    xq = np.random.default_rng(3).random((200, 8))
+    with egx.GpHandle(x, y) as h:
+        s = h.schedule()
+        assert s["flow"] == 1 and s["lockstep"] == 1
+        lk, st = h.likelihood(th)
+        lk2, _ = h.likelihood(th)
+        assert st == 0 and lk == lk2
+        g_lk, g, gst = h.likelihood_grad(th)                   # the C^-T rider follows the launch group by group
+        assert gst == 0 and g_lk == pytest.approx(lk, rel=1e-12)
+        h.finalize(th)
+        yp, vp = h.predict_valvar(xq)
+    with egx.GpHandle(x, y, n_workspaces=2) as h2:             # two workspaces: separate launches (no flow, no chain launch at this size)
+        assert h2.schedule()["flow"] == 0
+        lk_sep, st = h2.likelihood(th)
+        g2_lk, g2, _ = h2.likelihood_grad(th)
+        h2.finalize(th)
+        yp2, vp2 = h2.predict_valvar(xq)
+    assert st == 0 and abs(lk - lk_sep) <= 1e-10 * abs(lk_sep)
+    np.testing.assert_allclose(g, g2, rtol=1e-6, atol=1e-8 * np.abs(g2).max())
+    np.testing.assert_allclose(yp, yp2, rtol=1e-8)
+    np.testing.assert_allclose(vp, vp2, rtol=1e-6, atol=1e-12)
+
+
 def test_likelihood_does_not_depend_on_the_chain_form_beyond_rounding(egx, knobs):
     x, y = egx.workload.make_training_set(1500, 8, 42)     # (the benchmark's well-conditioned family: the 1e-8 bar applies)
     th = egx.workload.default_theta(8) * 3.0

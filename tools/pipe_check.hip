@@ -390,8 +390,10 @@ static int flow_main(int argc, char **argv) {
             spoil();
             if (P.factor(0, true)) return 3;
             CK(hipDeviceSynchronize());
-            verdict(P.infos()[0] == info_ref && info_ref == bad + 1 && P.abort_word() == 0, "flow    n=%d: lost pivot, info %d (separate %d), abort %d", n,
-                    P.infos()[0], info_ref, P.abort_word());
+            CK(hipMemcpy(hdr.data(), P.sync, 32, hipMemcpyDeviceToHost));
+            verdict(P.infos()[0] == info_ref && info_ref == bad + 1 && P.abort_word() == 0,
+                    "flow    n=%d: lost pivot, info %d (separate %d), abort %d (who %x word %d want %d saw %d)", n, P.infos()[0], info_ref, P.abort_word(), hdr[4], hdr[5],
+                    hdr[6], hdr[7]);
         }
         g_flow = false;
         const double t_sep = time_factor(P, false, scale, nugget, 5);
