@@ -250,9 +250,11 @@ def test_a_hand_off_that_never_arrives_is_retried_by_separate_launches_and_an_er
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     lk, st, sep, good, aborted, retried = out["fallback"]
-    assert st == 0 and lk == sep and abs(lk - good) <= 1e-10 * abs(good)
+    # (the fallback IS the separate-launch schedule: the same bits as a handle created with chain launches off; against the chain
+    #  launch's own value the two orders of summation agree within the parity bar, 6e-9 here)
+    assert st == 0 and lk == sep and abs(lk - good) <= 1e-8 * abs(good)
     assert aborted == 1 and retried == 1 and out["fallback_seconds"] < 5.0
-    assert abs(out["fit_after_fallback"] - good) <= 1e-10 * abs(good)
+    assert abs(out["fit_after_fallback"] - good) <= 1e-8 * abs(good)
     assert out["error"] is not None and "pipelined chain kernel" in out["error"] and out["error_seconds"] < 5.0
     assert out["again"] == [good, 0]
     assert out["potrf_resid"] < 1e-12 and out["potrf_error"] is not None
