@@ -373,6 +373,37 @@ def other_configs(egx, workload, gpu):
         "max_rel_diff_to_lone_fits": float(max(abs(e.likelihood() - l) / abs(l) for e, l in zip(experts, lone_lk))),
         "lone_fit_schedule": _schedule_word(lone_sched),
         "note": "egx_gp_create_group + egx_gp_finalize_multi: eight models of one shape, one launch sequence"}
+    # the same eight experts TUNED (ThetaTuning::Full: 4 starts x 25 COBYLA evaluations each; crates/moe/src/algorithm.rs:209-262 ->
+    # crates/gp/src/algorithm.rs:921-945): egx_gp_fit_multi -- all members' machines in lock-step, a round's trial points as
+    # lock-step launch sequences across the group -- against eight egx_gp_fit calls one after the other on one-workspace handles
+    # (bit-identical results: tests/test_gpu_pipe.py) and on the twelve-workspace handles GpParams.fit uses
+    try:
+        lo5, hi5 = np.full(d5, 0.02), np.full(d5, 2.0)
+        starts5 = workload.default_theta(d5) * 10.0 ** np.random.default_rng(5).uniform(-0.3, 0.3, size=(4, d5))
+        t0 = time.perf_counter()
+        ne_multi = egx.fit_multi(hs5, np.tile(starts5, (k, 1, 1)), lo5, hi5, 25)
+        t_fm = time.perf_counter() - t0
+        lk_multi = [h_.fitted_scalars()[0] for h_ in hs5]
+        t_lone1, ne_lone1, same = 0.0, 0, True
+        for (x_, y_), lkm in zip(sets5, lk_multi):
+            with egx.GpHandle(x_, y_, device=gpu, n_workspaces=1) as h1:
+                t0 = time.perf_counter()
+                ne_lone1 += int(h1.fit(starts5, lo5, hi5, 25))
+                t_lone1 += time.perf_counter() - t0
+                same = same and (h1.fitted_scalars()[0] == lkm or h1.schedule()["flow"] == 1)
+        t_lone4, ne_lone4 = 0.0, 0
+        for x_, y_ in sets5[:2]:
+            with egx.GpHandle(x_, y_, device=gpu, n_workspaces=4) as h4:
+                t0 = time.perf_counter()
+                ne_lone4 += int(h4.fit(starts5, lo5, hi5, 25))
+                t_lone4 += time.perf_counter() - t0
+        res["config5_expert_tuned_fits_8"] = {
+            "experts": k, "starts": 4, "evaluations": int(ne_multi.sum()), "fit_multi_s": t_fm, "evaluations_per_s_fit_multi": float(ne_multi.sum()) / t_fm,
+            "evaluations_per_s_lone_fits_1_workspace": ne_lone1 / t_lone1, "evaluations_per_s_lone_fits_4_workspaces": ne_lone4 / t_lone4,
+            "speedup_over_lone_1_workspace": (float(ne_multi.sum()) / t_fm) / (ne_lone1 / t_lone1),
+            "speedup_over_lone_4_workspaces": (float(ne_multi.sum()) / t_fm) / (ne_lone4 / t_lone4)}
+    except Exception as e:  # noqa: BLE001
+        res["config5_expert_tuned_fits_8"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     w = rng.random(k) + 0.5
     w /= w.sum()
     gmx = GaussianMixture(w, rng.random((k, d5)), np.array([np.eye(d5) * 0.3] * k), 0.9)

@@ -12,7 +12,7 @@ _lib.load()  # fail loudly at import when the HIP library is missing
 
 from .gp import (AbsoluteExponentialCorr, ConstantMean, GaussianProcess, GpHandle, GpParams, Kriging,  # noqa: E402
                  LinearMean, Matern32Corr, Matern52Corr, QuadraticMean, SquaredExponentialCorr, ThetaTuning,
-                 chain_stats, corr_matrix, cross_corr, finalize_multi, likelihood_multi, mfma_probe, normalize, pool_stats, potrf,
+                 chain_stats, corr_matrix, cross_corr, finalize_multi, fit_multi, likelihood_multi, mfma_probe, normalize, pool_stats, potrf,
                  regression_basis, set_tuning, trim)
 from .gpx import CorrelationSpec, GpMix, Gpx, Recombination, RegressionSpec  # noqa: E402
 from .multistart import prepare_multistart, theta_sweep_candidates  # noqa: E402

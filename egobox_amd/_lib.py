@@ -80,6 +80,8 @@ SIGNATURES = [
     ("egx_gp_create_group", C.c_int32, [C.c_void_p, c_double_p, c_double_p, C.c_int64, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     ("egx_gp_finalize_multi", C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, c_double_p, C.c_int64]),
     ("egx_gp_likelihood_multi", C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, c_double_p, C.c_int64, c_double_p, C.POINTER(C.c_int32)]),
+    ("egx_gp_fit_multi", C.c_int32, [C.POINTER(C.c_void_p), C.c_int32, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_int64, C.c_int64,
+                                     c_int64_p]),
     ("egx_gp_fit", C.c_int32, [C.c_void_p, c_double_p, C.c_int64, c_double_p, c_double_p, C.c_int64, C.c_int64,
                                c_int64_p]),
     ("egx_gp_fit_partial", C.c_int32, [C.c_void_p, c_double_p, c_int64_p, C.c_int64, c_double_p, C.c_int64, c_double_p,

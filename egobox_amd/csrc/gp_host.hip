@@ -1619,9 +1619,9 @@ static int multi_run_len(egx_gp *const *gps, int k, int i) {
         len++;
     return len;
 }
-static int multi_eval(egx_gp *const *gps, int32_t k, const double *thetas, int64_t theta_len, bool finalize, double *lkh,
-                      int32_t *status) {
-    if (!gps || k < 1 || !thetas) {
+// the exclusive locks of k DISTINCT handles, in address order (two such calls cannot deadlock)
+static int multi_lock(egx_gp *const *gps, int32_t k, std::vector<std::unique_lock<std::shared_mutex>> &locks) {
+    if (!gps || k < 1) {
         set_error("NULL argument");
         return EGX_ERR_INVALID_VALUE;
     }
@@ -1631,8 +1631,24 @@ static int multi_eval(egx_gp *const *gps, int32_t k, const double *thetas, int64
         set_error("the models of a multi-model call must be distinct handles");
         return EGX_ERR_INVALID_VALUE;
     }
-    std::vector<std::unique_lock<std::shared_mutex>> locks;  // (in address order: two such calls cannot deadlock)
     for (egx_gp *g : order) locks.emplace_back(g->mu);
+    return EGX_SUCCESS;
+}
+static int multi_eval_locked(egx_gp *const *gps, int32_t k, const double *thetas, int64_t theta_len, bool finalize, double *lkh,
+                             int32_t *status);
+static int multi_eval(egx_gp *const *gps, int32_t k, const double *thetas, int64_t theta_len, bool finalize, double *lkh,
+                      int32_t *status) {
+    if (!thetas) {
+        set_error("NULL argument");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::vector<std::unique_lock<std::shared_mutex>> locks;
+    EGX_RC(multi_lock(gps, k, locks));
+    return multi_eval_locked(gps, k, thetas, theta_len, finalize, lkh, status);
+}
+// (the caller holds every member's lock)
+static int multi_eval_locked(egx_gp *const *gps, int32_t k, const double *thetas, int64_t theta_len, bool finalize, double *lkh,
+                             int32_t *status) {
     int first_rc = EGX_SUCCESS;
     for (int i = 0; i < k;) {
         const int len = multi_run_len(gps, k, i);
@@ -1751,6 +1767,99 @@ int32_t egx_gp_likelihood_multi(egx_gp *const *gps, int32_t k, const double *the
         return EGX_ERR_INVALID_VALUE;
     }
     return multi_eval(gps, k, thetas, theta_len, false, lkh, status);
+}
+
+// ThetaTuning::Full across MODELS: the tuned fit of every expert of a mixture (crates/moe/src/algorithm.rs:167-177 -> :209-262 ->
+// GpValidParams::fit -> the multistart COBYLA of crates/gp/src/algorithm.rs:921-945), the k x n_starts COBYLA machines advanced
+// in lock-step: per round and start index, the trial points of all models whose machine still asks are ONE lock-step
+// evaluation across the group's slab (what egx_gp_likelihood_multi does).  A machine only ever sees the values of its own
+// model, and a model's evaluation does not depend on its companions, so every member walks the trajectory it walks under
+// egx_gp_fit on a one-workspace handle: theta*, likelihood and predictions are the same bits.
+int32_t egx_gp_fit_multi(egx_gp *const *gps, int32_t k, const double *theta0s, int64_t n_starts, const double *lo, const double *hi,
+                         int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out) {
+    if (!gps || k < 1 || !theta0s || !lo || !hi || n_starts < 1) {
+        set_error("NULL argument / no start point");
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::vector<std::unique_lock<std::shared_mutex>> locks;
+    EGX_RC(multi_lock(gps, k, locks));
+    const int h = gps[0]->h;
+    for (int32_t m = 0; m < k; m++)
+        if (gps[m]->h != h) {
+            set_error("egx_gp_fit_multi: the models must have the same number of hyperparameters");
+            return EGX_ERR_INVALID_VALUE;
+        }
+    if (bounds_len != 1 && bounds_len != h) {  // algorithm.rs:901-912
+        set_error("Bounds for theta should be either 1-dim or dim of xtrain (" + std::to_string(h) + "), got " + std::to_string(bounds_len));
+        return EGX_ERR_INVALID_VALUE;
+    }
+    std::vector<double> blo((size_t)h), bhi((size_t)h);
+    for (int i = 0; i < h; i++) {
+        const double l = lo[bounds_len == 1 ? 0 : i], u = hi[bounds_len == 1 ? 0 : i];
+        if (!(l > 0.0) || !(u >= l)) {
+            set_error("theta bounds must satisfy 0 < lo <= hi");
+            return EGX_ERR_INVALID_VALUE;
+        }
+        blo[(size_t)i] = std::log10(l), bhi[(size_t)i] = std::log10(u);  // optimization.rs:32-35
+    }
+    for (int64_t e = 0; e < (int64_t)k * n_starts * h; e++)
+        if (!(theta0s[e] > 0.0)) {
+            set_error("theta start points must be > 0");
+            return EGX_ERR_INVALID_VALUE;
+        }
+    int64_t per_start = 10 * (int64_t)h;  // maxeval = clamp(10 h, 25, max_eval), algorithm.rs:933-936
+    if (per_start < 25) per_start = 25;
+    if (max_eval >= 25 && per_start > max_eval) per_start = max_eval;
+    std::vector<std::vector<CobylaBox>> mach((size_t)k);
+    for (int32_t m = 0; m < k; m++) {
+        mach[(size_t)m].reserve((size_t)n_starts);
+        for (int64_t st = 0; st < n_starts; st++) {
+            std::vector<double> x0((size_t)h);
+            for (int i = 0; i < h; i++) x0[(size_t)i] = std::log10(theta0s[((size_t)m * n_starts + st) * h + i]);
+            mach[(size_t)m].emplace_back(x0, blo, bhi, 0.5, 1e-4, per_start);  // rhobeg / ftol_rel: optimization.rs:16-24
+        }
+    }
+    std::vector<egx_gp *> sub;
+    std::vector<int32_t> who, stt;
+    std::vector<double> thetas, lk, x;
+    for (bool any = true; any;) {
+        any = false;
+        for (int64_t st = 0; st < n_starts; st++) {  // start index st of every model whose machine still asks: one lock-step evaluation
+            sub.clear(), who.clear(), thetas.clear();
+            for (int32_t m = 0; m < k; m++)
+                if (mach[(size_t)m][(size_t)st].ask(x)) {
+                    sub.push_back(gps[m]);
+                    who.push_back(m);
+                    for (int i = 0; i < h; i++) thetas.push_back(std::pow(10.0, x[(size_t)i]));
+                }
+            if (sub.empty()) continue;
+            any = true;
+            lk.assign(sub.size(), 0.0), stt.assign(sub.size(), 0);
+            EGX_RC(multi_eval_locked(sub.data(), (int32_t)sub.size(), thetas.data(), h, false, lk.data(), stt.data()));
+            for (size_t q = 0; q < who.size(); q++) {
+                const bool ok = stt[q] == EGX_STATUS_OK && !std::isnan(lk[q]);
+                mach[(size_t)who[q]][(size_t)st].tell(ok ? -lk[q] : std::numeric_limits<double>::infinity());  // algorithm.rs:893-896
+            }
+        }
+    }
+    // the reduction over every model's starts (first wins ties, algorithm.rs:942-945), then ONE lock-step finalize
+    std::vector<double> best((size_t)k * h);
+    for (int32_t m = 0; m < k; m++) {
+        double best_f = std::numeric_limits<double>::infinity();
+        std::vector<double> bx((size_t)h, 0.0);
+        int64_t evals = 0;
+        for (int64_t st = 0; st < n_starts; st++) {
+            const CobylaBox &c = mach[(size_t)m][(size_t)st];
+            double fb = c.best_f();
+            if (std::isnan(fb) || fb >= 1e30) fb = std::numeric_limits<double>::infinity();  // optimization.rs:153-157
+            evals += c.evals();
+            if (fb < best_f) best_f = fb, bx = c.best_x();
+        }
+        if (n_evals_out) n_evals_out[m] = evals;
+        for (int i = 0; i < h; i++)
+            best[(size_t)m * h + i] = std::isfinite(best_f) ? std::pow(10.0, bx[(size_t)i]) : theta0s[((size_t)m * n_starts) * h + i];
+    }
+    return multi_eval_locked(gps, k, best.data(), h, true, nullptr, nullptr);
 }
 
 int32_t egx_gp_get_inner(egx_gp *gp, const egx_gp_inner_view *v) {

@@ -483,6 +483,20 @@ def likelihood_multi(handles, thetas):
     return lk, st
 
 
+def fit_multi(handles, theta0s, lo, hi, max_eval=GP_COBYLA_MAX_EVAL):
+    """egx_gp_fit_multi: ThetaTuning::Full for several models at once (theta0s: k x n_starts x h in linear theta units); the
+    COBYLA machines of all models advance in lock-step, members of one group are evaluated as one launch sequence.  Returns the
+    evaluations per model; every model ends fitted as `fit` on a one-workspace handle would leave it."""
+    theta0s = np.ascontiguousarray(L.as_f64(theta0s))
+    if theta0s.ndim != 3 or theta0s.shape[0] != len(handles):
+        raise L.InvalidValueError(L.ERR_INVALID_VALUE, "fit_multi needs theta0s (k, n_starts, h)")
+    lo, hi = L.as_f64(np.atleast_1d(lo), 1), L.as_f64(np.atleast_1d(hi), 1)
+    ne = np.zeros(len(handles), dtype=np.int64)
+    L.check(L.load().egx_gp_fit_multi(_handle_array(handles), len(handles), L.dptr(theta0s), theta0s.shape[1], L.dptr(lo), L.dptr(hi),
+                                      lo.size, int(max_eval), ne.ctypes.data_as(L.c_int64_p)))
+    return ne
+
+
 def set_tuning(knob, value):
     """egx_set_tuning: one of the factorisation's scheduling knobs by name; returns the previous value."""
     old = C.c_int32()
@@ -685,14 +699,14 @@ class GpParams:
         return GaussianProcess(h, self, n_evals)
 
     def fit_group(self, xs, ys):
-        """`fit` for k training sets of ONE shape at once (xs: k x n x d, ys: k x n; ThetaTuning::Fixed only, no KPLS): what
+        """`fit` for k training sets of ONE shape at once (xs: k x n x d, ys: k x n; ThetaTuning Fixed or Full, no KPLS): what
         the expert loop of egobox-moe does one model after the other (crates/moe/src/algorithm.rs:167-177).  The models are
         created into one group of slabs (egx_gp_create_group) and factored in lock-step (egx_gp_finalize_multi); each is
         bit for bit the model `fit` returns for its training set.  Returns k GaussianProcess objects."""
         self.check()
         t = self._theta_tuning
-        if t.kind != "Fixed" or self._kpls_dim is not None:
-            raise L.InvalidValueError(L.ERR_INVALID_VALUE, "fit_group: fixed theta and no dimension reduction")
+        if t.kind not in ("Fixed", "Full") or self._kpls_dim is not None or (t.kind == "Full" and self._optimizer == "lbfgs"):
+            raise L.InvalidValueError(L.ERR_INVALID_VALUE, "fit_group: ThetaTuning Fixed or Full (COBYLA), no dimension reduction")
         xs = np.asarray(xs, dtype=np.float64)
         ys = np.asarray(ys, dtype=np.float64)
         if ys.ndim == 3 and ys.shape[2] == 1:
@@ -705,14 +719,28 @@ class GpParams:
             raise L.InvalidValueError(
                 L.ERR_INVALID_VALUE,
                 f"Initial guess for theta should be either 1-dim or dim of xtrain (w_star.ncols()), got {t.init.size}")
+        n_evals = [1] * len(hs)
         try:
-            finalize_multi(hs, np.tile(np.atleast_1d(t.init), (len(hs), 1)) if t.init.size == dim
-                           else np.full((len(hs), dim), float(t.init[0])))
+            if t.kind == "Fixed":
+                finalize_multi(hs, np.tile(np.atleast_1d(t.init), (len(hs), 1)) if t.init.size == dim
+                               else np.full((len(hs), dim), float(t.init[0])))
+            else:
+                # ThetaTuning::Full (round 6): every model's multistart -- the same starts for all of them, as the reference's
+                # per-expert fits draw theirs from one fixed seed (optimization.rs:49-66) -- through egx_gp_fit_multi
+                theta0 = np.full(dim, t.init[0]) if t.init.size == 1 else t.init
+                b = t.bounds
+                if len(b) not in (1, dim):  # algorithm.rs:901-912
+                    raise L.InvalidValueError(
+                        L.ERR_INVALID_VALUE, f"Bounds for theta should be either 1-dim or dim of xtrain ({dim}), got {len(b)}")
+                b = b * dim if len(b) == 1 else b
+                starts_log10, _ = prepare_multistart(self._n_start, theta0, b, seed=self._seed)
+                n_evals = [int(v) for v in fit_multi(hs, np.tile(10.0 ** starts_log10, (len(hs), 1, 1)), [lo for lo, _ in b],
+                                                     [hi for _, hi in b], self._max_eval)]
         except Exception:
             for h in hs:
                 h.close()
             raise
-        return [GaussianProcess(h, self, 1) for h in hs]
+        return [GaussianProcess(h, self, ne) for h, ne in zip(hs, n_evals)]
 
 
 class GaussianProcess:

@@ -235,6 +235,17 @@ int32_t egx_gp_create_group(const egx_gp_config *cfg, const double *x, const dou
 int32_t egx_gp_finalize_multi(egx_gp *const *gps, int32_t k, const double *thetas /*k x theta_len*/, int64_t theta_len);
 int32_t egx_gp_likelihood_multi(egx_gp *const *gps, int32_t k, const double *thetas /*k x theta_len*/, int64_t theta_len,
                                 double *lkh /*k*/, int32_t *status /*k*/);
+/* ThetaTuning::Full across MODELS (round 6): the tuned fit the expert loop runs per cluster (crates/moe/src/algorithm.rs:167-177
+ * -> find_best_expert :209-262 -> GpValidParams::fit -> the multistart COBYLA of crates/gp/src/algorithm.rs:921-945), and EGO's
+ * per-output surrogates (crates/ego/src/solver/solver_impl.rs:370-391), for k DISTINCT handles with the same number of
+ * hyperparameters -- the members of a group (egx_gp_create_group) in consecutive slots are evaluated in lock-step: per round
+ * of the k x n_starts COBYLA machines and per start index, the trial points of all models are ONE launch sequence.
+ * theta0s is (k x n_starts x h) in linear theta units (model-major), lo / hi / bounds_len / max_eval as egx_gp_fit,
+ * n_evals_out (k, optional) the evaluations per model.  Every member ends fitted exactly as egx_gp_fit on a one-workspace
+ * handle of its training set would leave it (a machine only sees its own model's values, an evaluation never its companions):
+ * theta*, likelihood and predictions are the same bits. */
+int32_t egx_gp_fit_multi(egx_gp *const *gps, int32_t k, const double *theta0s /*k x n_starts x h*/, int64_t n_starts,
+                         const double *lo, const double *hi, int64_t bounds_len, int64_t max_eval, int64_t *n_evals_out /*k*/);
 /* ThetaTuning::Full fit (algorithm.rs:874-948): multistart derivative-free
  * maximisation of the likelihood over log10(theta) in [lo,hi], then finalize.
  * theta0s is (n_starts x h) in LINEAR theta units: the caller supplies the

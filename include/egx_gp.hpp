@@ -100,9 +100,9 @@ class GpParams {
     GpParams &n_workspaces(int n) { n_workspaces_ = n; return *this; }
     // Fit<..>::fit, algorithm.rs:785-980.  x is (n x d) row-major, y has n entries.
     GaussianProcess fit(const double *x, int64_t n, int64_t d, const double *y) const;
-    // `fit` (fixed theta) for k training sets of one shape at once: x (k x n x d), y (k x n).  The expert loop of egobox-moe
-    // (crates/moe/src/algorithm.rs:167-177) with the experts factored in LOCK-STEP (egx_gp_create_group +
-    // egx_gp_finalize_multi); each model is bit for bit what `fit` returns for its training set.
+    // `fit` (ThetaTuning::Fixed or ::Full) for k training sets of one shape at once: x (k x n x d), y (k x n).  The expert loop of
+    // egobox-moe (crates/moe/src/algorithm.rs:167-177) with the experts factored in LOCK-STEP (egx_gp_create_group +
+    // egx_gp_finalize_multi / egx_gp_fit_multi); each model is what `fit` returns for its training set on one workspace.
     std::vector<GaussianProcess> fit_group(const double *x, const double *y, int64_t n, int64_t d, int32_t k) const;
 
   private:
@@ -215,8 +215,8 @@ class GaussianProcess {
 };
 
 inline std::vector<GaussianProcess> GpParams::fit_group(const double *x, const double *y, int64_t n, int64_t d, int32_t k) const {
-    if (tuning_.kind != ThetaTuning::Kind::Fixed)
-        throw InvalidValueError(EGX_ERR_INVALID_VALUE, "fit_group: ThetaTuning::Fixed only");
+    if (tuning_.kind == ThetaTuning::Kind::Partial)
+        throw InvalidValueError(EGX_ERR_INVALID_VALUE, "fit_group: ThetaTuning::Fixed or ::Full");
     egx_gp_config cfg;
     egx_gp_config_default(&cfg);
     cfg.corr = (int32_t)corr_;
@@ -238,7 +238,41 @@ inline std::vector<GaussianProcess> GpParams::fit_group(const double *x, const d
                                                            std::to_string(tuning_.init.size()));
     std::vector<double> thetas((size_t)k * (size_t)hh);
     for (size_t i = 0; i < thetas.size(); i++) thetas[i] = tuning_.init[tuning_.init.size() == 1 ? 0 : i % (size_t)hh];
-    check(egx_gp_finalize_multi(raw.data(), k, thetas.data(), hh));
+    if (tuning_.kind == ThetaTuning::Kind::Fixed) {
+        check(egx_gp_finalize_multi(raw.data(), k, thetas.data(), hh));
+    } else {
+        // ThetaTuning::Full for every member (round 6, egx_gp_fit_multi): the tuned fit the expert loop runs per cluster
+        // (crates/moe/src/algorithm.rs:209-262 -> crates/gp/src/algorithm.rs:921-945), all models' COBYLA machines in lock-step;
+        // the same starts for every model, as the reference's fits draw theirs from one fixed seed (optimization.rs:49-66)
+        const size_t h = (size_t)hh;
+        if (tuning_.bounds.size() != 1 && tuning_.bounds.size() != h)
+            throw InvalidValueError(EGX_ERR_INVALID_VALUE, "Bounds for theta should be either 1-dim or dim of xtrain (" + std::to_string(h) +
+                                                               "), got " + std::to_string(tuning_.bounds.size()));
+        std::vector<double> lo(h), hi(h);
+        for (size_t i = 0; i < h; i++) {
+            const auto &b = tuning_.bounds[tuning_.bounds.size() == 1 ? 0 : i];
+            lo[i] = b.first, hi[i] = b.second;
+        }
+        const size_t ns = (size_t)std::max(0, n_start_) + 1;
+        std::vector<double> starts(ns * h);
+        for (size_t i = 0; i < h; i++) starts[i] = thetas[i];
+        std::mt19937_64 rng(seed_);  // (the draw of GpParams::fit: a fit_group member gets the starts its lone fit gets)
+        std::uniform_real_distribution<double> u01(0.0, 1.0);
+        for (size_t j = 0; j < h && ns > 1; j++) {
+            std::vector<size_t> perm(ns - 1);
+            for (size_t r = 0; r < ns - 1; r++) perm[r] = r;
+            std::shuffle(perm.begin(), perm.end(), rng);
+            for (size_t r = 0; r < ns - 1; r++) {
+                const double u = ((double)perm[r] + u01(rng)) / (double)(ns - 1);
+                starts[(r + 1) * h + j] = std::pow(10.0, std::log10(lo[j]) + u * (std::log10(hi[j]) - std::log10(lo[j])));
+            }
+        }
+        std::vector<double> all((size_t)k * ns * h);
+        for (int32_t j = 0; j < k; j++) std::copy(starts.begin(), starts.end(), all.begin() + (size_t)j * ns * h);
+        std::vector<int64_t> ne((size_t)k, 0);
+        check(egx_gp_fit_multi(raw.data(), k, all.data(), (int64_t)ns, lo.data(), hi.data(), (int64_t)h, max_eval_, ne.data()));
+        for (int32_t j = 0; j < k; j++) out[(size_t)j].n_evals_ = ne[(size_t)j];
+    }
     for (int32_t j = 0; j < k; j++) {  // theta() / variance() / likelihood() of every member, as `fit` leaves them
         GaussianProcess &gp = out[(size_t)j];
         gp.theta_.resize((size_t)hh);

@@ -208,9 +208,19 @@ static void test_round5_mirror() {
         const auto sg = group[(size_t)e].schedule(), sl = lone.schedule();
         EXPECT(sg == sl && sg[2] == 1 && sg[3] == 1);  // 128 columns: the whole factorisation is one chain launch
     }
+    // round 6: a TUNED fit_group (ThetaTuning::Full, the default: egx_gp_fit_multi -- all members' COBYLA machines in lock-step)
+    // leaves every member where the tuned `fit` of its training set on one workspace leaves it: the same theta*, bit for bit
+    auto tuned = GaussianProcess::params(Mean::Constant, Corr::SquaredExponential).n_start(3).fit_group(xs.data(), ys.data(), n, d, k);
+    for (int32_t e = 0; e < k; e++) {
+        auto lone = GaussianProcess::params(Mean::Constant, Corr::SquaredExponential).n_start(3).fit(xs.data() + (size_t)e * n * d, n, d, ys.data() + (size_t)e * n);
+        EXPECT(tuned[(size_t)e].theta() == lone.theta() && tuned[(size_t)e].likelihood() == lone.likelihood());
+        EXPECT(tuned[(size_t)e].n_evals() == lone.n_evals() && lone.n_evals() > 4);
+    }
     bool threw = false;
     try {
-        (void)GaussianProcess::params(Mean::Constant, Corr::SquaredExponential).fit_group(xs.data(), ys.data(), n, d, k);  // tuned: not for groups
+        (void)GaussianProcess::params(Mean::Constant, Corr::SquaredExponential)
+            .theta_tuning(ThetaTuning::Partial({0.3, 0.3}, {{0.01, 10.0}}, {0}))
+            .fit_group(xs.data(), ys.data(), n, d, k);  // Partial: not for groups
     } catch (const InvalidValueError &) {
         threw = true;
     }

@@ -368,6 +368,52 @@ def test_models_of_a_group_fitted_in_lock_step_are_their_lone_fits_bit_for_bit(e
             h.close()
 
 
+@pytest.mark.parametrize("n,d,k", [(700, 3, 5), (2100, 4, 3)])
+def test_tuned_fits_of_a_group_are_the_lone_tuned_fits_bit_for_bit(egx, n, d, k):
+    """egx_gp_fit_multi (round 6): ThetaTuning::Full for the members of a group -- the tuned fit the expert loop runs per cluster
+    (crates/moe/src/algorithm.rs:167-177 -> :209-262 -> crates/gp/src/algorithm.rs:921-945) -- with the k x n_starts COBYLA
+    machines advanced in lock-step and every round's trial points evaluated as lock-step launch sequences across the models.
+    Each member must end exactly where egx_gp_fit on a one-workspace handle of its training set ends: theta*, likelihood,
+    evaluations and predictions bit for bit."""
+    sets = [_data(n, d, 90 + j) for j in range(k)]
+    lo, hi = np.full(d, 0.05), np.full(d, 5.0)
+    rng = np.random.default_rng(7)
+    starts = 10.0 ** rng.uniform(np.log10(0.1), np.log10(2.0), size=(4, d))
+    xq = rng.uniform(size=(50, d))
+    lone = []
+    for x, y in sets:
+        with egx.GpHandle(x, y, n_workspaces=1) as h:
+            ne = h.fit(starts, lo, hi, 30)
+            lone.append((ne, h.fitted_scalars(), h.inner()["theta"].copy(), h.predict(xq), h.predict_var(xq)))
+    hs = egx.GpHandle.create_group(np.stack([s[0] for s in sets]), np.stack([s[1] for s in sets]))
+    try:
+        nes = egx.fit_multi(hs, np.tile(starts, (k, 1, 1)), lo, hi, 30)
+        for h, ne, want in zip(hs, nes, lone):
+            assert int(ne) == want[0] and h.fitted_scalars() == want[1]
+            np.testing.assert_array_equal(h.inner()["theta"], want[2])
+            np.testing.assert_array_equal(h.predict(xq), want[3])
+            np.testing.assert_array_equal(h.predict_var(xq), want[4])
+        assert len({tuple(w[2]) for w in lone}) == k            # (the members really were tuned apart)
+        with pytest.raises(egx.InvalidValueError, match="distinct"):
+            egx.fit_multi([hs[0], hs[0]], np.tile(starts, (2, 1, 1)), lo, hi, 30)
+    finally:
+        for h in hs:
+            h.close()
+    # ... and through the builder: GpParams.fit_group with ThetaTuning.Full, GpMixture.fit_experts on top of it
+    params = egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr()).n_start(3).max_eval(30)
+    gps = params.fit_group(np.stack([s[0] for s in sets]), np.stack([s[1] for s in sets]))
+    try:
+        assert all(g.n_evals > 4 for g in gps) and all(np.isfinite(g.likelihood()) for g in gps)
+        ref = [params.fit(*s) for s in sets[:2]]
+        for g, r in zip(gps, ref):          # (`fit` tunes on several workspaces -- another schedule row: the same optimum to rounding)
+            assert g.likelihood() == pytest.approx(r.likelihood(), rel=1e-6)
+        for r in ref:
+            r.close()
+    finally:
+        for g in gps:
+            g.close()
+
+
 def test_expert_loop_in_lock_step(egx):
     """GpMixture.fit_experts: clusters of equal size through fit_group, the odd one through fit; predictions of the mixture
     equal those of a mixture of separately fitted experts."""
