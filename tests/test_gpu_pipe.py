@@ -405,8 +405,8 @@ def test_tuned_fits_of_a_group_are_the_lone_tuned_fits_bit_for_bit(egx, n, d, k)
     try:
         assert all(g.n_evals > 4 for g in gps) and all(np.isfinite(g.likelihood()) for g in gps)
         ref = [params.fit(*s) for s in sets[:2]]
-        for g, r in zip(gps, ref):          # (`fit` tunes on several workspaces -- another schedule row: the same optimum to rounding)
-            assert g.likelihood() == pytest.approx(r.likelihood(), rel=1e-6)
+        for g, r in zip(gps, ref):          # (`fit` tunes on several workspaces -- another schedule row, 1e-10 per evaluation --: COBYLA
+            assert g.likelihood() == pytest.approx(r.likelihood(), rel=1e-4)    # stops within its ftol_rel = 1e-4 of the same optimum)
         for r in ref:
             r.close()
     finally:
