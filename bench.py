@@ -636,7 +636,7 @@ _DROP_ORDER = ["cpu_baseline_reference_shaped", "roofline_kernel_alone", "corr_b
 def _schedule_word(s):
     """a handle's schedule (GpHandle.schedule()) as one word"""
     if s.get("flow"):
-        form = "flow"
+        form = "flow" if s["flow"] == 1 else "separate+flow-tail"
     elif s.get("whole_factorisation_launch"):
         form = "whole"
     elif s.get("pipelined_chain"):

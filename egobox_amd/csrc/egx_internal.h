@@ -177,6 +177,7 @@ struct PotrfBatch {
     int pipe = 0;            // ... the chain of every group of panels is one chain launch (schedule.h: per handle)
     int whole = 0;           // ... the WHOLE factorisation is one chain launch (every update inside it)
     int flow = 0;            // ... the whole factorisation is one FLOW launch (pipe_flow.h; one matrix per launch)
+    int flow_tail = 0;       // ... the LAST flow_tail columns of a right-looking factorisation by separate launches are one flow launch
     int group_panels = 0;    // panels per trailing update, from the handle's schedule (0: by size, potrf_group_panels): launch_potrf
                              // never reads the process-wide knobs for a handle that carries its schedule
     int seqs = 1;            // launch sequences of this handle that may be in flight at once (workspaces / lock-step width):
@@ -251,7 +252,10 @@ int pipe_signal(hipStream_t s, const PotrfBatch &pb, int value);
 // The WHOLE factorisation of ONE large matrix as a flow launch (k_potrf_flow; pipe_flow.h: critical stage lists + bulk-class
 // rounds per column, round 6); pb.sync as for the chain launch (pipe_sync_ints covers both).  flow_fits: 256-column panels and
 // a workgroup per diagonal block + workers on the current device.
-int launch_potrf_flow(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info, const PotrfBatch &pb);
+// col_base != 0: (M, n_pad, m_tot, dinv) describe the trailing part of a larger matrix from that column on, which has received
+// every update of the columns before it (launch_potrf's flow tail); only the reported pivot index uses it.
+int launch_potrf_flow(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info, const PotrfBatch &pb,
+                      int col_base = 0);
 bool flow_fits(int n_pad);
 int pipe_enabled();    // EGX_PIPE (default on); 0 as well when the launch cannot be set up on this device
 bool pipe_fits(int nz, int np);  // one workgroup per diagonal block (np panels of nz matrices) + a worker fit the CURRENT device

@@ -405,9 +405,10 @@ static int enqueue_eval_core(egx_gp *const *owners, Workspace *const *wss, int c
     pb.pipe = separate ? 0 : gp->sched.pipe;
     pb.whole = separate ? 0 : gp->sched.whole;
     pb.flow = separate || count > 1 || gp->group ? 0 : gp->sched.flow;
+    pb.flow_tail = separate || count > 1 || gp->group ? 0 : gp->sched.flow_tail;
     pb.group_panels = gp->sched.group_panels;
     pb.seqs = gp->lockstep > 0 ? ((int)gp->ws.size() + gp->lockstep - 1) / gp->lockstep : 1;
-    pb.sync = pb.pipe || pb.flow ? lead_sync : nullptr;  // the chain of a group of panels as one persistent launch (kernels_pipe.hip)
+    pb.sync = pb.pipe || pb.flow || pb.flow_tail ? lead_sync : nullptr;  // the chain of a group of panels as one persistent launch (kernels_pipe.hip)
     pb.sS = gp->stride_S;
     for (int j = 0; j < count; j++) {  // what finish_eval needs to run this evaluation once more, alone, by separate launches
         wss[j]->retry_hcols = hcols;
@@ -1341,7 +1342,7 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
     }
     gp->lockstep = default_lockstep(nws, gp->n_pad);  // candidates of a likelihood batch factored in lock-step: egx_gp_set_lockstep
     gp->sched = schedule_for(gp->n_pad, gp->lockstep, nws);
-    if (t_group_ctx) gp->sched.flow = 0;  // (members of a group are factored in lock-step: the flow launch takes one matrix)
+    if (t_group_ctx) gp->sched.flow = gp->sched.flow_tail = 0;  // (members of a group are factored in lock-step: the flow launch takes one matrix)
     rc = pipe_prepare(gp->n_pad, gp->m_tot, gp->sched);  // the chain launches' task lists: not inside the first evaluation
     if (rc) return fail(rc);
     *out = gp;
@@ -1448,7 +1449,7 @@ int32_t egx_gp_set_lockstep(egx_gp *gp, int32_t width) {
     const int nws = (int)gp->ws.size();
     gp->lockstep = width == 0 ? default_lockstep(nws, gp->n_pad) : (width > nws ? nws : width);
     gp->sched = schedule_for(gp->n_pad, gp->lockstep, nws);
-    if (gp->group) gp->sched.flow = 0;
+    if (gp->group) gp->sched.flow = gp->sched.flow_tail = 0;
     EGX_RC(set_device(gp));
     return pipe_prepare(gp->n_pad, gp->m_tot, gp->sched);
 }
@@ -1530,7 +1531,7 @@ int32_t egx_gp_get_schedule(const egx_gp *gp, int32_t *out, int32_t out_len) {
     out[0] = gp->sched.left, out[1] = gp->sched.w_left, out[2] = gp->sched.pipe, out[3] = gp->sched.whole;
     out[4] = gp->sched.group_panels, out[5] = gp->lockstep;
     for (int32_t i = 6; i < out_len; i++) out[i] = 0;  // (reserved)
-    if (out_len >= 7) out[6] = gp->sched.flow;
+    if (out_len >= 7) out[6] = gp->sched.flow ? 1 : (gp->sched.flow_tail ? 2 : 0);
     return EGX_SUCCESS;
 }
 
@@ -2031,8 +2032,8 @@ int32_t egx_potrf(double *a, int64_t n, int32_t *info) {
     const PotrfSchedule sch = schedule_for(n_pad, 1, 1);
     DevBuf d_sync;  // (ints in double-sized slots)
     PotrfBatch pb;
-    pb.left = sch.left, pb.pipe = sch.pipe, pb.whole = sch.whole, pb.flow = sch.flow, pb.group_panels = sch.group_panels;
-    if (sch.pipe || sch.flow) {
+    pb.left = sch.left, pb.pipe = sch.pipe, pb.whole = sch.whole, pb.flow = sch.flow, pb.flow_tail = sch.flow_tail, pb.group_panels = sch.group_panels;
+    if (sch.pipe || sch.flow || sch.flow_tail) {
         EGX_RC(d_sync.alloc((pipe_sync_ints(n_pad, n_pad) + 1) / 2));
         pb.sync = reinterpret_cast<int *>(d_sync.p);
     }
@@ -2044,7 +2045,7 @@ int32_t egx_potrf(double *a, int64_t n, int32_t *info) {
         if (aborted && g_pipe_retry.load() != 0) {  // once more by separate launches (see finish_eval)
             g_chain_retries++;
             aborted = 0;
-            pb.pipe = pb.whole = pb.flow = 0, pb.sync = nullptr;
+            pb.pipe = pb.whole = pb.flow = pb.flow_tail = 0, pb.sync = nullptr;
             EGX_HIP_CHECK(hipMemset(d_info.p, 0, sizeof(double)));
             EGX_HIP_CHECK(hipMemcpy(d_M.p, hp.data(), sizeof(double) * hp.size(), hipMemcpyHostToDevice));
             EGX_RC(launch_potrf(0, d_M.p, n_pad, n_pad, n_pad, d_dinv.p, reinterpret_cast<int *>(d_info.p), nullptr, nullptr, &pb));

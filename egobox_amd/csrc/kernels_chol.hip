@@ -1097,9 +1097,14 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     //  the separate launches for the whole factorisation.)
     const int GW = (pb.group_panels > 0 ? pb.group_panels : potrf_group_panels(n_pad)) * kNB;
     const bool flow = pb.sync != nullptr && pb.flow != 0 && nz == 1 && flow_fits(n_pad);
-    const bool have_sync = flow || (pb.sync != nullptr && pb.pipe != 0 &&
+    // (a flow launch for the LAST columns of a right-looking factorisation: the switch happens on a group boundary)
+    const int tail_cols = (pb.sync != nullptr && pb.flow_tail > 0 && nz == 1 && !pb.left && pb.flow_tail < n_pad && (n_pad - pb.flow_tail) % GW == 0 &&
+                           flow_fits(pb.flow_tail))
+                              ? pb.flow_tail
+                              : 0;
+    const bool have_sync = flow || tail_cols > 0 || (pb.sync != nullptr && pb.pipe != 0 &&
                                     pipe_fits((int)nz, ((pb.whole || GW > n_pad ? n_pad : GW) + kNB - 1) / kNB));
-    const bool pipe = have_sync && !flow;
+    const bool pipe = have_sync && !flow && tail_cols == 0;
     if (have_sync) EGX_HIP_CHECK(hipMemsetAsync(pb.sync, 0, sizeof(int) * (nz > 1 ? (size_t)pb.sS * nz : pipe_sync_ints(n_pad, m_tot)), s));
     auto gwidth = [&](int g0) { return (n_pad - g0 < GW) ? (n_pad - g0) : GW; };
     // panels of one group on stream `st`; `side` != nullptr splits every in-group update into the next diagonal block
@@ -1292,6 +1297,19 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
         const int r1 = g0 + gw;  // first row/col of the trailing matrix
         if (r1 >= n_pad) break;  // (right-hand-side rows below the last block were solved by its panel)
         const int gw1 = gwidth(r1);
+        if (tail_cols > 0 && n_pad - r1 == tail_cols) {
+            // the flow tail: ONE update of the whole trailing matrix by this group, then the trailing matrix -- every update of the
+            // columns before it applied -- is a factorisation of its own, as one flow launch (pipe_flow.h)
+            rc = update(s, r1, r1, m_tot - r1, n_pad - r1, g0, gw, 1, nullptr);
+            if (rc) return rc;
+            rc = launch_potrf_flow(s, M + (int64_t)r1 * ld + r1, ld, n_pad - r1, m_tot - r1, dinv + (int64_t)(r1 / 64) * 4096, info, pb, r1);
+            if (rc) return rc;
+            for (int t0 = r1; t0 < n_pad; t0 += GW) {
+                rc = inverse_group(s, t0, gwidth(t0));
+                if (rc) return rc;
+            }
+            break;
+        }
         // the cross-stream hand-off costs ~2 x 10 us; below ~3k trailing columns RU is shorter than that (and with
         // several fits in flight the extra hand-offs cost more than they hide: profiles/r02_run23_tail_lookahead_ab.txt)
         const bool look = (s2 != nullptr) && (n_pad - r1 - gw1 >= g_look_min_cols);

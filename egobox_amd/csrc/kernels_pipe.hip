@@ -663,6 +663,8 @@ struct FlowArgs {
     int NI;              // 128-row tiles of the matrix (m_tot / 128)
     int RMAX, off_open, off_cnext, off_lnext, off_tnext, off_rcur, off_rcnt, off_trace;
     int bulk_pairs;      // a workgroup may take two consecutive far tiles with one claim (one look of the scheduler per two tiles)
+    int col_base;        // column of the enclosing matrix the launch's matrix starts at (a flow launch for the LAST columns of a
+                         // larger factorisation): only the reported pivot index needs it
     int lead_short, lead_long;  // a workgroup with a diagonal block ahead of it stops taking short / long tasks this many blocks before its own
     int trace_cap;       // trace slots (profiling builds)
 };
@@ -1171,8 +1173,8 @@ __global__ __launch_bounds__(1024) void k_potrf_flow(FlowArgs f) {
                 pub.trace = tr;
                 if (tr && threadIdx.x == 0) tr[3] = wall_clock64();
 #endif
-                (void)rb_factor_block<16, true>(a.M + (int64_t)k0 * a.ld + k0, a.ld, 256, a.dinv + (int64_t)(k0 / 64) * 4096, info, k0, a.n_pad, sm,
-                                                pub);
+                (void)rb_factor_block<16, true>(a.M + (int64_t)k0 * a.ld + k0, a.ld, 256, a.dinv + (int64_t)(k0 / 64) * 4096, info, f.col_base + k0,
+                                                f.col_base + a.n_pad, sm, pub);
 #ifdef EGX_PIPE_TRACE
                 if (tr && threadIdx.x == 0) tr[4] = wall_clock64();
 #endif
@@ -1338,12 +1340,16 @@ static int flow_plan_get(int dev, int n_pad, int m_tot, FlowPlan &out) {
 }
 // the plans a handle of this shape and schedule will launch, on the current device (egx_gp_create / egx_gp_set_lockstep)
 int pipe_prepare(int n_pad, int m_tot, const PotrfSchedule &sched) {
-    if (!sched.pipe || pipe_init() != EGX_SUCCESS) return EGX_SUCCESS;
+    if ((!sched.pipe && !sched.flow && !sched.flow_tail) || pipe_init() != EGX_SUCCESS) return EGX_SUCCESS;
     int dev = 0;
     EGX_HIP_CHECK(hipGetDevice(&dev));
     if (sched.flow) {
         FlowPlan fp;
         return flow_plan_get(dev, n_pad, m_tot, fp);
+    }
+    if (sched.flow_tail > 0 && sched.flow_tail < n_pad) {
+        FlowPlan fp;
+        return flow_plan_get(dev, sched.flow_tail, m_tot - (n_pad - sched.flow_tail), fp);
     }
     PipePlan pl;
     if (sched.whole) return pipe_plan_get(dev, n_pad, m_tot, 0, (n_pad + 255) / 256, 1, pl);
@@ -1398,7 +1404,7 @@ bool flow_fits(int n_pad) {  // one workgroup per diagonal block + workers on th
 }
 // The whole factorisation of ONE matrix (pb.count == 1) as a flow launch.  The hand-off words (pb.sync: pipe_sync_ints ints,
 // zeroed by launch_potrf) carry the chain launch's words and, behind them, the flow launch's (flow_layout).
-int launch_potrf_flow(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info, const PotrfBatch &pb) {
+int launch_potrf_flow(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, double *dinv, int *info, const PotrfBatch &pb, int col_base) {
     if (pipe_init() != EGX_SUCCESS) {
         set_error("potrf_flow: the launch cannot get its dynamic LDS on this device");
         return EGX_ERR_HIP;
@@ -1426,6 +1432,7 @@ int launch_potrf_flow(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot
     f.RMAX = fl.RMAX, f.off_open = fl.off_open, f.off_cnext = fl.off_cnext, f.off_rcur = fl.off_rcur, f.off_rcnt = fl.off_rcnt;
     f.off_lnext = fl.off_lnext, f.off_tnext = fl.off_tnext, f.off_trace = fl.off_trace;
     f.bulk_pairs = n_pad >= 8192 ? 1 : 0;  // (small matrices: one tile per claim keeps the last rounds balanced)
+    f.col_base = col_base;
     f.lead_short = 1, f.lead_long = 3;
     f.trace_cap = 0;
     int test_wgs = 0;

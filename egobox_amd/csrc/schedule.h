@@ -11,6 +11,7 @@
 //   >= 14336              4 .. 7            -                       0      1        0      0       4
 //   >= 14336              >= 8              -                       1      1        0      0       4
 //   5376 .. 14080         1                 1 workspace, no group   the whole factorisation is ONE FLOW launch (flow = 1; pipe_flow.h)
+//   >= 14336              1                 1 workspace, no group   right-looking by separate launches, the last 6144 .. 7167 columns as a flow launch (flow_tail)
 //
 // left / w_left  left-looking group updates of the factorisation / of the theta-gradient's C^-T rider (EGX_POTRF_LEFT: 0 never,
 //                1 by the table, 2 always).  Measured: n = 16384 in lock-step groups of eight +2.3 % on the sweep, a lone
@@ -36,6 +37,7 @@ namespace egx {
 
 constexpr int kFlowMinCols = 5120;       // a LONE handle (one workspace, not a member of a group) beyond this padded size ...
 constexpr int kFlowMaxCols = 14336;      // ... and below this one factors as ONE flow launch (pipe_flow.h, round 6)
+constexpr int kFlowTailCols = 6144;      // from kFlowMaxCols on: (at least) this many last columns of the right-looking factorisation as a flow launch
 constexpr int kPipeMaxCols = 4096;       // padded size up to which the chain of a group of panels is one launch
 constexpr int kPipeWholeMaxCols = 7168;  // ... up to which the WHOLE factorisation is one launch,
 constexpr int kPipeDiagBlocks = 32;      // while workspaces x panels stays within this
@@ -43,6 +45,7 @@ constexpr int kPipeDiagBlocks = 32;      // while workspaces x panels stays with
 struct PotrfSchedule {
     int left = 0, w_left = 0, pipe = 0, whole = 0, group_panels = 2;
     int flow = 0;  // the whole factorisation of ONE matrix per launch as a flow launch (pipe_flow.h, round 6)
+    int flow_tail = 0;  // columns at the END of a larger lone matrix' right-looking factorisation that are one flow launch (0: none)
 };
 struct ScheduleKnobs {  // egx_set_tuning / environment: "potrf_left", "pipe", "potrf_group"
     int potrf_left = 1, pipe = 1, potrf_group = 0;
@@ -74,6 +77,16 @@ inline PotrfSchedule schedule_table(int n_pad, int lockstep, int n_workspaces, c
     // One matrix per launch: handles with several workspaces and the members of a group (egx_gp_create_group clears the bit) keep
     // the rows above -- `whole` / `pipe` stay set as what such a handle falls back to (a retry, a device the launch does not fit).
     s.flow = k.pipe == 1 && n_workspaces == 1 && lockstep <= 1 && n_pad % 256 == 0 && n_pad > kFlowMinCols && n_pad < kFlowMaxCols;
+    // ... and from kFlowMaxCols on such a handle factors its first columns right-looking by separate launches -- where the trailing
+    // updates are chip-filling 128 x 256 stream launches with K = 1024 at 0.83 of peak -- and its LAST kFlowTailCols columns, where
+    // the chain is what the separate launches wait for, as one flow launch on the fully updated trailing matrix
+    // (profiles/r06_flow_tail_ab.txt)
+    // (n = 16384, ms: separate launches 28.89; the last 4096 / 6144 / 8192 / 10240 / 12288 columns as a flow launch 28.49 / 27.71 / 27.88 /
+    //  27.66 / 28.18; n = 20480: 52.23 against 50.86 / 51.30 with 8192 / 12288.  The switch sits on a boundary of the four-panel
+    //  groups, the tail is the 6144 .. 7167 columns that leaves.)
+    s.flow_tail = (k.pipe == 1 && n_workspaces == 1 && lockstep <= 1 && n_pad % 256 == 0 && n_pad >= kFlowMaxCols && !s.left)
+                      ? n_pad - 1024 * ((n_pad - kFlowTailCols) / 1024)
+                      : 0;
     return s;
 }
 

@@ -45,6 +45,14 @@ int main() {
     for (int n_pad : {1024, 4096, 5120, 14336, 16384})
         if (flow(n_pad, 1, 1, d)) std::printf("n_pad %d: no flow launch at this size\n", n_pad), fails++;
     if (flow(8192, 1, 2, d) || flow(8192, 2, 2, d) || flow(8320, 1, 1, d)) std::printf("flow needs one workspace, width 1, 256-column panels\n"), fails++;
+    // ... and from 14336 columns on its LAST 6144 .. 7167 columns, behind a switch on a four-panel group boundary
+    for (int n_pad = 14336; n_pad <= 24576; n_pad += 256) {
+        const egx::PotrfSchedule a = egx::schedule_table(n_pad, 1, 1, d);
+        if (a.flow || a.flow_tail < 6144 || a.flow_tail >= 7168 || (n_pad - a.flow_tail) % 1024 || a.flow_tail % 256)
+            std::printf("n_pad %d: flow tail %d\n", n_pad, a.flow_tail), fails++;
+        if (egx::schedule_table(n_pad, 1, 2, d).flow_tail || egx::schedule_table(n_pad, 8, 16, d).flow_tail) fails++;
+    }
+    if (egx::schedule_table(8192, 1, 1, d).flow_tail || egx::schedule_table(16384 + 128, 1, 1, d).flow_tail) fails++;
     // the width enters through the lock-step thresholds only, the workspaces through the whole-launch bound only
     for (int n_pad = 128; n_pad <= 20480; n_pad += 128)
         for (int w = 1; w <= 16; w++)

@@ -76,6 +76,7 @@ __global__ void k_resid(const double *L, int64_t ld, int n, double scale, double
 
 static bool g_whole = false;  // PotrfBatch::whole of the next factorisations (the library decides it per handle)
 static bool g_flow = false;   // PotrfBatch::flow: the whole factorisation as a FLOW launch (pipe_flow.h)
+static int g_flow_tail = 0;    // PotrfBatch::flow_tail: the last columns of a right-looking factorisation as a flow launch
 struct Problem {
     int n, n_pad, m_tot, nz;
     int64_t ld;
@@ -127,6 +128,7 @@ struct Problem {
         pb.pipe = pipe ? 1 : 0;
         pb.whole = g_whole ? 1 : 0;
         pb.flow = g_flow && pipe ? 1 : 0;
+        pb.flow_tail = pipe ? g_flow_tail : 0;
         return launch_potrf(s, M, ld, n_pad, m_tot, dinv, info, lk.s2 ? &lk : nullptr, nullptr, &pb, nullptr);
     }
     std::vector<double> download(int z) {
@@ -416,6 +418,50 @@ static int flow_main(int argc, char **argv) {
     return g_fail ? 1 : 0;
 }
 
+// ---- the flow TAIL: right-looking separate launches for the first columns, one flow launch for the last `tail` columns
+static int tail_main(int argc, char **argv) {
+    const double scale = 6.0, nugget = 1e-8;
+    pipe_set_knob("pipe_timeout_ms", 2000);
+    const int n = argc > 2 ? atoi(argv[2]) : 16384;
+    Problem P;
+    P.create(n, 1, true);
+    P.build(0, scale, nugget, 11);
+    if (P.factor(0, false)) return 3;
+    CK(hipDeviceSynchronize());
+    const std::vector<double> ref = P.download(0);
+    const double res_ref = residual(P, 0, scale, nugget, 11);
+    const double t_sep = time_factor(P, false, scale, nugget, 5);
+    printf("time    n=%d: separate launches %.3f ms\n", n, t_sep);
+    for (int i = 3; i < argc; i++) {
+        g_flow_tail = atoi(argv[i]);
+        P.build(0, scale, nugget, 11);
+        if (P.factor(0, true)) return 3;
+        CK(hipDeviceSynchronize());
+        double rel;
+        bool same;
+        compare(P, ref, P.download(0), rel, same);
+        const double res = residual(P, 0, scale, nugget, 11);
+        verdict(rel < 2e-5 && res < 50 * std::max(res_ref, 1e-15) && P.abort_word() == 0 && P.infos()[0] == 0,
+                "tail    n=%d last %d columns as a flow launch: vs separate launches %.2e, residual %.2e (separate %.2e), info %d abort %d", n, g_flow_tail, rel, res,
+                res_ref, P.infos()[0], P.abort_word());
+        const int bad = n - g_flow_tail / 2 + 33;  // a lost pivot inside the tail: the index of the whole matrix
+        P.build(0, scale, nugget, 11);
+        CK(hipDeviceSynchronize());
+        const double v = -1.0;
+        CK(hipMemcpy(P.M + (size_t)bad * P.ld + bad, &v, 8, hipMemcpyHostToDevice));
+        if (P.factor(0, true)) return 3;
+        CK(hipDeviceSynchronize());
+        verdict(P.infos()[0] == bad + 1 && P.abort_word() == 0, "tail    n=%d: lost pivot in the tail, info %d (want %d), abort %d", n, P.infos()[0], bad + 1, P.abort_word());
+        const double t = time_factor(P, true, scale, nugget, 5);
+        printf("time    n=%d: flow tail of %d columns %.3f ms (separate %.3f)\n", n, g_flow_tail, t, t_sep);
+        fflush(stdout);
+    }
+    g_flow_tail = 0;
+    P.destroy();
+    printf("%s\n", g_fail ? "TAIL CHECK FAILED" : "tail check ok");
+    return g_fail ? 1 : 0;
+}
+
 // one traced flow factorisation: every task with the times it was taken / became ready / finished (100 MHz clock)
 static int ftrace_main(int n, int verbose) {
     const double scale = 6.0, nugget = 1e-8;
@@ -510,6 +556,7 @@ static int ftrace_main(int n, int verbose) {
 int main(int argc, char **argv) {
     if (chol_init()) return 1;
     if (argc > 1 && std::string(argv[1]) == "flow") return flow_main(argc, argv);
+    if (argc > 1 && std::string(argv[1]) == "tail") return tail_main(argc, argv);
     if (argc > 1 && std::string(argv[1]) == "ftrace") return ftrace_main(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 0);
     if (argc > 1 && std::string(argv[1]) == "diag") return diag_alone_main();
     if (argc > 1 && std::string(argv[1]) == "trace")
