@@ -1081,7 +1081,7 @@ def main():
                                 "the measurement",
                     "kernel_source_sha256": ll_pmc.get("kernel_source_sha256"),
                     "file": "profiles/" + os.path.basename(ll_path) + " (from ..._pass1-3.json: separate rocprofv3 --pmc passes of "
-                            "tools/group_roofline.py, tools/gpu_pmc_r05.sh + tools/pmc_group_summary.py, offline)",
+                            "tools/group_roofline.py, tools/gpu_pmc.sh group + tools/pmc_group_summary.py, offline)",
                     "fetch_size_bytes_per_launch_raw": ll_pmc["fetch_bytes_per_launch"],
                     "write_size_bytes_per_launch_raw": ll_pmc["write_bytes_per_launch"],
                     "correction": ll_pmc["correction"], "l2_hit_rate": ll_pmc["l2_hit_rate"],
@@ -1106,7 +1106,7 @@ def main():
                          "how": "algorithmic flops (2*K*ncols*(ncols+1)/2 per launch, K = group width) / HIP-event durations around every "
                                 "launch on the stream it is launched on, one fit in flight (separate leg after the timed "
                                 "region; in the timed region the candidates in flight overlap and share the GPU)",
-                         "traffic_measured": "offline: separate rocprofv3 --pmc passes (tools/gpu_pmc_r03.sh), committed under "
+                         "traffic_measured": "offline: separate rocprofv3 --pmc passes (tools/gpu_pmc.sh lone), committed under "
                                              "profiles/ and READ here, not measured by this run",
                          "traffic_source": (None if pmc is None else
                                             {"file": os.path.relpath(PMC_SUMMARY, ROOT),

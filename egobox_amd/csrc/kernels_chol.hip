@@ -849,7 +849,7 @@ __global__ void k_gram_reduce(const double *__restrict__ P, int rows, int nsplit
 // =============================================================================================
 // The run-time settings that survive (environment, read once; egx_set_tuning for A/B runs inside one process).  With EGX_PIPE
 // and EGX_PIPE_TIMEOUT_MS (kernels_pipe.hip) that makes eight; everything else that was ever switchable is a constant now,
-// its A/B in profiles/ (DESIGN.md appendix B lists them).  Atomics: a setting may change while another thread evaluates --
+// its A/B in profiles/ (docs/HISTORY.md §B lists them).  Atomics: a setting may change while another thread evaluates --
 // that thread then sees the old or the new value per read, never a torn one (schedules are per handle and not affected).
 static std::atomic<int> g_potrf_group{0};         // EGX_POTRF_GROUP: panels per trailing update, 1..8 (0 = by size: 4 from n_pad 14336, else 2)
 static std::atomic<int> g_stream_min_tiles{128};  // EGX_STREAM_MIN: launches with at least this many 128x256 tiles PER MATRIX go to k_gemm_stream

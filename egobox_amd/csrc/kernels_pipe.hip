@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(1024) void k_potrf_flow(FlowArgs f) {
 // Run-time settings (egx_set_tuning / environment): EGX_PIPE, EGX_PIPE_TIMEOUT_MS and EGX_PIPE_RETRY (gp_host.hip).  What else
 // was switchable while the launch was developed is a constant now, with its measurement: workgroups of a launch (one per
 // compute unit; 96 beside other launches of the same factorisation), the queue order of the coarse updates (16 panels ahead =
-// right-looking), the size up to which the chain is one launch (schedule.h) -- profiles/r05_pipe_*.txt, DESIGN.md appendix B.
+// right-looking), the size up to which the chain is one launch (schedule.h) -- profiles/r05_pipe_*.txt, docs/HISTORY.md §B.
 static std::atomic<int> g_pipe{1};               // EGX_PIPE: 0 separate launches everywhere, 1 by the handle's schedule (schedule.h), 2 chain launches per group only
 static std::atomic<int> g_pipe_timeout_ms{2000};  // EGX_PIPE_TIMEOUT_MS: bound of every wait inside the launch
 constexpr int kPipeSharedWgs = 96;  // workgroups of a chain launch that runs beside other launches of its factorisation

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel PMC sums of the serial path's kernels (k_potf2_reg, k_panel_trsm16, k_gemm_nt_sub 64x64) from one
-rocprofv3 --kernel-trace --pmc pass of tools/one_fit.py (see tools/gpu_pmc_chain.sh):
+rocprofv3 --kernel-trace --pmc pass of tools/one_fit.py (see tools/gpu_pmc.sh chain):
     python tools/pmc_chain_kernels.py out.json results.db"""
 import json
 import sqlite3

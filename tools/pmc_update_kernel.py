@@ -56,7 +56,7 @@ def main(out, n, dbs):
             per_xcd[ctr] = per_xcd.get(ctr, 0) + 1
             ndisp.setdefault(ctr, set()).add((db, did))
     res = {"source": "rocprofv3 --kernel-trace --pmc (separate passes) -- python tools/one_fit.py 16384 32 3 0 (lone fits, one in flight; "
-                     "tools/gpu_pmc_r04.sh; EGX_STREAM_WALK selected the tile walk while that code existed)",
+                     "tools/gpu_pmc.sh lone; EGX_STREAM_WALK selected the tile walk while that code existed)",
            "kernel": "k_gemm_stream<LOWER> (>= 512 tiles of 128x256)", "n": n}
     def per_launch(c):
         if c not in agg:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One expert of BASELINE config 5 (n = 8192, d = 16): fit, then predict and predict_var on 100 000 points -- the command the
-predict-side PMC pass profiles (tools/gpu_pmc_predict.sh)."""
+predict-side PMC pass profiles (tools/gpu_pmc.sh predict)."""
 import os
 import sys
 
