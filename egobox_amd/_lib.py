@@ -17,6 +17,9 @@ LIB_PATH = os.path.join(_HERE, "lib", "libegx_gp_hip.so")
 #: instead of the product library only when EGX_TEST_LIBRARY=1 is set -- by tests that force a hand-off to fail, in a
 #: process of their own.  Never the default, never used by bench.py.
 TEST_LIB_PATH = os.path.join(_HERE, "lib", "_dev", "libegx_gp_hip_testhooks.so")
+#: EGX_TEST_LIBRARY=trace: the profiling build with per-tile stamps in the left-looking group updates (tools/dev_build.sh trace;
+#: tools/long_update_attribution.py) -- built by hand, never by build(), never the default
+TRACE_LIB_PATH = os.path.join(_HERE, "lib", "_dev", "libegx_gp_hip_trace.so")
 
 # return codes / status values (egx_rc, egx_status)
 SUCCESS, ERR_INVALID_VALUE, ERR_NO_DEVICE, ERR_HIP, ERR_NOT_FITTED, ERR_LINALG, ERR_LIKELIHOOD, ERR_UNSUPPORTED, ERR_PEER = range(9)
@@ -181,7 +184,8 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = TEST_LIB_PATH if os.environ.get("EGX_TEST_LIBRARY") == "1" else LIB_PATH
+    which = os.environ.get("EGX_TEST_LIBRARY")
+    path = TEST_LIB_PATH if which == "1" else TRACE_LIB_PATH if which == "trace" else LIB_PATH
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -208,6 +208,14 @@ typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 // accumulators start at ZERO and C <- -(W W^T) is written without being read (no memset of C, no read pass).
 // TAG: no effect on the code -- the left-looking group updates get kernel symbols of their own (1: the long update, 2: the
 // short one), so that `rocprofv3 --kernel-trace --stats` lists the launches bench.py's roofline times as their own row.
+#ifdef EGX_STREAM_TRACE
+// Profiling builds only (tools/dev_build.sh trace -> egobox_amd/lib/_dev/libegx_gp_hip_trace.so; tools/long_update_attribution.py):
+// every tile of the TAGGED launches (the left-looking long / short group updates) leaves one record of kStraceWords words --
+// where it ran, the 100-MHz wall clock at its start, around its K loop and at its end, the shader-clock counter around the K loop.
+// [0] = records taken so far, [1] = capacity; records from word 16 on.
+constexpr int kStraceWords = 10;
+__device__ long long *g_strace = nullptr;
+#endif
 template <bool LOWER, bool KTRI = false, int TAG = 0>
 __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, int64_t ldc, const double *__restrict__ A,
                                                         int64_t lda, const double *__restrict__ B, int64_t ldb, int K,
@@ -324,6 +332,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
         int bx, by;
         tile_of(t, bx, by);
         double *Ct = C + (int64_t)(bx * 128 + wm0) * ldc + by * 256 + wn0;
+#ifdef EGX_STREAM_TRACE
+        long long *trp = nullptr;
+        if (TAG != 0 && tid == 0 && g_strace != nullptr) {
+            const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long *>(g_strace), 1ull);
+            if ((long long)slot < g_strace[1]) trp = g_strace + 16 + kStraceWords * slot;
+        }
+        if (trp) {
+            trp[0] = (long long)(C - (int64_t)blockIdx.z * bt.sC);  // the launch: its first matrix' C
+            trp[1] = ((long long)TAG << 60) | ((long long)blockIdx.z << 52) | ((long long)nch << 32) | (long long)t;
+            trp[2] = (long long)__builtin_amdgcn_s_getreg(0xF804) | ((long long)__builtin_amdgcn_s_getreg(0xF814) << 32);  // HW_ID, XCC_ID
+            trp[3] = wall_clock64();
+            trp[9] = ((long long)bx << 32) | by;
+        }
+#endif
         double4_t acc[4][4];
 #pragma unroll
         for (int mi = 0; mi < 4; mi++)
@@ -362,6 +384,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
             __builtin_amdgcn_s_barrier();
             read_half(0, 0, a0, b0);
         }
+#ifdef EGX_STREAM_TRACE
+        if (trp) trp[4] = wall_clock64(), trp[5] = clock64();
+#endif
         for (int ch = 0; ch < nch; ch++, g++) {
             d2_t a1[4], b1[4];
             read_half(stage, 1, a1, b1);
@@ -386,6 +411,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
         }
         // (the 16 row pointers of the C tile are rebuilt here instead of staying live through the K loop: the opaque
         //  pass through an empty asm keeps the compiler from carrying 32 address VGPRs across 2048 MFMAs)
+#ifdef EGX_STREAM_TRACE
+        if (trp) trp[6] = wall_clock64(), trp[7] = clock64();
+#endif
 #pragma unroll
         for (int r = 0; r < 4; r++) asm volatile("" : "+v"(coff[r]));
 #pragma unroll
@@ -394,8 +422,46 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
             for (int ni = 0; ni < 4; ni++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) Ct[(int64_t)mi * 16 * ldc + ni * 16 + coff[r]] = -acc[mi][ni][r];
+#ifdef EGX_STREAM_TRACE
+        if (trp) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            trp[8] = wall_clock64();
+        }
+#endif
     }
 }
+
+#ifdef EGX_STREAM_TRACE
+}  // namespace egx
+// mode 1: start recording into a fresh device buffer of `cap` records; mode 0: stop, copy the records taken (at most cap) to
+// `out` (kStraceWords words each) and return their number
+extern "C" long long egx_dev_stream_trace(int mode, long long *out, long long cap) {
+    static long long *dbuf = nullptr;
+    static long long dcap = 0;
+    long long *null = nullptr;
+    if (mode == 1) {
+        if (dbuf) (void)hipFree(dbuf);
+        dcap = cap;
+        if (hipMalloc(&dbuf, sizeof(long long) * (16 + egx::kStraceWords * cap)) != hipSuccess) return -1;
+        (void)hipMemset(dbuf, 0, sizeof(long long) * (16 + egx::kStraceWords * cap));
+        (void)hipMemcpy(dbuf + 1, &cap, sizeof(long long), hipMemcpyHostToDevice);
+        if (hipMemcpyToSymbol(HIP_SYMBOL(egx::g_strace), &dbuf, sizeof(dbuf)) != hipSuccess) return -2;
+        return 0;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(egx::g_strace), &null, sizeof(null));
+    if (!dbuf) return 0;
+    long long taken = 0;
+    (void)hipMemcpy(&taken, dbuf, sizeof(long long), hipMemcpyDeviceToHost);
+    if (taken > dcap) taken = dcap;
+    if (taken > cap) taken = cap;
+    if (out && taken > 0) (void)hipMemcpy(out, dbuf + 16, sizeof(long long) * egx::kStraceWords * taken, hipMemcpyDeviceToHost);
+    (void)hipFree(dbuf);
+    dbuf = nullptr;
+    return taken;
+}
+namespace egx {
+#endif
 
 constexpr int TS = 64;
 constexpr int TLD = 65;  // padded LDS row (doubles): per-lane row accesses are conflict free

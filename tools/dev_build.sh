@@ -1,11 +1,16 @@
 #!/bin/bash
-# A/B builds: the library with -DEGX_DEV_KNOBS (environment overrides of schedule constants, schedule.h / kernels_pipe.hip) of the library into egobox_amd/lib/_dev/libegx_gp_hip.so (objects in /tmp)
+# Scratch builds of the library under egobox_amd/lib/_dev/ (objects in /tmp), never the product:
+#   tools/dev_build.sh          -DEGX_DEV_KNOBS  -> libegx_gp_hip.so        environment overrides of schedule constants (schedule.h / kernels_pipe.hip) for A/Bs
+#   tools/dev_build.sh trace    -DEGX_STREAM_TRACE -> libegx_gp_hip_trace.so  per-tile stamps of the left-looking group updates
+#                                (k_gemm_stream, kernels_chol.hip): what tools/long_update_attribution.py loads (EGX_TEST_LIBRARY=trace)
 set -e
-cd /root/repo/egobox_amd/csrc
-mkdir -p /tmp/devobj ../lib/_dev
+cd "$(dirname "$0")/../egobox_amd/csrc"
+MODE=${1:-knobs}
+if [ "$MODE" == "trace" ]; then DEF=-DEGX_STREAM_TRACE; OUT=libegx_gp_hip_trace.so; OBJ=/tmp/devobj_trace; else DEF=-DEGX_DEV_KNOBS; OUT=libegx_gp_hip.so; OBJ=/tmp/devobj; fi
+mkdir -p $OBJ ../lib/_dev
 for f in kernels_chol kernels_pipe kernels_corr gp_host gp_predict gp_fit sgp_host sweep; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DEGX_DEV_KNOBS -Wno-unused-value -Wno-unused-result -c $f.hip -o /tmp/devobj/$f.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $DEF -Wno-unused-value -Wno-unused-result -c $f.hip -o $OBJ/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/devobj/*.o -ldl -o ../lib/_dev/libegx_gp_hip.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJ/*.o -ldl -o ../lib/_dev/$OUT
 ls -la ../lib/_dev/
