@@ -185,7 +185,14 @@ def load():
     if _lib is not None:
         return _lib
     which = os.environ.get("EGX_TEST_LIBRARY")
-    path = TEST_LIB_PATH if which == "1" else TRACE_LIB_PATH if which == "trace" else LIB_PATH
+    if which == "1":
+        path = TEST_LIB_PATH
+    elif which == "trace":
+        path = TRACE_LIB_PATH
+    elif which:  # any other scratch build of tools/dev_build.sh <name> <defines>: A/B measurements (tools/ab_lib.py)
+        path = os.path.join(_HERE, "lib", "_dev", f"libegx_gp_hip_{which}.so")
+    else:
+        path = LIB_PATH
     if not os.path.exists(path):
         raise ImportError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

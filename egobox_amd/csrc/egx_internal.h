@@ -216,6 +216,11 @@ struct SolveBatchPtrs {
     const double *M[kMax], *dinv[kMax];
     double *dW[kMax], *rhs[kMax], *vec[kMax];
 };
+// the buffer of the 256 x 256 inverse blocks (launch_block_inverse: Wall / dW) carries, behind the blocks, the start ticket and
+// the exchange buffer of the one-launch back-substitution (k_trsv_t_fused): allocate block_inverse_doubles(n_pad) doubles
+inline size_t trsv_tail_doubles(int n_pad) { return 4 + (size_t)n_pad; }
+inline size_t block_inverse_doubles(int n_pad) { return (size_t)((n_pad + kNB - 1) / kNB) * 65536 + trsv_tail_doubles(n_pad); }
+long long pipe_timeout_ticks();  // EGX_PIPE_TIMEOUT_MS in ticks of the 100-MHz wall clock (kernels_pipe.hip)
 int launch_block_inverse_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64_t ld, int n_pad);
 int launch_trsv_t_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64_t ld, int n_pad);
 int launch_block_inverse(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *dinv, double *Wall);

@@ -791,7 +791,7 @@ int eval_one(egx_gp *gp, int widx, const double *theta, int64_t theta_len, EvalR
 
 // w.d_vec <- C^-T w.d_rhs  (block inverses are rebuilt: the factor in w.M has just changed)
 static int ensure_block_inverse_buffer(egx_gp *gp, Workspace &w) {
-    if (!w.dW) EGX_HIP_CHECK(dev_malloc(&w.dW, sizeof(double) * (size_t)((gp->n_pad + kNB - 1) / kNB) * 65536));
+    if (!w.dW) EGX_HIP_CHECK(dev_malloc(&w.dW, sizeof(double) * block_inverse_doubles(gp->n_pad)));
     return EGX_SUCCESS;
 }
 // The inverse blocks only need the factor, not the host's half of the likelihood: a fit launches them right behind the
@@ -937,6 +937,13 @@ static int finalize_tail_complete(egx_gp *gp, const std::vector<double> &coef, i
     EvalResult &res = ft.res;
     EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
     auto t2 = std::chrono::steady_clock::now();
+    // (the one-launch back-substitution poisons gamma with NaN when one of its bounded waits ran out, kernels_chol.hip)
+    for (int i = 0; i < gp->n; i++)
+        if (!std::isfinite(w.h_vec[i])) {
+            set_error("back-substitution gamma = C^-T rho: non-finite result (the launch ran into its wait bound, EGX_PIPE_TIMEOUT_MS, "
+                      "or rho is not finite)");
+            return EGX_ERR_HIP;
+        }
     gp->gamma.assign(w.h_vec, w.h_vec + gp->n);
     gp->theta = thfull;
     gp->likelihood = res.lkh;

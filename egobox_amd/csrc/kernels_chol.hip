@@ -208,9 +208,13 @@ typedef const __attribute__((address_space(1))) void *gbl_ptr_t;
 // accumulators start at ZERO and C <- -(W W^T) is written without being read (no memset of C, no read pass).
 // TAG: no effect on the code -- the left-looking group updates get kernel symbols of their own (1: the long update, 2: the
 // short one), so that `rocprofv3 --kernel-trace --stats` lists the launches bench.py's roofline times as their own row.
+#ifndef EGX_STREAM_ILV
+#define EGX_STREAM_ILV 1  // the LDS-DMA issues of a chunk interleaved with the first MFMAs behind its barrier (0: all six in a row, rounds 2-5)
+#endif
 #ifdef EGX_STREAM_TRACE
 // Profiling builds only (tools/dev_build.sh trace -> egobox_amd/lib/_dev/libegx_gp_hip_trace.so; tools/long_update_attribution.py):
-// every tile of the TAGGED launches (the left-looking long / short group updates) leaves one record of kStraceWords words --
+// every tile of the stream kernel (tag 1 / 2: the left-looking long / short group updates; 0: other LOWER launches; 4: rectangles --
+// the in-group updates) leaves one record of kStraceWords words --
 // where it ran, the 100-MHz wall clock at its start, around its K loop and at its end, the shader-clock counter around the K loop.
 // [0] = records taken so far, [1] = capacity; records from word 16 on.
 constexpr int kStraceWords = 10;
@@ -334,13 +338,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
         double *Ct = C + (int64_t)(bx * 128 + wm0) * ldc + by * 256 + wn0;
 #ifdef EGX_STREAM_TRACE
         long long *trp = nullptr;
-        if (TAG != 0 && tid == 0 && g_strace != nullptr) {
+        if (tid == 0 && g_strace != nullptr) {
             const unsigned long long slot = atomicAdd(reinterpret_cast<unsigned long long *>(g_strace), 1ull);
             if ((long long)slot < g_strace[1]) trp = g_strace + 16 + kStraceWords * slot;
         }
         if (trp) {
             trp[0] = (long long)(C - (int64_t)blockIdx.z * bt.sC);  // the launch: its first matrix' C
-            trp[1] = ((long long)TAG << 60) | ((long long)blockIdx.z << 52) | ((long long)nch << 32) | (long long)t;
+            trp[1] = ((long long)(TAG | (LOWER ? 0 : 4)) << 60) | ((long long)blockIdx.z << 52) | ((long long)nch << 32) | (long long)t;
             trp[2] = (long long)__builtin_amdgcn_s_getreg(0xF804) | ((long long)__builtin_amdgcn_s_getreg(0xF814) << 32);  // HW_ID, XCC_ID
             trp[3] = wall_clock64();
             trp[9] = ((long long)bx << 32) | by;
@@ -378,6 +382,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
             mma_quarter(a, b, 0);
             mma_quarter(a, b, 1);
         };
+        // MFMA i of a quarter, in mma_quarter's order (mi outer, ni inner)
+#define EGX_ST_MMA(a, b, h, i) \
+    acc[(i) >> 2][(i) & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[(i) >> 2][h], b[(i) & 3][h], acc[(i) >> 2][(i) & 3], 0, 0, 0)
         if (g == 0) {  // the workgroup's very first chunk: the classic wait + barrier in front of its first read
             if (issued > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -395,6 +402,38 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
             const bool next = g + 1 < total;   // another chunk follows (possibly the next tile's first)
             const bool more = issued < total;  // ... and one more to prefetch
             const int st1 = (stage == ST_NSTAGE - 1) ? 0 : stage + 1;
+#if EGX_STREAM_ILV
+            // round 6: behind the barrier every wave of the workgroup stands at the same instruction; six LDS-DMA issues in a row
+            // (address, M0, wait state, load: ~25 instructions) left all four MFMA pipes of the CU empty for as long.  The pieces
+            // of chunk g + 2 (-> stage of chunk g - 1) now go out one by one BETWEEN the first MFMAs behind the barrier, whose
+            // fragments were read before it (in-situ trace: MFMA issue inside the K loop 0.930 before)
+            if (next) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own pieces of chunk g + 1 (the only ones in flight)
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {   // (the MFMAs stay outside the branches: inside, the accumulators met again as 128 phi copies -- spills)
+                const bool ld = next && more;
+                const int ist = stage == 0 ? 2 : stage - 1;
+                // 3, 2, 2, 2, 2, 2 MFMAs in front of pieces 0 .. 5, three behind
+#define EGX_ST_PIECE(q) __builtin_amdgcn_sched_barrier(0); if (ld) issue_pieces(ist, q, q + 1); __builtin_amdgcn_sched_barrier(0)
+                EGX_ST_MMA(a1, b1, 0, 0); EGX_ST_MMA(a1, b1, 0, 1); EGX_ST_MMA(a1, b1, 0, 2);
+                EGX_ST_PIECE(0);
+                EGX_ST_MMA(a1, b1, 0, 3); EGX_ST_MMA(a1, b1, 0, 4);
+                EGX_ST_PIECE(1);
+                EGX_ST_MMA(a1, b1, 0, 5); EGX_ST_MMA(a1, b1, 0, 6);
+                EGX_ST_PIECE(2);
+                EGX_ST_MMA(a1, b1, 0, 7); EGX_ST_MMA(a1, b1, 0, 8);
+                EGX_ST_PIECE(3);
+                EGX_ST_MMA(a1, b1, 0, 9); EGX_ST_MMA(a1, b1, 0, 10);
+                EGX_ST_PIECE(4);
+                EGX_ST_MMA(a1, b1, 0, 11); EGX_ST_MMA(a1, b1, 0, 12);
+                EGX_ST_PIECE(5);
+                EGX_ST_MMA(a1, b1, 0, 13); EGX_ST_MMA(a1, b1, 0, 14); EGX_ST_MMA(a1, b1, 0, 15);
+#undef EGX_ST_PIECE
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#else
             if (next) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // own pieces of chunk g + 1 (the only ones in flight)
                 __builtin_amdgcn_s_barrier();
@@ -403,6 +442,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_stream(double *__restrict__ C, 
             __builtin_amdgcn_sched_barrier(0);
             mma_quarter(a1, b1, 0);  // (fragments read before the first half: nothing to wait for behind the barrier)
             __builtin_amdgcn_sched_barrier(0);
+#endif
             if (next && more) issue_done();
             if (next) read_half(st1, 0, a0, b0);
             __builtin_amdgcn_sched_barrier(0);
@@ -853,6 +893,110 @@ __global__ __launch_bounds__(256) void k_gemv_t_update_batch(SolveBatchPtrs b, i
 // ---------------------------------------------------------------------------------------------
 // MFMA layout probe: C(16x16) = A(16x16) B(16x16) with asymmetric operands.
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// gamma = C^-T rho as ONE launch (round 6; launch_trsv_t / launch_trsv_t_batch): the block back-substitution above is
+// 2 n / 256 launches of ~5 us in a row -- 0.81 ms of a 29.6-ms fit at n = 16384, 0.16 of 1.7 ms at n = 4096 -- for 1.07 GB of
+// factor that stream in 0.2 ms.  Here one workgroup per 64 COLUMNS of the right-hand side (a segment) keeps that piece of
+// rho in registers, takes the blocks' solutions x_b in order b = last ... as they appear (its 256 x 64 piece of L fetched
+// BEFORE it waits: the factor is final, only x_b is not), and when its own block is next the (up to) four segment workgroups
+// of that block exchange their finished pieces of the right-hand side, each applies 64 rows of W_b = (L_bb^-1)^T (fetched
+// before the wait as well) and publishes them.  Exactly the sums of k_trsv_w / k_gemv_t_update in their order: the same bits
+// as the launch-per-block form ("trsv_fused" = 0).
+//   * segments are taken by a START ticket from the LAST one down, so a workgroup only ever waits for segments that started
+//     before it (x_b of later blocks) or for the three other segments of its own block, whose tickets follow directly: no
+//     deadlock on any device that holds four of these workgroups at once, whatever the dispatch order.
+//   * hand-offs WITHOUT flags: the solution vector and the exchange buffer start as all-ones words (a NaN no arithmetic
+//     produces); a value is one 8-byte agent-scope store, a consumer polls the very word it needs with agent-scope loads --
+//     one trip through the fabric per hand-off instead of two (counter, then payload: 9 us per block measured, the launches
+//     it replaced 12.6).
+//   * every wait is bounded (the chain launch's EGX_PIPE_TIMEOUT_MS): a waiter whose time runs out goes on with a NaN of its
+//     own, which reaches every later block -- nobody hangs, and the host's finite-check of gamma reports EGX_ERR_HIP instead
+//     of returning a wrong model.
+// tail (behind the inverse blocks, 0xFF-filled by the launcher): [0] the start ticket (an int, from -1), [4 ..] the finished
+// right-hand side (n_pad doubles).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double trsv_poll(const double *p, long long limit) {
+    long long t0 = 0;
+    for (unsigned spins = 1;; spins++) {
+        const double v = load_sc1(p);
+        if (__double_as_longlong(v) != -1ll) return v;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 63) == 0) {
+            if (t0 == 0) t0 = wall_clock64();
+            else if (wall_clock64() - t0 > limit) return __builtin_nan("");
+        }
+    }
+}
+__device__ __forceinline__ void trsv_fused_body(const double *__restrict__ M, int64_t ld, int n_pad, const double *__restrict__ Wall,
+                                                const double *__restrict__ rhs, double *x, double *tail, long long limit) {
+    __shared__ double xs[256];
+    __shared__ double red[4][64];
+    __shared__ int s_seg;
+    const int tid = threadIdx.x, g = tid >> 6, jl = tid & 63;
+    const int nblocks = (n_pad + kNB - 1) / kNB, nseg = n_pad / 64;
+    double *rfin = tail + 4;
+    if (tid == 0) s_seg = nseg - 2 - __hip_atomic_fetch_add(reinterpret_cast<int *>(tail), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int seg = s_seg;
+    if (seg < 0) return;
+    const int blk = seg >> 2, j = seg * 64 + jl;
+    double r = (g == 0) ? rhs[j] : 0.0;
+    double mv[4][16];
+    for (int b = nblocks - 1; b > blk; b--) {
+        const int k0 = b * kNB;
+        const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;  // a multiple of 64
+        const double *Mrow = M + (int64_t)k0 * ld;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (q * 64 < nbk) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) mv[q][u] = Mrow[(int64_t)(g + 64 * q + 4 * u) * ld + j];
+            }
+        if (tid < nbk) xs[tid] = trsv_poll(x + k0 + tid, limit);
+        __syncthreads();
+        double part = 0.0;  // (the order of k_gemv_t_update: rows g, g + 4, ... of each 64-row quarter, quarter by quarter)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (q * 64 < nbk) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) part = __builtin_fma(mv[q][u], xs[g + 64 * q + 4 * u], part);
+            }
+        red[g][jl] = part;
+        __syncthreads();
+        if (g == 0) r -= ((red[0][jl] + red[1][jl]) + red[2][jl]) + red[3][jl];
+    }
+    // this segment of the right-hand side is final: publish it, then 64 rows of x_blk = W_blk r_blk
+    const int k0 = blk * kNB;
+    const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;
+    if (g == 0) __hip_atomic_store(rfin + j, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int lane = jl, wave = g;
+    const int row0 = (seg & 3) * 64 + wave * 16;  // this wave's 16 rows of the block
+    const double *W = Wall + (int64_t)blk * 65536;
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const double *row = W + (int64_t)(row0 + u) * 256;
+        mv[0][u] = row[lane], mv[1][u] = row[lane + 64], mv[2][u] = row[lane + 128], mv[3][u] = row[lane + 192];
+    }
+    __syncthreads();  // (xs: the last update's reads are done)
+    xs[tid] = (tid < nbk) ? trsv_poll(rfin + k0 + tid, limit) : 0.0;
+    __syncthreads();
+    const double v0 = xs[lane], v1 = xs[lane + 64], v2 = xs[lane + 128], v3 = xs[lane + 192];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        double a = mv[0][u] * v0 + mv[1][u] * v1 + mv[2][u] * v2 + mv[3][u] * v3;  // (k_trsv_w's expression)
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0 && row0 + u < nbk) __hip_atomic_store(x + k0 + row0 + u, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__global__ __launch_bounds__(256) void k_trsv_t_fused(const double *__restrict__ M, int64_t ld, int n_pad, const double *__restrict__ Wall,
+                                                      const double *__restrict__ rhs, double *x, double *tail, long long limit) {
+    trsv_fused_body(M, ld, n_pad, Wall, rhs, x, tail, limit);
+}
+__global__ __launch_bounds__(256) void k_trsv_t_fused_batch(SolveBatchPtrs b, int64_t ld, int n_pad, long long limit) {
+    const int z = blockIdx.y;
+    trsv_fused_body(b.M[z], ld, n_pad, b.dW[z], b.rhs[z], b.vec[z], b.dW[z] + (int64_t)((n_pad + kNB - 1) / kNB) * 65536, limit);
+}
+
 __global__ void k_mfma_probe(const double *A, const double *B, double *C) {
     const int lane = threadIdx.x;
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -922,6 +1066,7 @@ static std::atomic<int> g_stream_min_tiles{128};  // EGX_STREAM_MIN: launches wi
 static std::atomic<int> g_gemm_small_max{1024};   // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used
 static std::atomic<int> g_look_min_cols{3072};    // EGX_LOOK_MIN: look-ahead while at least this many columns trail the next group
 static std::atomic<int> g_lur_side{1};            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU (bench.py's roofline leg)
+static std::atomic<int> g_trsv_fused{1};          // EGX_TRSV_FUSED=0: the back-substitution gamma = C^-T rho as one launch PER BLOCK (rounds 1-5) instead of one launch
 static std::atomic<int> g_potrf_left{1};          // EGX_POTRF_LEFT: left-looking group updates (factor and C^-T rider) 0 never, 1 by schedule.h, 2 always
 constexpr int kTrsmGroupPanels = 4;   // panels per update in the solves after the factorisation
 constexpr int kLurSideMinCols = 6144; // LUr on the side stream only while at least this many columns trail the look-ahead group
@@ -938,6 +1083,7 @@ int chol_init() {
         if (const char *e = std::getenv("EGX_STREAM_MIN")) g_stream_min_tiles = std::atoi(e) > 0 ? std::atoi(e) : 1;
         if (const char *e = std::getenv("EGX_LOOK_MIN")) g_look_min_cols = std::atoi(e);
         if (const char *e = std::getenv("EGX_LUR_SIDE")) g_lur_side = std::atoi(e);
+        if (const char *e = std::getenv("EGX_TRSV_FUSED")) g_trsv_fused = std::atoi(e);
         if (const char *e = std::getenv("EGX_POTRF_LEFT")) g_potrf_left = std::atoi(e);
         auto set = [](const void *fn, int bytes) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -981,7 +1127,8 @@ int set_knob(const char *name, int value) {
     (void)chol_init();  // the environment is read first, once; a later call here wins
     struct { const char *n; std::atomic<int> *v; } tab[] = {{"potrf_group", &g_potrf_group}, {"stream_min", &g_stream_min_tiles},
                                                            {"gemm_small", &g_gemm_small_max}, {"look_min", &g_look_min_cols},
-                                                           {"lur_side", &g_lur_side},         {"potrf_left", &g_potrf_left}};
+                                                           {"lur_side", &g_lur_side},         {"potrf_left", &g_potrf_left},
+                                                           {"trsv_fused", &g_trsv_fused}};
     for (auto &e : tab)
         if (std::string(name) == e.n) return e.v->exchange(value);
     return -2147483647 - 1;
@@ -1162,9 +1309,14 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
     //  true.  A device on which the launch does not fit -- one workgroup per diagonal block and matrix: a partitioned GPU -- takes
     //  the separate launches for the whole factorisation.)
     const int GW = (pb.group_panels > 0 ? pb.group_panels : potrf_group_panels(n_pad)) * kNB;
-    const bool flow = pb.sync != nullptr && pb.flow != 0 && nz == 1 && flow_fits(n_pad);
+    // (not with the theta-gradient's rider: a flow launch holds every compute unit, so the rider's substitution -- as many flops as
+    //  the factorisation, which otherwise fill the chain's bubbles group by group -- would run behind it instead of beside it.
+    //  Measured, one candidate, flow / separate launches: n = 8192 13.5 / 12.2 ms, 12288 38.6 / 35.3, 16384 77.8 / 76.5:
+    //  profiles/r06_gradient_flow_ab.txt.  The likelihood egx_gp_likelihood_grad returns on such a handle is egx_gp_likelihood's
+    //  to rounding, 1e-12, not bit for bit.)
+    const bool flow = pb.sync != nullptr && pb.flow != 0 && nz == 1 && inv == nullptr && flow_fits(n_pad);
     // (a flow launch for the LAST columns of a right-looking factorisation: the switch happens on a group boundary)
-    const int tail_cols = (pb.sync != nullptr && pb.flow_tail > 0 && nz == 1 && !pb.left && pb.flow_tail < n_pad && (n_pad - pb.flow_tail) % GW == 0 &&
+    const int tail_cols = (pb.sync != nullptr && pb.flow_tail > 0 && nz == 1 && inv == nullptr && !pb.left && pb.flow_tail < n_pad && (n_pad - pb.flow_tail) % GW == 0 &&
                            flow_fits(pb.flow_tail))
                               ? pb.flow_tail
                               : 0;
@@ -1607,6 +1759,15 @@ int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const d
                   double *xout) {
     // v holds the right-hand side and is updated in place above the current block; the solution goes to xout
     const int nblocks = (n_pad + kNB - 1) / kNB;
+    if (g_trsv_fused.load() != 0 && n_pad % 64 == 0) {  // one launch (k_trsv_t_fused); its hand-off words sit behind the inverse blocks
+        double *tail = const_cast<double *>(Wall) + (int64_t)nblocks * 65536;
+        EGX_HIP_CHECK(hipMemsetAsync(tail, 0xFF, sizeof(double) * trsv_tail_doubles(n_pad), s));
+        EGX_HIP_CHECK(hipMemsetAsync(xout, 0xFF, sizeof(double) * (size_t)n_pad, s));
+        hipLaunchKernelGGL(k_trsv_t_fused, dim3((unsigned)(n_pad / 64)), dim3(256), 0, s, M, ld, n_pad, Wall, (const double *)v, xout, tail,
+                           pipe_timeout_ticks());
+        EGX_HIP_CHECK(hipGetLastError());
+        return EGX_SUCCESS;
+    }
     for (int b = nblocks - 1; b >= 0; b--) {
         const int k0 = b * kNB;
         const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;
@@ -1632,6 +1793,16 @@ int launch_block_inverse_batch(hipStream_t s, const SolveBatchPtrs &b, int count
 }
 int launch_trsv_t_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64_t ld, int n_pad) {
     const int nblocks = (n_pad + kNB - 1) / kNB;
+    if (g_trsv_fused.load() != 0 && n_pad % 64 == 0) {
+        for (int z = 0; z < count; z++) {
+            EGX_HIP_CHECK(hipMemsetAsync(b.dW[z] + (int64_t)nblocks * 65536, 0xFF, sizeof(double) * trsv_tail_doubles(n_pad), s));
+            EGX_HIP_CHECK(hipMemsetAsync(b.vec[z], 0xFF, sizeof(double) * (size_t)n_pad, s));
+        }
+        hipLaunchKernelGGL(k_trsv_t_fused_batch, dim3((unsigned)(n_pad / 64), (unsigned)count), dim3(256), 0, s, b, ld, n_pad,
+                           pipe_timeout_ticks());
+        EGX_HIP_CHECK(hipGetLastError());
+        return EGX_SUCCESS;
+    }
     for (int blk = nblocks - 1; blk >= 0; blk--) {
         const int k0 = blk * kNB;
         const int nbk = (n_pad - k0 < kNB) ? (n_pad - k0) : kNB;

@@ -1244,6 +1244,7 @@ int pipe_set_knob(const char *name, int value) {
         if (std::string(name) == e.n) return e.v->exchange(value);
     return INT_MIN;
 }
+long long pipe_timeout_ticks() { return pipe_init() == EGX_SUCCESS ? (long long)g_pipe_timeout_ms * 100000ll : 200000000ll; }
 int pipe_enabled() { return pipe_init() == EGX_SUCCESS ? g_pipe.load() : 0; }
 
 // compute units of a device (per device: a process may drive a partitioned and a whole GPU)

@@ -427,7 +427,7 @@ int32_t egx_sgp_create(const egx_sgp_config *cfg_in, const double *x, const doub
     SGP_TRY(g->brow.alloc(zp));
     SGP_TRY(g->vec.alloc(zp));
     SGP_TRY(g->tmpv.alloc(zp));
-    SGP_TRY(g->wall.alloc(((zp + kNB - 1) / kNB) * 65536));
+    SGP_TRY(g->wall.alloc(block_inverse_doubles(zp)));
     SGP_HIP(dev_malloc(&g->d_info, 2 * sizeof(int)));
     SGP_HIP(hipMemcpy(g->xT.p, xT.data(), sizeof(double) * xT.size(), hipMemcpyHostToDevice));
     SGP_HIP(hipMemcpy(g->zT.p, zT.data(), sizeof(double) * zT.size(), hipMemcpyHostToDevice));

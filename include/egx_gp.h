@@ -187,7 +187,10 @@ int32_t egx_gp_get_lockstep(const egx_gp *gp);
  * launch, panels per group, lock-step width }; out_len >= 6.  out[6] (when out_len >= 7): the whole factorisation as ONE FLOW
  * launch -- critical stage lists + bulk-class rounds per column, csrc/pipe_flow.h; round 6: a lone one-workspace handle that
  * is not a member of a group, padded size 5376 .. 14080 (value 1); from 14336 on (value 2) such a handle factors right-looking by
- * separate launches and hands its LAST 6144 .. 7167 columns, fully updated, to one flow launch.  Further slots are set to 0. */
+ * separate launches and hands its LAST 6144 .. 7167 columns, fully updated, to one flow launch.  (An evaluation WITH the
+ * theta-gradient factors by separate launches on such a handle too -- the rider C^-T runs beside them, behind a flow launch it
+ * would wait: the likelihood egx_gp_likelihood_grad returns there is egx_gp_likelihood's to rounding, 1e-12 relative, not bit for
+ * bit.)  Further slots are set to 0. */
 int32_t egx_gp_get_schedule(const egx_gp *gp, int32_t *out, int32_t out_len);
 /* Give back what only an optimisation needed: the handle keeps its first n_keep (>= 1) workspaces -- workspace 0 holds the
  * fitted factor, which survives -- and frees the others together with the theta-gradient's scratch.  A tuned fit runs its

@@ -400,13 +400,17 @@ def test_tuned_fits_of_a_group_are_the_lone_tuned_fits_bit_for_bit(egx, n, d, k)
         for h in hs:
             h.close()
     # ... and through the builder: GpParams.fit_group with ThetaTuning.Full, GpMixture.fit_experts on top of it
-    params = egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr()).n_start(3).max_eval(30)
+    # (`fit` tunes on several workspaces -- another schedule row, 1e-10 per evaluation.  COBYLA run to convergence stops within
+    #  its ftol_rel = 1e-4 of the same optimum either way; cut off after 30 evaluations it may stand somewhere else entirely -- one
+    #  flipped comparison early on: n = 2100, seed 91 gave 2457.8 on one or two workspaces and 2065.0 on four, and 2538.544 /
+    #  2538.553 with 100 evaluations, profiles/r06_tuned_fit_by_workspaces.txt -- hence max_eval = 100 here)
+    params = egx.GaussianProcess.params(egx.ConstantMean(), egx.SquaredExponentialCorr()).n_start(3).max_eval(100)
     gps = params.fit_group(np.stack([s[0] for s in sets]), np.stack([s[1] for s in sets]))
     try:
         assert all(g.n_evals > 4 for g in gps) and all(np.isfinite(g.likelihood()) for g in gps)
         ref = [params.fit(*s) for s in sets[:2]]
-        for g, r in zip(gps, ref):          # (`fit` tunes on several workspaces -- another schedule row, 1e-10 per evaluation --: COBYLA
-            assert g.likelihood() == pytest.approx(r.likelihood(), rel=1e-4)    # stops within its ftol_rel = 1e-4 of the same optimum)
+        for g, r in zip(gps, ref):
+            assert g.likelihood() == pytest.approx(r.likelihood(), rel=1e-4)
         for r in ref:
             r.close()
     finally:
@@ -432,3 +436,69 @@ def test_expert_loop_in_lock_step(egx):
     np.testing.assert_array_equal(mix.predict_var(xq), ref.predict_var(xq))
     for e in mix.experts + ref.experts:
         e.close()
+
+
+@pytest.mark.parametrize("n,d", [(300, 3), (1000, 3), (2100, 4), (5000, 4), (9000, 5)])
+def test_one_launch_back_substitution_gives_the_bits_of_the_launch_per_block_form(egx, knobs, n, d):
+    """gamma = C^-T rho (crates/gp/src/algorithm.rs:1034) as ONE launch (k_trsv_t_fused, round 6: a workgroup per 64 columns of
+    the right-hand side, segments handed out from the last one down by a start ticket, the blocks' solutions published through
+    agent-scope counters) against the 2 n / 256 launches of rounds 1-5 (egx_set_tuning "trsv_fused" = 0): the same sums in the
+    same order -- gamma, hence every prediction, bit for bit; a padded size that is not a multiple of 256 (n = 2100, 5000, 9000:
+    a last block of 128 columns) included; and against the oracle's gamma."""
+    from oracle import gp_oracle as O
+    x, y = _data(n, d, 11 + n)
+    theta = np.full(d, 2.0)
+    xq = np.random.default_rng(1).uniform(size=(40, d))
+    out = {}
+    for fused in (1, 0, 1):
+        knobs("trsv_fused", fused)
+        with egx.GpHandle(x, y, n_workspaces=1) as h:
+            h.finalize(theta)
+            out.setdefault(fused, []).append((h.inner()["gamma"].copy(), h.predict(xq), h.predict_var(xq)))
+    for got in out[1]:
+        for a, b in zip(got, out[0][0]):
+            np.testing.assert_array_equal(a, b)
+    if n <= 2100:
+        want = np.asarray(O.fit_fixed(x, y, theta).inner.gamma).ravel()
+        np.testing.assert_allclose(out[1][0][0].ravel(), want, rtol=1e-6, atol=1e-7 * np.abs(want).max())
+
+
+def test_one_launch_back_substitution_of_a_group_and_under_load(egx, knobs):
+    """... for the members of a group (blockIdx.y = model: egx_gp_finalize_multi) and with other launches keeping the chip busy
+    (the segments' start tickets, not the dispatch order, decide who waits for whom): the bits of the launch-per-block form."""
+    k, n, d = 5, 2100, 3
+    sets = [_data(n, d, 40 + j) for j in range(k)]
+    thetas = np.full((k, d), 2.0) * (1.0 + 0.1 * np.arange(k))[:, None]
+    res = {}
+    for fused in (1, 0):
+        knobs("trsv_fused", fused)
+        hs = egx.GpHandle.create_group(np.stack([s[0] for s in sets]), np.stack([s[1] for s in sets]))
+        try:
+            egx.finalize_multi(hs, thetas)
+            res[fused] = [h.inner()["gamma"].copy() for h in hs]
+        finally:
+            for h in hs:
+                h.close()
+    for a, b in zip(res[1], res[0]):
+        np.testing.assert_array_equal(a, b)
+    # under load: a twelve-workspace handle evaluates a batch on its own streams while another handle finalizes, ten times over
+    knobs("trsv_fused", 1)
+    xb, yb = _data(4096, 4, 5)
+    x1, y1 = sets[0]
+    import threading
+    with egx.GpHandle(xb, yb, n_workspaces=12) as hb, egx.GpHandle(x1, y1, n_workspaces=1) as h1:
+        cands = np.full((24, 4), 2.0) * (1.0 + 0.01 * np.arange(24))[:, None]
+        stop = threading.Event()
+
+        def load():
+            while not stop.is_set():
+                hb.likelihood_batch(cands)
+        t = threading.Thread(target=load)
+        t.start()
+        try:
+            for _ in range(10):
+                h1.finalize(thetas[0])
+                np.testing.assert_array_equal(h1.inner()["gamma"], res[0][0])
+        finally:
+            stop.set()
+            t.join()

@@ -75,24 +75,33 @@ def tile_flops(k):  # executed by one 128 x 256 tile
 
 
 for tg, name in ((1, "LONG update (K = every column before the previous group; bench.py's `roofline` launch)"),
-                 (2, "SHORT update (K = the previous group, 1024)")):
+                 (2, "SHORT update (K = the previous group, 1024)"),
+                 (4, "IN-GROUP updates that take the stream kernel (rectangles below the next diagonal block, K = 256)")):
     m = tag == tg
     if not m.any():
         continue
     print(f"\n== {name}: {m.sum()} tiles")
-    launches = {}
+    # a launch = the tiles of one (first matrix' C, K); a slot's next group reuses both, so split where no tile of the key started
+    # for 20 ms (the longest tile runs 4 ms)
+    by_key = {}
     for i in np.nonzero(m)[0]:
-        launches.setdefault((int(key[i]), int(nch[i])), []).append(i)
-    rows = []
-    for (kk, nc), idx in sorted(launches.items(), key=lambda kv: w_begin[kv[1]].min()):
+        by_key.setdefault((int(key[i]), int(nch[i])), []).append(i)
+    launches = []
+    for (kk, nc), idx in by_key.items():
         idx = np.array(idx)
+        idx = idx[np.argsort(w_begin[idx])]
+        cuts = np.nonzero(np.diff(w_begin[idx]) > 2.0e6)[0] + 1
+        for part in np.split(idx, cuts):
+            launches.append((nc, part))
+    rows = []
+    for nc, idx in sorted(launches, key=lambda kv: w_begin[kv[1]].min()):
         K = nc * 16
         span = us(w_end[idx].max() - w_begin[idx].min())
         nmat = len(np.unique(z[idx]))
         # useful flops of the launch: the lower triangle's share of the tiles that cross the diagonal (rows bx*128.., cols by*256..)
         gw = (by[idx].max() + 1) * 256
         rows_m = (bx[idx].max() + 1) * 128
-        useful = nmat * 2.0 * K * (rows_m * gw - 0.5 * gw * (gw - 1.0))
+        useful = nmat * 2.0 * K * (rows_m * gw - (0.5 * gw * (gw - 1.0) if tg != 4 else 0.0))
         executed = len(idx) * tile_flops(K)
         occ = res_us[idx].sum() / (256.0 * span)
         loop_share = loop_us[idx].sum() / res_us[idx].sum()
@@ -102,7 +111,7 @@ for tg, name in ((1, "LONG update (K = every column before the previous group; b
         rows.append((us(w_begin[idx].min() - T0), K, nmat, len(idx), span, ach, useful / executed, occ, loop_share, b, f,
                      np.median(res_us[idx]), executed, useful, res_us[idx].sum(), loop_us[idx].sum()))
     print("   start us      K  mats  tiles   span us  TFLOP/s  of peak = useful x occupancy x loop share x MFMA issue x clock/2.4   (clock GHz, median tile us)")
-    for (ts, K, nmat, nt, span, ach, u, occ, ls, b, f, med, *_rest) in rows:
+    for (ts, K, nmat, nt, span, ach, u, occ, ls, b, f, med, *_rest) in (rows if tg != 4 else rows[:12]):  # (the in-group launches: the first few)
         print(f"  {ts:9.0f}  {K:5d}  {nmat:4d}  {nt:5d}  {span:8.0f}  {ach:7.2f}  {ach / PEAK:.3f} = {u:.3f} x {occ:.3f} x {ls:.3f} x {b:.3f} x {f / F_NOM:.3f}"
               f"   ({f:.3f}, {med:.0f})   product {u * occ * ls * b * f / F_NOM:.3f}")
     A = np.array([[q[4], q[12], q[13], q[14], q[15]] for q in rows])
@@ -122,11 +131,11 @@ for tg, name in ((1, "LONG update (K = every column before the previous group; b
 # ---- the compute units' time over the whole traced batch
 win0, win1 = w_begin.min(), w_end.max()
 window = us(win1 - win0)
-tot = {1: res_us[tag == 1].sum(), 2: res_us[tag == 2].sum()}
+tot = {1: res_us[tag == 1].sum(), 2: res_us[tag == 2].sum(), 4: res_us[(tag != 1) & (tag != 2)].sum()}
 print(f"\n== compute-unit time over the traced batch ({window / 1e3:.1f} ms from the first to the last traced tile, {len(np.unique(cu))} CUs)")
-print(f"  in LONG-update tiles {tot[1] / (256 * window):.3f}, in SHORT-update tiles {tot[2] / (256 * window):.3f}, in neither "
-      f"{1 - (tot[1] + tot[2]) / (256 * window):.3f} (the chain's kernels -- diagonal blocks, panel solves, in-group updates --, the "
-      f"correlation builds, and idle)")
+print(f"  in LONG-update tiles {tot[1] / (256 * window):.3f}, in SHORT-update tiles {tot[2] / (256 * window):.3f}, in the in-group updates' "
+      f"stream tiles {tot[4] / (256 * window):.3f}, in none of them {1 - (tot[1] + tot[2] + tot[4]) / (256 * window):.3f} (diagonal blocks, panel "
+      f"solves, the in-group updates on the 64 x 64 kernel, the correlation builds, and idle)")
 gaps = []
 for c in np.unique(cu):
     i = np.nonzero(cu == c)[0]
