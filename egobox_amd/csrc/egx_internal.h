@@ -224,9 +224,10 @@ long long pipe_timeout_ticks();  // EGX_PIPE_TIMEOUT_MS in ticks of the 100-MHz 
 int launch_block_inverse_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64_t ld, int n_pad);
 int launch_trsv_t_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64_t ld, int n_pad);
 int launch_block_inverse(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *dinv, double *Wall);
-// xout (n_pad) <- C^-T v ; v (n_pad) is destroyed   (needs launch_block_inverse first)
+// xout (n_pad) <- C^-T v   (needs launch_block_inverse first).  One launch (k_trsv_t_fused; v is left alone) unless
+// per_block or "trsv_fused" = 0: then one launch per 256-column block, and v is destroyed
 int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *Wall, double *v,
-                  double *xout);
+                  double *xout, bool per_block = false);
 // C (M x N, ldc) -= A (M x K, lda) * B (N x K, ldb)^T ; lower != 0 skips tiles strictly above the diagonal
 // ktri != 0 (with lower): A and B are upper triangular, the K loop of tile (bx, by) starts at row bx*tile
 // info != nullptr: device flag of the enclosing factorisation; the kernel returns at once when it is non-zero

@@ -937,13 +937,31 @@ static int finalize_tail_complete(egx_gp *gp, const std::vector<double> &coef, i
     EvalResult &res = ft.res;
     EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
     auto t2 = std::chrono::steady_clock::now();
-    // (the one-launch back-substitution poisons gamma with NaN when one of its bounded waits ran out, kernels_chol.hip)
-    for (int i = 0; i < gp->n; i++)
-        if (!std::isfinite(w.h_vec[i])) {
+    // The one-launch back-substitution leaves NaN in gamma when one of its bounded waits ran out (kernels_chol.hip): like an
+    // aborted chain launch -- not a numerical event, the reference knows no such failure -- it is run ONCE more, launch per
+    // block, from the right-hand side it left untouched (egx_chain_stats counts it; "pipe_retry" = 0: the error at once)
+    auto finite = [&]() {
+        for (int i = 0; i < gp->n; i++)
+            if (!std::isfinite(w.h_vec[i])) return false;
+        return true;
+    };
+    if (!finite()) {
+        g_chain_aborts++;
+        bool ok = false;
+        if (g_pipe_retry.load() != 0 && w.dW != nullptr) {
+            g_chain_retries++;
+            EGX_RC(launch_trsv_t(w.stream, w.M, gp->ld, gp->n_pad, w.dW, w.d_rhs, w.d_vec, true));
+            EGX_HIP_CHECK(hipMemcpyAsync(gp->d_gamma, w.d_vec, sizeof(double) * gp->n_pad, hipMemcpyDeviceToDevice, w.stream));
+            EGX_HIP_CHECK(hipMemcpyAsync(w.h_vec, w.d_vec, sizeof(double) * gp->n_pad, hipMemcpyDeviceToHost, w.stream));
+            EGX_HIP_CHECK(hipStreamSynchronize(w.stream));
+            ok = finite();
+        }
+        if (!ok) {
             set_error("back-substitution gamma = C^-T rho: non-finite result (the launch ran into its wait bound, EGX_PIPE_TIMEOUT_MS, "
                       "or rho is not finite)");
             return EGX_ERR_HIP;
         }
+    }
     gp->gamma.assign(w.h_vec, w.h_vec + gp->n);
     gp->theta = thfull;
     gp->likelihood = res.lkh;

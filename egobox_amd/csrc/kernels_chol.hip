@@ -928,7 +928,7 @@ __device__ __forceinline__ double trsv_poll(const double *p, long long limit) {
     }
 }
 __device__ __forceinline__ void trsv_fused_body(const double *__restrict__ M, int64_t ld, int n_pad, const double *__restrict__ Wall,
-                                                const double *__restrict__ rhs, double *x, double *tail, long long limit) {
+                                                const double *__restrict__ rhs, double *x, double *tail, long long limit, int stall) {
     __shared__ double xs[256];
     __shared__ double red[4][64];
     __shared__ int s_seg;
@@ -939,6 +939,7 @@ __device__ __forceinline__ void trsv_fused_body(const double *__restrict__ M, in
     __syncthreads();
     const int seg = s_seg;
     if (seg < 0) return;
+    if (stall != 0 && seg == nseg - 1) return;  // (test builds, "trsv_stall": the last segment never publishes anything)
     const int blk = seg >> 2, j = seg * 64 + jl;
     double r = (g == 0) ? rhs[j] : 0.0;
     double mv[4][16];
@@ -989,12 +990,12 @@ __device__ __forceinline__ void trsv_fused_body(const double *__restrict__ M, in
     }
 }
 __global__ __launch_bounds__(256) void k_trsv_t_fused(const double *__restrict__ M, int64_t ld, int n_pad, const double *__restrict__ Wall,
-                                                      const double *__restrict__ rhs, double *x, double *tail, long long limit) {
-    trsv_fused_body(M, ld, n_pad, Wall, rhs, x, tail, limit);
+                                                      const double *__restrict__ rhs, double *x, double *tail, long long limit, int stall) {
+    trsv_fused_body(M, ld, n_pad, Wall, rhs, x, tail, limit, stall);
 }
-__global__ __launch_bounds__(256) void k_trsv_t_fused_batch(SolveBatchPtrs b, int64_t ld, int n_pad, long long limit) {
+__global__ __launch_bounds__(256) void k_trsv_t_fused_batch(SolveBatchPtrs b, int64_t ld, int n_pad, long long limit, int stall) {
     const int z = blockIdx.y;
-    trsv_fused_body(b.M[z], ld, n_pad, b.dW[z], b.rhs[z], b.vec[z], b.dW[z] + (int64_t)((n_pad + kNB - 1) / kNB) * 65536, limit);
+    trsv_fused_body(b.M[z], ld, n_pad, b.dW[z], b.rhs[z], b.vec[z], b.dW[z] + (int64_t)((n_pad + kNB - 1) / kNB) * 65536, limit, stall);
 }
 
 __global__ void k_mfma_probe(const double *A, const double *B, double *C) {
@@ -1066,6 +1067,12 @@ static std::atomic<int> g_stream_min_tiles{128};  // EGX_STREAM_MIN: launches wi
 static std::atomic<int> g_gemm_small_max{1024};   // EGX_GEMM_SMALL: below this many 128x128 tiles the 64x64-tile kernel is used
 static std::atomic<int> g_look_min_cols{3072};    // EGX_LOOK_MIN: look-ahead while at least this many columns trail the next group
 static std::atomic<int> g_lur_side{1};            // EGX_LUR_SIDE=0: the look-ahead columns' update stays in front of RU (bench.py's roofline leg)
+#ifdef EGX_TEST_HOOKS
+static std::atomic<int> g_trsv_stall{0};  // egx_set_tuning "trsv_stall" (test build only): the one-launch back-substitution's last segment never publishes
+#define EGX_TRSV_STALL g_trsv_stall.load()
+#else
+#define EGX_TRSV_STALL 0
+#endif
 static std::atomic<int> g_trsv_fused{1};          // EGX_TRSV_FUSED=0: the back-substitution gamma = C^-T rho as one launch PER BLOCK (rounds 1-5) instead of one launch
 static std::atomic<int> g_potrf_left{1};          // EGX_POTRF_LEFT: left-looking group updates (factor and C^-T rider) 0 never, 1 by schedule.h, 2 always
 constexpr int kTrsmGroupPanels = 4;   // panels per update in the solves after the factorisation
@@ -1131,6 +1138,9 @@ int set_knob(const char *name, int value) {
                                                            {"trsv_fused", &g_trsv_fused}};
     for (auto &e : tab)
         if (std::string(name) == e.n) return e.v->exchange(value);
+#ifdef EGX_TEST_HOOKS
+    if (std::string(name) == "trsv_stall") return g_trsv_stall.exchange(value);
+#endif
     return -2147483647 - 1;
 }
 
@@ -1424,6 +1434,10 @@ int launch_potrf(hipStream_t s, double *M, int64_t ld, int n_pad, int m_tot, dou
                                nby, nt, (const int *)info, gbw);
             EGX_HIP_CHECK(hipGetLastError());
         } else if (ncols > 0) {
+            // (round 6 measured this update SPLIT into the next group's columns on this stream and the rest on a second rider stream
+            //  beside the next group's solves -- the timeline shows the rider six groups behind the factorisation with ~0.7 ms of
+            //  small launches exposed per group: one candidate 76.5 -> 79.4 ms at n = 16384, 35.3 -> 39.5 at 12288, 12.2 -> 14.2 at 8192
+            //  (a third stream competing with the factorisation, two launches' tails for one): profiles/r06_rider_split_ab.txt; gone)
             int rc2 = launch_gemm_nt_sub(sw, inv->W + gend, inv->ldw, inv->W + g0, inv->ldw, M + (int64_t)gend * ld + g0, ld, gend,
                                          ncols, gw, 0, 0, nullptr, info, &gbw);
             if (rc2) return rc2;
@@ -1756,15 +1770,15 @@ int launch_block_inverse(hipStream_t s, const double *M, int64_t ld, int n_pad, 
 }
 
 int launch_trsv_t(hipStream_t s, const double *M, int64_t ld, int n_pad, const double *Wall, double *v,
-                  double *xout) {
-    // v holds the right-hand side and is updated in place above the current block; the solution goes to xout
+                  double *xout, bool per_block) {
+    // the one-launch form leaves v alone; the launch-per-block form updates it in place above the current block
     const int nblocks = (n_pad + kNB - 1) / kNB;
-    if (g_trsv_fused.load() != 0 && n_pad % 64 == 0) {  // one launch (k_trsv_t_fused); its hand-off words sit behind the inverse blocks
+    if (!per_block && g_trsv_fused.load() != 0 && n_pad % 64 == 0) {  // one launch (k_trsv_t_fused); its hand-off words sit behind the inverse blocks
         double *tail = const_cast<double *>(Wall) + (int64_t)nblocks * 65536;
         EGX_HIP_CHECK(hipMemsetAsync(tail, 0xFF, sizeof(double) * trsv_tail_doubles(n_pad), s));
         EGX_HIP_CHECK(hipMemsetAsync(xout, 0xFF, sizeof(double) * (size_t)n_pad, s));
         hipLaunchKernelGGL(k_trsv_t_fused, dim3((unsigned)(n_pad / 64)), dim3(256), 0, s, M, ld, n_pad, Wall, (const double *)v, xout, tail,
-                           pipe_timeout_ticks());
+                           pipe_timeout_ticks(), EGX_TRSV_STALL);
         EGX_HIP_CHECK(hipGetLastError());
         return EGX_SUCCESS;
     }
@@ -1799,7 +1813,7 @@ int launch_trsv_t_batch(hipStream_t s, const SolveBatchPtrs &b, int count, int64
             EGX_HIP_CHECK(hipMemsetAsync(b.vec[z], 0xFF, sizeof(double) * (size_t)n_pad, s));
         }
         hipLaunchKernelGGL(k_trsv_t_fused_batch, dim3((unsigned)(n_pad / 64), (unsigned)count), dim3(256), 0, s, b, ld, n_pad,
-                           pipe_timeout_ticks());
+                           pipe_timeout_ticks(), EGX_TRSV_STALL);
         EGX_HIP_CHECK(hipGetLastError());
         return EGX_SUCCESS;
     }

@@ -213,12 +213,12 @@ int sgp_eval(egx_sgp *g, const double *theta, int64_t theta_len, double sigma2, 
         EGX_HIP_CHECK(hipMemcpyAsync(g->tmpv.p, tmp.data(), sizeof(double) * z_pad, hipMemcpyHostToDevice, s));
         rc = launch_block_inverse(s, g->A.p, z_pad, z_pad, g->dinv_a.p, g->wall.p);
         if (rc) return rc;
-        rc = launch_trsv_t(s, g->A.p, z_pad, z_pad, g->wall.p, g->tmpv.p, g->vec.p);
+        rc = launch_trsv_t(s, g->A.p, z_pad, z_pad, g->wall.p, g->tmpv.p, g->vec.p, true);  // (a few blocks: launch per block)
         if (rc) return rc;
         EGX_HIP_CHECK(hipMemcpyAsync(g->tmpv.p, g->vec.p, sizeof(double) * z_pad, hipMemcpyDeviceToDevice, s));
         rc = launch_block_inverse(s, g->Kz.p, z_pad, z_pad, g->dinv_z.p, g->wall.p);
         if (rc) return rc;
-        rc = launch_trsv_t(s, g->Kz.p, z_pad, z_pad, g->wall.p, g->tmpv.p, g->vec.p);
+        rc = launch_trsv_t(s, g->Kz.p, z_pad, z_pad, g->wall.p, g->tmpv.p, g->vec.p, true);
         if (rc) return rc;
         g->w_vec.assign(z_pad, 0.0);
         EGX_HIP_CHECK(hipMemcpyAsync(g->w_vec.data(), g->vec.p, sizeof(double) * z_pad, hipMemcpyDeviceToHost, s));

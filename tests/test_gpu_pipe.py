@@ -502,3 +502,56 @@ def test_one_launch_back_substitution_of_a_group_and_under_load(egx, knobs):
         finally:
             stop.set()
             t.join()
+
+
+_TRSV_STALL_SCRIPT = r"""
+import json, time
+import numpy as np
+import egobox_amd as egx
+rng = np.random.default_rng(5)
+x = rng.uniform(size=(2100, 3))
+y = np.sin(3 * x[:, 0]) + x[:, 1:].sum(axis=1) ** 2 + 0.1 * rng.standard_normal(2100)
+th = np.full(3, 2.0)
+xq = rng.uniform(size=(20, 3))
+out = {}
+with egx.GpHandle(x, y) as h:
+    h.finalize(th)
+    good = (h.inner()["gamma"].copy(), h.predict(xq))
+    egx.set_tuning("pipe_timeout_ms", 25)
+    egx.set_tuning("trsv_stall", 1)                    # the last segment of the one-launch back-substitution never publishes
+    s0 = egx.chain_stats()
+    t0 = time.perf_counter()
+    h.finalize(th)                                     # ... the fit still succeeds: launch per block, once more
+    out["fallback_seconds"] = time.perf_counter() - t0
+    s1 = egx.chain_stats()
+    out["counted"] = [s1["aborted"] - s0["aborted"], s1["retried"] - s0["retried"]]
+    out["same_gamma"] = bool(np.array_equal(h.inner()["gamma"], good[0])) and bool(np.array_equal(h.predict(xq), good[1]))
+    egx.set_tuning("pipe_retry", 0)
+    t0 = time.perf_counter()
+    try:
+        h.finalize(th)
+        out["error"] = None
+    except egx.EgxError as e:
+        out["error"] = str(e)
+    out["error_seconds"] = time.perf_counter() - t0
+    egx.set_tuning("trsv_stall", 0)
+    egx.set_tuning("pipe_retry", 1)
+    egx.set_tuning("pipe_timeout_ms", 2000)
+    h.finalize(th)
+    out["again"] = bool(np.array_equal(h.inner()["gamma"], good[0]))
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_a_back_substitution_whose_hand_off_never_arrives_is_run_again_launch_per_block(egx):
+    """The one-launch back-substitution bounds its waits like the chain launch: a segment that never publishes (forced: the TEST
+    build's "trsv_stall") leaves NaN in gamma within the bound, finalize runs the launch-per-block form from the untouched
+    right-hand side -- the same gamma, the same predictions, counted by egx_chain_stats -- and only with the fallback off it is
+    EGX_ERR_HIP; never a hang, never a wrong model; the next fit on the handle is clean."""
+    import json
+    r = _run_script(_TRSV_STALL_SCRIPT, {"EGX_TEST_LIBRARY": "1"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert out["counted"] == [1, 1] and out["same_gamma"] and out["fallback_seconds"] < 5.0
+    assert out["error"] is not None and "back-substitution" in out["error"] and out["error_seconds"] < 5.0
+    assert out["again"]
