@@ -628,7 +628,8 @@ def dry_launch(args, rank, world):
 DETAILS_FILE = os.path.join("profiles", "bench_last_run_details.json")
 _DROP_KEYS = {"metric_note", "thread_settings_tried", "settings_tried", "traffic_source", "how", "kernel", "launch_shape", "note",
               "note_numa", "traffic_measured", "query", "first_handle_in_process", "rccl_version", "pool", "traffic_stale",
-              "extra_rows_note", "flops_per_launch_avg", "likelihood_checksum_ok_rows", "correction", "what", "reading"}
+              "extra_rows_note", "flops_per_launch_avg", "likelihood_checksum_ok_rows", "correction", "what", "reading", "threads",
+              "wall_start", "wall_end"}
 _DROP_ORDER = ["cpu_baseline_reference_shaped", "roofline_kernel_alone", "corr_build_roofline", "cpu_baseline_concurrent",
                "pcie_inclusive", "last_step_balance", "stage_ms_single_fit", "vendor_yardstick", "roofline_single_matrix"]
 
@@ -648,7 +649,7 @@ def _schedule_word(s):
 
 def _compact(o, key=None):
     if isinstance(o, dict):
-        if key == "schedule" and "panels_per_group" in o:
+        if key is not None and key.startswith("schedule") and "panels_per_group" in o:
             return _schedule_word(o)
         return {k: _compact(v, k) for k, v in o.items() if k not in _DROP_KEYS}
     if isinstance(o, (list, tuple)):

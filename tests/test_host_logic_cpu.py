@@ -140,3 +140,47 @@ def test_pls_rotations_match_scikit_learn_up_to_sign():
         ref = sk.PLSRegression(n_components=k).fit(x, y).x_rotations_
         np.testing.assert_allclose(np.abs(mine), np.abs(ref), rtol=1e-8, atol=1e-10)
     assert np.all(pls_rotations(x, np.full(100, 3.1), 2) == 0.0)  # constant response -> zero weights (algorithm.rs:846-850)
+
+
+def test_one_launch_back_substitution_cannot_deadlock_on_four_resident_workgroups():
+    """The scheduling argument of k_trsv_t_fused (egobox_amd/csrc/kernels_chol.hip), restated and run: segments (64 columns) are
+    handed out by a START ticket from the last one down; a workgroup waits (a) for the solutions x_b of every block behind its own,
+    published by the segment workgroups of those blocks, and (b) for the finished right-hand-side pieces of the other segments of
+    its own block before it publishes its rows of x_blk.  With R workgroups resident at a time (a new one starts, in ticket
+    order, whenever one leaves) every segment finishes for every R >= 4 -- and R = 3 shows the rule is tight."""
+    def run(nseg, resident):
+        nblk = (nseg + 3) // 4
+        segs_of = lambda b: [s for s in range(4 * b, min(4 * b + 4, nseg))]  # noqa: E731
+        r_final, x_rows = set(), set()      # segments whose piece of rho is final / whose rows of x are published
+        x_done = lambda b: all(s in x_rows for s in segs_of(b))  # noqa: E731
+        state = {}                          # running workgroup: segment -> next block it waits for (None: in its mat-vec)
+        next_ticket, finished = 0, 0
+        while finished < nseg:
+            while len(state) < resident and next_ticket < nseg:   # the dispatcher starts workgroups as slots free up
+                seg = nseg - 1 - next_ticket
+                state[seg] = nblk - 1
+                next_ticket += 1
+            progressed = False
+            for seg in list(state):
+                blk = seg // 4
+                b = state[seg]
+                while b is not None and b > blk and x_done(b):     # apply the blocks' solutions in order
+                    b -= 1
+                    progressed = True
+                if b is not None and b == blk:                     # own block is next: publish the piece, then the mat-vec
+                    r_final.add(seg)
+                    b = None
+                    progressed = True
+                state[seg] = b
+                if b is None and all(s in r_final for s in segs_of(blk)):
+                    x_rows.add(seg)
+                    del state[seg]
+                    finished += 1
+                    progressed = True
+            if not progressed:
+                return False
+        return True
+    for nseg in (2, 4, 6, 34, 64, 130, 256):        # n_pad / 64, incl. a last block of two segments
+        for resident in (4, 5, 8, 33, 256):
+            assert run(nseg, resident), (nseg, resident)
+    assert not run(64, 3)
