@@ -35,6 +35,19 @@ def variant(name):
         b = "            if (next) read_half(st1, 0, a0, b0);"
         assert s.count(b) == 1
         s = s.replace(b, "")
+    if name == "asmloads":  # the LDS-DMA pieces as inline asm in the SADDR form: SGPR base + 32-bit VGPR byte offset, M0 set by hand
+        a = """                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(ga + offA[i]), (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gb + offB[i - 2]), (lds_ptr_t)(dst + 2048 + (i - 2) * 1024), 16,
+                                                 0, 0);"""
+        assert s.count(a) == 1
+        s = s.replace(a, r"""                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"((unsigned)(size_t)(lds_ptr_t)(dst + i * 1024)), "v"(offA[i]), "s"(ga) : "memory");
+            else
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"((unsigned)(size_t)(lds_ptr_t)(dst + 2048 + (i - 2) * 1024)), "v"(offB[i - 2]), "s"(gb) : "memory");""")
+        for ab, ldx in (("A", "lda"), ("B", "ldb")):
+            b = f"off{ab}[i] = (unsigned)((8 * (wave + 8 * i) + lrow) * (int){ldx}) + lpart;"
+            assert s.count(b) == 1, b
+            s = s.replace(b, f"off{ab}[i] = 8u * ((unsigned)((8 * (wave + 8 * i) + lrow) * (int){ldx}) + lpart);")
     if name == "noloads":
         c = "if (ld) issue_pieces(ist, q, q + 1);"
         assert s.count(c) == 1
@@ -79,10 +92,16 @@ int main() {
         const double nch = (double)((q[1] >> 32) & 0xfffff), cyc = (double)(q[7] - q[5]), wall = (double)(q[6] - q[4]) * 10.0;  // ns
         busy.push_back(nch * 8192.0 / cyc), ghz.push_back(cyc / wall), us.push_back((double)(q[8] - q[3]) * 0.01);
     }
+    std::vector<double> crow((size_t)1024);
+    double chk = 0.0;
+    for (int rr = 0; rr < 3; rr++) {  // three rows of the updated region of the last matrix: a checksum against the base variant
+        hipMemcpy(crow.data(), M + (nz - 1) * sM + (int64_t)(g0 + 1500 + 1777 * rr) * ld + g0, sizeof(double) * 1024, hipMemcpyDeviceToHost);
+        for (double v : crow) chk += v;
+    }
     std::sort(busy.begin(), busy.end()), std::sort(ghz.begin(), ghz.end()), std::sort(us.begin(), us.end());
     const size_t m = busy.size() / 2;
-    printf("VARIANT_NAME: %zu tiles, MFMA issue in the K loop median %.3f (5 %% %.3f, 95 %% %.3f), clock %.3f GHz, tile %.0f us\n", busy.size(), busy[m],
-           busy[busy.size() / 20], busy[busy.size() * 19 / 20], ghz[m], us[m]);
+    printf("VARIANT_NAME: %zu tiles, MFMA issue in the K loop median %.3f (5 %% %.3f, 95 %% %.3f), clock %.3f GHz, tile %.0f us, checksum %.17g\n", busy.size(), busy[m],
+           busy[busy.size() / 20], busy[busy.size() * 19 / 20], ghz[m], us[m], chk);
     return 0;
 }
 '''
