@@ -120,9 +120,10 @@ void egx_chain_stats(int64_t *aborted, int64_t *retried);
  *                      launches, see egx_chain_stats -- never a hang)
  *   "pipe_retry"       1 (default): that retry; 0: EGX_ERR_HIP at once
  *   "trsv_fused"       1 (default): the back-substitution gamma = C^-T rho (crates/gp/src/algorithm.rs:1034) is ONE launch whose
- *                      workgroups hand the blocks' solutions to each other on the device (waits bounded by "pipe_timeout_ms": a wait
- *                      that runs out makes egx_gp_finalize fail with EGX_ERR_HIP, never a wrong gamma); 0: one launch per 256-column
- *                      block (rounds 1-5).  The same sums in the same order either way: the same bits
+ *                      workgroups hand the blocks' solutions to each other on the device (waits bounded by "pipe_timeout_ms": after a
+ *                      wait that ran out the launch-per-block form is run once, counted by egx_chain_stats; EGX_ERR_HIP only if that
+ *                      fails too or with "pipe_retry" = 0 -- never a wrong gamma); 0: one launch per 256-column block (rounds 1-5).
+ *                      The same sums in the same order either way: the same bits
  * (the test hook "pipe_stall" exists only in the test build of the library, -DEGX_TEST_HOOKS).  They move launches between streams and kernels between tile shapes, never the
  * arithmetic inside a kernel; "potrf_group" / "stream_min" / "gemm_small" / "potrf_left" / "pipe" change which kernel
  * updates a block, or the order in which updates are summed, hence the rounding -- and "potrf_left" / "pipe" /
