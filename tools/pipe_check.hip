@@ -88,7 +88,7 @@ struct Problem {
         n = n_, nz = nz_;
         n_pad = (int)round_up(n, n >= 4096 ? 256 : 128);
         m_tot = n_pad + 128;
-        ld = n_pad;
+        ld = n_pad + (getenv("EGX_LD_PAD") ? atoi(getenv("EGX_LD_PAD")) : 0);  // A/B of a padded leading dimension
         mat = (size_t)m_tot * ld;
         dinv_n = (dinv_doubles(n_pad) + 63) / 64 * 64;
         sync_n = pipe_sync_ints(n_pad, m_tot);
