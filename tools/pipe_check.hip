@@ -232,6 +232,8 @@ static int diag_alone_main() {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag_alone<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_diag_alone<false>), hipFuncAttributeMaxDynamicSharedMemorySize, RB_LDS_BYTES));
     for (int pipe = 0; pipe < 2; pipe++) {
         std::vector<float> ms;
         for (int r = 0; r < 8; r++) {
