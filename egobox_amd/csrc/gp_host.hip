@@ -1098,8 +1098,12 @@ int likelihood_batch_core(egx_gp *gp, const double *thetas, int64_t k, int64_t t
 // fits/s): 12 / 4 40.7, 24 / 6 40.8, 24 / 8 41.3, 32 / 8 40.8, 36 / 12 41.2 -- three groups in flight were the constant.  Round 4
 // (handles of that size with width >= 8 factor left-looking, launch_potrf): 8 / 8 40.7, 16 / 8 42.2, 24 / 8 41.9, 32 / 16 42.2,
 // 36 / 12 41.2 -- TWO groups in flight (profiles/r04_run6_left_looking_in_flight_and_width.txt).
+// Round 6 (profiles/r06_lockstep_one_or_two_slots_ab.txt): below the left-looking sizes ONE slot of up to 12 is the robust choice --
+// n = 8192: 12 workspaces 267 likelihoods/s as one slot, 240 as three slots of four (the default until then), 8 workspaces 260 / 240;
+// n = 12288, 8 workspaces: 86.0 / 82.5; what two slots in flight gain or lose (-9 ... +5 %) is which of their streams share a
+// hardware queue.
 static int default_lockstep(int nws, int n_pad) {
-    int ls = n_pad <= 4096 ? 12 : (nws >= 16 ? 8 : 4);
+    int ls = n_pad < 14336 ? 12 : (nws >= 16 ? 8 : 4);
     return ls < 1 ? 1 : (ls > nws ? nws : ls);
 }
 

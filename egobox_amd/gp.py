@@ -642,7 +642,7 @@ class GpParams:
         else:
             # every start of the multistart gets a workspace (the reference runs them on a rayon pool, algorithm.rs:928-945):
             # COBYLA advances all starts in lock-step, so a round's trial points are ONE likelihood batch, factored in
-            # lock-step groups of four -- bounded by 12 workspaces and 16 GiB of correlation matrices
+            # lock-step (one slot below n_pad 14336, groups of four beyond) -- bounded by 12 workspaces and 16 GiB of correlation matrices
             n_pad = -(-x.shape[0] // 128) * 128
             nws = max(1, min(self._n_start + 1, 12, int((16 << 30) // max(1, 8 * n_pad * (n_pad + 128)))))
         h = GpHandle(x, y, mean=self._mean.code, corr=self._corr.code, nugget=self._nugget, device=self._device,

@@ -173,8 +173,8 @@ int32_t egx_gp_likelihood_batch(egx_gp *gp, const double *thetas, int64_t k, int
  * workspaces) are factored by ONE launch sequence -- the candidates of a sweep have the same n, hence the same
  * schedule; the serial chain of the factorisation then costs its latency once per group and every launch has `width`
  * times the tiles.  1 = every candidate on its own stream set (round 2's pipeline); 0 = the default
- * (4 for large matrices, 8 from 16 workspaces on; min(n_workspaces, 12) up to a padded n of 4096 where an evaluation is
- * launch-latency bound, or the EGX_LOCKSTEP environment variable); at most n_workspaces.  A candidate's result does
+ * (min(n_workspaces, 12) below a padded n of 14336 -- one slot: the serial chain is what such an evaluation waits for --,
+ * from there on 4, and 8 from 16 workspaces on); at most n_workspaces.  A candidate's result does
  * not depend on its companions or on how many of them share its launch (same kernels, same arithmetic: bit-identical);
  * it does not depend on the width either, with ONE exception: a handle with a padded n >= 14336 and a width >= 8 factors
  * LEFT-looking over its panel groups (two long-K updates per tile of the factor instead of one per earlier group), a

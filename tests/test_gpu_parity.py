@@ -365,7 +365,7 @@ def test_lockstep_groups_are_bit_identical_to_single_candidates(egx, n, d, mean,
             ok = st == 0
             assert ok.sum() >= 3
             np.testing.assert_array_equal(lk[ok], ref_lk[ok])   # bit identical
-        assert h.set_lockstep(0) == (6 if n <= 4096 else 4)   # the default: min(n_workspaces, 12 up to n_pad 4096, else 4)
+        assert h.set_lockstep(0) == 6   # the default: min(n_workspaces, 12) below n_pad 14336
         # a fit keeps workspace 0; the batch then uses slots of the remaining five
         h.finalize(thetas[0])
         lk, st = h.likelihood_batch(thetas)
