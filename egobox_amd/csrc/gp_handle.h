@@ -125,12 +125,8 @@ struct GroupSlabs {
     int device = 0, k = 0;
     double *M = nullptr, *D = nullptr;
     int *I = nullptr;
-    ~GroupSlabs() {
-        (void)hipSetDevice(device);
-        if (M) (void)hipFree(M);
-        if (D) (void)hipFree(D);
-        if (I) (void)hipFree(I);
-    }
+    size_t bytes_M = 0, bytes_D = 0, bytes_I = 0;
+    ~GroupSlabs();  // gp_host.hip: the slabs go to the resource pool (the next group of this shape adopts them), or are freed
 };
 }  // namespace egx
 

@@ -132,8 +132,10 @@ static int alloc_workspace(egx_gp *gp, Workspace &w, int index) {
 struct PoolKey {
     int device = 0, n_pad = 0, d = 0, q = 0, hmax = 1, nws = 0;
     bool gls = false;
+    bool member = false;  // a member of a group (egx_gp_create_group): everything but the slabs, which belong to the group
     bool operator==(const PoolKey &o) const {
-        return device == o.device && n_pad == o.n_pad && d == o.d && q == o.q && hmax == o.hmax && nws == o.nws && gls == o.gls;
+        return device == o.device && n_pad == o.n_pad && d == o.d && q == o.q && hmax == o.hmax && nws == o.nws && gls == o.gls &&
+               member == o.member;
     }
 };
 struct PoolEntry {
@@ -144,8 +146,19 @@ struct PoolEntry {
     std::vector<Workspace> ws;
     size_t bytes = 0;
 };
+// the slabs of a destroyed GROUP (GroupSlabs: k matrices, tile inverses, flags + hand-off words of one shape): adopted by the
+// next egx_gp_create_group whose three sizes match (round 6: eight n = 8192 experts were 107 ms to create and 100 ms to
+// destroy -- a 4.4 GB hipMalloc / hipFree and eight workspaces' streams, ~400 events and pinned buffers each -- for a 33 ms fit)
+struct SlabEntry {
+    int device = 0;
+    double *M = nullptr, *D = nullptr;
+    int *I = nullptr;
+    size_t bytes_M = 0, bytes_D = 0, bytes_I = 0;
+    size_t bytes() const { return bytes_M + bytes_D + bytes_I; }
+};
 static std::mutex g_pool_mu;
 static std::list<PoolEntry> g_pool;  // front = most recently returned
+static std::list<SlabEntry> g_slab_pool;  // front = most recently returned
 static int64_t g_pool_hits = 0, g_pool_misses = 0;
 
 // bytes pooled on one device (the bound EGX_POOL_MAX_GB is PER DEVICE)
@@ -153,7 +166,16 @@ static size_t pool_bytes_on(int device) {
     size_t b = 0;
     for (const auto &e : g_pool)
         if (e.key.device == device) b += e.bytes;
+    for (const auto &e : g_slab_pool)
+        if (e.device == device) b += e.bytes();
     return b;
+}
+static void free_slab_entry(SlabEntry &e) {
+    (void)hipSetDevice(e.device);
+    if (e.M) (void)hipFree(e.M);
+    if (e.D) (void)hipFree(e.D);
+    if (e.I) (void)hipFree(e.I);
+    e = SlabEntry();
 }
 static size_t pool_cap_bytes() {
     static const size_t cap = [] {
@@ -174,6 +196,7 @@ static void free_entry(PoolEntry &e) {
 // everything pooled on `device` (-1: on every device) is freed; returns the bytes
 static size_t pool_trim(int device) {
     std::list<PoolEntry> out;
+    std::list<SlabEntry> out_slabs;
     size_t bytes = 0;
     {
         std::lock_guard<std::mutex> lock(g_pool_mu);
@@ -185,10 +208,19 @@ static size_t pool_trim(int device) {
             }
             it = next;
         }
+        for (auto it = g_slab_pool.begin(); it != g_slab_pool.end();) {
+            auto next = std::next(it);
+            if (device < 0 || it->device == device) {
+                bytes += it->bytes();
+                out_slabs.splice(out_slabs.end(), g_slab_pool, it);
+            }
+            it = next;
+        }
     }
     int cur = 0;
     const bool have_cur = hipGetDevice(&cur) == hipSuccess;
     for (auto &e : out) free_entry(e);
+    for (auto &e : out_slabs) free_slab_entry(e);
     if (have_cur) (void)hipSetDevice(cur);
     return bytes;
 }
@@ -201,13 +233,15 @@ static PoolKey pool_key(const egx_gp *gp, int nws) {
     k.hmax = gp->has_w ? gp->h : 1;
     k.nws = nws;
     k.gls = gp->gls_device;
+    k.member = gp->group != nullptr;
     return k;
 }
 // device bytes a handle of this shape hands to the pool: the slabs, the training-set buffers and every workspace's own
 // buffers (the lazily allocated ones -- block inverses, theta-gradient scratch -- counted when present)
 static size_t pooled_bytes(const egx_gp *gp, const std::vector<Workspace> &ws) {
     const size_t n_pad = (size_t)gp->n_pad, d = (size_t)gp->d, hmax = gp->has_w ? (size_t)gp->h : 1;
-    size_t b = sizeof(double) * ((size_t)gp->stride_M + (size_t)gp->stride_D) * ws.size() + sizeof(int) * slab_I_ints(gp, (int)ws.size());
+    size_t b = gp->group ? 0  // (a member of a group: the slabs are the group's, pooled on their own)
+                         : sizeof(double) * ((size_t)gp->stride_M + (size_t)gp->stride_D) * ws.size() + sizeof(int) * slab_I_ints(gp, (int)ws.size());
     b += sizeof(double) * (2 * d * n_pad + (size_t)gp->q * n_pad + n_pad + d * hmax + 2 * d);
     for (const auto &w : ws) {
         b += sizeof(double) * (d * hmax + d * n_pad + 3 * n_pad);
@@ -257,12 +291,17 @@ static void pool_give(egx_gp *gp) {
     gp->d_xT = gp->d_rhsT = gp->d_gamma = gp->d_fit_coef = gp->slab_M = gp->slab_D = nullptr;
     gp->slab_I = nullptr;
     gp->ws.clear();
-    bool complete = e.slab_M && e.slab_D && e.slab_I && e.d_xT && e.d_rhsT && e.d_gamma && e.d_fit_coef && !e.ws.empty();
+    bool complete = (e.key.member || (e.slab_M && e.slab_D && e.slab_I)) && e.d_xT && e.d_rhsT && e.d_gamma && e.d_fit_coef && !e.ws.empty();
     for (auto &w : e.ws) {
         complete = complete && w.stream && w.trace.ready && w.inv_stream && w.ev_inv_grp && w.ev_inv_done;
         w.eval_stream = w.stream;
         w.trace.used = 0;
         w.gls_enqueued = false;
+        w.block_inv_ready = false;
+        w.retried = false;
+        w.retry_W = nullptr;
+        w.sync_lead = nullptr;
+        if (e.key.member) w.M = w.dinv = nullptr, w.d_info = nullptr;  // (views of a group's slabs: set again by the adopting member)
     }
     const size_t cap = pool_cap_bytes();
     if (!complete || e.bytes > cap) {  // a handle whose creation failed half way, or a pool too small for it
@@ -270,12 +309,20 @@ static void pool_give(egx_gp *gp) {
         return;
     }
     std::list<PoolEntry> evicted;
+    std::list<SlabEntry> evicted_slabs;
     {
         std::lock_guard<std::mutex> lock(g_pool_mu);
         const int dev = e.key.device;
         g_pool.push_front(std::move(e));
-        // least recently returned entries OF THIS DEVICE go first (the newcomer itself stays)
+        // least recently returned entries OF THIS DEVICE go first (the newcomer itself stays), groups' slabs before them
         while (pool_bytes_on(dev) > cap) {
+            auto sv = g_slab_pool.end();
+            for (auto it = g_slab_pool.begin(); it != g_slab_pool.end(); ++it)
+                if (it->device == dev) sv = it;
+            if (sv != g_slab_pool.end()) {
+                evicted_slabs.splice(evicted_slabs.begin(), g_slab_pool, sv);
+                continue;
+            }
             auto victim = g_pool.end();
             for (auto it = std::next(g_pool.begin()); it != g_pool.end(); ++it)
                 if (it->key.device == dev) victim = it;
@@ -284,7 +331,70 @@ static void pool_give(egx_gp *gp) {
         }
     }
     for (auto &v : evicted) free_entry(v);
+    for (auto &v : evicted_slabs) free_slab_entry(v);
 }
+// a group's slabs: adopt pooled ones of exactly these sizes, or allocate
+static int group_slabs_take(GroupSlabs &g) {
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        for (auto it = g_slab_pool.begin(); it != g_slab_pool.end(); ++it)
+            if (it->device == g.device && it->bytes_M == g.bytes_M && it->bytes_D == g.bytes_D && it->bytes_I == g.bytes_I) {
+                g.M = it->M, g.D = it->D, g.I = it->I;
+                g_slab_pool.erase(it);
+                g_pool_hits++;
+                return EGX_SUCCESS;
+            }
+        g_pool_misses++;
+    }
+    EGX_HIP_CHECK(dev_malloc_bytes(reinterpret_cast<void **>(&g.M), g.bytes_M));
+    EGX_HIP_CHECK(dev_malloc_bytes(reinterpret_cast<void **>(&g.D), g.bytes_D));
+    EGX_HIP_CHECK(dev_malloc_bytes(reinterpret_cast<void **>(&g.I), g.bytes_I));
+    return EGX_SUCCESS;
+}
+}  // namespace egx
+// the last member of a group is gone: its slabs go to the pool (least recently returned slabs of the device make room), or
+// are freed when the pool is disabled, they alone exceed its bound, or the group was never completely allocated
+egx::GroupSlabs::~GroupSlabs() {
+    using namespace egx;
+    SlabEntry e;
+    e.device = device, e.M = M, e.D = D, e.I = I, e.bytes_M = bytes_M, e.bytes_D = bytes_D, e.bytes_I = bytes_I;
+    M = D = nullptr, I = nullptr;
+    const size_t cap = pool_cap_bytes();
+    if (!(e.M && e.D && e.I) || e.bytes() > cap) {
+        int cur = 0;
+        const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+        free_slab_entry(e);
+        if (have_cur) (void)hipSetDevice(cur);
+        return;
+    }
+    std::list<PoolEntry> evicted;
+    std::list<SlabEntry> evicted_slabs;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        const int dev = e.device;
+        g_slab_pool.push_front(e);
+        while (pool_bytes_on(dev) > cap) {
+            auto sv = g_slab_pool.end();
+            for (auto it = std::next(g_slab_pool.begin()); it != g_slab_pool.end(); ++it)
+                if (it->device == dev) sv = it;
+            if (sv != g_slab_pool.end()) {
+                evicted_slabs.splice(evicted_slabs.begin(), g_slab_pool, sv);
+                continue;
+            }
+            auto victim = g_pool.end();
+            for (auto it = g_pool.begin(); it != g_pool.end(); ++it)
+                if (it->key.device == dev) victim = it;
+            if (victim == g_pool.end()) break;
+            evicted.splice(evicted.begin(), g_pool, victim);
+        }
+    }
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (auto &v : evicted) free_entry(v);
+    for (auto &v : evicted_slabs) free_slab_entry(v);
+    if (have_cur) (void)hipSetDevice(cur);
+}
+namespace egx {
 
 hipError_t dev_malloc_bytes(void **p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes);
@@ -1146,6 +1256,7 @@ void egx_pool_stats(int64_t *cached_bytes, int64_t *hits, int64_t *misses) {
     if (cached_bytes) {
         size_t b = 0;
         for (const auto &e : g_pool) b += e.bytes;
+        for (const auto &e : g_slab_pool) b += e.bytes();
         *cached_bytes = (int64_t)b;
     }
     if (hits) *hits = g_pool_hits;
@@ -1337,17 +1448,25 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
         nws = 1;
         gp->group = g.slabs;
         gp->group_slot = g.slot;
+        // (a destroyed member of a group of this shape left its workspace -- streams, events, pinned buffers -- and its
+        //  training-set buffers in the pool: adopt them; the slab views are this group's)
+        const bool pooled = pool_take(gp, 1);
         gp->slab_M = g.slabs->M + (int64_t)g.slot * gp->stride_M;
         gp->slab_D = g.slabs->D + (int64_t)g.slot * gp->stride_D;
         gp->slab_I = g.slabs->I + g.slot;
         gp->sync_off = g.sync_off + (int64_t)g.slot * gp->stride_S - g.slot;  // dev_sync(gp, 0) = the slot's words
-        EGX_HIPF(dev_malloc(&gp->d_xT, sizeof(double) * 2 * xT.size()));
-        EGX_HIPF(dev_malloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
-        EGX_HIPF(dev_malloc(&gp->d_gamma, sizeof(double) * gp->n_pad));
-        EGX_HIPF(dev_malloc(&gp->d_fit_coef, sizeof(double) * ((size_t)d * (gp->has_w ? gp->h : 1) + 2 * (size_t)d)));
-        gp->ws.resize(1);
-        rc = alloc_workspace(gp, gp->ws[0], 0);
-        if (rc) return fail(rc);
+        if (pooled) {
+            Workspace &w = gp->ws[0];
+            w.M = gp->slab_M, w.dinv = gp->slab_D, w.d_info = gp->slab_I;
+        } else {
+            EGX_HIPF(dev_malloc(&gp->d_xT, sizeof(double) * 2 * xT.size()));
+            EGX_HIPF(dev_malloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
+            EGX_HIPF(dev_malloc(&gp->d_gamma, sizeof(double) * gp->n_pad));
+            EGX_HIPF(dev_malloc(&gp->d_fit_coef, sizeof(double) * ((size_t)d * (gp->has_w ? gp->h : 1) + 2 * (size_t)d)));
+            gp->ws.resize(1);
+            rc = alloc_workspace(gp, gp->ws[0], 0);
+            if (rc) return fail(rc);
+        }
     } else if (!pool_take(gp, nws)) {  // no destroyed handle of this shape left its resources behind: allocate
         EGX_HIPF(dev_malloc(&gp->d_xT, sizeof(double) * 2 * xT.size()));  // + dev_xs_fit()
         EGX_HIPF(dev_malloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
@@ -1615,9 +1734,10 @@ int32_t egx_gp_create_group(const egx_gp_config *cfg_in, const double *x, const 
     ctx.slabs->device = dev;
     ctx.slabs->k = k;
     ctx.sync_off = round_up(k, 64);
-    EGX_HIP_CHECK(dev_malloc(&ctx.slabs->M, sizeof(double) * (size_t)sM * k));
-    EGX_HIP_CHECK(dev_malloc(&ctx.slabs->D, sizeof(double) * (size_t)sD * k));
-    EGX_HIP_CHECK(dev_malloc(&ctx.slabs->I, sizeof(int) * ((size_t)ctx.sync_off + (size_t)sS * k)));
+    ctx.slabs->bytes_M = sizeof(double) * (size_t)sM * k;
+    ctx.slabs->bytes_D = sizeof(double) * (size_t)sD * k;
+    ctx.slabs->bytes_I = sizeof(int) * ((size_t)ctx.sync_off + (size_t)sS * k);
+    EGX_RC(group_slabs_take(*ctx.slabs));
     int rc = EGX_SUCCESS;
     for (int32_t j = 0; j < k && rc == EGX_SUCCESS; j++) {
         ctx.slot = j;

@@ -438,6 +438,64 @@ def test_expert_loop_in_lock_step(egx):
         e.close()
 
 
+def test_one_shot_groups_are_warm_groups(egx):
+    """The expert loop of egobox-moe creates its experts per fit (crates/moe/src/algorithm.rs:167-177 -> params.train).  A
+    destroyed GROUP leaves its slabs and its members' workspaces (streams, events, pinned buffers, training-set buffers) in the
+    library's pool like a destroyed lone handle does: create_group -> fit -> close cycles on different data of one shape hit the
+    pool from the second cycle on, give the bits of the first cycle for the same data, cost little more than the fit on resident
+    members, do not grow device memory; egx_trim gives everything back."""
+    import torch
+    k, n, d = 4, 2100, 3
+    th = np.tile(np.full(d, 0.6), (k, 1))
+
+    def sets(seed):
+        dd = [_data(n, d, seed + j) for j in range(k)]
+        return np.stack([s[0] for s in dd]), np.stack([s[1] for s in dd])
+
+    egx.trim()
+    xs, ys = sets(300)
+    hs = egx.GpHandle.create_group(xs, ys, corr=1)   # (absolute exponential: well conditioned at any density)
+    egx.finalize_multi(hs, th)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        egx.finalize_multi(hs, th)
+    resident = (time.perf_counter() - t0) / 3
+    ref = [h.fitted_scalars()[0] for h in hs]
+    for h in hs:
+        h.close()
+    stats0 = egx.pool_stats()
+    assert stats0["cached_bytes"] >= k * 8 * n * n   # the group's matrices are in the pool, not freed
+    free0 = torch.cuda.mem_get_info()[0]
+    cycle, used = [], []
+    for c in range(8):
+        xs, ys = sets(300 + 10 * (c % 2))
+        t0 = time.perf_counter()
+        hs = egx.GpHandle.create_group(xs, ys, corr=1)
+        egx.finalize_multi(hs, th)
+        lk = [h.fitted_scalars()[0] for h in hs]
+        for h in hs:
+            h.close()
+        cycle.append(time.perf_counter() - t0)
+        used.append(free0 - torch.cuda.mem_get_info()[0])
+        if c % 2 == 0:
+            assert lk == ref                  # same data, same bits, whatever the slabs held before
+    stats = egx.pool_stats()
+    assert stats["misses"] == stats0["misses"] and stats["hits"] - stats0["hits"] == 8 * (k + 1)   # k members + the slabs
+    print(f"resident group fit {resident * 1e3:.2f} ms, create_group + fit + close cycles {np.median(cycle) * 1e3:.2f} ms (median)")
+    assert np.median(cycle) <= 1.3 * resident + 5e-3   # + the members' normalisation, k-major copies and uploads on the host
+    assert max(used) - min(used) < 64 << 20
+    # a lone handle of the members' shape does not take a member's entry (its slabs are the group's), nor the other way round
+    x1, y1 = _data(n, d, 300)
+    with egx.GpHandle(x1, y1, corr=1) as h:
+        assert egx.pool_stats()["misses"] == stats["misses"] + 1
+        h.finalize(th[0])
+        assert h.fitted_scalars()[0] == ref[0]   # (n_pad <= 4096 on one workspace: the schedule row of the group's members)
+    freed = egx.trim()
+    assert freed >= stats["cached_bytes"] > 0 and egx.pool_stats()["cached_bytes"] == 0
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 + k * 8 * n * n - (64 << 20)   # the pooled matrices went back to the device
+
+
 @pytest.mark.parametrize("n,d", [(300, 3), (1000, 3), (2100, 4), (5000, 4), (9000, 5)])
 def test_one_launch_back_substitution_gives_the_bits_of_the_launch_per_block_form(egx, knobs, n, d):
     """gamma = C^-T rho (crates/gp/src/algorithm.rs:1034) as ONE launch (k_trsv_t_fused, round 6: a workgroup per 64 columns of
