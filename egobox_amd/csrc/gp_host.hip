@@ -26,7 +26,84 @@ int set_device(const egx_gp *gp) {
     return EGX_SUCCESS;
 }
 
-static void free_workspace(Workspace &w) {
+// The four streams of a workspace -- evaluation, C^-T rider, look-ahead chain, its side stream -- are the expensive part of a
+// FIRST handle of a shape: the HIP runtime takes ~3 ms to create a stream and ~2.7 ms to destroy one, serialised over host
+// threads (profiles/r06_first_handle_of_a_shape_costs.txt: 14.5 ms per workspace whatever n, 175-190 ms for the twelve workspaces
+// of a tuned fit, against 0.05 ms for 400 events and 0.02 ms for the matrix).  They carry no shape, so idle workspaces -- pooled or
+// freed -- hand their streams to a per-device free list as a SET (created together, in the order the runtime deals them to its
+// hardware queues: section 4.4 of DESIGN.md) and any workspace that comes to life, of whatever shape, takes a set from there
+// before it creates one: a model per cluster / fold / candidate specification with sizes all different (crates/moe/src/algorithm.rs:167-262,
+// clustering.rs) pays the runtime once per stream, not once per shape.
+struct StreamSet {
+    hipStream_t stream = nullptr, inv_stream = nullptr, s2 = nullptr, s3 = nullptr;
+};
+static std::mutex g_stream_mu;
+static std::vector<std::pair<int, StreamSet>> g_stream_sets;  // (device, idle set); the back is taken first
+constexpr size_t kMaxIdleStreamSets = 96;
+static void destroy_stream_set(StreamSet &ss) {
+    if (ss.s2) (void)hipStreamDestroy(ss.s2);
+    if (ss.s3) (void)hipStreamDestroy(ss.s3);
+    if (ss.inv_stream) (void)hipStreamDestroy(ss.inv_stream);
+    if (ss.stream) (void)hipStreamDestroy(ss.stream);
+    ss = StreamSet();
+}
+// the workspace's streams (idle: every caller has synchronised them) go to the free list; a partial set is destroyed
+static void give_streams(int device, Workspace &w) {
+    StreamSet ss;
+    ss.stream = w.stream, ss.inv_stream = w.inv_stream, ss.s2 = w.lk.s2, ss.s3 = w.lk.s3;
+    w.stream = w.eval_stream = w.inv_stream = nullptr;
+    w.lk.s2 = w.lk.s3 = nullptr;
+    if (ss.stream && ss.inv_stream && ss.s2 && ss.s3) {
+        std::lock_guard<std::mutex> lock(g_stream_mu);
+        if (g_stream_sets.size() < kMaxIdleStreamSets) {
+            g_stream_sets.emplace_back(device, ss);
+            return;
+        }
+    }
+    destroy_stream_set(ss);
+}
+// four streams for a workspace of `device`: an idle set, or new ones (evaluation, rider, then the two high-priority ones)
+static hipError_t take_streams(int device, Workspace &w) {
+    {
+        std::lock_guard<std::mutex> lock(g_stream_mu);
+        for (size_t i = g_stream_sets.size(); i-- > 0;)
+            if (g_stream_sets[i].first == device) {
+                const StreamSet ss = g_stream_sets[i].second;
+                g_stream_sets.erase(g_stream_sets.begin() + (long)i);
+                w.stream = w.eval_stream = ss.stream, w.inv_stream = ss.inv_stream, w.lk.s2 = ss.s2, w.lk.s3 = ss.s3;
+                return hipSuccess;
+            }
+    }
+    hipError_t e = hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking);
+    w.eval_stream = w.stream;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&w.inv_stream, hipStreamNonBlocking);
+    int lo = 0, hi = 0;
+    if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&w.lk.s2, hipStreamNonBlocking, hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&w.lk.s3, hipStreamNonBlocking, hi);
+    return e;
+}
+// egx_trim: the idle sets of `device` (-1: of every device) are destroyed
+static void destroy_idle_streams(int device) {
+    std::vector<std::pair<int, StreamSet>> out;
+    {
+        std::lock_guard<std::mutex> lock(g_stream_mu);
+        for (size_t i = g_stream_sets.size(); i-- > 0;)
+            if (device < 0 || g_stream_sets[i].first == device) {
+                out.push_back(g_stream_sets[i]);
+                g_stream_sets.erase(g_stream_sets.begin() + (long)i);
+            }
+    }
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+    for (auto &d : out) {
+        (void)hipSetDevice(d.first);
+        destroy_stream_set(d.second);
+    }
+    if (have_cur) (void)hipSetDevice(cur);
+}
+
+static void free_workspace(Workspace &w, int device) {
     // (M, dinv, d_info are views into the handle's slabs)
     if (w.dW) hipFree(w.dW);
     if (w.d_coef) hipFree(w.d_coef);
@@ -57,12 +134,9 @@ static void free_workspace(Workspace &w) {
         }
     for (hipEvent_t e : {w.lk.ev_lu, w.lk.ev_lur, w.lk.ev_panel, w.lk.ev_a, w.lk.ev_b})
         if (e) hipEventDestroy(e);
-    if (w.lk.s2) hipStreamDestroy(w.lk.s2);
-    if (w.lk.s3) hipStreamDestroy(w.lk.s3);
     if (w.ev_inv_grp) hipEventDestroy(w.ev_inv_grp);
     if (w.ev_inv_done) hipEventDestroy(w.ev_inv_done);
-    if (w.inv_stream) hipStreamDestroy(w.inv_stream);
-    if (w.stream) hipStreamDestroy(w.stream);
+    give_streams(device, w);  // (idle: whoever frees a workspace has synchronised its streams)
     w = Workspace();
 }
 
@@ -70,19 +144,13 @@ static int alloc_workspace(egx_gp *gp, Workspace &w, int index) {
     w.M = gp->slab_M + (int64_t)index * gp->stride_M;
     w.dinv = gp->slab_D + (int64_t)index * gp->stride_D;
     w.d_info = gp->slab_I + index;
-    EGX_HIP_CHECK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
-    w.eval_stream = w.stream;
-    EGX_HIP_CHECK(hipStreamCreateWithFlags(&w.inv_stream, hipStreamNonBlocking));
+    // evaluation stream, the C^-T rider's stream, the look-ahead chain's stream and the side stream of the split updates
+    // (launch_potrf; the last two high priority): an idle set of the device, or new ones
+    EGX_HIP_CHECK(take_streams(gp->device, w));
     EGX_HIP_CHECK(hipEventCreateWithFlags(&w.ev_inv_grp, hipEventDisableTiming));
     EGX_HIP_CHECK(hipEventCreateWithFlags(&w.ev_inv_done, hipEventDisableTiming));
-    {  // the look-ahead chain's stream and the side stream of the split updates (launch_potrf): high priority
-        int lo = 0, hi = 0;
-        EGX_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        EGX_HIP_CHECK(hipStreamCreateWithPriority(&w.lk.s2, hipStreamNonBlocking, hi));
-        EGX_HIP_CHECK(hipStreamCreateWithPriority(&w.lk.s3, hipStreamNonBlocking, hi));
-        for (hipEvent_t *e : {&w.lk.ev_lu, &w.lk.ev_lur, &w.lk.ev_panel, &w.lk.ev_a, &w.lk.ev_b})
-            EGX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    }
+    for (hipEvent_t *e : {&w.lk.ev_lu, &w.lk.ev_lur, &w.lk.ev_panel, &w.lk.ev_a, &w.lk.ev_b})
+        EGX_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     const int hmax = gp->has_w ? gp->h : 1;
     EGX_HIP_CHECK(dev_malloc(&w.d_coef, sizeof(double) * (size_t)gp->d * hmax));
     EGX_HIP_CHECK(dev_malloc(&w.d_xs, sizeof(double) * (size_t)gp->d * gp->n_pad));
@@ -187,7 +255,7 @@ static size_t pool_cap_bytes() {
 }
 static void free_entry(PoolEntry &e) {
     (void)hipSetDevice(e.key.device);
-    for (auto &w : e.ws) free_workspace(w);
+    for (auto &w : e.ws) free_workspace(w, e.key.device);
     for (double *q : {e.d_xT, e.d_rhsT, e.d_gamma, e.d_fit_coef, e.slab_M, e.slab_D})
         if (q) (void)hipFree(q);
     if (e.slab_I) (void)hipFree(e.slab_I);
@@ -308,6 +376,9 @@ static void pool_give(egx_gp *gp) {
         free_entry(e);
         return;
     }
+    // the pooled workspaces keep everything but their streams: those are idle now and may serve a handle of any shape (the last
+    // workspace's set goes first, so that a handle which adopts this entry next finds every set where it was)
+    for (size_t i = e.ws.size(); i-- > 0;) give_streams(e.key.device, e.ws[i]);
     std::list<PoolEntry> evicted;
     std::list<SlabEntry> evicted_slabs;
     {
@@ -1228,7 +1299,11 @@ int32_t egx_device_count(void) {
     return c;
 }
 
-int64_t egx_trim(void) { return (int64_t)(pool_trim(-1) + pipe_release_plans()); }
+int64_t egx_trim(void) {
+    const size_t bytes = pool_trim(-1) + pipe_release_plans();
+    destroy_idle_streams(-1);  // (after the pool: its workspaces' streams were handed over when they were pooled / freed)
+    return (int64_t)bytes;
+}
 
 void egx_chain_stats(int64_t *aborted, int64_t *retried) {
     if (aborted) *aborted = g_chain_aborts.load();
@@ -1458,6 +1533,7 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
         if (pooled) {
             Workspace &w = gp->ws[0];
             w.M = gp->slab_M, w.dinv = gp->slab_D, w.d_info = gp->slab_I;
+            EGX_HIPF(take_streams(gp->device, w));  // (pooled workspaces are kept without streams)
         } else {
             EGX_HIPF(dev_malloc(&gp->d_xT, sizeof(double) * 2 * xT.size()));
             EGX_HIPF(dev_malloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
@@ -1467,7 +1543,9 @@ int32_t egx_gp_create(const egx_gp_config *cfg_in, const double *x, const double
             rc = alloc_workspace(gp, gp->ws[0], 0);
             if (rc) return fail(rc);
         }
-    } else if (!pool_take(gp, nws)) {  // no destroyed handle of this shape left its resources behind: allocate
+    } else if (pool_take(gp, nws)) {  // a destroyed handle of this shape left its resources behind; its streams went to the free list
+        for (auto &w : gp->ws) EGX_HIPF(take_streams(gp->device, w));
+    } else {  // allocate
         EGX_HIPF(dev_malloc(&gp->d_xT, sizeof(double) * 2 * xT.size()));  // + dev_xs_fit()
         EGX_HIPF(dev_malloc(&gp->d_rhsT, sizeof(double) * rhsT.size()));
         EGX_HIPF(dev_malloc(&gp->d_gamma, sizeof(double) * gp->n_pad));
@@ -1654,7 +1732,7 @@ int32_t egx_gp_shrink(egx_gp *gp, int32_t n_keep) {
     gp->slab_D = nD;
     gp->slab_I = nI;
     gp->sync_off = round_up(n_keep, 64);  // (the hand-off words need no copy: every factorisation zeroes its own)
-    for (int i = n_keep; i < nws; i++) free_workspace(gp->ws[i]);
+    for (int i = n_keep; i < nws; i++) free_workspace(gp->ws[i], gp->device);
     gp->ws.resize((size_t)n_keep);
     for (int i = 0; i < n_keep; i++) {
         gp->ws[i].M = gp->slab_M + (int64_t)i * gp->stride_M;

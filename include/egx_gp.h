@@ -101,7 +101,9 @@ void egx_gp_config_default(egx_gp_config *cfg);
  * starts warm instead of paying a multi-GiB allocation and a first factorisation on untouched memory.  Bounded by
  * EGX_POOL_MAX_GB (environment, default 48, 0 = no pool).  egx_trim frees everything cached and returns the bytes.
  * The same holds for GROUPS (egx_gp_create_group): the group's slabs are pooled by their three sizes, every member's workspace
- * and training-set buffers under the member's shape -- the next group of that shape adopts them (hits: k members + 1). */
+ * and training-set buffers under the member's shape -- the next group of that shape adopts them (hits: k members + 1).
+ * Streams carry no shape: idle workspaces (pooled or freed) leave theirs in a per-device free list and a handle of ANY shape
+ * takes them from there (the runtime needs ~3 ms to create a stream, a workspace has four); egx_trim destroys the idle ones. */
 int64_t egx_trim(void);
 void egx_pool_stats(int64_t *cached_bytes, int64_t *hits, int64_t *misses);
 /* Chain launches (the serial chain of a factorisation as one persistent launch) bound every device-side

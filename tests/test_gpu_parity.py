@@ -420,7 +420,9 @@ def test_one_shot_fits_are_warm_fits_and_the_pool_is_bounded(egx):
     assert max(used) - min(used) < 64 << 20            # no growth
     freed = egx.trim()
     assert freed >= stats["cached_bytes"] > 0 and egx.pool_stats()["cached_bytes"] == 0
-    assert free0 - torch.cuda.mem_get_info()[0] < 64 << 20
+    # (200 MB, not 64: when this test is the first of its process the cycles may have touched one or two hardware queues more
+    #  than the baseline had -- ~90 MB of runtime scratch each, see above; a leak PER CYCLE is what the line before the trim catches)
+    assert free0 - torch.cuda.mem_get_info()[0] < 200 << 20
 
 
 def test_concurrent_likelihood_calls_on_one_handle(egx):
@@ -963,6 +965,38 @@ def test_reference_style_cpp_host_tests(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0, (out.stdout, out.stderr)
     assert out.stdout.startswith("OK")
+
+
+def test_a_first_handle_of_a_new_shape_reuses_idle_streams(egx):
+    """The HIP runtime takes ~3 ms to create a stream and a workspace has four (profiles/r06_first_handle_of_a_shape_costs.txt:
+    14.5 ms per workspace, whatever n): idle workspaces -- pooled or freed -- hand their streams to a free list, and a handle of
+    ANY shape takes them from there.  Models of different sizes created and dropped one after the other (a mixture's clusters,
+    crates/moe/src/algorithm.rs:167-262) pay the runtime once; egx_trim destroys the idle streams and the library keeps working."""
+    import time
+    d = 3
+    theta = np.full(d, 1.0)
+
+    def cycle(n, nws):
+        x, y = _data(n, d, seed=n)
+        t0 = time.perf_counter()
+        h = egx.GpHandle(x, y, corr=1, n_workspaces=nws)
+        t = time.perf_counter() - t0
+        lk = h.likelihood_batch(np.stack([theta * (1 + 0.01 * c) for c in range(nws)]))[0]
+        h.finalize(theta)
+        out = (h.fitted_scalars()[0], lk.copy())
+        h.close()
+        return t, out
+
+    egx.trim()
+    t_first, ref = cycle(900, 4)                       # creates four stream sets (or finds none idle)
+    times = [cycle(n, 4)[0] for n in (1300, 1700, 2300, 2900)]   # four NEW shapes: pool misses, idle streams
+    print(f"first handle {t_first * 1e3:.1f} ms, first handles of four other shapes {[round(t * 1e3, 2) for t in times]} ms")
+    assert max(times) < 0.025                          # (4 x 14.5 ms when every shape created its own streams)
+    egx.trim()                                         # pooled entries freed, idle streams destroyed
+    t_again, again = cycle(900, 4)
+    assert again[0] == ref[0]
+    np.testing.assert_array_equal(again[1], ref[1])
+    egx.trim()
 
 
 def test_no_device_memory_leak_over_handle_lifecycles(egx, O):
