@@ -555,9 +555,57 @@ static int ftrace_main(int n, int verbose) {
     return 0;
 }
 
+// flowk <n> <wgs> <k>: k matrices of size n as k CONCURRENT flow launches of `wgs` workgroups each, one stream per matrix
+// (round 6, last session: would eight experts fare better as eight narrow flow launches than as one lock-step group?)
+static int flowk_main(int n, int wgs, int k) {
+    const double scale = 6.0, nugget = 1e-8;
+    pipe_set_knob("pipe_timeout_ms", 2000);
+    std::vector<Problem> P(k);
+    std::vector<hipStream_t> st(k);
+    for (int j = 0; j < k; j++) {
+        P[j].create(n, 1, false);
+        CK(hipStreamCreateWithFlags(&st[j], hipStreamNonBlocking));
+    }
+    g_flow = true;
+    pipe_test_set_workgroups(wgs);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    std::vector<hipEvent_t> done(k);
+    for (auto &e : done) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    std::vector<double> ms;
+    int aborts = 0;
+    for (int rep = 0; rep < 5; rep++) {
+        for (int j = 0; j < k; j++) P[j].build(0, scale, nugget, 11 + j);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int j = 0; j < k; j++) {
+            CK(hipStreamWaitEvent(st[j], e0, 0));
+            if (P[j].factor(st[j], true)) return 3;
+            CK(hipEventRecord(done[j], st[j]));
+            CK(hipStreamWaitEvent(0, done[j], 0));
+        }
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float t;
+        CK(hipEventElapsedTime(&t, e0, e1));
+        if (rep) ms.push_back(t);
+        for (int j = 0; j < k; j++) aborts += P[j].abort_word() != 0;
+    }
+    std::sort(ms.begin(), ms.end());
+    const double fl = (double)k * n * n * n / 3.0;
+    printf("flowk   n=%d, %d matrices as %d concurrent flow launches of %d workgroups: median %.3f ms (min %.3f) = %.1f TFLOP/s (%.3f of 78.6), aborted launches %d, info %d\n",
+           n, k, k, wgs, ms[ms.size() / 2], ms[0], fl / (ms[ms.size() / 2] * 1e-3) / 1e12, fl / (ms[ms.size() / 2] * 1e-3) / 1e12 / 78.6, aborts, P[0].infos()[0]);
+    pipe_test_set_workgroups(0);
+    g_flow = false;
+    for (int j = 0; j < k; j++) P[j].destroy();
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (chol_init()) return 1;
     if (argc > 1 && std::string(argv[1]) == "flow") return flow_main(argc, argv);
+    if (argc > 4 && std::string(argv[1]) == "flowk") return flowk_main(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
     if (argc > 1 && std::string(argv[1]) == "tail") return tail_main(argc, argv);
     if (argc > 1 && std::string(argv[1]) == "ftrace") return ftrace_main(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 0);
     if (argc > 1 && std::string(argv[1]) == "diag") return diag_alone_main();
