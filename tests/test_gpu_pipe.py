@@ -496,6 +496,50 @@ def test_one_shot_groups_are_warm_groups(egx):
     assert torch.cuda.mem_get_info()[0] >= free0 + k * 8 * n * n - (64 << 20)   # the pooled matrices went back to the device
 
 
+_BOUNDED_GROUP_POOL_SCRIPT = r"""
+import json, sys
+import numpy as np
+import egobox_amd as egx
+
+def data(n, d, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(size=(n, d))
+    return x, np.sin(3 * x[:, 0]) + x[:, 1:].sum(axis=1) ** 2 + 0.1 * rng.standard_normal(n)
+
+k, d = 3, 3
+th = np.tile(np.full(d, 0.6), (k, 1))
+out = {"lk": [], "cached": []}
+for n in (1500, 1500, 2300, 1500, 2300):          # 3 x 19 MB and 3 x 44 MB of matrices against a 0.08 GB bound
+    sets = [data(n, d, 400 + j) for j in range(k)]
+    hs = egx.GpHandle.create_group(np.stack([s[0] for s in sets]), np.stack([s[1] for s in sets]), corr=1)
+    egx.finalize_multi(hs, th)
+    out["lk"].append([n] + [h.fitted_scalars()[0] for h in hs])
+    for h in hs:
+        h.close()
+    out["cached"].append(egx.pool_stats()["cached_bytes"])
+out["stats"] = egx.pool_stats()
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_group_pool_stays_within_its_bound(egx):
+    """EGX_POOL_MAX_GB bounds what destroyed handles AND destroyed groups leave behind (read once per process, hence a process of
+    its own): with 0.08 GB a group of three n = 1500 models is kept, a group of three n = 2300 models (134 MB of matrices) is freed
+    on the spot and pushes nothing else out beyond the bound; results do not depend on what the pool held."""
+    import json
+    r = _run_script(_BOUNDED_GROUP_POOL_SCRIPT, {"EGX_POOL_MAX_GB": "0.08"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert all(c <= 0.08 * 2 ** 30 for c in out["cached"]), out["cached"]
+    assert out["cached"][0] > 50e6              # the first group's slabs (3 x 19 MB) were kept ...
+    assert out["stats"]["hits"] >= 4            # ... and adopted by the second group (slabs + three members)
+    by_n = {}
+    for row in out["lk"]:
+        by_n.setdefault(row[0], []).append(row[1:])
+    for rows in by_n.values():
+        assert all(r_ == rows[0] for r_ in rows)   # the same data, the same bits, whatever was pooled
+
+
 @pytest.mark.parametrize("n,d", [(300, 3), (1000, 3), (2100, 4), (5000, 4), (9000, 5)])
 def test_one_launch_back_substitution_gives_the_bits_of_the_launch_per_block_form(egx, knobs, n, d):
     """gamma = C^-T rho (crates/gp/src/algorithm.rs:1034) as ONE launch (k_trsv_t_fused, round 6: a workgroup per 64 columns of
